@@ -1,0 +1,394 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE on CPU.
+
+Run only in the build container (needs ``/root/reference``)::
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz, prints oracle agreement
+
+The reference modules are imported unmodified through ``reference_shim.py``; inputs and
+weights come from ``e4s2024_amd.seeded`` so the fixtures only need to store *outputs*
+(plus the small explicit inputs).  Each fixture is then re-derived with ``oracle/e4s_oracle.py``
+and the max-abs disagreement is printed — the same comparison ``tests/test_oracle_golden.py``
+asserts without the reference.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import reference_shim as shim  # noqa: E402
+from e4s2024_amd import seeded  # noqa: E402
+from oracle import e4s_oracle as O  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def rnd(seed, key, shape, std=1.0):
+    return T(seeded.seeded_array(seed, key, shape, 0.0, std, "normal"))
+
+
+def report(name, ref, ora):
+    d = (ref - ora).abs().max().item()
+    print(f"  {name:40s} ref|max|={ref.abs().max().item():9.4f}  oracle max-abs diff={d:.3e}")
+    return d
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrs.items()})
+    print(f"wrote {os.path.relpath(path, ROOT)}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# ------------------------------------------------------------------------------- G1
+def g1(op):
+    print("G1 fused_leaky_relu (reference CPU path: gpen/face_model/op/fused_act.py:92-96)")
+    x = rnd(11, "g1.x", (2, 8, 5, 7))
+    b = rnd(11, "g1.b", (8,), 0.5)
+    go = rnd(11, "g1.go", (2, 8, 5, 7))
+    with torch.enable_grad():
+        xr = x.clone().requires_grad_(True)
+        br = b.clone().requires_grad_(True)
+        y = op.fused_leaky_relu(xr, br)
+        y.backward(go)
+    y2 = op.fused_leaky_relu(x.view(2, 8, 35)[:, :, :3].contiguous().view(2, 8 * 3), b.repeat(3))  # 2-D use (EqualLinear)
+    report("fwd", y.detach(), O.fused_leaky_relu(x, b))
+    gi, gb = O.fused_leaky_relu_backward(go, y.detach())
+    report("bwd grad_in", xr.grad, gi)
+    report("bwd grad_bias", br.grad, gb)
+    save("g1_fused_act", x=x, bias=b, y=y.detach(), grad_out=go, grad_in=xr.grad, grad_bias=br.grad,
+         x2d=x.view(2, 8, 35)[:, :, :3].contiguous().view(2, 24), b2d=b.repeat(3), y2d=y2)
+
+
+# ------------------------------------------------------------------------------- G2
+def g2(op):
+    print("G2 upfirdn2d (reference CPU path: gpen/face_model/op/upfirdn2d.py:160-194)")
+    k4 = O.make_blur_kernel((1, 3, 3, 1))
+    karb = rnd(12, "g2.k", (3, 5))  # asymmetric, non-square: catches flips / transposes
+    cases = [
+        ("blur_pad11", (2, 3, 9, 9), k4 * 4, 1, 1, (1, 1)),
+        ("up2_pad21", (2, 3, 8, 8), k4 * 4, 2, 1, (2, 1)),
+        ("down2_pad11", (1, 2, 8, 8), k4, 1, 2, (1, 1)),
+        ("odd_up2", (1, 2, 5, 7), k4 * 4, 2, 1, (2, 1)),
+        ("odd_blur", (1, 3, 17, 11), k4 * 4, 1, 1, (1, 1)),
+        ("asym_k", (1, 2, 9, 10), karb, 1, 1, (2, 2)),
+        ("asym_up3_down2", (1, 2, 6, 5), karb, 3, 2, (3, 1)),
+        ("neg_pad", (1, 2, 10, 10), k4, 1, 1, (-1, 2)),
+        ("wide_blur", (1, 2, 33, 65), k4 * 4, 1, 1, (1, 1)),
+    ]
+    out = {}
+    for name, shp, k, up, down, pad in cases:
+        x = rnd(12, "g2." + name, shp)
+        y = op.upfirdn2d(x, k, up=up, down=down, pad=pad)
+        report(name, y, O.upfirdn2d(x, k, up, down, pad))
+        out[name + ".x"], out[name + ".k"], out[name + ".y"] = x, k, y
+        out[name + ".p"] = np.array([up, down, pad[0], pad[1]], dtype=np.int64)
+    out["names"] = np.array([c[0] for c in cases])
+    save("g2_upfirdn2d", **out)
+
+
+# ------------------------------------------------------------------------------- G3
+def g3(sg2):
+    print("G3 ModulatedConv2d fused branch (models/stylegan2/model.py:276-320)")
+    out = {}
+    for name, kw in (("same", dict(kernel_size=3)), ("up", dict(kernel_size=3, upsample=True)), ("rgb", dict(kernel_size=1, demodulate=False))):
+        cout = 3 if name == "rgb" else 24
+        m = sg2.ModulatedConv2d(16, cout, kw.pop("kernel_size"), 512, **kw)
+        m.weight.copy_(rnd(13, f"g3.{name}.w", tuple(m.weight.shape)))
+        m.modulation.weight.copy_(rnd(13, f"g3.{name}.mw", (16, 512)))
+        m.modulation.bias.copy_(rnd(13, f"g3.{name}.mb", (16,), 0.3) + 1)
+        x = rnd(13, f"g3.{name}.x", (2, 16, 10, 12))
+        s = rnd(13, f"g3.{name}.s", (2, 512))
+        y = m(x, s)
+        bk = m.blur.kernel if name == "up" else None
+        report(name, y, O.modulated_conv2d(x, s, m.weight, m.modulation.weight, m.modulation.bias, name != "rgb", name == "up", bk))
+        out.update({f"{name}.w": m.weight, f"{name}.mw": m.modulation.weight, f"{name}.mb": m.modulation.bias, f"{name}.x": x, f"{name}.s": s, f"{name}.y": y})
+        if bk is not None:
+            out["up.blur"] = bk
+    save("g3_modconv", **out)
+
+
+# ------------------------------------------------------------------------------- G4
+def _mini_labels(seed, bs, ncls, size, empty):
+    lab = np.random.RandomState(seed).randint(0, ncls, (bs, size, size)).astype(np.uint8)
+    lab[lab == empty] = (empty + 1) % ncls           # one region is empty everywhere
+    lab[:, : size // 2, : size // 2] = lab[:, :1, :1]  # a constant quadrant (uniform tiles)
+    return lab
+
+
+def g4(sg2):
+    print("G4 masked StyledConv / ToRGB (models/stylegan2/model.py:382-423, 439-479)")
+    out = {}
+    ncls = 5
+    lab = _mini_labels(14, 2, ncls, 32, empty=3)
+    mask = seeded.labels_to_onehot(lab, ncls)
+    out["labels"] = lab
+    for name, up in (("same", False), ("up", True)):
+        m = sg2.StyledConv(16, 24, 3, 512, upsample=up, mask_op=True)
+        sd = {k: v for k, v in m.state_dict().items()}
+        for k in sd:
+            if k.endswith("kernel"):
+                continue
+            sd[k] = rnd(14, f"g4.{name}.{k}", tuple(sd[k].shape), 1.0 if k.endswith("weight") and "noise" not in k else 0.3)
+        sd["conv.modulation.bias"] = sd["conv.modulation.bias"] + 1
+        m.load_state_dict(sd)
+        hin = 16 if up else 32
+        x = rnd(14, f"g4.{name}.x", (2, 16, hin, hin))
+        st = rnd(14, f"g4.{name}.s", (2, ncls, 512))
+        nz = rnd(14, f"g4.{name}.nz", (1, 1, 32, 32))
+        y = m(x, st, mask, noise=nz)
+        osd = {"L." + k: v for k, v in m.state_dict().items()}
+        report("styled_" + name, y, O.styled_conv(osd, "L.", x, st, mask, nz, True, up))
+        for k, v in m.state_dict().items():
+            out[f"{name}.sd.{k}"] = v
+        out.update({f"{name}.x": x, f"{name}.s": st, f"{name}.nz": nz, f"{name}.y": y})
+    m = sg2.ToRGB(16, 512, upsample=True, mask_op=True)
+    sd = {k: v for k, v in m.state_dict().items()}
+    for k in sd:
+        if k.endswith("kernel"):
+            continue
+        sd[k] = rnd(14, f"g4.rgb.{k}", tuple(sd[k].shape), 1.0 if k.endswith("weight") else 0.3)
+    sd["conv.modulation.bias"] = sd["conv.modulation.bias"] + 1
+    m.load_state_dict(sd)
+    x = rnd(14, "g4.rgb.x", (2, 16, 32, 32))
+    st = rnd(14, "g4.rgb.s", (2, ncls, 512))
+    skip = rnd(14, "g4.rgb.skip", (2, 3, 16, 16))
+    y = m(x, st, mask, skip)
+    osd = {"L." + k: v for k, v in m.state_dict().items()}
+    report("to_rgb", y, O.to_rgb(osd, "L.", x, st, mask, skip, True))
+    for k, v in m.state_dict().items():
+        out[f"rgb.sd.{k}"] = v
+    out.update({"rgb.x": x, "rgb.s": st, "rgb.skip": skip, "rgb.y": y})
+    save("g4_styled", **out)
+
+
+# ------------------------------------------------------------------------------- G5
+def g5(sg2):
+    print("G5 small Generators (models/stylegan2/model.py:482-698)")
+    out = {}
+    for size, rli, ncls, bs in ((64, 5, 4, 2), (256, 13, 12, 1)):
+        g = sg2.Generator(size, 512, 8, split_layer_idx=5, remaining_layer_idx=rli)
+        seeded.apply_seeded(g, 21, "net3", prefix="G.")
+        lab = seeded.blocky_labels(22, bs, ncls, 64, cells=8)
+        lab[:, 5:9, 3:40] = (lab[:, 5:9, 3:40] + 1) % ncls   # ragged edges, not aligned to any tile
+        mask = seeded.labels_to_onehot(lab, ncls)
+        codes = seeded.seeded_codes(23, bs, ncls, g.n_latent, seeded.seeded_latent_avg(2, g.n_latent))
+        t = time.time()
+        img, _, feats = g([codes], None, mask, input_is_latent=True, randomize_noise=False)
+        print(f"  reference Generator({size}) bs={bs}: {time.time() - t:.2f}s")
+        sd = {"G." + k: v for k, v in g.state_dict().items()}
+        oi, of = O.generator_forward(sd, codes, mask, None, size=size, remaining_layer_idx=rli)
+        report(f"gen{size}.image", img, oi)
+        report(f"gen{size}.feats", feats, of)
+        tag = f"s{size}"
+        out[tag + ".labels"] = lab
+        out[tag + ".image"] = img
+        out[tag + ".feats_sample"] = feats.flatten()[:: max(1, feats.numel() // 4096)]
+        out[tag + ".cfg"] = np.array([size, rli, ncls, bs], dtype=np.int64)
+    save("g5_generator_small", **out)
+
+
+# ------------------------------------------------------------------------- G6/G7/G8
+def g678(Net3):
+    import argparse as ap
+    print("G6-G8 full-size Net3 (models/networks.py:206-277)")
+    opts = ap.Namespace(fsencoder_type="psp", remaining_layer_idx=13, num_seg_cls=12, out_size=1024,
+                        train_G=False, start_from_latent_avg=True, learn_in_w=False)
+    net = Net3(opts).eval()
+    seeded.apply_seeded(net, 4, "net3")
+    net.latent_avg = seeded.seeded_latent_avg(2, 18)
+    sd = net.state_dict()
+
+    # G7: encoder
+    lab = seeded.blocky_labels(3, 1, 12, 512, cells=16)
+    lab[lab == 9] = 0      # regions 9 and 11 are empty -> zero style vectors
+    lab[lab == 11] = 0
+    lab[0, 100:131, 57:300] = 5
+    mask = seeded.labels_to_onehot(lab, 12)
+    img = seeded.seeded_image(5, 1, 1024)
+    t = time.time()
+    vec, struct = net.get_style_vectors(img, mask)
+    print(f"  reference get_style_vectors: {time.time() - t:.2f}s")
+    ov, ost = O.get_style_vectors({k: v for k, v in sd.items() if k.startswith("encoder.")}, img, mask)
+    report("style_vectors", vec, ov)
+    assert struct.abs().max().item() == 0 and tuple(struct.shape) == (1, 512, 16, 16)
+    save("g7_style_vectors", labels_rle=_rle(lab), vectors=vec, struct_shape=np.array(struct.shape))
+
+    # G8: MLPs
+    codes = net.cal_style_codes(vec)
+    oc = O.cal_style_codes(sd, vec, net.latent_avg, 13)
+    report("style_codes", codes, oc)
+    idx = np.random.RandomState(8).choice(codes.numel(), 8192, replace=False)
+    save("g8_style_codes", vectors=vec, idx=idx, codes_sample=codes.flatten()[idx], codes_sum=codes.double().sum().item(),
+         codes_abs_sum=codes.double().abs().sum().item(), shape=np.array(codes.shape))
+
+    # G6: synthesis at 1024, config-2 inputs (one sample)
+    codes2 = seeded.seeded_codes(1, 1, 12, 18, net.latent_avg)
+    lab2 = seeded.blocky_labels(3, 1, 12, 512, cells=16)
+    mask2 = seeded.labels_to_onehot(lab2, 12)
+    t = time.time()
+    image, minus1, feats = net.gen_img(torch.zeros(1, 512, 32, 32), codes2, mask2, randomize_noise=False)
+    print(f"  reference gen_img 1024 bs=1: {time.time() - t:.2f}s  |image|max={image.abs().max().item():.3f} mean={image.mean().item():.4f} std={image.std().item():.4f}")
+    assert minus1 == -1
+    t = time.time()
+    oi, of = O.generator_forward(sd, codes2, mask2, None)
+    print(f"  oracle generator_forward: {time.time() - t:.2f}s")
+    report("gen1024.image", image, oi)
+    report("gen1024.feats", feats, of)
+    pidx = np.random.RandomState(6).choice(image.numel(), 16384, replace=False)
+    save("g6_gen1024", pix_idx=pidx, pix=image.flatten()[pidx], crop=image[0, :, 480:544, 480:544],
+         row=image[0, :, 777, :], stats=np.array([image.double().mean().item(), image.double().std().item(), image.abs().max().item(),
+                                                  image.double().abs().sum().item()]),
+         feats_sample=feats.flatten()[::32], feats_stats=np.array([feats.double().mean().item(), feats.double().std().item()]))
+
+    # adversarial i.i.d. labels, same codes: a 128x128 crop + sampled pixels
+    lab3 = seeded.iid_labels(9, 1, 12, 512)
+    mask3 = seeded.labels_to_onehot(lab3, 12)
+    image3, _, _ = net.gen_img(torch.zeros(1, 512, 32, 32), codes2, mask3, randomize_noise=False)
+    save("g6_gen1024_iid", pix_idx=pidx, pix=image3.flatten()[pidx], crop=image3[0, :, 448:576, 448:576])
+
+
+def _rle(lab):
+    """labels are regenerated from seeds in the tests; keep a checksum so drift is caught."""
+    return np.array([int(lab.astype(np.int64).sum()), int((lab.astype(np.int64) * np.arange(lab.size).reshape(lab.shape) % 9973).sum())], dtype=np.int64)
+
+
+# ---------------------------------------------------------------------------- G9/G10
+def g9_10():
+    print("G9 BiSeNet / G10 parser pre- and post-processing (swap_face_fine/face_parsing/*)")
+    bis, rn, _ = shim.import_bisenet()
+    net = bis.BiSeNet(19).eval()
+    seeded.apply_seeded(net, 7, "bisenet")
+    sd = net.state_dict()
+    fpd = shim.import_face_parsing_demo()
+
+    img01 = (seeded.seeded_image(5, 1, 1024) + 1) / 2
+    # make the image piecewise smooth so that the parse is not pure noise
+    img01 = torch.nn.functional.avg_pool2d(img01, 31, 1, 15) * 3 - 1
+    img01 = img01.clamp(0, 1)
+    ds = fpd.BicubicDownSample(factor=2, cuda=False)
+    down = ds(img01)
+    report("bicubic_down", down, O.bicubic_downsample(img01, 2))
+    x = (down.clamp(0, 1) - bis.seg_mean.cpu()) / bis.seg_std.cpu()
+    report("parser_preprocess", x, O.parser_preprocess(img01))
+    t = time.time()
+    logits, l16, l32 = net(x)
+    print(f"  reference BiSeNet 512: {time.time() - t:.2f}s")
+    ol, o16, o32 = O.bisenet_forward(sd, x, aux=True)
+    report("bisenet logits", logits, ol)
+    report("bisenet aux16", l16, o16)
+    report("bisenet aux32", l32, o32)
+    seg = torch.argmax(logits, dim=1)[0].long().numpy().astype(np.uint8)
+    oseg = torch.argmax(ol, dim=1)[0].numpy().astype(np.uint8)
+    top2 = torch.topk(logits[0], 2, dim=0).values
+    gap = (top2[0] - top2[1]).flatten()
+    print(f"  argmax: classes used={np.unique(seg).size}  oracle mismatches={(seg != oseg).sum()}  min top-2 gap={gap.min().item():.3e}  "
+          f"gap quantiles 1e-4/1e-3/1e-2 = {[float(torch.quantile(gap, q)) for q in (1e-4, 1e-3, 1e-2)]}")
+    pidx = np.random.RandomState(10).choice(512 * 512, 1024, replace=False)
+    seg12 = fpd.__dict__["__ffhq_masks_to_faceParser_mask_detailed"](seg) if "__ffhq_masks_to_faceParser_mask_detailed" in fpd.__dict__ else None
+    if seg12 is None:
+        import datasets.dataset as dsmod
+        seg12 = getattr(dsmod, "__ffhq_masks_to_faceParser_mask_detailed")(seg)
+    assert (seg12 == O.remap_19_to_12(seg)).all()
+    allv = np.arange(19, dtype=np.uint8).reshape(1, 19)
+    import datasets.dataset as dsmod
+    remap_tbl = getattr(dsmod, "__ffhq_masks_to_faceParser_mask_detailed")(allv)[0]
+    assert (remap_tbl == O.remap_19_to_12(allv)[0]).all()
+    save("g9_bisenet", seg=seg, seg12=seg12, pix_idx=pidx, logits_sample=logits[0].reshape(19, -1)[:, pidx], gap=gap.numpy().astype(np.float32).reshape(512, 512)[::8, ::8],
+         gap_min=gap.min().item(), remap_table=remap_tbl)
+    small = img01[:, :, :64, :64].contiguous()
+    save("g10_preprocess", img64=small, down64=ds(small), taps=ds.k1[0, 0, :, 0], x_sample=x.flatten()[::257], down_sample=down.flatten()[::257])
+
+
+# ------------------------------------------------------------------------------- G11
+def g11():
+    print("G11 boundary helpers (utils/torch_utils.py:64-76, 207-213)")
+    shim.install()
+    # utils/torch_utils.py imports torchvision/PIL at module scope; load just the functions we need
+    import importlib.util
+    import types
+    sys.modules.setdefault("torchvision.utils", types.ModuleType("torchvision.utils"))
+    spec = importlib.util.spec_from_file_location("_ref_torch_utils", os.path.join(shim.REF, "utils", "torch_utils.py"))
+    tu = importlib.util.module_from_spec(spec)
+    try:
+        spec.loader.exec_module(tu)
+    except Exception as e:  # pragma: no cover
+        print("  could not import utils/torch_utils.py:", repr(e))
+        raise
+    v = rnd(15, "g11.img", (3, 9, 11), 0.8)
+    v[0, 0, 0], v[0, 0, 1], v[0, 0, 2] = 1.0, -1.0, 0.99999
+    im = np.array(tu.tensor2im(v))
+    assert (im == O.tensor2im_array(v.clone())).all()
+    lab = T(np.random.RandomState(16).randint(0, 12, (2, 1, 6, 7)).astype(np.int64))
+    oh = tu.labelMap2OneHot(lab, 12)
+    assert (oh == O.label_map_to_onehot(lab, 12)).all()
+    save("g11_helpers", img=v, im=im, lab=lab, onehot=oh)
+
+
+def g0(Net3, sg2):
+    """state_dict manifests (key -> shape, dtype) of the reference modules: pure data."""
+    import argparse as ap
+    import json
+    print("G0 state_dict manifests")
+    opts = ap.Namespace(fsencoder_type="psp", remaining_layer_idx=13, num_seg_cls=12, out_size=1024,
+                        train_G=False, start_from_latent_avg=True, learn_in_w=False)
+    bis, _, _ = shim.import_bisenet()
+
+    def man(m, prefix=""):
+        return {prefix + k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()}
+
+    net = Net3(opts)
+    out = {
+        "net3_1024_rli13": man(net),
+        "net3_1024_rli13_requires_grad_false": sorted(k for k, p in net.named_parameters() if not p.requires_grad),
+        "generator_64_rli5": man(sg2.Generator(64, 512, 8, split_layer_idx=5, remaining_layer_idx=5), "G."),
+        "generator_256_rli13": man(sg2.Generator(256, 512, 8, split_layer_idx=5, remaining_layer_idx=13), "G."),
+        "bisenet_19": man(bis.BiSeNet(19)),
+    }
+    opts.train_G = True
+    net = Net3(opts)
+    out["net3_1024_rli13_trainG_requires_grad_false"] = sorted(k for k, p in net.named_parameters() if not p.requires_grad)
+    path = os.path.join(HERE, "manifest.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0, sort_keys=False)
+    print(f"wrote tests/golden/manifest.json ({os.path.getsize(path) / 1024:.1f} KiB): " + ", ".join(f"{k}={len(v)}" for k, v in out.items()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    only = set(args.only.split(",")) if args.only else None
+    op = shim.install()
+    Net3, sg2, _, _ = shim.import_net3()
+
+    def want(n):
+        return only is None or n in only
+
+    if want("g0"): g0(Net3, sg2)
+    if want("g1"): g1(op)
+    if want("g2"): g2(op)
+    if want("g3"): g3(sg2)
+    if want("g4"): g4(sg2)
+    if want("g5"): g5(sg2)
+    if want("g678"): g678(Net3)
+    if want("g9"): g9_10()
+    if want("g11"): g11()
+
+
+if __name__ == "__main__":
+    main()
