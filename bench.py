@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 1024x1024 faces/sec of the region-aware StyleGAN2 synthesis (BASELINE.json configs[1]:
+``Net3.gen_img`` from random W+ codes and random 12-class masks, batch 4 per GPU, randomize_noise=False).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one ``gen_img`` call on a batch of 4 faces whose codes / masks / weights are already resident in HBM.
+Frames are independent units: with N GPUs every rank synthesises its own batch (weak scaling, no data-path collective;
+RCCL is used for the start/stop barriers and the max-over-ranks reduction of the elapsed time only).
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     — dominant kernel (the fp32-MFMA implicit-GEMM modulated conv): algorithmic FLOPs of its launches in a step
+                 / their HIP-event durations measured inside the timed region, against the 157.3 TFLOP/s fp32 matrix peak
+  cpu_baseline — the faithful 12-pass CPU oracle timed on one face on this host's cores (rank 0, N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
+BATCH = 4
+
+
+def conv3x3_flops_per_face(size=1024):
+    """Algorithmic FLOPs of the 3x3 modulated convs per face, each counted once, keyed by kernel instantiation
+    (the transposed convs are counted per INPUT pixel)."""
+    from e4s2024_amd.ops import modconv_kernel_name
+    ch = {4: 512, 8: 512, 16: 512, 32: 512, 64: 512, 128: 256, 256: 128, 512: 64, 1024: 32}
+    out = {}
+
+    def add(cout, w, fl):
+        k = modconv_kernel_name(cout, w)
+        out[k] = out.get(k, 0.0) + fl
+    add(512, 4, 2 * 512 * 512 * 9 * 16)
+    cin, r = 512, 8
+    while r <= size:
+        co = ch[r]
+        add(co, r // 2, 2 * cin * co * 9 * (r // 2) ** 2)       # up-conv: launched on the input grid
+        add(co, r, 2 * co * co * 9 * r * r)
+        cin, r = co, r * 2
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--labels", choices=["blocky", "iid"], default="blocky")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with python -m torch.distributed.run --nproc-per-node {args.gpus})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+
+    import e4s2024_amd
+    from e4s2024_amd import ops, seeded
+    e4s2024_amd.install()
+    from models.networks import Net3
+    import argparse as _ap
+
+    opts = _ap.Namespace(fsencoder_type="psp", remaining_layer_idx=13, num_seg_cls=12, out_size=1024, train_G=False,
+                         start_from_latent_avg=True, learn_in_w=False)
+    net = Net3(opts).eval()
+    seeded.apply_seeded(net.G, 4, "net3", prefix="G.")          # synthesis only: encoder / MLP weights are not touched by gen_img
+    la = seeded.seeded_latent_avg(2, 18)
+    net.latent_avg = la.to(dev)
+    sd_cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sd_cpu = {"G." + k: v.clone() for k, v in net.G.state_dict().items()}
+    net = net.to(dev)
+
+    bs = args.batch
+    # codes = latent_avg + 0.5 N(0,1) (seed 1 + rank), blocky 16x16-cell label maps (seed 3 + rank)
+    codes = seeded.seeded_codes(1 + rank, bs, 12, 18, la).to(dev)
+    lab = (seeded.blocky_labels(3 + rank, bs, 12, 512, 16) if args.labels == "blocky" else seeded.iid_labels(9 + rank, bs, 12, 512))
+    mask = seeded.labels_to_onehot(lab, 12).to(dev)
+    ops.STRICT_MASK = False                                       # the one-hot check costs a host sync; masks here are one-hot by construction
+
+    def step():
+        with torch.no_grad():
+            return net.gen_img(None, codes, mask, randomize_noise=False)[0]
+
+    for _ in range(args.warmup):
+        img = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with ops.KernelTimer() as kt:
+        for _ in range(args.steps):
+            img = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    ksum = kt.summary()
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(img).all()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        faces = bs * world * args.steps
+        value = faces / elapsed
+        # ---- roofline of the dominant kernel
+        fl = conv3x3_flops_per_face()
+        dom = max(ksum, key=lambda k: ksum[k][1]) if ksum else None
+        roof = None
+        if dom:
+            calls, tot_ms = ksum[dom]
+            per_launch_flops = fl[dom] * bs * args.steps / calls
+            avg_ms = tot_ms / calls
+            ach = per_launch_flops / (avg_ms * 1e-3) / 1e12
+            all_ms = sum(v[1] for v in ksum.values())
+            all_fl = sum(fl.values()) * bs * args.steps
+            roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": calls // args.steps, "avg_launch_ms": round(avg_ms, 4),
+                    "algorithmic_gflop_per_launch": round(per_launch_flops / 1e9, 3),
+                    "all_modconv3x3": {"achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 2), "ms_per_step": round(all_ms / args.steps, 3),
+                                       "by_kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(ksum.items())}}}
+        # ---- CPU baseline: the faithful 12-pass oracle on one face
+        cpu = None
+        if sd_cpu is not None:
+            from oracle import e4s_oracle as O
+            torch.set_num_threads(os.cpu_count() or 1)
+            c1, m1 = codes[:1].cpu(), mask[:1].cpu()
+            t1 = time.perf_counter()
+            with torch.no_grad():
+                ref, _ = O.generator_forward(sd_cpu, c1, m1, None)
+            dt = time.perf_counter() - t1
+            err = (img[:1].cpu() - ref).abs().max().item()
+            cpu = {"value": round(1.0 / dt, 4), "unit": "faces/s", "cores": torch.get_num_threads(), "kind": "port",
+                   "sample": f"1 face (bs=1) of the same workload through oracle.generator_forward (12 region passes per masked layer), {dt:.1f} s",
+                   "max_abs_pixel_diff_vs_gpu": float(f"{err:.3e}")}
+        line = {
+            "metric": "1024x1024 faces/sec (StyleGAN2 regional synthesis, gen_img)", "value": round(value, 3), "unit": "faces/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: StyleGAN2 1024x1024 synthesis from random W+ (Net3.gen_img, randomize_noise=False), "
+                                   f"12-region {args.labels} masks, batch={bs}/GPU, fp32 (bf16 variant not built: misses the 1e-3 pixel bar)",
+                       "batch_per_gpu": bs, "global_batch": bs * world, "resolution": 1024, "regions": 12, "parallelism": f"frames x{world}"},
+            "roofline": roof, "cpu_baseline": cpu,
+            "algorithmic_gflop_per_face": 148.52,
+            "job_fraction_of_fp32_mfma_peak": round(value * 148.52e9 / (FP32_MATRIX_PEAK_TFLOPS * 1e12 * world), 4),
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

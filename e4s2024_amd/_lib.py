@@ -1,0 +1,68 @@
+"""ctypes binding of ``libe4s_hip.so`` (the C ABI declared in ``include/e4s_hip.h``).
+
+The library is built ahead of time (``python -m e4s2024_amd.build`` / ``__graft_entry__.build()``), never
+at import.  There is no CPU fallback: if the shared object is missing or a symbol cannot be resolved the
+import fails loudly, and every wrapper raises ``RuntimeError`` with the library's message on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "lib", "libe4s_hip.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "e4s_hip.h")
+
+c_int, c_i64, c_f32, c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+# name -> argtypes; every function returns int status except the two noted below
+_PROTOS = {
+    "e4s_fused_bias_act": [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_f32, c_f32, c_i64, c_i64, c_i64, c_ptr],
+    "e4s_upfirdn2d": [c_ptr, c_ptr, c_ptr] + [c_int] * 13 + [c_ptr],
+    "e4s_onehot_to_labels": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr],
+    "e4s_modconv_prep_weights": [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr],
+    "e4s_style_demod": [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr],
+    "e4s_region_modconv3x3": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr, c_int] + [c_int] * 7 + [c_ptr],
+    "e4s_region_torgb": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr] + [c_int] * 5 + [c_ptr],
+    "e4s_grouped_linear": [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_int, c_f32] + [c_int] * 4 + [c_ptr],
+}
+
+
+def declared_symbols(header: str = HEADER):
+    """Names of every entry point declared in include/e4s_hip.h."""
+    with open(header) as f:
+        return re.findall(r"E4S_API\s+[\w\s\*]+?\b(e4s_\w+)\s*\(", f.read())
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(SO_PATH):
+            raise ImportError(
+                f"{SO_PATH} not found: build the HIP library first (python -m e4s2024_amd.build). "
+                "e4s2024_amd has no CPU fallback.")
+        self.cdll = ctypes.CDLL(SO_PATH)
+        self.cdll.e4s_last_error.restype = ctypes.c_char_p
+        self.cdll.e4s_last_error.argtypes = []
+        self.cdll.e4s_abi_version.restype = c_int
+        self.cdll.e4s_abi_version.argtypes = []
+        for name, args in _PROTOS.items():
+            fn = getattr(self.cdll, name)  # AttributeError if the .so is stale
+            fn.argtypes = args
+            fn.restype = c_int
+        self.path = SO_PATH
+
+    def call(self, name: str, *args):
+        st = getattr(self.cdll, name)(*args)
+        if st != 0:
+            raise RuntimeError(f"{name} failed (status {st}): {self.cdll.e4s_last_error().decode()}")
+
+
+_lib = None
+
+
+def lib() -> _Lib:
+    global _lib
+    if _lib is None:
+        _lib = _Lib()
+    return _lib

@@ -1,0 +1,483 @@
+// a3-a6: region-aware modulated synthesis kernels (gfx950).
+//
+//   e4s_modconv_prep_weights : parameter re-layout [Cout,Cin,k,k] -> K-major [par][Cin][k*k][Cout] (+ blur composition for up layers)
+//   e4s_style_demod          : per (sample, region) modulation vector s and demodulation vector d (wave-shuffle reductions)
+//   e4s_region_modconv3x3    : implicit-GEMM 3x3 conv on fp32 MFMA (v_mfma_f32_32x32x2_f32), LDS-tiled, one pass per layer
+//   e4s_region_torgb         : 1x1 modulated conv to 3 channels + bias + fused x2 FIR upsample of the skip (HBM-bound)
+//
+// GEMM view of the conv:  D[co][pix] = sum_{k=(ci,tap)} A[co][k] * B[k][pix]
+//   A = shared un-modulated weights (scale folded in), B = x[ci][pix+tap] * s[region(pix)][ci]  (scaled on the LDS read path),
+//   epilogue: * d[region(pix)][co] + noise_w*noise[pix] + bias[co], leaky-relu * sqrt2.
+// Pixels are the MFMA "column" index so that each lane owns one pixel: region, noise and the (coalesced along x) store
+// address are per-lane constants, and a wave stores 32 consecutive pixels of one channel per instruction.
+#include "common.h"
+
+using namespace e4s;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ============================================================================ weight preparation
+// Up layers: conv_transpose2d(stride 2, 3x3) followed by upfirdn2d(blur 4x4, pad (1,1)) is, per output parity (a,b),
+//   y[2m+a, 2n+b] = sum_{dy,dx in {-1,0,1}} Weff[a,b][dy+1][dx+1] * x[m+dy, n+dx]     (zero padded x)
+//   Weff[a,b][dy+1][dx+1] = sum_{ty-ky = 2dy+1-a} sum_{tx-kx = 2dx+1-b} blur[3-ty][3-tx] * W[ky][kx]
+// (q = 2m' + k indexes the transposed conv output, y[p] = sum_t z[p+t-1]*blur_flipped[t]).
+__global__ __launch_bounds__(256) void prep_weights_kernel(float* __restrict__ wt, const float* __restrict__ weight,
+                                                           const float* __restrict__ blur, int cout, int cin, int k, int up,
+                                                           float scale) {
+    const int kk = k * k;
+    const int npar = up ? 4 : 1;
+    const int64_t total = (int64_t)npar * cin * kk * cout;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int co = (int)(i % cout);
+        int64_t r = i / cout;
+        const int tap = (int)(r % kk);
+        r /= kk;
+        const int ci = (int)(r % cin);
+        const int par = (int)(r / cin);
+        const float* w = weight + ((size_t)co * cin + ci) * kk;
+        float v;
+        if (!up) {
+            v = w[tap];
+        } else {
+            const int a = par >> 1, b = par & 1;
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            v = 0.f;
+            for (int ky = 0; ky < 3; ++ky) {
+                const int ty = ky + 2 * dy + 1 - a;
+                if (ty < 0 || ty > 3) continue;
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int tx = kx + 2 * dx + 1 - b;
+                    if (tx < 0 || tx > 3) continue;
+                    v += blur[(3 - ty) * 4 + (3 - tx)] * w[ky * 3 + kx];
+                }
+            }
+        }
+        wt[i] = v * scale;
+    }
+}
+
+__global__ __launch_bounds__(256) void wsq_kernel(float* __restrict__ wsq, const float* __restrict__ weight, int cout, int cin, int kk,
+                                                  float scale) {
+    const int i = blockIdx.x * 256 + threadIdx.x;  // over cin*cout, co fastest
+    if (i >= cin * cout) return;
+    const int co = i % cout, ci = i / cout;
+    const float* w = weight + ((size_t)co * cin + ci) * kk;
+    float a = 0.f;
+    for (int t = 0; t < kk; ++t) {
+        const float v = w[t] * scale;
+        a += v * v;
+    }
+    wsq[i] = a;
+}
+
+extern "C" int e4s_modconv_prep_weights(float* wt, float* wsq, const float* weight, const float* blur, int cout, int cin, int k, int up,
+                                        void* stream) {
+    E4S_REQUIRE(wt && weight, "modconv_prep_weights: null tensor");
+    E4S_REQUIRE(k == 1 || k == 3, "modconv_prep_weights: kernel size %d not supported (1 or 3)", k);
+    E4S_REQUIRE(cout >= 1 && cin >= 1, "modconv_prep_weights: bad channel counts");
+    E4S_REQUIRE(!up || (k == 3 && blur), "modconv_prep_weights: up-conv needs k=3 and the 4x4 blur kernel");
+    const float scale = 1.0f / sqrtf((float)cin * k * k);
+    const int64_t total = (int64_t)(up ? 4 : 1) * cin * k * k * cout;
+    const int grid = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(prep_weights_kernel, dim3(grid), dim3(256), 0, st, wt, weight, blur, cout, cin, k, up, scale);
+    if (wsq) hipLaunchKernelGGL(wsq_kernel, dim3(cdiv(cin * cout, 256)), dim3(256), 0, st, wsq, weight, cout, cin, k * k, scale);
+    return check_launch("modconv_prep_weights");
+}
+
+// ============================================================================ style + demod tables
+// One wave per input channel: the channel's modulation row stays in registers (sdim/64 floats per lane) and is
+// dotted against every (sample, region) style vector with a wave-shuffle reduction.
+__global__ __launch_bounds__(256) void style_kernel(float* __restrict__ s, const float* __restrict__ styles, int64_t stride_b,
+                                                    int64_t stride_r, const float* __restrict__ mod_weight,
+                                                    const float* __restrict__ mod_bias, int bs, int nreg, int cin, int sdim, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int ci = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ci >= cin) return;
+    const float* wrow = mod_weight + (size_t)ci * sdim;
+    const float mb = mod_bias ? mod_bias[ci] : 0.f;
+    for (int br = 0; br < bs * nreg; ++br) {
+        const int b = br / nreg, r = br - b * nreg;
+        const float* sv = styles + b * stride_b + r * stride_r;
+        float a = 0.f;
+        for (int j = lane; j < sdim; j += 64) a += sv[j] * wrow[j];
+        a = wave_sum(a);
+        if (lane == 0) s[(size_t)br * cin + ci] = a * scale + mb;
+    }
+}
+
+__global__ __launch_bounds__(256) void demod_kernel(float* __restrict__ d, const float* __restrict__ s, const float* __restrict__ wsq,
+                                                    int nbr, int cin, int cout) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nbr * cout) return;
+    const int co = i % cout, br = i / cout;
+    const float* sv = s + (size_t)br * cin;
+    float a = 0.f;
+    for (int ci = 0; ci < cin; ++ci) {
+        const float t = sv[ci];
+        a += t * t * wsq[(size_t)ci * cout + co];
+    }
+    d[i] = rsqrtf(a + 1e-8f);
+}
+
+extern "C" int e4s_style_demod(float* s, float* d, const float* styles, int64_t stride_b, int64_t stride_r, const float* mod_weight,
+                               const float* mod_bias, const float* wsq, int bs, int nreg, int cin, int cout, int sdim, void* stream) {
+    E4S_REQUIRE(s && styles && mod_weight, "style_demod: null tensor");
+    E4S_REQUIRE(nreg >= 1 && nreg <= E4S_MAX_REGIONS, "style_demod: %d regions (max %d)", nreg, E4S_MAX_REGIONS);
+    E4S_REQUIRE(bs >= 0 && cin >= 1 && sdim >= 1, "style_demod: bad size");
+    E4S_REQUIRE((d == nullptr) == (wsq == nullptr), "style_demod: d and wsq must both be given or both be NULL");
+    if (bs == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(style_kernel, dim3(cdiv(cin, 4)), dim3(256), 0, st, s, styles, stride_b, stride_r, mod_weight, mod_bias, bs, nreg,
+                       cin, sdim, 1.0f / sqrtf((float)sdim));
+    if (d) {
+        E4S_REQUIRE(cout >= 1, "style_demod: bad cout");
+        hipLaunchKernelGGL(demod_kernel, dim3(cdiv(bs * nreg * cout, 256)), dim3(256), 0, st, d, s, wsq, bs * nreg, cin, cout);
+    }
+    return check_launch("style_demod");
+}
+
+// ============================================================================ region-aware 3x3 modulated conv
+struct ConvParams {
+    float* out;
+    const float* x;
+    const float* wt;
+    const float* s;
+    const float* d;
+    const uint8_t* labels;
+    const float* noise;
+    const float* noise_weight;
+    const float* act_bias;
+    int lh, lw;
+    float lscale_y, lscale_x;  // label-map size / output size (PyTorch 'nearest' scale)
+    int noise_bstride;
+    int act;
+    int bs, cin, cout, h, w, nreg, up;
+    int tiles_x, tiles_y;
+};
+
+constexpr int CK = 8;  // input channels staged per K-chunk (K per chunk = 72)
+
+template <int CB, int PB, int WC, int WP, int LOG_TW>
+struct ConvCfg {
+    static constexpr int TN = WC * CB * 32;       // output channels per block
+    static constexpr int NPB = WP * PB;           // 32-pixel blocks per block
+    static constexpr int TW = 1 << LOG_TW;        // tile width in pixels
+    static constexpr int RPB = 32 >> LOG_TW;      // rows per pixel block
+    static constexpr int TH = NPB * RPB;          // tile height
+    static constexpr int PW = TW + 2, PH = TH + 2;
+    static constexpr int PATCH = PH * PW;         // staged input patch per channel (with halo)
+    static constexpr int EPT = (PATCH + 255) / 256;
+    static constexpr int XS = CK * PATCH, WS = CK * 9 * TN, SS = E4S_MAX_REGIONS * CK;
+    static constexpr int LDS_FLOATS = XS + WS + SS;
+    static_assert(WC * WP == 4, "256-thread blocks");
+    static_assert(E4S_MAX_REGIONS * TN <= WS, "demod table overlays the weight stage");
+};
+
+template <int CB, int PB, int WC, int WP, int LOG_TW>
+__global__ __launch_bounds__(256) void region_modconv_kernel(const ConvParams p) {
+    using C = ConvCfg<CB, PB, WC, WP, LOG_TW>;
+    __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+    float* xs = lds;
+    float* ws = lds + C::XS;
+    float* ss = lds + C::XS + C::WS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l5 = lane & 31, khalf = lane >> 5;
+    const int wc = wave / WP, wp = wave % WP;
+
+    const int ntile = p.tiles_x * p.tiles_y;
+    const int tile = blockIdx.x % ntile;
+    const int par = blockIdx.x / ntile;  // 0 when !up
+    const int pa = par >> 1, pb_ = par & 1;
+    const int y0 = (tile / p.tiles_x) * C::TH, x0 = (tile % p.tiles_x) * C::TW;
+    const int co0 = blockIdx.y * C::TN;
+    const int b = blockIdx.z;
+    const int hw = p.h * p.w;
+    const int ho = p.up ? 2 * p.h : p.h, wo = p.up ? 2 * p.w : p.w;
+
+    // ---- per-thread staging map of the input patch (independent of the channel)
+    int goff[C::EPT];
+    bool ginb[C::EPT];
+#pragma unroll
+    for (int j = 0; j < C::EPT; ++j) {
+        const int e = tid + j * 256;
+        const int py = e / C::PW, px = e - py * C::PW;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        ginb[j] = (e < C::PATCH) && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+        goff[j] = gy * p.w + gx;
+    }
+    const float* xb = p.x + (size_t)b * p.cin * hw;
+    const float* wpar = p.wt + (size_t)par * p.cin * 9 * p.cout;
+    const float* sb = p.s + (size_t)b * p.nreg * p.cin;
+
+    // ---- per-lane pixel bookkeeping
+    int xoff[PB], cls[PB];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int pbk = wp * PB + q;
+        const int ty = pbk * C::RPB + (l5 >> LOG_TW), tx = l5 & (C::TW - 1);
+        xoff[q] = ty * C::PW + tx;
+        const int y = y0 + ty, x = x0 + tx;
+        int c = 0;
+        if (p.labels) {
+            c = E4S_LABEL_NONE;
+            if (y < p.h && x < p.w) {
+                const int oy = p.up ? 2 * y + pa : y, ox = p.up ? 2 * x + pb_ : x;
+                c = p.labels[((size_t)b * p.lh + nearest_src(oy, p.lscale_y, p.lh)) * p.lw + nearest_src(ox, p.lscale_x, p.lw)];
+            }
+        }
+        cls[q] = (c < p.nreg) ? c : -1;
+    }
+
+    f32x16 acc[CB][PB];
+#pragma unroll
+    for (int i = 0; i < CB; ++i)
+#pragma unroll
+        for (int q = 0; q < PB; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.f;
+
+    const bool wvec = (p.cout & 3) == 0;
+
+    for (int ci0 = 0; ci0 < p.cin; ci0 += CK) {
+        __syncthreads();
+        // stage x patch: CK channels x PATCH (zero padded)
+#pragma unroll
+        for (int c = 0; c < CK; ++c) {
+            const bool cok = ci0 + c < p.cin;
+            const float* xc = xb + (size_t)(ci0 + c) * hw;
+#pragma unroll
+            for (int j = 0; j < C::EPT; ++j) {
+                const int e = tid + j * 256;
+                if (e < C::PATCH) xs[c * C::PATCH + e] = (cok && ginb[j]) ? xc[goff[j]] : 0.f;
+            }
+        }
+        // stage weights: ws[c][tap][n] <- wt[par][ci0+c][tap][co0+n]
+        if (wvec) {
+            constexpr int NV = CK * 9 * C::TN / 4;
+            for (int v = tid; v < NV; v += 256) {
+                const int n4 = v % (C::TN / 4);
+                const int ct = v / (C::TN / 4);  // c*9 + tap
+                const int c = ct / 9;
+                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ci0 + c < p.cin && co0 + n4 * 4 < p.cout)
+                    val = *reinterpret_cast<const float4*>(wpar + ((size_t)ci0 * 9 + ct) * p.cout + co0 + n4 * 4);
+                *reinterpret_cast<float4*>(ws + ct * C::TN + n4 * 4) = val;
+            }
+        } else {
+            constexpr int NS = CK * 9 * C::TN;
+            for (int v = tid; v < NS; v += 256) {
+                const int n = v % C::TN;
+                const int ct = v / C::TN;
+                const int c = ct / 9;
+                ws[v] = (ci0 + c < p.cin && co0 + n < p.cout) ? wpar[((size_t)ci0 * 9 + ct) * p.cout + co0 + n] : 0.f;
+            }
+        }
+        // stage the modulation chunk: ss[r][c] <- s[b][r][ci0+c]
+        if (tid < E4S_MAX_REGIONS * CK) {
+            const int r = tid / CK, c = tid % CK;
+            ss[tid] = (r < p.nreg && ci0 + c < p.cin) ? sb[(size_t)r * p.cin + ci0 + c] : 0.f;
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int cp = 0; cp < CK / 2; ++cp) {
+            const int ci = 2 * cp + khalf;  // k index within the MFMA: lanes 0-31 even channel, 32-63 odd channel
+            float sv[PB];
+#pragma unroll
+            for (int q = 0; q < PB; ++q) sv[q] = cls[q] >= 0 ? ss[cls[q] * CK + ci] : 0.f;
+            const float* xrow = xs + ci * C::PATCH;
+            const float* wrow = ws + ci * 9 * C::TN + wc * CB * 32 + l5;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int toff = (tap / 3) * C::PW + (tap % 3);
+                float bv[PB], av[CB];
+#pragma unroll
+                for (int q = 0; q < PB; ++q) bv[q] = xrow[xoff[q] + toff] * sv[q];
+#pragma unroll
+                for (int i = 0; i < CB; ++i) av[i] = wrow[tap * C::TN + i * 32];
+#pragma unroll
+                for (int i = 0; i < CB; ++i)
+#pragma unroll
+                    for (int q = 0; q < PB; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[q], acc[i][q], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: demod table through LDS (overlays the weight stage), noise, bias, activation, store
+    __syncthreads();
+    float* dt = ws;  // [E4S_MAX_REGIONS][TN]
+    for (int v = tid; v < E4S_MAX_REGIONS * C::TN; v += 256) {
+        const int r = v / C::TN, n = v % C::TN;
+        float val = 0.f;
+        if (r < p.nreg && co0 + n < p.cout) val = p.d ? p.d[((size_t)b * p.nreg + r) * p.cout + co0 + n] : 1.f;
+        dt[v] = val;
+    }
+    __syncthreads();
+    const float nw = p.noise ? p.noise_weight[0] : 0.f;
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int pbk = wp * PB + q;
+        const int y = y0 + pbk * C::RPB + (l5 >> LOG_TW), x = x0 + (l5 & (C::TW - 1));
+        if (y >= p.h || x >= p.w) continue;
+        const int oy = p.up ? 2 * y + pa : y, ox = p.up ? 2 * x + pb_ : x;
+        const size_t opix = (size_t)oy * wo + ox;
+        const float nz = p.noise ? nw * p.noise[(size_t)b * p.noise_bstride + opix] : 0.f;
+        const float* drow = dt + (cls[q] >= 0 ? cls[q] : 0) * C::TN;
+        const float dz = cls[q] >= 0 ? 1.f : 0.f;
+#pragma unroll
+        for (int i = 0; i < CB; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = (wc * CB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                const int co = co0 + n;
+                if (co < p.cout) {
+                    float v = acc[i][q][r] * drow[n] * dz + nz;
+                    if (p.act_bias) v += p.act_bias[co];
+                    if (p.act) v = (v > 0.f ? v : v * 0.2f) * 1.41421356237309515f;
+                    p.out[((size_t)b * p.cout + co) * ho * wo + opix] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int CB, int PB, int WC, int WP, int LOG_TW>
+static int launch_conv(ConvParams& p, hipStream_t st) {
+    using C = ConvCfg<CB, PB, WC, WP, LOG_TW>;
+    p.tiles_x = cdiv(p.w, C::TW);
+    p.tiles_y = cdiv(p.h, C::TH);
+    dim3 grid(p.tiles_x * p.tiles_y * (p.up ? 4 : 1), cdiv(p.cout, C::TN), p.bs);
+    hipLaunchKernelGGL((region_modconv_kernel<CB, PB, WC, WP, LOG_TW>), grid, dim3(256), 0, st, p);
+    return check_launch("region_modconv3x3");
+}
+
+extern "C" int e4s_region_modconv3x3(float* out, const float* x, const float* wt, const float* s, const float* d, const uint8_t* labels,
+                                     int lh, int lw, const float* noise, int noise_bs, const float* noise_weight, const float* act_bias,
+                                     int act, int bs, int cin, int cout, int h, int w, int nreg, int up, void* stream) {
+    E4S_REQUIRE(out && x && wt && s, "region_modconv3x3: null tensor");
+    E4S_REQUIRE(bs >= 0 && cin >= 1 && cout >= 1 && h >= 1 && w >= 1, "region_modconv3x3: bad size");
+    E4S_REQUIRE(nreg >= 1 && nreg <= E4S_MAX_REGIONS, "region_modconv3x3: %d regions (max %d)", nreg, E4S_MAX_REGIONS);
+    E4S_REQUIRE(labels || nreg == 1, "region_modconv3x3: nreg > 1 needs a label map");
+    E4S_REQUIRE(!labels || (lh >= 1 && lw >= 1), "region_modconv3x3: bad label map size");
+    E4S_REQUIRE(!noise || (noise_weight && (noise_bs == 1 || noise_bs == bs)), "region_modconv3x3: noise needs its weight and batch 1 or bs");
+    E4S_REQUIRE(bs <= 65535, "region_modconv3x3: batch too large");
+    if (bs == 0) return 0;
+    ConvParams p;
+    p.out = out; p.x = x; p.wt = wt; p.s = s; p.d = d; p.labels = labels; p.noise = noise; p.noise_weight = noise_weight;
+    p.act_bias = act_bias; p.lh = lh; p.lw = lw; p.act = act;
+    p.bs = bs; p.cin = cin; p.cout = cout; p.h = h; p.w = w; p.nreg = nreg; p.up = up ? 1 : 0;
+    const int ho = up ? 2 * h : h, wo = up ? 2 * w : w;
+    p.lscale_y = labels ? (float)lh / (float)ho : 1.f;
+    p.lscale_x = labels ? (float)lw / (float)wo : 1.f;
+    p.noise_bstride = (noise && noise_bs > 1) ? ho * wo : 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (w >= 32) {
+        if (cout > 64) return launch_conv<2, 2, 2, 2, 5>(p, st);   // 128 co x 128 px
+        if (cout > 32) return launch_conv<2, 2, 1, 4, 5>(p, st);   //  64 co x 256 px
+        return launch_conv<1, 2, 1, 4, 5>(p, st);                  //  32 co x 256 px
+    }
+    if (w >= 16) return launch_conv<2, 2, 2, 2, 4>(p, st);
+    if (w >= 8) return launch_conv<2, 1, 2, 2, 3>(p, st);
+    return launch_conv<2, 1, 2, 2, 2>(p, st);
+}
+
+// ============================================================================ ToRGB
+// out[b,o,p] = sum_ci wt[ci][o] * s[b,c(p),ci] * x[b,ci,p] + bias[o] + upfirdn2d(skip, up=2, pad=(2,1))[p]
+// One thread per 4 consecutive pixels (float4 loads of x); the s table [nreg][cin] and wt [cin][3] sit in LDS.
+__global__ __launch_bounds__(256) void region_torgb_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ wt,
+                                                           const float* __restrict__ s, const uint8_t* __restrict__ labels, int lh, int lw,
+                                                           float lsy, float lsx, const float* __restrict__ bias,
+                                                           const float* __restrict__ skip, const float* __restrict__ upk, int cin, int h,
+                                                           int w, int nreg) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* st = sm;                     // [nreg][cin]
+    float* wl = sm + nreg * cin;        // [cin][3]
+    float* kf = wl + cin * 3;           // [16] flipped upsample taps
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < nreg * cin; i += 256) st[i] = s[(size_t)b * nreg * cin + i];
+    for (int i = threadIdx.x; i < cin * 3; i += 256) wl[i] = wt[i];
+    if (threadIdx.x < 16) kf[threadIdx.x] = upk ? upk[15 - threadIdx.x] : 0.f;  // kf[ky*4+kx] = k[3-ky][3-kx]
+    __syncthreads();
+    const int hw = h * w;
+    const int q = blockIdx.x * 256 + threadIdx.x;  // pixel quad
+    if (q * 4 >= hw) return;
+    const int pix = q * 4;
+    const int y = pix / w, x0 = pix - y * w;  // w % 4 == 0: the quad stays in one row
+    int cls[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int c = 0;
+        if (labels) c = labels[((size_t)b * lh + nearest_src(y, lsy, lh)) * lw + nearest_src(x0 + j, lsx, lw)];
+        cls[j] = c < nreg ? c : -1;
+    }
+    float acc[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j][0] = acc[j][1] = acc[j][2] = 0.f;
+    const float* xb = x + (size_t)b * cin * hw + pix;
+#pragma unroll 4
+    for (int ci = 0; ci < cin; ++ci) {
+        const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)ci * hw);
+        const float w0 = wl[ci * 3 + 0], w1 = wl[ci * 3 + 1], w2 = wl[ci * 3 + 2];
+        const float xv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = cls[j] >= 0 ? xv[j] * st[cls[j] * cin + ci] : 0.f;
+            acc[j][0] += t * w0;
+            acc[j][1] += t * w1;
+            acc[j][2] += t * w2;
+        }
+    }
+    const int hs = h >> 1, wsk = w >> 1;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        float r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = acc[j][o] + bias[o];
+            if (skip) {
+                // upfirdn2d(up=2, pad=(2,1), 4x4 kernel): out[p] = sum_{t} in[i0+t] * kflip[k0 + 2t],  mid = p - 1
+                const int xx = x0 + j;
+                const int iy0 = (y - 1) >> 1, ix0 = (xx - 1) >> 1;  // floor((p-1)/2), arithmetic shift
+                const int ky0 = 2 * iy0 + 2 - y, kx0 = 2 * ix0 + 2 - xx;
+                const float* sp = skip + ((size_t)b * 3 + o) * hs * wsk;
+                float u = 0.f;
+#pragma unroll
+                for (int ty = 0; ty < 2; ++ty) {
+                    const int iy = iy0 + ty;
+                    if (iy < 0 || iy >= hs) continue;
+#pragma unroll
+                    for (int tx = 0; tx < 2; ++tx) {
+                        const int ix = ix0 + tx;
+                        if (ix < 0 || ix >= wsk) continue;
+                        u += sp[(size_t)iy * wsk + ix] * kf[(ky0 + 2 * ty) * 4 + kx0 + 2 * tx];
+                    }
+                }
+                v += u;
+            }
+            r[j] = v;
+        }
+        *reinterpret_cast<float4*>(out + ((size_t)b * 3 + o) * hw + pix) = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+extern "C" int e4s_region_torgb(float* out, const float* x, const float* wt, const float* s, const uint8_t* labels, int lh, int lw,
+                                const float* bias, const float* skip, const float* up_kernel, int bs, int cin, int h, int w, int nreg,
+                                void* stream) {
+    E4S_REQUIRE(out && x && wt && s && bias, "region_torgb: null tensor");
+    E4S_REQUIRE(bs >= 0 && cin >= 1 && h >= 1 && w >= 4 && (w % 4) == 0, "region_torgb: width must be a multiple of 4");
+    E4S_REQUIRE(nreg >= 1 && nreg <= E4S_MAX_REGIONS, "region_torgb: %d regions (max %d)", nreg, E4S_MAX_REGIONS);
+    E4S_REQUIRE(labels || nreg == 1, "region_torgb: nreg > 1 needs a label map");
+    E4S_REQUIRE(!skip || (up_kernel && (h % 2) == 0), "region_torgb: skip needs the 4x4 upsample kernel and even size");
+    E4S_REQUIRE(bs <= 65535, "region_torgb: batch too large");
+    if (bs == 0) return 0;
+    const size_t shm = ((size_t)nreg * cin + cin * 3 + 16) * sizeof(float);
+    E4S_REQUIRE(shm <= 64 * 1024, "region_torgb: style table does not fit LDS (cin=%d nreg=%d)", cin, nreg);
+    const float lsy = labels ? (float)lh / (float)h : 1.f, lsx = labels ? (float)lw / (float)w : 1.f;
+    dim3 grid(cdiv(h * w / 4, 256), bs);
+    hipLaunchKernelGGL(region_torgb_kernel, grid, dim3(256), shm, (hipStream_t)stream, out, x, wt, s, labels, lh, lw, lsy, lsx, bias, skip,
+                       up_kernel, cin, h, w, nreg);
+    return check_launch("region_torgb");
+}

@@ -1,0 +1,128 @@
+"""Drop-in for the regional-style encoder of the reference: ``FSEncoder_PSP`` (models/encoders/psp_encoders.py:319-401)
+together with the unit it is built from, ``bottleneck_IR_SE_Ours`` / ``SEModule`` / ``get_block``
+(models/encoders/helpers.py:19-24, 56-72, 122-144).  The reference's ``helpers.py`` itself is NOT overridden: its other
+blocks belong to the ArcFace ID-loss network (criteria/, out of scope) and keep running on stock PyTorch.
+
+Same constructor, state_dict keys and ``forward(x, segmap) -> (codes_vector [bs, n_cls, 1280], zeros [bs, 512, 16, 16])``.
+The other encoders of that file (``GradualStyleEncoder``, ``Backbone*``, ``FSEncoder_SEAN``, :35-316) are unused with the
+default ``--fsencoder_type psp`` and out of scope.
+
+The torch.nn layers below are *parameter holders* that give the state_dict the reference's key names
+(``res_layer.{1,2,3}.weight``, ``res_layer.5.fc{1,2}.weight``, ``shortcut_layer.0.weight``); the arithmetic runs in
+libe4s_hip.so (conv.hip / norm.hip).  One unit = five fused launches:
+
+    stats(x) -> conv3x3(IN(x) applied while staging, PReLU epilogue) -> conv3x3(stride) -> stats
+             -> [shortcut conv1x1(stride) -> stats] -> SE gate + IN apply + shortcut add
+"""
+from collections import namedtuple
+
+import torch
+from torch.nn import Conv2d, PReLU, ReLU, Sigmoid, MaxPool2d, AdaptiveAvgPool2d, Sequential, Module, InstanceNorm2d
+
+from e4s2024_amd import ops
+
+
+class Bottleneck(namedtuple('Block', ['in_channel', 'depth', 'stride'])):
+    """A named tuple describing a ResNet block."""
+
+
+def get_block(in_channel, depth, num_units, stride=2):
+    return [Bottleneck(in_channel, depth, stride)] + [Bottleneck(depth, depth, 1) for _ in range(num_units - 1)]
+
+
+class SEModule(Module):
+    """reference :56-72 — squeeze-excite gate ``x * sigmoid(fc2(relu(fc1(mean(x)))))``, no biases."""
+
+    def __init__(self, channels, reduction):
+        super(SEModule, self).__init__()
+        self.avg_pool = AdaptiveAvgPool2d(1)
+        self.fc1 = Conv2d(channels, channels // reduction, kernel_size=1, padding=0, bias=False)
+        self.relu = ReLU(inplace=True)
+        self.fc2 = Conv2d(channels // reduction, channels, kernel_size=1, padding=0, bias=False)
+        self.sigmoid = Sigmoid()
+
+    def forward(self, x):
+        mean, _ = ops.plane_stats(x)
+        gate = ops.se_gate(mean, self.fc1.weight, self.fc2.weight)
+        return ops.norm_gate_add(x, None, None, gate, None)
+
+
+class bottleneck_IR_SE_Ours(Module):
+    """reference :122-144."""
+
+    def __init__(self, in_channel, depth, stride):
+        super(bottleneck_IR_SE_Ours, self).__init__()
+        self.stride = stride
+        if in_channel == depth:
+            self.shortcut_layer = MaxPool2d(1, stride)
+        else:
+            self.shortcut_layer = Sequential(Conv2d(in_channel, depth, (1, 1), stride, bias=False), InstanceNorm2d(depth))
+        self.res_layer = Sequential(
+            InstanceNorm2d(in_channel),
+            Conv2d(in_channel, depth, (3, 3), (1, 1), 1, bias=False),
+            PReLU(depth),
+            Conv2d(depth, depth, (3, 3), stride, 1, bias=False),
+            InstanceNorm2d(depth),
+            SEModule(depth, 16),
+        )
+        self._w = [ops.PreparedConv() for _ in range(3)]
+
+    def forward(self, x):
+        rl = self.res_layer
+        eps = rl[0].eps
+        mean, rstd = ops.plane_stats(x, eps)                                           # InstanceNorm2d(in_channel) statistics
+        r = ops.conv2d(x, self._w[0].get(rl[1].weight), 3, 1, 1, in_norm=(mean, rstd), prelu=rl[2].weight)
+        r = ops.conv2d(r, self._w[1].get(rl[3].weight), 3, self.stride, 1)
+        m2, r2 = ops.plane_stats(r, rl[4].eps)
+        # mean of the normalised map is what the SE squeeze sees: (m2 - m2) * r2 == 0 up to rounding, computed on device
+        gate = ops.se_gate_from_normed(r, m2, r2, rl[5].fc1.weight, rl[5].fc2.weight)
+        if isinstance(self.shortcut_layer, MaxPool2d):
+            sc, sc_stats, sc_stride = x, None, self.stride                             # MaxPool2d(1, stride) == strided subsample
+        else:
+            sc = ops.conv2d(x, self._w[2].get(self.shortcut_layer[0].weight), 1, self.stride, 0)
+            sc_stats, sc_stride = ops.plane_stats(sc, self.shortcut_layer[1].eps), 1
+        out = ops.norm_gate_add(r, m2, r2, gate, sc, sc_stats, sc_stride)
+        return ops._attach("bottleneck_IR_SE_Ours", out, x, *[p for p in self.parameters()])
+
+
+
+class FSEncoder_PSP(Module):
+    def __init__(self, mode='ir_se', opts=None):
+        super(FSEncoder_PSP, self).__init__()
+        if mode != 'ir_se':
+            raise NotImplementedError("only mode='ir_se' (bottleneck_IR_SE_Ours) is used by Net3 (models/networks.py:59)")
+        blocks = [
+            get_block(in_channel=64, depth=128, num_units=3),
+            get_block(in_channel=128, depth=256, num_units=4),
+            get_block(in_channel=256, depth=512, num_units=14),
+            get_block(in_channel=512, depth=512, num_units=3),
+        ]
+        self.n_styles = 11
+        self.input_layer = Sequential(Conv2d(3, 64, (3, 3), 1, 1, bias=False), InstanceNorm2d(64), PReLU(64))
+        modules = []
+        for block in blocks:
+            for bottleneck in block:
+                modules.append(bottleneck_IR_SE_Ours(bottleneck.in_channel, bottleneck.depth, bottleneck.stride))
+        self.body = Sequential(*modules)
+        self._w_in = ops.PreparedConv()
+
+    def get_per_comp_styleCode(self, style_feats, segmap):
+        """Masked average pooling per region (reference :355-375): the mask is sampled 'nearest' at the feature size; a region
+        with no pixel gives a zero vector.  One launch, no host sync (the reference loops bs x n_cls times in Python)."""
+        return ops.masked_avg_pool(style_feats, ops.mask_to_labels(segmap), segmap.shape[1])
+
+    def forward(self, x, segmap):
+        il = self.input_layer
+        y = ops.conv2d(x, self._w_in.get(il[0].weight), 3, 1, 1)
+        mean, rstd = ops.plane_stats(y, il[1].eps)
+        x = ops.norm_gate_add(y, mean, rstd, None, None, prelu=il[2].weight)
+        taps = {}
+        for i, unit in enumerate(self.body):
+            x = unit(x)
+            if i in (6, 20, 23):
+                taps[i] = x
+        structure_feats = torch.zeros_like(x)                                           # reference :392
+        codes_vector = torch.cat([self.get_per_comp_styleCode(taps[6], segmap),
+                                  self.get_per_comp_styleCode(taps[20], segmap),
+                                  self.get_per_comp_styleCode(taps[23], segmap)], dim=2)
+        return codes_vector, structure_feats

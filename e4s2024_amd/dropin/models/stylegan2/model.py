@@ -1,0 +1,357 @@
+"""Drop-in for the reference's ``models/stylegan2/model.py`` (synthesis side only).
+
+Same class names, constructor arguments, ``forward`` signatures, parameter/buffer names and shapes as the reference
+(``Generator`` :482-698, ``StyledConv`` :351-423, ``ToRGB`` :426-479, ``ModulatedConv2d`` :184-320, ``NoiseInjection``
+:323-335, ``ConstantInput`` :338-348, ``Blur`` :78-94, ``Upsample`` :34-53, ``EqualLinear`` :135-164, ``PixelNorm`` :15-20),
+so reference checkpoints load unchanged.  What differs is *how* a masked layer is evaluated: the reference loops over the
+12 regions, running a full modulated convolution per region and summing ``out_i * segmap_i`` (:395-398, :451-454); here
+one region-aware HIP kernel per layer looks up the region of every output pixel and applies that region's modulation and
+demodulation inside a single implicit-GEMM pass (``e4s2024_amd/csrc/modconv.hip``).
+
+Out of scope (training only): ``Discriminator``, ``ConvLayer``, ``ResBlock``, ``Downsample``, ``EqualConv2d``.
+"""
+import math
+import random
+
+import torch
+from torch import nn
+
+from e4s2024_amd import ops
+from models.stylegan2.op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
+
+
+class PixelNorm(nn.Module):
+    """reference :15-20.  Only reached with ``input_is_latent=False`` (mapping network), which no caller of the RGI path uses."""
+
+    def __init__(self):
+        super().__init__()
+
+    def forward(self, input):
+        return input * torch.rsqrt(torch.mean(input ** 2, dim=1, keepdim=True) + 1e-8)
+
+
+def make_kernel(k):
+    k = torch.tensor(k, dtype=torch.float32)
+    if k.ndim == 1:
+        k = k[None, :] * k[:, None]
+    k /= k.sum()
+    return k
+
+
+class Upsample(nn.Module):
+    """reference :34-53 — FIR x2 upsample of the RGB skip.  Inside ``ToRGB`` it is fused into the ToRGB kernel; called on
+    its own it runs the stand-alone upfirdn2d kernel."""
+
+    def __init__(self, kernel, factor=2):
+        super().__init__()
+        self.factor = factor
+        kernel = make_kernel(kernel) * (factor ** 2)
+        self.register_buffer("kernel", kernel)
+        p = kernel.shape[0] - factor
+        pad0 = (p + 1) // 2 + factor - 1
+        pad1 = p // 2
+        self.pad = (pad0, pad1)
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, up=self.factor, down=1, pad=self.pad)
+
+
+class Blur(nn.Module):
+    """reference :78-94.  Inside an up-sampling ``ModulatedConv2d`` the blur is composed into the convolution weights."""
+
+    def __init__(self, kernel, pad, upsample_factor=1):
+        super().__init__()
+        kernel = make_kernel(kernel)
+        if upsample_factor > 1:
+            kernel = kernel * (upsample_factor ** 2)
+        self.register_buffer("kernel", kernel)
+        self.pad = pad
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, pad=self.pad)
+
+
+class EqualLinear(nn.Module):
+    """reference :135-164."""
+
+    def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul))
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(out_dim).fill_(bias_init))
+        else:
+            self.bias = None
+        self.activation = activation
+        self.scale = (1 / math.sqrt(in_dim)) * lr_mul
+        self.lr_mul = lr_mul
+
+    def forward(self, input):
+        shp = input.shape
+        x = input.reshape(-1, 1, shp[-1])
+        out = ops.grouped_linear(x, [self.weight], None if self.bias is None else [self.bias], scale=self.scale, bias_mul=self.lr_mul,
+                                 act=2 if self.activation else 0, slope=0.2)
+        out = out.reshape(*shp[:-1], self.weight.shape[0])
+        return ops._attach("EqualLinear", out, input, self.weight, self.bias)
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]})"
+
+
+class ModulatedConv2d(nn.Module):
+    """reference :184-320 (fused branch).  ``forward(input, style)`` with ``style [bs, 512]`` is the plain (single-region)
+    call; ``forward_regions`` is the one-pass masked form used by ``StyledConv`` / ``ToRGB``."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True, upsample=False, downsample=False,
+                 blur_kernel=[1, 3, 3, 1], fused=True):
+        super().__init__()
+        if downsample:
+            raise NotImplementedError("downsample=True is only used by the training-only Discriminator (out of scope)")
+        if kernel_size not in (1, 3):
+            raise NotImplementedError("kernel_size must be 1 or 3")
+        if kernel_size == 1 and (upsample or out_channel != 3 or demodulate):
+            raise NotImplementedError("1x1 modulated conv is supported in its ToRGB form (3 outputs, no demodulation)")
+        self.eps = 1e-8
+        self.kernel_size = kernel_size
+        self.in_channel = in_channel
+        self.out_channel = out_channel
+        self.upsample = upsample
+        self.downsample = downsample
+        if upsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) - (kernel_size - 1)
+            pad0 = (p + 1) // 2 + factor - 1
+            pad1 = p // 2 + 1
+            if len(blur_kernel) != 4:
+                raise NotImplementedError("up-conv blur must have 4 taps")
+            self.blur = Blur(blur_kernel, pad=(pad0, pad1), upsample_factor=factor)
+        fan_in = in_channel * kernel_size ** 2
+        self.scale = 1 / math.sqrt(fan_in)
+        self.padding = kernel_size // 2
+        self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
+        self.demodulate = demodulate
+        self.fused = fused
+        self._prepared = ops.PreparedWeights()
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, "
+                f"upsample={self.upsample}, downsample={self.downsample})")
+
+    def tables(self, styles):
+        """styles ``[bs, nreg, 512]`` → (wt, s, d) device tables for this layer."""
+        wt, wsq = self._prepared.get(self.weight, self.blur.kernel if self.upsample else None, self.upsample, self.demodulate)
+        s, d = ops.style_demod(styles, self.modulation.weight, self.modulation.bias, wsq, self.out_channel)
+        return wt, s, d
+
+    def forward_regions(self, input, styles, labels, noise=None, noise_weight=None, act_bias=None, act=False):
+        wt, s, d = self.tables(styles)
+        out = ops.region_modconv3x3(input, wt, s, d, labels, noise, noise_weight, act_bias, act, self.out_channel, self.upsample)
+        return ops._attach("ModulatedConv2d", out, input, styles, self.weight, self.modulation.weight, self.modulation.bias, noise_weight,
+                           act_bias)
+
+    def forward(self, input, style):
+        if self.kernel_size == 1:
+            wt, s, _ = self.tables(style[:, None, :])
+            out = ops.region_torgb(input, wt, s, None, torch.zeros(3, device=input.device), None, None)
+            return ops._attach("ModulatedConv2d", out, input, style, self.weight, self.modulation.weight, self.modulation.bias)
+        return self.forward_regions(input, style[:, None, :], None)
+
+
+class NoiseInjection(nn.Module):
+    """reference :323-335.  Inside ``StyledConv`` the injection is fused into the conv epilogue."""
+
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(1))
+
+    def forward(self, image, noise=None):
+        if noise is None:
+            batch, _, height, width = image.shape
+            noise = image.new_empty(batch, 1, height, width).normal_()
+        return image + self.weight * noise
+
+
+class ConstantInput(nn.Module):
+    """reference :338-348."""
+
+    def __init__(self, channel, size=4):
+        super().__init__()
+        self.input = nn.Parameter(torch.randn(1, channel, size, size))
+
+    def forward(self, input):
+        batch = input.shape[0]
+        return self.input.repeat(batch, 1, 1, 1)
+
+
+class StyledConv(nn.Module):
+    """reference :351-423."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False, blur_kernel=[1, 3, 3, 1], demodulate=True,
+                 mask_op=False):
+        super().__init__()
+        self.conv = ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim, upsample=upsample, blur_kernel=blur_kernel,
+                                    demodulate=demodulate)
+        self.noise = NoiseInjection()
+        self.activate = FusedLeakyReLU(out_channel)
+        self.mask_op = mask_op
+
+    def forward(self, input, style, mask, noise=None):
+        bs, _, H, W = input.shape
+        H_out, W_out = (H * 2, W * 2) if self.conv.upsample else (H, W)
+        if noise is None:  # reference :331-333
+            noise = input.new_empty(bs, 1, H_out, W_out).normal_()
+        if self.activate.negative_slope != 0.2 or abs(self.activate.scale - 2 ** 0.5) > 1e-12:
+            raise NotImplementedError("fused epilogue implements leaky_relu(0.2) * sqrt(2)")
+        if self.mask_op:
+            labels = ops.mask_to_labels(mask)          # [bs, h, w] uint8, cached per mask object
+            styles = style                              # [bs, n_regions, 512]
+        else:
+            if style.dim() != 2:
+                raise ValueError(f"unmasked StyledConv expects style [bs, 512], got {tuple(style.shape)}")
+            labels = None
+            styles = style[:, None, :]
+        return self.conv.forward_regions(input, styles, labels, noise, self.noise.weight, self.activate.bias, act=True)
+
+
+class ToRGB(nn.Module):
+    """reference :426-479."""
+
+    def __init__(self, in_channel, style_dim, upsample=True, blur_kernel=[1, 3, 3, 1], mask_op=False):
+        super().__init__()
+        if upsample:
+            self.upsample = Upsample(blur_kernel)
+        self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
+        self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
+        self.mask_op = mask_op
+
+    def forward(self, input, style, mask, skip=None):
+        if self.mask_op:
+            labels = ops.mask_to_labels(mask)
+            styles = style
+        else:
+            if style.dim() != 2:
+                raise ValueError(f"unmasked ToRGB expects style [bs, 512], got {tuple(style.shape)}")
+            labels = None
+            styles = style[:, None, :]
+        wt, s, _ = self.conv.tables(styles)
+        fuse_skip = skip is not None and tuple(self.upsample.kernel.shape) == (4, 4) and self.upsample.factor == 2
+        out = ops.region_torgb(input, wt, s, labels, self.bias, skip if fuse_skip else None, self.upsample.kernel if fuse_skip else None)
+        if skip is not None and not fuse_skip:
+            out = out + self.upsample(skip)
+        return ops._attach("ToRGB", out, input, style, skip, self.conv.weight, self.conv.modulation.weight, self.conv.modulation.bias, self.bias)
+
+
+class Generator(nn.Module):
+    """reference :482-698."""
+
+    def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], lr_mlp=0.01, split_layer_idx=7,
+                 remaining_layer_idx=18):
+        super().__init__()
+        self.split_layer_idx = split_layer_idx
+        self.remaining_layer_idx = remaining_layer_idx
+        self.size = size
+        self.style_dim = style_dim
+
+        layers = [PixelNorm()]
+        for i in range(n_mlp):
+            layers.append(EqualLinear(style_dim, style_dim, lr_mul=lr_mlp, activation="fused_lrelu"))
+        self.style = nn.Sequential(*layers)
+
+        self.channels = {
+            4: 512, 8: 512, 16: 512, 32: 512,
+            64: 256 * channel_multiplier, 128: 128 * channel_multiplier, 256: 64 * channel_multiplier,
+            512: 32 * channel_multiplier, 1024: 16 * channel_multiplier,
+        }
+        self.input = ConstantInput(self.channels[4])
+        self.conv1 = StyledConv(self.channels[4], self.channels[4], 3, style_dim, blur_kernel=blur_kernel, mask_op=True)
+        self.to_rgb1 = ToRGB(self.channels[4], style_dim, upsample=False, mask_op=True)
+
+        self.log_size = int(math.log(size, 2))
+        self.num_layers = (self.log_size - 2) * 2 + 1
+
+        self.convs = nn.ModuleList()
+        self.upsamples = nn.ModuleList()
+        self.to_rgbs = nn.ModuleList()
+        self.noises = nn.Module()
+
+        in_channel = self.channels[4]
+        for layer_idx in range(self.num_layers):
+            res = (layer_idx + 5) // 2
+            self.noises.register_buffer(f"noise_{layer_idx}", torch.randn(1, 1, 2 ** res, 2 ** res))
+
+        for i in range(3, self.log_size + 1):
+            out_channel = self.channels[2 ** i]
+            masked = not (i > (2 + self.remaining_layer_idx // 2))
+            self.convs.append(StyledConv(in_channel, out_channel, 3, style_dim, upsample=True, blur_kernel=blur_kernel, mask_op=masked))
+            self.convs.append(StyledConv(out_channel, out_channel, 3, style_dim, blur_kernel=blur_kernel, mask_op=masked))
+            self.to_rgbs.append(ToRGB(out_channel, style_dim,
+                                      mask_op=not (self.remaining_layer_idx != 17 and i >= (2 + self.remaining_layer_idx // 2))))
+            in_channel = out_channel
+
+        self.n_latent = self.log_size * 2 - 2
+
+    def make_noise(self):
+        device = self.input.input.device
+        noises = [torch.randn(1, 1, 2 ** 2, 2 ** 2, device=device)]
+        for i in range(3, self.log_size + 1):
+            for _ in range(2):
+                noises.append(torch.randn(1, 1, 2 ** i, 2 ** i, device=device))
+        return noises
+
+    def mean_latent(self, n_latent):
+        latent_in = torch.randn(n_latent, self.style_dim, device=self.input.input.device)
+        return self.style(latent_in).mean(0, keepdim=True)
+
+    def get_latent(self, input):
+        return self.style(input)
+
+    def forward(self, styles, structure_feats, mask, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
+                input_is_latent=False, noise=None, randomize_noise=True, use_structure_code=False):
+        if not input_is_latent:
+            styles = [self.style(s) for s in styles]
+
+        if noise is None:
+            if randomize_noise:
+                noise = [None] * self.num_layers
+            else:
+                noise = [getattr(self.noises, f"noise_{i}") for i in range(self.num_layers)]
+
+        if truncation < 1:
+            styles = [truncation_latent + truncation * (style - truncation_latent) for style in styles]
+
+        if len(styles) < 2:
+            inject_index = self.n_latent
+            if styles[0].ndim < 4:
+                latent = styles[0].unsqueeze(1).repeat(1, inject_index, 1)
+            else:
+                latent = styles[0]
+        else:
+            if inject_index is None:
+                inject_index = random.randint(1, self.n_latent - 1)
+            latent = styles[0].unsqueeze(1).repeat(1, inject_index, 1)
+            latent2 = styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)
+            latent = torch.cat([latent, latent2], 1)
+
+        rli = self.remaining_layer_idx
+        out = self.input(latent)
+        out = self.conv1(out, latent[:, :, 0], mask, noise=noise[0])
+        skip = self.to_rgb1(out, latent[:, :, 1], mask)
+
+        intermediate_feats = None
+        for j, to_rgb in enumerate(self.to_rgbs):
+            i = 2 * j + 1                      # W+ index shared by to_rgbs[j-1] and this resolution's up-conv
+            per_region = i < rli               # reference :670 — below it every layer receives one code per region
+            code = (lambda k: latent[:, :, k]) if per_region else (lambda k: latent[:, 0, k])
+            out = self.convs[2 * j](out, code(i), mask, noise=noise[1 + 2 * j])
+            if per_region and i + 2 == self.split_layer_idx:   # reference :673-678
+                if use_structure_code:
+                    out = structure_feats
+                intermediate_feats = out
+            out = self.convs[2 * j + 1](out, code(i + 1), mask, noise=noise[2 + 2 * j])
+            single = (not per_region) or (rli != 17 and i + 2 == rli)   # reference :681-688
+            skip = to_rgb(out, latent[:, 0, i + 2] if single else latent[:, :, i + 2], mask, skip)
+
+        image = skip
+        if return_latents:
+            return image, latent, intermediate_feats
+        return image, None, intermediate_feats

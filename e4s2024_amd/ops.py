@@ -1,0 +1,394 @@
+"""Tensor-level wrappers over the C ABI (``include/e4s_hip.h``).
+
+PyTorch is plumbing here: it owns device memory (``torch.empty`` for outputs) and the stream
+(``torch.cuda.current_stream()`` is handed to every launch).  All arithmetic of the hot path runs in
+``libe4s_hip.so``.  Tensors must be fp32 CUDA tensors; anything else raises (no fallback).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import weakref
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from ._lib import lib
+
+SQRT2 = 2.0 ** 0.5
+MAX_REGIONS = 16
+LABEL_NONE = 255
+
+
+# ----------------------------------------------------------------------------- helpers
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")  # same failure class as the reference's TORCH_CHECK(x.is_cuda())
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype} (the MI355X path computes in fp32)")
+    return t
+
+
+def _c(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    return _req(t, name, dtype).contiguous()
+
+
+class _ForwardOnly(torch.autograd.Function):
+    """Keeps a fused forward-only kernel in the autograd graph so that a backward through it fails loudly
+    instead of silently producing no gradient (backward kernels are the next row)."""
+
+    @staticmethod
+    def forward(ctx, name, out, *deps):
+        ctx.name = name
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, grad):
+        raise NotImplementedError(
+            f"backward of {ctx.name} is not built yet (SURVEY §8 f1); run the fused synthesis path under torch.no_grad()")
+
+
+def _attach(name: str, out: torch.Tensor, *deps: Optional[torch.Tensor]) -> torch.Tensor:
+    if torch.is_grad_enabled() and any(d is not None and d.requires_grad for d in deps):
+        return _ForwardOnly.apply(name, out, *[d for d in deps if d is not None and d.requires_grad])
+    return out
+
+
+# ------------------------------------------------------------------------------------ a1
+def fused_bias_act(x: torch.Tensor, bias: Optional[torch.Tensor], ref: Optional[torch.Tensor], act: int, grad: int,
+                   alpha: float, scale: float) -> torch.Tensor:
+    """``fused.fused_bias_act`` of the reference (models/stylegan2/op/fused_bias_act.cpp:11-21)."""
+    x = _c(x, "input")
+    b = _c(bias, "bias") if bias is not None and bias.numel() else None
+    r = _c(ref, "refer") if ref is not None and ref.numel() else None
+    out = torch.empty_like(x)
+    step_b = 1
+    for i in range(2, x.dim()):
+        step_b *= x.size(i)
+    lib().call("e4s_fused_bias_act", _p(out), _p(x), _p(b), _p(r), act, grad, float(alpha), float(scale), x.numel(), step_b,
+               0 if b is None else b.numel(), _stream())
+    return out
+
+
+class _FusedLeakyReLUBackward(torch.autograd.Function):
+    # models/stylegan2/op/fused_act.py:18-47
+    @staticmethod
+    def forward(ctx, grad_output, out, negative_slope, scale):
+        ctx.save_for_backward(out)
+        ctx.negative_slope, ctx.scale = negative_slope, scale
+        grad_input = fused_bias_act(grad_output, None, out, 3, 1, negative_slope, scale)
+        dim = [0] + list(range(2, grad_input.ndim))
+        return grad_input, grad_input.sum(dim).detach()
+
+    @staticmethod
+    def backward(ctx, gradgrad_input, gradgrad_bias):
+        out, = ctx.saved_tensors
+        return fused_bias_act(gradgrad_input, gradgrad_bias, out, 3, 1, ctx.negative_slope, ctx.scale), None, None, None
+
+
+class _FusedLeakyReLU(torch.autograd.Function):
+    # models/stylegan2/op/fused_act.py:50-69
+    @staticmethod
+    def forward(ctx, input, bias, negative_slope, scale):
+        out = fused_bias_act(input, bias, None, 3, 0, negative_slope, scale)
+        ctx.save_for_backward(out)
+        ctx.negative_slope, ctx.scale = negative_slope, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        out, = ctx.saved_tensors
+        gi, gb = _FusedLeakyReLUBackward.apply(grad_output, out, ctx.negative_slope, ctx.scale)
+        return gi, gb, None, None
+
+
+def fused_leaky_relu(input: torch.Tensor, bias: torch.Tensor, negative_slope: float = 0.2, scale: float = SQRT2) -> torch.Tensor:
+    """Drop-in for ``models.stylegan2.op.fused_leaky_relu`` (op/fused_act.py:84-85)."""
+    return _FusedLeakyReLU.apply(input, bias, negative_slope, scale)
+
+
+# ------------------------------------------------------------------------------------ a2
+def upfirdn2d_raw(x: torch.Tensor, kernel: torch.Tensor, up: Tuple[int, int], down: Tuple[int, int], pad: Tuple[int, int, int, int]) -> torch.Tensor:
+    """``upfirdn2d_op.upfirdn2d`` on an NCHW tensor; up/down = (x, y), pad = (x0, x1, y0, y1)."""
+    x = _c(x, "input")
+    k = _c(kernel, "kernel")
+    n, c, h, w = x.shape
+    kh, kw = k.shape
+    oh = (h * up[1] + pad[2] + pad[3] - kh) // down[1] + 1
+    ow = (w * up[0] + pad[0] + pad[1] - kw) // down[0] + 1
+    out = torch.empty((n, c, oh, ow), dtype=x.dtype, device=x.device)
+    lib().call("e4s_upfirdn2d", _p(out), _p(x), _p(k), n * c, h, w, kh, kw, up[0], up[1], down[0], down[1], pad[0], pad[1], pad[2], pad[3],
+               _stream())
+    return out
+
+
+class _UpFirDn2dBackward(torch.autograd.Function):
+    # models/stylegan2/op/upfirdn2d.py:17-82
+    @staticmethod
+    def forward(ctx, grad_output, kernel, grad_kernel, up, down, pad, g_pad, in_size, out_size):
+        grad_input = upfirdn2d_raw(grad_output, grad_kernel, down, up, g_pad)
+        grad_input = grad_input.view(in_size[0], in_size[1], in_size[2], in_size[3])
+        ctx.save_for_backward(kernel)
+        ctx.up, ctx.down, ctx.pad, ctx.in_size, ctx.out_size = up, down, pad, in_size, out_size
+        return grad_input
+
+    @staticmethod
+    def backward(ctx, gradgrad_input):
+        kernel, = ctx.saved_tensors
+        gg = upfirdn2d_raw(gradgrad_input, kernel, ctx.up, ctx.down, ctx.pad)
+        return gg, None, None, None, None, None, None, None, None
+
+
+class _UpFirDn2d(torch.autograd.Function):
+    # models/stylegan2/op/upfirdn2d.py:85-139
+    @staticmethod
+    def forward(ctx, input, kernel, up, down, pad):
+        up_x, up_y = up
+        down_x, down_y = down
+        pad_x0, pad_x1, pad_y0, pad_y1 = pad
+        kernel_h, kernel_w = kernel.shape
+        _, _, in_h, in_w = input.shape
+        ctx.in_size = input.shape
+        out = upfirdn2d_raw(input, kernel, up, down, pad)
+        out_h, out_w = out.shape[2:]
+        ctx.save_for_backward(kernel, torch.flip(kernel, [0, 1]))
+        ctx.out_size = (out_h, out_w)
+        ctx.up, ctx.down, ctx.pad = up, down, pad
+        g_pad_x0 = kernel_w - pad_x0 - 1
+        g_pad_y0 = kernel_h - pad_y0 - 1
+        g_pad_x1 = in_w * up_x - out_w * down_x + pad_x0 - up_x + 1
+        g_pad_y1 = in_h * up_y - out_h * down_y + pad_y0 - up_y + 1
+        ctx.g_pad = (g_pad_x0, g_pad_x1, g_pad_y0, g_pad_y1)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        kernel, grad_kernel = ctx.saved_tensors
+        gi = _UpFirDn2dBackward.apply(grad_output, kernel, grad_kernel, ctx.up, ctx.down, ctx.pad, ctx.g_pad, ctx.in_size, ctx.out_size)
+        return gi, None, None, None, None
+
+
+def upfirdn2d(input: torch.Tensor, kernel: torch.Tensor, up: int = 1, down: int = 1, pad: Sequence[int] = (0, 0)) -> torch.Tensor:
+    """Drop-in for ``models.stylegan2.op.upfirdn2d`` (op/upfirdn2d.py:142-147)."""
+    return _UpFirDn2d.apply(input, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))
+
+
+# ------------------------------------------------------------------------------ region map
+_label_cache = {}
+STRICT_MASK = os.environ.get("E4S_STRICT_MASK", "1") != "0"
+
+
+def mask_to_labels(mask: torch.Tensor, strict: Optional[bool] = None) -> torch.Tensor:
+    """One-hot ``[bs, ncls, H, W]`` float mask (``labelMap2OneHot``, utils/torch_utils.py:207-213) → uint8 ``[bs, H, W]``
+    region map.  The result is cached per mask *object* (all 26 layers of one ``Generator.forward`` share it).
+    ``strict`` (default on; ``E4S_STRICT_MASK=0`` disables) checks on the device that the mask really is one-hot and
+    raises otherwise — the one-pass kernels are only equivalent to the reference's masked sum for one-hot masks."""
+    if mask.dtype == torch.uint8 and mask.dim() == 3:
+        return _req(mask, "labels", torch.uint8).contiguous()
+    key = id(mask)
+    ent = _label_cache.get(key)
+    if ent is not None and ent[0]() is mask and ent[1] == mask._version:
+        return ent[2]
+    for k in [k for k, e in _label_cache.items() if e[0]() is None]:
+        del _label_cache[k]
+    m = _c(mask, "mask")
+    if m.dim() != 4:
+        raise ValueError(f"mask must be [bs, n_cls, H, W], got {tuple(m.shape)}")
+    bs, ncls, h, w = m.shape
+    if ncls > MAX_REGIONS:
+        raise ValueError(f"{ncls} regions > {MAX_REGIONS}")
+    labels = torch.empty((bs, h, w), dtype=torch.uint8, device=m.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=m.device)
+    lib().call("e4s_onehot_to_labels", _p(labels), _p(flag), _p(m), bs, ncls, h, w, _stream())
+    if STRICT_MASK if strict is None else strict:
+        f = int(flag.item())
+        if f:
+            raise ValueError("mask is not one-hot (" + ("values other than 0/1; " if f & 1 else "") + ("several classes per pixel" if f & 2 else "") +
+                             "): the region-aware kernels require labelMap2OneHot-style masks")
+    if len(_label_cache) > 8:
+        _label_cache.clear()
+    _label_cache[key] = (weakref.ref(mask), mask._version, labels)
+    return labels
+
+
+# ------------------------------------------------------------------------- prepared weights
+class PreparedWeights:
+    """K-major, scale-folded copy of a ModulatedConv2d weight (+ blur-composed parity kernels for up layers, + the
+    squared-sum table for demodulation).  Rebuilt when the parameter (or blur buffer) changes version or storage."""
+
+    __slots__ = ("key", "wt", "wsq")
+
+    def __init__(self):
+        self.key, self.wt, self.wsq = None, None, None
+
+    def get(self, weight: torch.Tensor, blur: Optional[torch.Tensor], up: bool, demodulate: bool):
+        key = (weight.data_ptr(), weight._version, weight.device, None if blur is None else (blur.data_ptr(), blur._version), up, demodulate)
+        if key != self.key:
+            w = _c(weight.detach(), "weight")
+            _, cout, cin, k, _ = w.shape
+            npar = 4 if up else 1
+            wt = torch.empty((npar, cin, k * k, cout), dtype=torch.float32, device=w.device)
+            wsq = torch.empty((cin, cout), dtype=torch.float32, device=w.device) if demodulate else None
+            bk = _c(blur, "blur kernel") if up else None
+            if up and tuple(bk.shape) != (4, 4):
+                raise NotImplementedError(f"up-conv blur kernel must be 4x4, got {tuple(bk.shape)}")
+            lib().call("e4s_modconv_prep_weights", _p(wt), _p(wsq), _p(w), _p(bk), cout, cin, k, 1 if up else 0, _stream())
+            self.key, self.wt, self.wsq = key, wt, wsq
+        return self.wt, self.wsq
+
+
+def style_demod(styles: torch.Tensor, mod_weight: torch.Tensor, mod_bias: torch.Tensor, wsq: Optional[torch.Tensor], cout: int):
+    """styles ``[bs, nreg, sdim]`` (any batch/region strides, unit inner stride) → (s ``[bs,nreg,cin]``, d ``[bs,nreg,cout]`` or None)."""
+    _req(styles, "style")
+    if styles.stride(-1) != 1:
+        styles = styles.contiguous()
+    bs, nreg, sdim = styles.shape
+    mw = _c(mod_weight, "modulation.weight")
+    mb = _c(mod_bias, "modulation.bias")
+    cin = mw.shape[0]
+    s = torch.empty((bs, nreg, cin), dtype=torch.float32, device=styles.device)
+    d = torch.empty((bs, nreg, cout), dtype=torch.float32, device=styles.device) if wsq is not None else None
+    lib().call("e4s_style_demod", _p(s), _p(d), _p(styles), styles.stride(0), styles.stride(1), _p(mw), _p(mb), _p(wsq), bs, nreg, cin, cout,
+               sdim, _stream())
+    return s, d
+
+
+def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: bool, cout: int, up: bool) -> torch.Tensor:
+    x = _c(x, "input")
+    bs, cin, h, w = x.shape
+    nreg = s.shape[1]
+    ho, wo = (2 * h, 2 * w) if up else (h, w)
+    out = torch.empty((bs, cout, ho, wo), dtype=torch.float32, device=x.device)
+    lh = lw = 0
+    if labels is not None:
+        lh, lw = labels.shape[1:]
+        if labels.shape[0] != bs:
+            raise ValueError(f"mask batch {labels.shape[0]} != input batch {bs}")
+    nz = nbs = None
+    if noise is not None:
+        nz = _c(noise, "noise")
+        nbs = nz.shape[0]
+        if nz.numel() != nbs * ho * wo:
+            raise ValueError(f"noise shape {tuple(nz.shape)} does not match output {ho}x{wo}")
+    ev = _timed(modconv_kernel_name(cout, w))
+    lib().call("e4s_region_modconv3x3", _p(out), _p(x), _p(wt), _p(s), _p(d), _p(labels), lh, lw, _p(nz), nbs or 0,
+               _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, 1 if up else 0, _stream())
+    if ev is not None:
+        ev.record()
+    return out
+
+
+def region_torgb(x, wt, s, labels, bias, skip, up_kernel) -> torch.Tensor:
+    x = _c(x, "input")
+    bs, cin, h, w = x.shape
+    nreg = s.shape[1]
+    out = torch.empty((bs, 3, h, w), dtype=torch.float32, device=x.device)
+    lh = lw = 0
+    if labels is not None:
+        lh, lw = labels.shape[1:]
+    sk = uk = None
+    if skip is not None:
+        sk = _c(skip, "skip")
+        if tuple(sk.shape) != (bs, 3, h // 2, w // 2):
+            raise ValueError(f"skip shape {tuple(sk.shape)} != {(bs, 3, h // 2, w // 2)}")
+        uk = _c(up_kernel, "upsample.kernel")
+        if tuple(uk.shape) != (4, 4):
+            raise NotImplementedError("ToRGB skip upsample kernel must be 4x4")
+    lib().call("e4s_region_torgb", _p(out), _p(x), _p(wt), _p(s), _p(labels), lh, lw, _p(_c(bias, "bias")), _p(sk), _p(uk), bs, cin, h, w, nreg,
+               _stream())
+    return out
+
+
+# --------------------------------------------------------------------------- a8 / a9 (conv.hip)
+class PreparedConv:
+    """K-major copy of a plain conv weight (optionally with a folded BatchNorm), rebuilt when the parameter changes."""
+
+    __slots__ = ("key", "wt", "bias", "meta")
+
+    def __init__(self):
+        self.key, self.wt, self.bias, self.meta = None, None, None, None
+
+
+# ------------------------------------------------------------------------------------ a7
+def grouped_linear(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Optional[Sequence[Optional[torch.Tensor]]], *, scale: float,
+                   bias_mul: float = 1.0, act: int = 0, slope: float = 0.2, addend: Optional[torch.Tensor] = None,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x ``[bs, groups, in]`` → ``[bs, groups, out]``; ``weights[g]`` is ``[out, in]``."""
+    _req(x, "input")
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    bs, groups, in_dim = x.shape
+    ws = [_c(w.detach() if not w.requires_grad else w, "weight") for w in weights]
+    out_dim = ws[0].shape[0]
+    if out is None:
+        out = torch.empty((bs, groups, out_dim), dtype=torch.float32, device=x.device)
+    PtrArr = ctypes.c_void_p * groups
+    wp = PtrArr(*[w.data_ptr() for w in ws])
+    bp = None
+    keep = []
+    if biases is not None:
+        bl = [None if b is None else _c(b, "bias") for b in biases]
+        keep = bl
+        bp = PtrArr(*[None if b is None else b.data_ptr() for b in bl])
+    ad = _c(addend, "addend") if addend is not None else None
+    lib().call("e4s_grouped_linear", _p(out), out.stride(0), out.stride(1), _p(x), x.stride(0), x.stride(1), wp, bp, _p(ad), float(scale),
+               float(bias_mul), act, float(slope), bs, groups, in_dim, out_dim, _stream())
+    del keep
+    return out
+
+
+# ----------------------------------------------------------------------------- kernel timing hook
+class KernelTimer:
+    """Optional HIP-event timing of individual launches on the current stream (used by bench.py for the roofline of
+    the dominant kernel).  ``with KernelTimer() as kt: ...`` then ``kt.summary()`` → {name: (calls, total_ms)}."""
+
+    active = None
+
+    def __init__(self):
+        self.events = []
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b in self.events:
+            c, t = out.get(name, (0, 0.0))
+            out[name] = (c + 1, t + a.elapsed_time(b))
+        return out
+
+
+def _timed(name: str):
+    kt = KernelTimer.active
+    if kt is None:
+        return None
+    a = torch.cuda.Event(enable_timing=True)
+    b = torch.cuda.Event(enable_timing=True)
+    kt.events.append((name, a, b))
+    a.record()
+    return b
+
+
+def modconv_kernel_name(cout: int, w: int) -> str:
+    """Template instantiation e4s_region_modconv3x3 dispatches to (mirrors the switch in csrc/modconv.hip)."""
+    if w >= 32:
+        cfg = "2,2,2,2,5" if cout > 64 else ("2,2,1,4,5" if cout > 32 else "1,2,1,4,5")
+    else:
+        cfg = "2,2,2,2,4" if w >= 16 else ("2,1,2,2,3" if w >= 8 else "2,1,2,2,2")
+    return f"region_modconv_kernel<{cfg}>"

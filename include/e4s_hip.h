@@ -1,0 +1,123 @@
+/* libe4s_hip.so — C ABI of the MI355X (gfx950) kernels behind the E4S regional-GAN-inversion
+ * hot path.  Plain pointers and sizes only: every pointer is a DEVICE pointer to fp32 data
+ * (unless the name says otherwise), every tensor is dense NCHW, the caller owns all buffers
+ * and passes the HIP stream to launch on (`stream` = hipStream_t, 0 = default stream).
+ * Every entry point returns 0 on success, E4S_ERR_ARG (-1) for a rejected argument, or the
+ * positive hipError_t of a failed launch; e4s_last_error() returns the message (thread-local).
+ * Nothing here synchronises the device, allocates device memory or keeps global state.
+ *
+ * Each entry point names the reference interface (paths relative to the reference tree) it
+ * replaces; INTEGRATION.md shows the Python/ctypes binding a maintainer would add there.
+ */
+#ifndef E4S_HIP_H
+#define E4S_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define E4S_API __attribute__((visibility("default")))
+#define E4S_ABI_VERSION 1
+#define E4S_ERR_ARG (-1)
+#define E4S_MAX_REGIONS 16 /* regions (segmentation classes) a masked layer can mix; the reference uses 12 */
+#define E4S_LABEL_NONE 255 /* label of a pixel whose one-hot column is all zero (output of the masked sum is 0) */
+
+E4S_API int e4s_abi_version(void);
+E4S_API const char* e4s_last_error(void);
+
+/* ------------------------------------------------------------------------------------ a1
+ * Replaces `fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)` —
+ * models/stylegan2/op/fused_bias_act.cpp:11-21, kernel fused_bias_act_kernel.cu:18-49, launcher :52-99.
+ *   out[i] = f(x[i] + bias[(i / step_b) % size_b]) * scale,  selector act*10+grad:
+ *   10/11 linear, 12 zero, 30 leaky-relu, 31 leaky-relu backward (slope chosen by sign of ref[i]), 32 zero.
+ * bias may be NULL (size_b = 0), ref may be NULL (treated as 0). In-place (out == x) is allowed. */
+E4S_API int e4s_fused_bias_act(float* out, const float* x, const float* bias, const float* ref,
+                       int act, int grad, float alpha, float scale,
+                       int64_t size_x, int64_t step_b, int64_t size_b, void* stream);
+
+/* ------------------------------------------------------------------------------------ a2
+ * Replaces `upfirdn2d_op.upfirdn2d(input[major,H,W,minor], kernel[kh,kw], up_x, up_y, down_x, down_y,
+ * pad_x0, pad_x1, pad_y0, pad_y1)` — models/stylegan2/op/upfirdn2d.cpp:12-23, kernel
+ * upfirdn2d_kernel.cu:52-137, launcher :140-272.  minor must be 1 (the only layout the reference's
+ * Python wrapper produces: op/upfirdn2d.py:96).  out is [major, out_h, out_w] with
+ * out_h = (in_h*up_y + pad_y0 + pad_y1 - kh)/down_y + 1 (op/upfirdn2d.py:100-101); kh,kw <= 32. */
+E4S_API int e4s_upfirdn2d(float* out, const float* in, const float* kernel,
+                  int major, int in_h, int in_w, int kh, int kw,
+                  int up_x, int up_y, int down_x, int down_y,
+                  int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+
+/* --------------------------------------------------------------------------- a3 - a6
+ * Region-aware modulated synthesis.  The reference evaluates a masked layer as
+ *   out = sum_c ModulatedConv2d(x, style[:, c]) * nearest(mask)[:, c]      (models/stylegan2/model.py:385-400, 442-456)
+ * i.e. 12 full convolutions.  With one-hot masks this equals, per output pixel p of class c(p),
+ *   out[b,o,p] = d[b,c(p),o] * sum_{i,k} (W[o,i,k]/sqrt(Cin k^2)) * s[b,c(p),i] * x[b,i,p+k]
+ * which the kernels below evaluate ONCE per layer.  */
+
+/* One-hot mask [bs, ncls, h, w] (values 0/1, utils/torch_utils.py:207-213) -> uint8 labels [bs, h, w].
+ * A pixel with no class set gets E4S_LABEL_NONE.  *flag (device int, caller zeroes it) is OR-ed with
+ * 1 if any value is neither 0 nor 1, with 2 if a pixel has more than one class set. */
+E4S_API int e4s_onehot_to_labels(uint8_t* labels, int* flag, const float* mask, int bs, int ncls, int h, int w, void* stream);
+
+/* Weight preparation, once per parameter version (replaces the per-call weight materialisation of
+ * models/stylegan2/model.py:277-294).
+ *   weight : [cout, cin, k, k]  (the ModulatedConv2d parameter without its leading 1), k = 3 or 1
+ *   blur   : [4,4] FIR of the layer's Blur (model.py:212-213) when up != 0, else NULL
+ *   wt     : out, [npar, cin, k*k, cout] = weight / sqrt(cin k^2), K-major; npar = 4 when up: the stride-2
+ *            transposed 3x3 conv (model.py:295-297) composed with the blur (upfirdn2d pad (1,1), model.py:300)
+ *            is, for each output parity (y&1, x&1), a 3x3 correlation over the INPUT grid; parity index = 2*(y&1)+(x&1)
+ *   wsq    : out, [cin, cout] = sum_k (weight/sqrt(cin k^2))^2 for the demodulation table (may be NULL) */
+E4S_API int e4s_modconv_prep_weights(float* wt, float* wsq, const float* weight, const float* blur,
+                             int cout, int cin, int k, int up, void* stream);
+
+/* Style and demodulation tables of one layer (model.py:276-281 for every (sample, region) at once).
+ *   styles : W+ codes for this layer, element (b, r, j) at styles[b*stride_b + r*stride_r + j], j < sdim
+ *   s      : out, [bs, nreg, cin]  = styles @ (mod_weight/sqrt(sdim))^T + mod_bias      (EqualLinear, model.py:154-162)
+ *   d      : out, [bs, nreg, cout] = rsqrt(sum_i s^2 * wsq[i, o] + 1e-8); pass d = NULL / wsq = NULL for demodulate=False */
+E4S_API int e4s_style_demod(float* s, float* d, const float* styles, int64_t stride_b, int64_t stride_r,
+                    const float* mod_weight, const float* mod_bias, const float* wsq,
+                    int bs, int nreg, int cin, int cout, int sdim, void* stream);
+
+/* StyledConv forward in one pass (model.py:382-423): 3x3 modulated conv (same resolution, or x2 up-conv
+ * + blur when up != 0) with per-pixel region modulation, demodulation, noise injection, bias, leaky-relu*sqrt2.
+ *   x       : [bs, cin, h, w]            out : [bs, cout, ho, wo]  (ho = h, or 2h when up)
+ *   wt, s, d: from the two calls above (d may be NULL: no demodulation)
+ *   labels  : uint8 [bs, lh, lw] region map, sampled nearest at the OUTPUT pixel (model.py:389-391); NULL = every pixel is
+ *             region 0 (unmasked layer, nreg must be 1)
+ *   noise   : [noise_bs (1 or bs), 1, ho, wo] or NULL;  noise_weight: device pointer to the NoiseInjection scalar (model.py:335)
+ *   act_bias: [cout] FusedLeakyReLU bias or NULL; act != 0 applies leaky_relu(0.2)*sqrt(2) (model.py:421) */
+E4S_API int e4s_region_modconv3x3(float* out, const float* x, const float* wt, const float* s, const float* d,
+                          const uint8_t* labels, int lh, int lw,
+                          const float* noise, int noise_bs, const float* noise_weight, const float* act_bias, int act,
+                          int bs, int cin, int cout, int h, int w, int nreg, int up, void* stream);
+
+/* ToRGB forward in one pass (model.py:439-479): 1x1 modulated conv without demodulation, + bias, + upsampled skip.
+ *   x : [bs, cin, h, w]   wt : [cin, 3] from e4s_modconv_prep_weights(k=1)   s : [bs, nreg, cin]   bias : [3]
+ *   skip : previous RGB [bs, 3, h/2, w/2] or NULL; up_kernel : [4,4] FIR of Upsample (model.py:34-53; up=2, pad=(2,1))
+ *   out : [bs, 3, h, w] */
+E4S_API int e4s_region_torgb(float* out, const float* x, const float* wt, const float* s,
+                     const uint8_t* labels, int lh, int lw, const float* bias,
+                     const float* skip, const float* up_kernel,
+                     int bs, int cin, int h, int w, int nreg, void* stream);
+
+/* ------------------------------------------------------------------------------------ a7
+ * Grouped equalised linear: for g < groups, out[b,g,:] = act(x[b,g,:] @ (W[g]*scale)^T + bias[g]*bias_mul) (+ addend)
+ * Replaces the 12 LocalMLP layers of models/networks.py:32-36, 226-230 (groups = 12) and EqualLinear
+ * (models/stylegan2/model.py:154-164, groups = 1).
+ *   x   : element (b,g,i) at x[b*x_stride_b + g*x_stride_g + i], i < in_dim
+ *   W   : HOST array of `groups` (<= 16) device pointers, W[g] -> [out_dim, in_dim] (the 12 MLPs are separate parameters);
+ *   bias: HOST array of `groups` device pointers to [out_dim] (entries may be NULL), or NULL
+ *   act : 0 none, 1 leaky_relu(slope), 2 leaky_relu(slope) * sqrt(2) (fused_lrelu)
+ *   addend : [out_dim] added to every (b,g) row, or NULL (latent_avg, networks.py:247)
+ *   out : element (b,g,o) at out[b*out_stride_b + g*out_stride_g + o] */
+E4S_API int e4s_grouped_linear(float* out, int64_t out_stride_b, int64_t out_stride_g,
+                       const float* x, int64_t x_stride_b, int64_t x_stride_g,
+                       const float* const* W, const float* const* bias, const float* addend,
+                       float scale, float bias_mul, int act, float slope,
+                       int bs, int groups, int in_dim, int out_dim, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* E4S_HIP_H */

@@ -52,3 +52,31 @@ def net3_sd(manifest):
 def bisenet_sd(manifest):
     from e4s2024_amd import seeded
     return seeded.seeded_state_dict(template_from_manifest(manifest["bisenet_19"]), 7, "bisenet")
+
+
+# ------------------------------------------------------------------------------- GPU fixtures
+def install_dropin():
+    import e4s2024_amd
+    e4s2024_amd.install()
+
+
+def default_opts(**kw):
+    import argparse
+    d = dict(fsencoder_type="psp", remaining_layer_idx=13, num_seg_cls=12, out_size=1024, train_G=False,
+             start_from_latent_avg=True, learn_in_w=False)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+@pytest.fixture(scope="session")
+def gpu_net3(net3_sd):
+    """The MI355X Net3 (drop-in) with the seeded weights, on cuda:0."""
+    install_dropin()
+    from models.networks import Net3
+    from e4s2024_amd import seeded
+    net = Net3(default_opts()).eval()
+    net.load_state_dict(net3_sd)
+    net.latent_avg = seeded.seeded_latent_avg(2, 18)
+    net = net.to("cuda:0")
+    net.latent_avg = net.latent_avg.to("cuda:0")
+    return net

@@ -1,0 +1,157 @@
+"""GPU parity of the region-aware synthesis path against the golden fixtures (outputs of the
+reference) and the faithful 12-pass CPU oracle, through the drop-in modules -> ctypes -> libe4s_hip.so."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, install_dropin, template_from_manifest
+from e4s2024_amd import seeded
+from oracle import e4s_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+PIXEL_TOL = 1e-3   # BASELINE.json north_star: <= 1e-3 max-abs fp32 on generated pixels
+
+
+def maxdiff(a, b):
+    return (a.detach().double().cpu() - torch.as_tensor(b).double()).abs().max().item()
+
+
+@pytest.fixture(scope="module")
+def sg2():
+    install_dropin()
+    from models.stylegan2 import model
+    return model
+
+
+def _load(m, g, prefix):
+    sd = {k[len(prefix):]: T(g[k]) for k in g.files if k.startswith(prefix)}
+    m.load_state_dict(sd)
+    return m.to(DEV)
+
+
+def test_g3_modulated_conv(sg2):
+    g = load_golden("g3_modconv")
+    for name, kw in (("same", dict(kernel_size=3)), ("up", dict(kernel_size=3, upsample=True)), ("rgb", dict(kernel_size=1, demodulate=False))):
+        m = sg2.ModulatedConv2d(16, 3 if name == "rgb" else 24, kw.pop("kernel_size"), 512, **kw)
+        with torch.no_grad():
+            m.weight.copy_(T(g[f"{name}.w"]))
+            m.modulation.weight.copy_(T(g[f"{name}.mw"]))
+            m.modulation.bias.copy_(T(g[f"{name}.mb"]))
+        m = m.to(DEV)
+        with torch.no_grad():
+            y = m(T(g[f"{name}.x"]).to(DEV), T(g[f"{name}.s"]).to(DEV))
+        assert tuple(y.shape) == g[f"{name}.y"].shape
+        assert maxdiff(y, g[f"{name}.y"]) <= 2e-5, name
+
+
+def test_g4_masked_layers_incl_empty_region(sg2):
+    g = load_golden("g4_styled")
+    mask = seeded.labels_to_onehot(g["labels"], 5).to(DEV)
+    with torch.no_grad():
+        for name, up in (("same", False), ("up", True)):
+            m = _load(sg2.StyledConv(16, 24, 3, 512, upsample=up, mask_op=True), g, f"{name}.sd.")
+            y = m(T(g[f"{name}.x"]).to(DEV), T(g[f"{name}.s"]).to(DEV), mask, noise=T(g[f"{name}.nz"]).to(DEV))
+            assert maxdiff(y, g[f"{name}.y"]) <= 3e-5, name
+        m = _load(sg2.ToRGB(16, 512, upsample=True, mask_op=True), g, "rgb.sd.")
+        y = m(T(g["rgb.x"]).to(DEV), T(g["rgb.s"]).to(DEV), mask, T(g["rgb.skip"]).to(DEV))
+        assert maxdiff(y, g["rgb.y"]) <= 3e-5
+
+
+def test_forward_only_kernels_refuse_backward(sg2):
+    m = sg2.StyledConv(16, 24, 3, 512, mask_op=False).to(DEV)
+    x = torch.randn(1, 16, 8, 8, device=DEV, requires_grad=True)
+    y = m(x, torch.randn(1, 512, device=DEV), None, noise=torch.zeros(1, 1, 8, 8, device=DEV))
+    with pytest.raises(NotImplementedError):
+        y.sum().backward()
+
+
+@pytest.mark.parametrize("tag,man", [("s64", "generator_64_rli5"), ("s256", "generator_256_rli13")])
+def test_g5_small_generators(sg2, manifest, tag, man):
+    g = load_golden("g5_generator_small")
+    size, rli, ncls, bs = (int(v) for v in g[tag + ".cfg"])
+    lab = seeded.blocky_labels(22, bs, ncls, 64, cells=8)
+    lab[:, 5:9, 3:40] = (lab[:, 5:9, 3:40] + 1) % ncls
+    n_latent = int(np.log2(size)) * 2 - 2
+    codes = seeded.seeded_codes(23, bs, ncls, n_latent, seeded.seeded_latent_avg(2, n_latent))
+    sd = seeded.seeded_state_dict(template_from_manifest(manifest[man]), 21, "net3")
+    gen = sg2.Generator(size, 512, 8, split_layer_idx=5, remaining_layer_idx=rli)
+    gen.load_state_dict({k[2:]: v for k, v in sd.items()})
+    gen = gen.to(DEV).eval()
+    with torch.no_grad():
+        img, none, feats = gen([codes.to(DEV)], None, seeded.labels_to_onehot(lab, ncls).to(DEV), input_is_latent=True, randomize_noise=False)
+    assert none is None
+    assert maxdiff(img, g[tag + ".image"]) <= 2e-4
+    f = feats.flatten().cpu()
+    assert maxdiff(f[:: max(1, f.numel() // 4096)], g[tag + ".feats_sample"]) <= 2e-4
+
+
+def _config2_inputs(bs, seed_labels=3, iid=False):
+    la = seeded.seeded_latent_avg(2, 18)
+    codes = seeded.seeded_codes(1, bs, 12, 18, la)
+    lab = seeded.iid_labels(9, bs, 12, 512) if iid else seeded.blocky_labels(seed_labels, bs, 12, 512, cells=16)
+    return codes, seeded.labels_to_onehot(lab, 12)
+
+
+def test_g6_gen_img_1024_golden(gpu_net3):
+    g = load_golden("g6_gen1024")
+    codes, mask = _config2_inputs(1)
+    with torch.no_grad():
+        img, minus1, feats = gpu_net3.gen_img(torch.zeros(1, 512, 32, 32, device=DEV), codes.to(DEV), mask.to(DEV), randomize_noise=False)
+    assert minus1 == -1 and tuple(img.shape) == (1, 3, 1024, 1024) and tuple(feats.shape) == (1, 512, 16, 16)
+    ic = img.cpu()
+    d = max(maxdiff(ic.flatten()[g["pix_idx"]], g["pix"]), maxdiff(ic[0, :, 480:544, 480:544], g["crop"]), maxdiff(ic[0, :, 777, :], g["row"]))
+    print(f"gen_img 1024 blocky: max-abs pixel diff vs reference golden = {d:.3e}")
+    assert d <= PIXEL_TOL
+    assert maxdiff(feats.flatten().cpu()[::32], g["feats_sample"]) <= PIXEL_TOL
+    assert abs(ic.double().mean().item() - g["stats"][0]) < 1e-4
+
+
+def test_g6_gen_img_1024_iid_labels_golden(gpu_net3):
+    """Adversarial masks: every tile mixes all 12 regions."""
+    g = load_golden("g6_gen1024_iid")
+    codes, mask = _config2_inputs(1, iid=True)
+    with torch.no_grad():
+        img, _, _ = gpu_net3.gen_img(torch.zeros(1, 512, 32, 32, device=DEV), codes.to(DEV), mask.to(DEV), randomize_noise=False)
+    ic = img.cpu()
+    d = max(maxdiff(ic.flatten()[g["pix_idx"]], g["pix"]), maxdiff(ic[0, :, 448:576, 448:576], g["crop"]))
+    print(f"gen_img 1024 iid: max-abs pixel diff vs reference golden = {d:.3e}")
+    assert d <= PIXEL_TOL
+
+
+def test_gen_img_batch4_properties(gpu_net3):
+    """BASELINE config 2 size (bs=4): samples are independent (sample b of the batch == the single-sample run, bit for
+    bit), the run is deterministic, and explicit noise == registered buffers."""
+    codes, mask = _config2_inputs(4)
+    codes, mask = codes.to(DEV), mask.to(DEV)
+    with torch.no_grad():
+        img4, _, f4 = gpu_net3.gen_img(None, codes, mask, randomize_noise=False)
+        img4b, _, _ = gpu_net3.gen_img(None, codes, mask, randomize_noise=False)
+        assert torch.equal(img4, img4b)
+        for b in (0, 3):
+            img1, _, f1 = gpu_net3.gen_img(None, codes[b:b + 1], mask[b:b + 1].contiguous(), randomize_noise=False)
+            assert torch.equal(img1[0], img4[b]) and torch.equal(f1[0], f4[b])
+        noise = [getattr(gpu_net3.G.noises, f"noise_{i}") for i in range(17)]
+        img_n, _, _ = gpu_net3.gen_img(None, codes, mask, noise=noise)
+        assert torch.equal(img_n, img4)
+        # randomize_noise=True draws fresh noise: different output, same statistics
+        img_r, _, _ = gpu_net3.gen_img(None, codes, mask)
+        assert not torch.equal(img_r, img4) and abs(img_r.mean().item() - img4.mean().item()) < 0.05
+    g = load_golden("g6_gen1024")          # sample 0 of the batch uses the golden's codes / labels
+    assert maxdiff(img4[0].flatten().cpu()[g["pix_idx"]], g["pix"]) <= PIXEL_TOL
+
+
+def test_g8_cal_style_codes(gpu_net3):
+    g = load_golden("g8_style_codes")
+    with torch.no_grad():
+        codes = gpu_net3.cal_style_codes(T(g["vectors"]).to(DEV))
+    assert tuple(codes.shape) == tuple(g["shape"])
+    assert maxdiff(codes.flatten().cpu()[g["idx"]], g["codes_sample"]) <= 2e-5
+    assert maxdiff(codes[0, 7, 13:].cpu(), seeded.seeded_latent_avg(2, 18)[13:]) == 0
+    # bs = 3 against the oracle
+    v = T(seeded.seeded_array(41, "vec3", (3, 12, 1280), dist="normal"))
+    with torch.no_grad():
+        c3 = gpu_net3.cal_style_codes(v.to(DEV))
+    sd = {k: p.detach().cpu() for k, p in gpu_net3.state_dict().items() if k.startswith("MLPs.")}
+    assert maxdiff(c3, O.cal_style_codes(sd, v, seeded.seeded_latent_avg(2, 18), 13)) <= 5e-5
