@@ -25,6 +25,17 @@ _PROTOS = {
     "e4s_style_demod": [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_region_modconv3x3": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr, c_int] + [c_int] * 7 + [c_ptr],
     "e4s_region_torgb": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr] + [c_int] * 5 + [c_ptr],
+    "e4s_conv_prep_weights": [c_ptr] * 7 + [c_f32, c_ptr, c_int, c_int, c_int, c_int, c_ptr],
+    "e4s_conv2d": [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int] + [c_int] * 8 + [c_ptr],
+    "e4s_plane_stats": [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_f32, c_ptr],
+    "e4s_vec_fc": [c_ptr] * 7 + [c_f32, c_int, c_int, c_int, c_int, c_ptr],
+    "e4s_norm_gate_add": [c_ptr] * 8 + [c_int, c_ptr, c_int, c_int, c_int, c_int, c_ptr],
+    "e4s_masked_avg_pool": [c_ptr, c_ptr, c_ptr] + [c_int] * 7 + [c_ptr],
+    "e4s_bilinear_resize": [c_ptr, c_ptr] + [c_int] * 6 + [c_ptr],
+    "e4s_maxpool3x3s2": [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
+    "e4s_gate_add_upsample": [c_ptr] * 5 + [c_int] * 4 + [c_ptr],
+    "e4s_bilinear_argmax": [c_ptr, c_ptr, c_ptr] + [c_int] * 6 + [c_ptr],
+    "e4s_bicubic_down_normalize": [c_ptr] * 5 + [c_int] * 5 + [c_ptr],
     "e4s_grouped_linear": [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_int, c_f32] + [c_int] * 4 + [c_ptr],
 }
 

@@ -1,0 +1,276 @@
+// a8 / a9: plain 2-D convolution (encoder IR-SE units, BiSeNet / ResNet-18) as an implicit GEMM on fp32 MFMA
+// (v_mfma_f32_32x32x2_f32), NCHW fp32 in and out.
+//
+//   D[co][pix] = sum_{k=(ci,tap)} Wt[co][k] * X[k][pix]        (same operand roles as modconv.hip: lanes own pixels)
+//
+// Fusions: InstanceNorm of the INPUT applied while staging ((x-mean)*rstd for in-bounds pixels, padding stays 0),
+// channel-concatenated input (two source tensors), folded-BatchNorm bias, residual add, ReLU / PReLU epilogue.
+// Tile shape is chosen per launch so that small feature maps (32x32, 16x16) still put >= ~200 workgroups on the chip.
+#include "common.h"
+
+using namespace e4s;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------ weight prep
+// wt[ci][tap][co] = weight[co][ci][tap] * g[co],  bias_out[co] = beta - mean*g (+ conv_bias*g),  g = gamma / sqrt(var + eps)
+__global__ __launch_bounds__(256) void conv_prep_kernel(float* __restrict__ wt, float* __restrict__ bias_out, const float* __restrict__ weight,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                                        const float* __restrict__ conv_bias, int cout, int cin, int kk) {
+    const int64_t total = (int64_t)cin * kk * cout;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int co = (int)(i % cout);
+        const int64_t r = i / cout;
+        const int tap = (int)(r % kk);
+        const int ci = (int)(r / kk);
+        const float g = var ? gamma[co] / sqrtf(var[co] + eps) : 1.f;
+        wt[i] = weight[((size_t)co * cin + ci) * kk + tap] * g;
+    }
+    if (bias_out) {
+        for (int co = blockIdx.x * 256 + threadIdx.x; co < cout; co += gridDim.x * 256) {
+            const float g = var ? gamma[co] / sqrtf(var[co] + eps) : 1.f;
+            float b = var ? beta[co] - mean[co] * g : 0.f;
+            if (conv_bias) b += conv_bias[co] * g;
+            bias_out[co] = b;
+        }
+    }
+}
+
+extern "C" int e4s_conv_prep_weights(float* wt, float* bias_out, const float* weight, const float* bn_gamma, const float* bn_beta,
+                                     const float* bn_mean, const float* bn_var, float bn_eps, const float* conv_bias, int cout, int cin, int kh,
+                                     int kw, void* stream) {
+    E4S_REQUIRE(wt && weight, "conv_prep_weights: null tensor");
+    E4S_REQUIRE(cout >= 1 && cin >= 1 && kh >= 1 && kw >= 1, "conv_prep_weights: bad size");
+    const bool bn = bn_var != nullptr;
+    E4S_REQUIRE(!bn || (bn_gamma && bn_beta && bn_mean && bias_out), "conv_prep_weights: BatchNorm fold needs gamma, beta, mean, var and bias_out");
+    E4S_REQUIRE(!conv_bias || bias_out, "conv_prep_weights: conv bias needs bias_out");
+    const int64_t total = (int64_t)cin * kh * kw * cout;
+    const int grid = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
+    hipLaunchKernelGGL(conv_prep_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wt, bias_out, weight, bn_gamma, bn_beta, bn_mean, bn_var,
+                       bn_eps, conv_bias, cout, cin, kh * kw);
+    return check_launch("conv_prep_weights");
+}
+
+// ------------------------------------------------------------------------------------ the conv kernel
+struct Conv2dParams {
+    float* out;
+    const float* x0;       // channels [0, cin0)
+    const float* x1;       // channels [cin0, cin) or NULL
+    const float* wt;       // [cin][KS*KS][cout]
+    const float* bias;     // [cout] or NULL
+    const float* in_mean;  // [bs][cin] or NULL  (instance-norm-on-load)
+    const float* in_rstd;
+    const float* slope;    // [cout] PReLU slopes (act == 2)
+    const float* residual; // [bs][cout][ho][wo] or NULL
+    int act;               // 0 none, 1 relu, 2 prelu
+    int bs, cin, cin0, cout, h, w, ho, wo, pad;
+    int tiles_x, tiles_y;
+};
+
+template <int KS, int S, int CKK, int CB, int PB, int WC, int WP, int LOG_TW>
+struct C2Cfg {
+    static constexpr int KK = KS * KS;
+    static constexpr int TN = WC * CB * 32;
+    static constexpr int NPB = WP * PB;
+    static constexpr int TW = 1 << LOG_TW;
+    static constexpr int RPB = 32 >> LOG_TW;
+    static constexpr int TH = NPB * RPB;
+    static constexpr int PW = (TW - 1) * S + KS, PH = (TH - 1) * S + KS;
+    static constexpr int PATCH = PH * PW;
+    static constexpr int EPT = (PATCH + 255) / 256;
+    static constexpr int XS = CKK * PATCH, WS = CKK * KK * TN;
+    static constexpr int LDS_FLOATS = XS + WS;
+    static_assert(WC * WP == 4, "256-thread blocks");
+    static_assert(CKK % 2 == 0, "K pairs");
+    static_assert(LDS_FLOATS * 4 <= 64 * 1024, "static LDS limit");
+};
+
+template <int KS, int S, int CKK, int CB, int PB, int WC, int WP, int LOG_TW>
+__global__ __launch_bounds__(256) void conv2d_kernel(const Conv2dParams p) {
+    using C = C2Cfg<KS, S, CKK, CB, PB, WC, WP, LOG_TW>;
+    __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+    float* xs = lds;
+    float* ws = lds + C::XS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l5 = lane & 31, khalf = lane >> 5;
+    const int wc = wave / WP, wp = wave % WP;
+    const int tile = blockIdx.x;
+    const int oy0 = (tile / p.tiles_x) * C::TH, ox0 = (tile % p.tiles_x) * C::TW;
+    const int co0 = blockIdx.y * C::TN;
+    const int b = blockIdx.z;
+    const int hw = p.h * p.w;
+    const int iy0 = oy0 * S - p.pad, ix0 = ox0 * S - p.pad;
+
+    int goff[C::EPT];
+    bool ginb[C::EPT];
+#pragma unroll
+    for (int j = 0; j < C::EPT; ++j) {
+        const int e = tid + j * 256;
+        const int py = e / C::PW, px = e - py * C::PW;
+        const int gy = iy0 + py, gx = ix0 + px;
+        ginb[j] = (e < C::PATCH) && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+        goff[j] = gy * p.w + gx;
+    }
+    const int cin1 = p.cin - p.cin0;
+    const float* xb0 = p.x0 + (size_t)b * p.cin0 * hw;
+    const float* xb1 = p.x1 ? p.x1 + (size_t)b * cin1 * hw : nullptr;
+
+    int xoff[PB];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int pbk = wp * PB + q;
+        const int ty = pbk * C::RPB + (l5 >> LOG_TW), tx = l5 & (C::TW - 1);
+        xoff[q] = ty * S * C::PW + tx * S;
+    }
+
+    f32x16 acc[CB][PB];
+#pragma unroll
+    for (int i = 0; i < CB; ++i)
+#pragma unroll
+        for (int q = 0; q < PB; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.f;
+
+    const bool wvec = (p.cout & 3) == 0;
+
+    for (int ci0 = 0; ci0 < p.cin; ci0 += CKK) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CKK; ++c) {
+            const int ci = ci0 + c;
+            const bool cok = ci < p.cin;
+            const float* xc = (ci < p.cin0) ? xb0 + (size_t)ci * hw : xb1 + (size_t)(ci - p.cin0) * hw;
+            float mu = 0.f, rs = 1.f;
+            if (p.in_mean && cok) {
+                mu = p.in_mean[(size_t)b * p.cin + ci];
+                rs = p.in_rstd[(size_t)b * p.cin + ci];
+            }
+#pragma unroll
+            for (int j = 0; j < C::EPT; ++j) {
+                const int e = tid + j * 256;
+                if (e < C::PATCH) xs[c * C::PATCH + e] = (cok && ginb[j]) ? (xc[goff[j]] - mu) * rs : 0.f;
+            }
+        }
+        if (wvec) {
+            constexpr int NV = CKK * C::KK * C::TN / 4;
+            for (int v = tid; v < NV; v += 256) {
+                const int n4 = v % (C::TN / 4);
+                const int ct = v / (C::TN / 4);
+                const int c = ct / C::KK;
+                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ci0 + c < p.cin && co0 + n4 * 4 < p.cout)
+                    val = *reinterpret_cast<const float4*>(p.wt + ((size_t)ci0 * C::KK + ct) * p.cout + co0 + n4 * 4);
+                *reinterpret_cast<float4*>(ws + ct * C::TN + n4 * 4) = val;
+            }
+        } else {
+            constexpr int NS = CKK * C::KK * C::TN;
+            for (int v = tid; v < NS; v += 256) {
+                const int n = v % C::TN;
+                const int ct = v / C::TN;
+                const int c = ct / C::KK;
+                ws[v] = (ci0 + c < p.cin && co0 + n < p.cout) ? p.wt[((size_t)ci0 * C::KK + ct) * p.cout + co0 + n] : 0.f;
+            }
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int cp = 0; cp < CKK / 2; ++cp) {
+            const int ci = 2 * cp + khalf;
+            const float* xrow = xs + ci * C::PATCH;
+            const float* wrow = ws + ci * C::KK * C::TN + wc * CB * 32 + l5;
+#pragma unroll
+            for (int tap = 0; tap < C::KK; ++tap) {
+                const int toff = (tap / KS) * C::PW + (tap % KS);
+                float bv[PB], av[CB];
+#pragma unroll
+                for (int q = 0; q < PB; ++q) bv[q] = xrow[xoff[q] + toff];
+#pragma unroll
+                for (int i = 0; i < CB; ++i) av[i] = wrow[tap * C::TN + i * 32];
+#pragma unroll
+                for (int i = 0; i < CB; ++i)
+#pragma unroll
+                    for (int q = 0; q < PB; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[q], acc[i][q], 0, 0, 0);
+            }
+        }
+    }
+
+    const size_t ohw = (size_t)p.ho * p.wo;
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int pbk = wp * PB + q;
+        const int oy = oy0 + pbk * C::RPB + (l5 >> LOG_TW), ox = ox0 + (l5 & (C::TW - 1));
+        if (oy >= p.ho || ox >= p.wo) continue;
+        const size_t opix = (size_t)oy * p.wo + ox;
+#pragma unroll
+        for (int i = 0; i < CB; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wc * CB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (co < p.cout) {
+                    const size_t o = ((size_t)b * p.cout + co) * ohw + opix;
+                    float v = acc[i][q][r];
+                    if (p.bias) v += p.bias[co];
+                    if (p.residual) v += p.residual[o];
+                    if (p.act == 1) v = fmaxf(v, 0.f);
+                    if (p.act == 2) v = v > 0.f ? v : v * p.slope[co];
+                    p.out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int KS, int S, int CKK, int CB, int PB, int WC, int WP, int LOG_TW>
+static int launch2d(Conv2dParams& p, hipStream_t st) {
+    using C = C2Cfg<KS, S, CKK, CB, PB, WC, WP, LOG_TW>;
+    p.tiles_x = cdiv(p.wo, C::TW);
+    p.tiles_y = cdiv(p.ho, C::TH);
+    dim3 grid(p.tiles_x * p.tiles_y, cdiv(p.cout, C::TN), p.bs);
+    hipLaunchKernelGGL((conv2d_kernel<KS, S, CKK, CB, PB, WC, WP, LOG_TW>), grid, dim3(256), 0, st, p);
+    return check_launch("conv2d");
+}
+
+// blocks a (TN x TM-pixel) tiling would launch
+static int64_t nblocks(const Conv2dParams& p, int tn, int th, int tw) {
+    return (int64_t)cdiv(p.wo, tw) * cdiv(p.ho, th) * cdiv(p.cout, tn) * p.bs;
+}
+
+template <int KS, int S, int CKK>
+static int dispatch2d(Conv2dParams& p, hipStream_t st) {
+    constexpr int64_t FILL = 192;  // ~0.75 x 256 CUs
+    if (p.wo >= 32) {
+        if (p.cout > 64 && nblocks(p, 128, 4, 32) >= FILL) return launch2d<KS, S, CKK, 2, 2, 2, 2, 5>(p, st);   // 128 co x 128 px
+        if (p.cout > 32 && nblocks(p, 64, 8, 32) >= FILL) return launch2d<KS, S, CKK, 2, 2, 1, 4, 5>(p, st);    //  64 co x 256 px
+        return launch2d<KS, S, CKK, 1, 1, 2, 2, 5>(p, st);                                                       //  64 co x  64 px
+    }
+    return launch2d<KS, S, CKK, 1, 1, 2, 2, 4>(p, st);                                                           //  64 co x 64 px (16 x 4)
+}
+
+extern "C" int e4s_conv2d(float* out, const float* x0, const float* x1, int cin0, const float* wt, const float* bias, const float* in_mean,
+                          const float* in_rstd, const float* prelu_slope, const float* residual, int act, int bs, int cin, int cout, int h, int w,
+                          int ks, int stride, int pad, void* stream) {
+    E4S_REQUIRE(out && x0 && wt, "conv2d: null tensor");
+    E4S_REQUIRE(bs >= 0 && bs <= 65535 && cin >= 1 && cout >= 1 && h >= 1 && w >= 1, "conv2d: bad size");
+    E4S_REQUIRE(stride == 1 || stride == 2, "conv2d: stride %d not supported (1 or 2)", stride);
+    E4S_REQUIRE(pad >= 0 && pad <= ks, "conv2d: bad padding");
+    E4S_REQUIRE(act >= 0 && act <= 2 && (act != 2 || prelu_slope), "conv2d: bad activation");
+    E4S_REQUIRE((in_mean == nullptr) == (in_rstd == nullptr), "conv2d: in_mean and in_rstd go together");
+    E4S_REQUIRE(x1 ? (cin0 >= 1 && cin0 < cin) : true, "conv2d: bad channel split");
+    if (bs == 0) return 0;
+    Conv2dParams p;
+    p.out = out; p.x0 = x0; p.x1 = x1; p.wt = wt; p.bias = bias; p.in_mean = in_mean; p.in_rstd = in_rstd; p.slope = prelu_slope;
+    p.residual = residual; p.act = act; p.bs = bs; p.cin = cin; p.cin0 = x1 ? cin0 : cin; p.cout = cout; p.h = h; p.w = w; p.pad = pad;
+    p.ho = (h + 2 * pad - ks) / stride + 1;
+    p.wo = (w + 2 * pad - ks) / stride + 1;
+    E4S_REQUIRE(p.ho >= 1 && p.wo >= 1, "conv2d: empty output");
+    hipStream_t st = (hipStream_t)stream;
+    if (ks == 3 && stride == 1) return dispatch2d<3, 1, 8>(p, st);
+    if (ks == 3 && stride == 2) return dispatch2d<3, 2, 8>(p, st);
+    if (ks == 1 && stride == 1) return dispatch2d<1, 1, 32>(p, st);
+    if (ks == 1 && stride == 2) return dispatch2d<1, 2, 8>(p, st);
+    if (ks == 7 && stride == 2) return dispatch2d<7, 2, 2>(p, st);
+    return fail(E4S_ERR_ARG, "conv2d: kernel %dx%d stride %d not supported", ks, ks, stride);
+}

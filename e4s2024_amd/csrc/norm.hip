@@ -1,0 +1,253 @@
+// a8 support kernels (regional-style encoder): per-plane statistics (InstanceNorm), squeeze-excite gate, fused
+// InstanceNorm-apply * gate + shortcut, masked average pooling per region, bilinear resize.  All HBM/L2-streaming.
+#include "common.h"
+
+using namespace e4s;
+
+// block-wide sum of one float per thread (256 threads); result valid in every thread
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ------------------------------------------------------------------------------------ plane statistics
+// One block per (b, c) plane.  Two passes (the plane is L2-resident): mean, then centred second moment — the same
+// biased variance InstanceNorm2d uses (no affine, no running stats).  nmean = mean of the NORMALISED plane, which is what
+// the encoder's SE squeeze sees (it is 0 up to rounding; computed, not assumed).
+__global__ __launch_bounds__(256) void plane_stats_kernel(float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ nmean,
+                                                          const float* __restrict__ x, int hw, float eps) {
+    __shared__ float sh[4];
+    const float* xp = x + (size_t)blockIdx.x * hw;
+    float s = 0.f;
+    if ((hw & 3) == 0) {
+        for (int i = threadIdx.x * 4; i < hw; i += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(xp + i);
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+    } else {
+        for (int i = threadIdx.x; i < hw; i += 256) s += xp[i];
+    }
+    const float m = block_sum(s, sh) / (float)hw;
+    if (threadIdx.x == 0) mean[blockIdx.x] = m;
+    if (!rstd) return;
+    float q = 0.f, c1 = 0.f;
+    if ((hw & 3) == 0) {
+        for (int i = threadIdx.x * 4; i < hw; i += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(xp + i);
+            const float a = v.x - m, b = v.y - m, c = v.z - m, d = v.w - m;
+            q += (a * a + b * b) + (c * c + d * d);
+            c1 += (a + b) + (c + d);
+        }
+    } else {
+        for (int i = threadIdx.x; i < hw; i += 256) {
+            const float a = xp[i] - m;
+            q += a * a;
+            c1 += a;
+        }
+    }
+    const float var = block_sum(q, sh) / (float)hw;
+    const float r = 1.0f / sqrtf(var + eps);
+    const float cs = block_sum(c1, sh);
+    if (threadIdx.x == 0) {
+        rstd[blockIdx.x] = r;
+        if (nmean) nmean[blockIdx.x] = cs * r / (float)hw;
+    }
+}
+
+extern "C" int e4s_plane_stats(float* mean, float* rstd, float* nmean, const float* x, int planes, int hw, float eps, void* stream) {
+    E4S_REQUIRE(mean && x, "plane_stats: null tensor");
+    E4S_REQUIRE(planes >= 0 && hw >= 1, "plane_stats: bad size");
+    E4S_REQUIRE(!nmean || rstd, "plane_stats: nmean needs rstd");
+    if (planes == 0) return 0;
+    hipLaunchKernelGGL(plane_stats_kernel, dim3(planes), dim3(256), 0, (hipStream_t)stream, mean, rstd, nmean, x, hw, eps);
+    return check_launch("plane_stats");
+}
+
+// ------------------------------------------------------------------------------------ small fully-connected on [bs, C] vectors
+// y[b, o] = act( bn( sum_i W[o, i] * x[b, i] ) );  bn (optional, eval-mode BatchNorm) = (v - mean)*gamma/sqrt(var+eps) + beta.
+// One wave per (b, o).  Used for the SE gate, ARM / FFM attentions and the global-context 1x1 ConvBNReLU of BiSeNet.
+__global__ __launch_bounds__(256) void vec_fc_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ W,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ mean, const float* __restrict__ var, float eps, int act,
+                                                     int cin, int cout) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (o >= cout) return;
+    const float* xr = x + (size_t)b * cin;
+    const float* wr = W + (size_t)o * cin;
+    float a = 0.f;
+    for (int i = lane; i < cin; i += 64) a += wr[i] * xr[i];
+    a = wave_sum(a);
+    if (lane == 0) {
+        if (var) a = (a - mean[o]) * (gamma[o] / sqrtf(var[o] + eps)) + beta[o];
+        if (act == 1) a = fmaxf(a, 0.f);
+        if (act == 3) a = 1.0f / (1.0f + expf(-a));
+        y[(size_t)b * cout + o] = a;
+    }
+}
+
+extern "C" int e4s_vec_fc(float* y, const float* x, const float* W, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
+                          const float* bn_var, float bn_eps, int act, int bs, int cin, int cout, void* stream) {
+    E4S_REQUIRE(y && x && W, "vec_fc: null tensor");
+    E4S_REQUIRE(bs >= 0 && bs <= 65535 && cin >= 1 && cout >= 1, "vec_fc: bad size");
+    E4S_REQUIRE(act == 0 || act == 1 || act == 3, "vec_fc: act must be 0 (none), 1 (relu) or 3 (sigmoid)");
+    E4S_REQUIRE(!bn_var || (bn_gamma && bn_beta && bn_mean), "vec_fc: incomplete BatchNorm parameters");
+    if (bs == 0) return 0;
+    hipLaunchKernelGGL(vec_fc_kernel, dim3(cdiv(cout, 4), bs), dim3(256), 0, (hipStream_t)stream, y, x, W, bn_gamma, bn_beta, bn_mean, bn_var,
+                       bn_eps, act, cin, cout);
+    return check_launch("vec_fc");
+}
+
+// ------------------------------------------------------------------------------------ fused normalise * gate + shortcut (+ PReLU)
+// out[b,c,y,x] = act( ((x - mean[b,c]) * rstd[b,c]) * gate[b,c] + sc' )
+//   sc' = shortcut[b,c,y*ss,x*ss] (MaxPool2d(1, ss) == strided subsample), optionally instance-normalised with (sc_mean, sc_rstd)
+// Any of mean/rstd, gate, shortcut, prelu may be NULL.
+__global__ __launch_bounds__(256) void norm_gate_add_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ gate,
+                                                            const float* __restrict__ sc, const float* __restrict__ sc_mean,
+                                                            const float* __restrict__ sc_rstd, int ss, const float* __restrict__ prelu, int C,
+                                                            int h, int w) {
+    const int plane = blockIdx.y;  // b*C + c
+    const int c = plane % C;
+    const int hw = h * w;
+    const float m = mean ? mean[plane] : 0.f, r = rstd ? rstd[plane] : 1.f, g = gate ? gate[plane] : 1.f;
+    const float sm = sc_mean ? sc_mean[plane] : 0.f, sr = sc_rstd ? sc_rstd[plane] : 1.f;
+    const float sl = prelu ? prelu[c] : 1.f;
+    const float* xp = x + (size_t)plane * hw;
+    float* op = out + (size_t)plane * hw;
+    const float* sp = sc ? sc + (size_t)plane * hw * ss * ss : nullptr;
+    const int ws_ = w * ss;
+    for (int i = (blockIdx.x * 256 + threadIdx.x) * 4; i < hw; i += gridDim.x * 1024) {
+        float v[4];
+        if ((hw & 3) == 0) {
+            const float4 t = *reinterpret_cast<const float4*>(xp + i);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = i + j < hw ? xp[i + j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t = (v[j] - m) * r * g;
+            if (sp && i + j < hw) {
+                const int yy = (i + j) / w, xx = (i + j) - yy * w;
+                const float s = (ss == 1) ? sp[i + j] : sp[(size_t)yy * ss * ws_ + xx * ss];
+                t += (s - sm) * sr;
+            }
+            v[j] = t > 0.f ? t : t * sl;
+        }
+        if ((hw & 3) == 0) {
+            *reinterpret_cast<float4*>(op + i) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (i + j < hw) op[i + j] = v[j];
+        }
+    }
+}
+
+extern "C" int e4s_norm_gate_add(float* out, const float* x, const float* mean, const float* rstd, const float* gate, const float* shortcut,
+                                 const float* sc_mean, const float* sc_rstd, int sc_stride, const float* prelu, int bs, int C, int h, int w,
+                                 void* stream) {
+    E4S_REQUIRE(out && x, "norm_gate_add: null tensor");
+    E4S_REQUIRE(bs >= 0 && C >= 1 && h >= 1 && w >= 1 && (int64_t)bs * C <= 65535, "norm_gate_add: bad size");
+    E4S_REQUIRE((mean == nullptr) == (rstd == nullptr) && (sc_mean == nullptr) == (sc_rstd == nullptr), "norm_gate_add: mean/rstd go together");
+    E4S_REQUIRE(!shortcut || sc_stride >= 1, "norm_gate_add: bad shortcut stride");
+    if (bs == 0) return 0;
+    const int gx = cdiv(h * w, 1024) < 64 ? cdiv(h * w, 1024) : 64;
+    hipLaunchKernelGGL(norm_gate_add_kernel, dim3(gx, bs * C), dim3(256), 0, (hipStream_t)stream, out, x, mean, rstd, gate, shortcut, sc_mean,
+                       sc_rstd, shortcut ? sc_stride : 1, prelu, C, h, w);
+    return check_launch("norm_gate_add");
+}
+
+// ------------------------------------------------------------------------------------ masked average pooling per region
+// out[b, r, c] = mean over {p : label(p) == r} of feats[b, c, p]  (0 when the region is empty); labels sampled 'nearest'.
+// One block per (b, c); the label row is re-read from L1 for each region pass.
+__global__ __launch_bounds__(256) void masked_avg_pool_kernel(float* __restrict__ out, const float* __restrict__ feats,
+                                                              const uint8_t* __restrict__ labels, int lh, int lw, float lsy, float lsx, int C,
+                                                              int h, int w, int nreg) {
+    __shared__ float sh[4];
+    extern __shared__ uint8_t lab[];  // [h*w] labels at feature resolution
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int hw = h * w;
+    for (int i = threadIdx.x; i < hw; i += 256) {
+        const int y = i / w, x = i - y * w;
+        lab[i] = labels[((size_t)b * lh + nearest_src(y, lsy, lh)) * lw + nearest_src(x, lsx, lw)];
+    }
+    __syncthreads();
+    const float* fp = feats + ((size_t)b * C + c) * hw;
+    for (int r = 0; r < nreg; ++r) {
+        float s = 0.f, n = 0.f;
+        for (int i = threadIdx.x; i < hw; i += 256) {
+            if (lab[i] == r) {
+                s += fp[i];
+                n += 1.f;
+            }
+        }
+        s = block_sum(s, sh);
+        n = block_sum(n, sh);
+        if (threadIdx.x == 0) out[((size_t)b * nreg + r) * C + c] = n > 0.f ? s / n : 0.f;
+    }
+}
+
+extern "C" int e4s_masked_avg_pool(float* out, const float* feats, const uint8_t* labels, int lh, int lw, int bs, int C, int h, int w, int nreg,
+                                   void* stream) {
+    E4S_REQUIRE(out && feats && labels, "masked_avg_pool: null tensor");
+    E4S_REQUIRE(bs >= 0 && bs <= 65535 && C >= 1 && h >= 1 && w >= 1 && lh >= 1 && lw >= 1, "masked_avg_pool: bad size");
+    E4S_REQUIRE(nreg >= 1 && nreg <= E4S_MAX_REGIONS, "masked_avg_pool: %d regions (max %d)", nreg, E4S_MAX_REGIONS);
+    E4S_REQUIRE(h * w <= 48 * 1024, "masked_avg_pool: feature map %dx%d too large for the LDS label tile", h, w);
+    if (bs == 0) return 0;
+    hipLaunchKernelGGL(masked_avg_pool_kernel, dim3(C, bs), dim3(256), (size_t)h * w, (hipStream_t)stream, out, feats, labels, lh, lw,
+                       (float)lh / (float)h, (float)lw / (float)w, C, h, w, nreg);
+    return check_launch("masked_avg_pool");
+}
+
+// ------------------------------------------------------------------------------------ bilinear resize
+// F.interpolate(mode='bilinear') for both align_corners settings (no antialias), planes = bs*C.
+//   align_corners=False: src = max(0, (dst + 0.5) * in/out - 0.5)      align_corners=True: src = dst * (in-1)/(out-1)
+__device__ __forceinline__ void bilinear_coord(int dst, float scale, int align, int in_size, int& i0, int& i1, float& l1) {
+    float src = align ? (float)dst * scale : ((float)dst + 0.5f) * scale - 0.5f;
+    if (!align && src < 0.f) src = 0.f;
+    i0 = (int)src;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void bilinear_kernel(float* __restrict__ out, const float* __restrict__ in, int ih, int iw, int oh, int ow,
+                                                       float sy, float sx, int align) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= ow || y >= oh) return;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bilinear_coord(y, sy, align, ih, y0, y1, ly);
+    bilinear_coord(x, sx, align, iw, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* p = in + (size_t)blockIdx.z * ih * iw;
+    // ATen upsample_bilinear2d: w00*v00 + w01*v01 + w10*v10 + w11*v11 grouped per row
+    const float v = hy * (hx * p[(size_t)y0 * iw + x0] + lx * p[(size_t)y0 * iw + x1]) + ly * (hx * p[(size_t)y1 * iw + x0] + lx * p[(size_t)y1 * iw + x1]);
+    out[((size_t)blockIdx.z * oh + y) * ow + x] = v;
+}
+
+extern "C" int e4s_bilinear_resize(float* out, const float* in, int planes, int ih, int iw, int oh, int ow, int align_corners, void* stream) {
+    E4S_REQUIRE(out && in, "bilinear_resize: null tensor");
+    E4S_REQUIRE(planes >= 0 && planes <= 65535 && ih >= 1 && iw >= 1 && oh >= 1 && ow >= 1, "bilinear_resize: bad size");
+    if (planes == 0) return 0;
+    float sy, sx;
+    if (align_corners) {
+        sy = oh > 1 ? (float)(ih - 1) / (float)(oh - 1) : 0.f;
+        sx = ow > 1 ? (float)(iw - 1) / (float)(ow - 1) : 0.f;
+    } else {
+        sy = (float)ih / (float)oh;
+        sx = (float)iw / (float)ow;
+    }
+    hipLaunchKernelGGL(bilinear_kernel, dim3(cdiv(ow, 64), cdiv(oh, 4), planes), dim3(256), 0, (hipStream_t)stream, out, in, ih, iw, oh, ow, sy, sx,
+                       align_corners ? 1 : 0);
+    return check_launch("bilinear_resize");
+}

@@ -1,0 +1,182 @@
+// a9 / a10 support kernels (BiSeNet face parser): max-pool, attention gating + nearest upsample, fused bilinear
+// (align_corners) upsample + argmax (+ 19->12 remap) writing uint8 labels, bicubic down-sample + clamp + normalise.
+#include "common.h"
+
+using namespace e4s;
+
+// ------------------------------------------------------------------------------------ MaxPool2d(3, 2, 1)
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(float* __restrict__ out, const float* __restrict__ in, int h, int w, int oh, int ow) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= ow || y >= oh) return;
+    const float* p = in + (size_t)blockIdx.z * h * w;
+    float m = -INFINITY;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int iy = 2 * y + dy;
+        if (iy < 0 || iy >= h) continue;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int ix = 2 * x + dx;
+            if (ix < 0 || ix >= w) continue;
+            m = fmaxf(m, p[(size_t)iy * w + ix]);
+        }
+    }
+    out[((size_t)blockIdx.z * oh + y) * ow + x] = m;
+}
+
+extern "C" int e4s_maxpool3x3s2(float* out, const float* in, int planes, int h, int w, void* stream) {
+    E4S_REQUIRE(out && in, "maxpool3x3s2: null tensor");
+    E4S_REQUIRE(planes >= 0 && planes <= 65535 && h >= 1 && w >= 1, "maxpool3x3s2: bad size");
+    if (planes == 0) return 0;
+    const int oh = (h + 2 - 3) / 2 + 1, ow = (w + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(cdiv(ow, 64), cdiv(oh, 4), planes), dim3(256), 0, (hipStream_t)stream, out, in, h, w, oh, ow);
+    return check_launch("maxpool3x3s2");
+}
+
+// ------------------------------------------------------------------------------------ gate * feat + addend, nearest x`up`
+// out[b,c,Y,X] = feat[b,c,Y/up,X/up] * gate[b,c] + (add_map ? add_map[b,c,Y/up,X/up] : 0) + (add_vec ? add_vec[b,c] : 0)
+__global__ __launch_bounds__(256) void gate_add_up_kernel(float* __restrict__ out, const float* __restrict__ feat, const float* __restrict__ gate,
+                                                          const float* __restrict__ add_map, const float* __restrict__ add_vec, int h, int w,
+                                                          int up) {
+    const int ow = w * up, oh = h * up;
+    const int X = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (X >= ow || Y >= oh) return;
+    const int plane = blockIdx.z;
+    const size_t src = (size_t)plane * h * w + (size_t)(Y / up) * w + X / up;
+    float v = feat[src] * (gate ? gate[plane] : 1.f);
+    if (add_map) v += add_map[src];
+    if (add_vec) v += add_vec[plane];
+    out[((size_t)plane * oh + Y) * ow + X] = v;
+}
+
+extern "C" int e4s_gate_add_upsample(float* out, const float* feat, const float* gate, const float* add_map, const float* add_vec, int planes,
+                                     int h, int w, int up, void* stream) {
+    E4S_REQUIRE(out && feat, "gate_add_upsample: null tensor");
+    E4S_REQUIRE(planes >= 0 && planes <= 65535 && h >= 1 && w >= 1 && up >= 1, "gate_add_upsample: bad size");
+    if (planes == 0) return 0;
+    hipLaunchKernelGGL(gate_add_up_kernel, dim3(cdiv(w * up, 64), cdiv(h * up, 4), planes), dim3(256), 0, (hipStream_t)stream, out, feat, gate,
+                       add_map, add_vec, h, w, up);
+    return check_launch("gate_add_upsample");
+}
+
+// ------------------------------------------------------------------------------------ bilinear(align_corners=True) + argmax
+// labels[b,Y,X] = lut[ argmax_c bilinear(logits[b,c])(Y,X) ]   (first maximum wins, like torch.argmax); the ncls x H x W
+// up-sampled logits (60 MB at 19 x 512^2 x 3 heads in the reference) never reach HBM.
+__global__ __launch_bounds__(256) void bilinear_argmax_kernel(uint8_t* __restrict__ labels, const float* __restrict__ logits,
+                                                              const uint8_t* __restrict__ lut, int ncls, int ih, int iw, int oh, int ow,
+                                                              float sy, float sx) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= ow || y >= oh) return;
+    const float fy = (float)y * sy, fx = (float)x * sx;
+    int y0 = (int)fy, x0 = (int)fx;
+    if (y0 > ih - 1) y0 = ih - 1;
+    if (x0 > iw - 1) x0 = iw - 1;
+    const int y1 = y0 + (y0 < ih - 1 ? 1 : 0), x1 = x0 + (x0 < iw - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float* p = logits + (size_t)blockIdx.z * ncls * ih * iw;
+    float best = -INFINITY;
+    int bi = 0;
+    for (int c = 0; c < ncls; ++c) {
+        const float* q = p + (size_t)c * ih * iw;
+        const float v = hy * (hx * q[(size_t)y0 * iw + x0] + lx * q[(size_t)y0 * iw + x1]) + ly * (hx * q[(size_t)y1 * iw + x0] + lx * q[(size_t)y1 * iw + x1]);
+        if (v > best) {
+            best = v;
+            bi = c;
+        }
+    }
+    labels[((size_t)blockIdx.z * oh + y) * ow + x] = lut ? lut[bi] : (uint8_t)bi;
+}
+
+extern "C" int e4s_bilinear_argmax(uint8_t* labels, const float* logits, const uint8_t* lut, int bs, int ncls, int ih, int iw, int oh, int ow,
+                                   void* stream) {
+    E4S_REQUIRE(labels && logits, "bilinear_argmax: null tensor");
+    E4S_REQUIRE(bs >= 0 && bs <= 65535 && ncls >= 1 && ncls <= 255 && ih >= 1 && iw >= 1 && oh >= 1 && ow >= 1, "bilinear_argmax: bad size");
+    if (bs == 0) return 0;
+    const float sy = oh > 1 ? (float)(ih - 1) / (float)(oh - 1) : 0.f, sx = ow > 1 ? (float)(iw - 1) / (float)(ow - 1) : 0.f;
+    hipLaunchKernelGGL(bilinear_argmax_kernel, dim3(cdiv(ow, 64), cdiv(oh, 4), bs), dim3(256), 0, (hipStream_t)stream, labels, logits, lut, ncls,
+                       ih, iw, oh, ow, sy, sx);
+    return check_launch("bilinear_argmax");
+}
+
+// ------------------------------------------------------------------------------------ bicubic down-sample + clamp + normalise
+// BicubicDownSample (separable 4*f-tap kernel, a = -0.5, reflect padding, vertical pass then horizontal pass) followed by
+// clamp(0,1) and (x - mean[c]) / std[c].   in [planes = bs*3, H, W] -> out [planes, H/f, W/f]
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+template <int F>
+__global__ __launch_bounds__(256) void bicubic_down_norm_kernel(float* __restrict__ out, const float* __restrict__ in,
+                                                                const float* __restrict__ taps, const float* __restrict__ mean,
+                                                                const float* __restrict__ stdv, int C, int h, int w, int oh, int ow, int do_norm) {
+    constexpr int K = 4 * F;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= ow || y >= oh) return;
+    const int plane = blockIdx.z;
+    const float* p = in + (size_t)plane * h * w;
+    constexpr int PADT = (K - F) / 2;
+    float t[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) t[i] = taps[i];
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {                 // horizontal tap j of the second pass ...
+        const int ix = reflect_idx(x * F - PADT + j, w);
+        float col = 0.f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {             // ... applied to the vertically filtered column (first pass)
+            const int iy = reflect_idx(y * F - PADT + i, h);
+            col += t[i] * p[(size_t)iy * w + ix];
+        }
+        acc += t[j] * col;
+    }
+    if (do_norm) {
+        const int c = plane % C;
+        acc = fminf(fmaxf(acc, 0.f), 1.f);
+        acc = (acc - mean[c]) / stdv[c];
+    }
+    out[((size_t)plane * oh + y) * ow + x] = acc;
+}
+
+__global__ __launch_bounds__(256) void clamp_normalize_kernel(float* __restrict__ out, const float* __restrict__ in, const float* __restrict__ mean,
+                                                              const float* __restrict__ stdv, int C, int hw) {
+    const int plane = blockIdx.y, c = plane % C;
+    const float m = mean[c], s = stdv[c];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
+        const float v = fminf(fmaxf(in[(size_t)plane * hw + i], 0.f), 1.f);
+        out[(size_t)plane * hw + i] = (v - m) / s;
+    }
+}
+
+extern "C" int e4s_bicubic_down_normalize(float* out, const float* in, const float* taps, const float* mean, const float* stdv, int bs, int C,
+                                          int h, int w, int factor, void* stream) {
+    E4S_REQUIRE(out && in, "bicubic_down_normalize: null tensor");
+    E4S_REQUIRE(bs >= 0 && C >= 1 && (int64_t)bs * C <= 65535 && h >= 1 && w >= 1, "bicubic_down_normalize: bad size");
+    if (factor == 1) {  // no resampling (input already at the parser resolution): clamp + normalise only
+        E4S_REQUIRE(mean && stdv, "bicubic_down_normalize: factor 1 needs mean/std");
+        if (bs == 0) return 0;
+        const int gx = cdiv(h * w, 256) < 256 ? cdiv(h * w, 256) : 256;
+        hipLaunchKernelGGL(clamp_normalize_kernel, dim3(gx, bs * C), dim3(256), 0, (hipStream_t)stream, out, in, mean, stdv, C, h * w);
+        return check_launch("clamp_normalize");
+    }
+    E4S_REQUIRE(taps, "bicubic_down_normalize: null taps");
+    E4S_REQUIRE(factor == 2 || factor == 4, "bicubic_down_normalize: factor %d not supported (1, 2 or 4)", factor);
+    E4S_REQUIRE((mean == nullptr) == (stdv == nullptr), "bicubic_down_normalize: mean and std go together");
+    E4S_REQUIRE(h >= 4 * factor && w >= 4 * factor, "bicubic_down_normalize: image smaller than the filter");
+    if (bs == 0) return 0;
+    // conv output size with pad (K - F) and stride F: (h + K - F - K) / F + 1 = h / F  (floor)
+    const int oh = (h - factor) / factor + 1, ow = (w - factor) / factor + 1;
+    dim3 grid(cdiv(ow, 64), cdiv(oh, 4), bs * C);
+    hipStream_t st = (hipStream_t)stream;
+    if (factor == 2)
+        hipLaunchKernelGGL(bicubic_down_norm_kernel<2>, grid, dim3(256), 0, st, out, in, taps, mean, stdv, C, h, w, oh, ow, mean ? 1 : 0);
+    else
+        hipLaunchKernelGGL(bicubic_down_norm_kernel<4>, grid, dim3(256), 0, st, out, in, taps, mean, stdv, C, h, w, oh, ow, mean ? 1 : 0);
+    return check_launch("bicubic_down_normalize");
+}

@@ -31,7 +31,7 @@ def get_block(in_channel, depth, num_units, stride=2):
 
 
 class SEModule(Module):
-    """reference :56-72 — squeeze-excite gate ``x * sigmoid(fc2(relu(fc1(mean(x)))))``, no biases."""
+    """reference helpers.py:56-72 — squeeze-excite gate ``x * sigmoid(fc2(relu(fc1(mean(x)))))``, no biases."""
 
     def __init__(self, channels, reduction):
         super(SEModule, self).__init__()
@@ -41,14 +41,17 @@ class SEModule(Module):
         self.fc2 = Conv2d(channels // reduction, channels, kernel_size=1, padding=0, bias=False)
         self.sigmoid = Sigmoid()
 
+    def gate(self, pooled):
+        """pooled ``[bs, C]`` -> gate ``[bs, C]``."""
+        return ops.vec_fc(ops.vec_fc(pooled, self.fc1.weight, act=ops.ACT_RELU), self.fc2.weight, act=ops.ACT_SIGMOID)
+
     def forward(self, x):
-        mean, _ = ops.plane_stats(x)
-        gate = ops.se_gate(mean, self.fc1.weight, self.fc2.weight)
-        return ops.norm_gate_add(x, None, None, gate, None)
+        out = ops.norm_gate_add(x, gate=self.gate(ops.plane_stats(x)))
+        return ops._attach("SEModule", out, x, self.fc1.weight, self.fc2.weight)
 
 
 class bottleneck_IR_SE_Ours(Module):
-    """reference :122-144."""
+    """reference helpers.py:122-144."""
 
     def __init__(self, in_channel, depth, stride):
         super(bottleneck_IR_SE_Ours, self).__init__()
@@ -69,21 +72,18 @@ class bottleneck_IR_SE_Ours(Module):
 
     def forward(self, x):
         rl = self.res_layer
-        eps = rl[0].eps
-        mean, rstd = ops.plane_stats(x, eps)                                           # InstanceNorm2d(in_channel) statistics
-        r = ops.conv2d(x, self._w[0].get(rl[1].weight), 3, 1, 1, in_norm=(mean, rstd), prelu=rl[2].weight)
-        r = ops.conv2d(r, self._w[1].get(rl[3].weight), 3, self.stride, 1)
-        m2, r2 = ops.plane_stats(r, rl[4].eps)
-        # mean of the normalised map is what the SE squeeze sees: (m2 - m2) * r2 == 0 up to rounding, computed on device
-        gate = ops.se_gate_from_normed(r, m2, r2, rl[5].fc1.weight, rl[5].fc2.weight)
+        mean, rstd = ops.plane_stats(x, rl[0].eps)                                      # InstanceNorm2d(in_channel) statistics
+        r = ops.conv2d(x, self._w[0].get(rl[1].weight), 1, 1, in_norm=(mean, rstd), prelu=rl[2].weight)
+        r = ops.conv2d(r, self._w[1].get(rl[3].weight), self.stride, 1)
+        m2, r2, pooled = ops.plane_stats(r, rl[4].eps, want_nmean=True)                 # IN statistics + mean of the normalised map
+        gate = rl[5].gate(pooled)
         if isinstance(self.shortcut_layer, MaxPool2d):
-            sc, sc_stats, sc_stride = x, None, self.stride                             # MaxPool2d(1, stride) == strided subsample
+            sc, sc_stats, sc_stride = x, None, self.stride                              # MaxPool2d(1, stride) == strided subsample
         else:
-            sc = ops.conv2d(x, self._w[2].get(self.shortcut_layer[0].weight), 1, self.stride, 0)
+            sc = ops.conv2d(x, self._w[2].get(self.shortcut_layer[0].weight), self.stride, 0)
             sc_stats, sc_stride = ops.plane_stats(sc, self.shortcut_layer[1].eps), 1
         out = ops.norm_gate_add(r, m2, r2, gate, sc, sc_stats, sc_stride)
         return ops._attach("bottleneck_IR_SE_Ours", out, x, *[p for p in self.parameters()])
-
 
 
 class FSEncoder_PSP(Module):
@@ -113,9 +113,9 @@ class FSEncoder_PSP(Module):
 
     def forward(self, x, segmap):
         il = self.input_layer
-        y = ops.conv2d(x, self._w_in.get(il[0].weight), 3, 1, 1)
+        y = ops.conv2d(x, self._w_in.get(il[0].weight), 1, 1)
         mean, rstd = ops.plane_stats(y, il[1].eps)
-        x = ops.norm_gate_add(y, mean, rstd, None, None, prelu=il[2].weight)
+        x = ops.norm_gate_add(y, mean, rstd, prelu=il[2].weight)
         taps = {}
         for i, unit in enumerate(self.body):
             x = unit(x)

@@ -83,7 +83,8 @@ class Net3(nn.Module):
 
     # ------------------------------------------------------------------ pieces shared by the public methods
     def _encode(self, img, mask):
-        return self.encoder(F.interpolate(img, (256, 256), mode='bilinear'), mask)
+        # F.interpolate(img, (256, 256), mode='bilinear')  (reference :217) -> device kernel, align_corners=False, no antialias
+        return self.encoder(ops.bilinear_resize(img, (256, 256), align_corners=False), mask)
 
     def _codes_from_vectors(self, style_vectors):
         rli = self.remaining_layer_idx

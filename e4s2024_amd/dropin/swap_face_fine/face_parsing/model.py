@@ -1,0 +1,197 @@
+"""Drop-in for the reference's ``swap_face_fine/face_parsing/model.py``: ``BiSeNet`` (:236-260) with ``ContextPath`` (:98-131),
+``AttentionRefinementModule`` (:73-89), ``FeatureFusionModule`` (:186-216), ``BiSeNetOutput`` (:43-53), ``ConvBNReLU`` (:20-35).
+
+Same names / state_dict keys / ``forward`` results (three logit maps up-sampled to the input size).  Differences:
+``seg_mean`` / ``seg_std`` are created on the CPU (the reference calls ``.cuda()`` at import, :15-16); BatchNorm is folded into
+the convolutions (eval mode only); ``BiSeNet.parse`` is the fused inference path used by ``FaceParser`` — it skips the two
+auxiliary heads (dead work at inference) and writes uint8 labels straight from the bilinear+argmax kernel."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from e4s2024_amd import ops
+from swap_face_fine.face_parsing.resnet import Resnet18, _eval_only
+
+seg_mean = torch.from_numpy(np.array([[0.485, 0.456, 0.406]])).float().reshape(1, 3, 1, 1)
+seg_std = torch.from_numpy(np.array([[0.229, 0.224, 0.225]])).float().reshape(1, 3, 1, 1)
+seg_criterion = nn.CrossEntropyLoss()
+
+
+def _kaiming(module):
+    for ly in module.children():
+        if isinstance(ly, nn.Conv2d):
+            nn.init.kaiming_normal_(ly.weight, a=1)
+            if ly.bias is not None:
+                nn.init.constant_(ly.bias, 0)
+
+
+def _params(module):
+    wd_params, nowd_params = [], []
+    for _, m in module.named_modules():
+        if isinstance(m, (nn.Linear, nn.Conv2d)):
+            wd_params.append(m.weight)
+            if m.bias is not None:
+                nowd_params.append(m.bias)
+        elif isinstance(m, nn.BatchNorm2d):
+            nowd_params += list(m.parameters())
+    return wd_params, nowd_params
+
+
+class ConvBNReLU(nn.Module):
+    def __init__(self, in_chan, out_chan, ks=3, stride=1, padding=1, *args, **kwargs):
+        super(ConvBNReLU, self).__init__()
+        self.conv = nn.Conv2d(in_chan, out_chan, kernel_size=ks, stride=stride, padding=padding, bias=False)
+        self.bn = nn.BatchNorm2d(out_chan)
+        self.stride, self.padding = stride, padding
+        self._w = ops.PreparedConv()
+        self.init_weight()
+
+    def forward(self, x, x1=None):
+        _eval_only(self)
+        return ops.conv2d(x, self._w.get(self.conv.weight, self.bn), self.stride, self.padding, x1=x1, relu=True)
+
+    def on_vector(self, v):
+        """The same layer applied to a pooled ``[bs, C]`` vector (a 1x1 map): only valid for 1x1 kernels."""
+        _eval_only(self)
+        assert self.conv.kernel_size == (1, 1)
+        return ops.vec_fc(v, self.conv.weight, bn=self.bn, act=ops.ACT_RELU)
+
+    def init_weight(self):
+        _kaiming(self)
+
+
+class BiSeNetOutput(nn.Module):
+    def __init__(self, in_chan, mid_chan, n_classes, *args, **kwargs):
+        super(BiSeNetOutput, self).__init__()
+        self.conv = ConvBNReLU(in_chan, mid_chan, ks=3, stride=1, padding=1)
+        self.conv_out = nn.Conv2d(mid_chan, n_classes, kernel_size=1, bias=False)
+        self._w = ops.PreparedConv()
+        self.init_weight()
+
+    def forward(self, x):
+        return ops.conv2d(self.conv(x), self._w.get(self.conv_out.weight), 1, 0)
+
+    def init_weight(self):
+        _kaiming(self)
+
+    def get_params(self):
+        return _params(self)
+
+
+class AttentionRefinementModule(nn.Module):
+    def __init__(self, in_chan, out_chan, *args, **kwargs):
+        super(AttentionRefinementModule, self).__init__()
+        self.conv = ConvBNReLU(in_chan, out_chan, ks=3, stride=1, padding=1)
+        self.conv_atten = nn.Conv2d(out_chan, out_chan, kernel_size=1, bias=False)
+        self.bn_atten = nn.BatchNorm2d(out_chan)
+        self.sigmoid_atten = nn.Sigmoid()
+        self.init_weight()
+
+    def feat_and_gate(self, x):
+        _eval_only(self)
+        feat = self.conv(x)
+        atten = ops.vec_fc(ops.plane_stats(feat), self.conv_atten.weight, bn=self.bn_atten, act=ops.ACT_SIGMOID)   # [bs, C]
+        return feat, atten
+
+    def forward(self, x):
+        feat, atten = self.feat_and_gate(x)
+        return ops.gate_add_upsample(feat, gate=atten)
+
+    def init_weight(self):
+        _kaiming(self)
+
+
+class ContextPath(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super(ContextPath, self).__init__()
+        self.resnet = Resnet18()
+        self.arm16 = AttentionRefinementModule(256, 128)
+        self.arm32 = AttentionRefinementModule(512, 128)
+        self.conv_head32 = ConvBNReLU(128, 128, ks=3, stride=1, padding=1)
+        self.conv_head16 = ConvBNReLU(128, 128, ks=3, stride=1, padding=1)
+        self.conv_avg = ConvBNReLU(512, 128, ks=1, stride=1, padding=0)
+        self.init_weight()
+
+    def forward(self, x):
+        feat8, feat16, feat32 = self.resnet(x)
+        (H8, W8), (H16, W16), (H32, W32) = feat8.shape[2:], feat16.shape[2:], feat32.shape[2:]
+        if (H16, W16) != (2 * H32, 2 * W32) or (H8, W8) != (2 * H16, 2 * W16):
+            raise NotImplementedError("input size must be a multiple of 32 (the parser always runs at 512x512)")
+        avg = self.conv_avg.on_vector(ops.plane_stats(feat32))                       # global context [bs, 128]; nearest-up of a 1x1 map = broadcast
+        f32, a32 = self.arm32.feat_and_gate(feat32)
+        feat32_up = self.conv_head32(ops.gate_add_upsample(f32, gate=a32, add_vec=avg, up=2))      # (arm + avg) -> nearest x2 -> conv
+        f16, a16 = self.arm16.feat_and_gate(feat16)
+        feat16_up = self.conv_head16(ops.gate_add_upsample(f16, gate=a16, add_map=feat32_up, up=2))
+        return feat8, feat16_up, feat32_up  # x8, x8, x16
+
+    def init_weight(self):
+        _kaiming(self)
+
+    def get_params(self):
+        return _params(self)
+
+
+class FeatureFusionModule(nn.Module):
+    def __init__(self, in_chan, out_chan, *args, **kwargs):
+        super(FeatureFusionModule, self).__init__()
+        self.convblk = ConvBNReLU(in_chan, out_chan, ks=1, stride=1, padding=0)
+        self.conv1 = nn.Conv2d(out_chan, out_chan // 4, kernel_size=1, stride=1, padding=0, bias=False)
+        self.conv2 = nn.Conv2d(out_chan // 4, out_chan, kernel_size=1, stride=1, padding=0, bias=False)
+        self.relu = nn.ReLU(inplace=True)
+        self.sigmoid = nn.Sigmoid()
+        self.init_weight()
+
+    def forward(self, fsp, fcp):
+        feat = self.convblk(fsp, x1=fcp)                                             # conv over cat([fsp, fcp], 1) without the copy
+        atten = ops.vec_fc(ops.vec_fc(ops.plane_stats(feat), self.conv1.weight, act=ops.ACT_RELU), self.conv2.weight, act=ops.ACT_SIGMOID)
+        return ops.gate_add_upsample(feat, gate=atten, add_map=feat)                 # feat * atten + feat
+
+    def init_weight(self):
+        _kaiming(self)
+
+    def get_params(self):
+        return _params(self)
+
+
+class BiSeNet(nn.Module):
+    def __init__(self, n_classes, *args, **kwargs):
+        super(BiSeNet, self).__init__()
+        self.cp = ContextPath()
+        self.ffm = FeatureFusionModule(256, 256)
+        self.conv_out = BiSeNetOutput(256, 256, n_classes)
+        self.conv_out16 = BiSeNetOutput(128, 64, n_classes)
+        self.conv_out32 = BiSeNetOutput(128, 64, n_classes)
+        self.init_weight()
+
+    def _main_logits(self, x):
+        feat_res8, feat_cp8, feat_cp16 = self.cp(x)
+        return self.conv_out(self.ffm(feat_res8, feat_cp8)), feat_cp8, feat_cp16
+
+    def forward(self, x):
+        H, W = x.size()[2:]
+        feat_out, feat_cp8, feat_cp16 = self._main_logits(x)
+        feat_out16 = self.conv_out16(feat_cp8)
+        feat_out32 = self.conv_out32(feat_cp16)
+        up = lambda t: ops.bilinear_resize(t, (H, W), align_corners=True)            # noqa: E731  (reference :257-259)
+        return up(feat_out), up(feat_out16), up(feat_out32)
+
+    def parse(self, x, lut=None):
+        """Fused inference: uint8 ``[bs, H, W]`` = (lut of) argmax over the bilinearly up-sampled main-head logits."""
+        H, W = x.size()[2:]
+        feat_out, _, _ = self._main_logits(x)
+        return ops.bilinear_argmax(feat_out, (H, W), lut)
+
+    def init_weight(self):
+        _kaiming(self)
+
+    def get_params(self):
+        wd_params, nowd_params, lr_mul_wd_params, lr_mul_nowd_params = [], [], [], []
+        for _, child in self.named_children():
+            child_wd_params, child_nowd_params = child.get_params()
+            if isinstance(child, (FeatureFusionModule, BiSeNetOutput)):
+                lr_mul_wd_params += child_wd_params
+                lr_mul_nowd_params += child_nowd_params
+            else:
+                wd_params += child_wd_params
+                nowd_params += child_nowd_params
+        return wd_params, nowd_params, lr_mul_wd_params, lr_mul_nowd_params

@@ -310,14 +310,176 @@ def region_torgb(x, wt, s, labels, bias, skip, up_kernel) -> torch.Tensor:
     return out
 
 
-# --------------------------------------------------------------------------- a8 / a9 (conv.hip)
+# --------------------------------------------------------------------------- a8 / a9 (conv.hip, norm.hip, parser.hip)
 class PreparedConv:
-    """K-major copy of a plain conv weight (optionally with a folded BatchNorm), rebuilt when the parameter changes."""
+    """K-major copy of a plain conv weight ``[cout, cin, k, k]`` (optionally with an eval-mode BatchNorm2d folded in),
+    rebuilt when a parameter or BN buffer changes version or storage."""
 
-    __slots__ = ("key", "wt", "bias", "meta")
+    __slots__ = ("key", "wt", "bias", "shape")
 
     def __init__(self):
-        self.key, self.wt, self.bias, self.meta = None, None, None, None
+        self.key, self.wt, self.bias, self.shape = None, None, None, None
+
+    def get(self, weight: torch.Tensor, bn=None, conv_bias: Optional[torch.Tensor] = None):
+        ts = [weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else []) + ([conv_bias] if conv_bias is not None else [])
+        key = tuple((t.data_ptr(), t._version) for t in ts) + (weight.device,)
+        if key != self.key:
+            w = _c(weight.detach(), "weight")
+            cout, cin, kh, kw = w.shape
+            wt = torch.empty((cin, kh * kw, cout), dtype=torch.float32, device=w.device)
+            bias = torch.empty((cout,), dtype=torch.float32, device=w.device) if (bn is not None or conv_bias is not None) else None
+            if bn is not None:
+                if bn.training:
+                    raise RuntimeError("BatchNorm2d must be in eval mode to be folded into the convolution (the parser runs in eval mode)")
+                g, be, mu, var, eps = _c(bn.weight.detach(), "bn.weight"), _c(bn.bias.detach(), "bn.bias"), _c(bn.running_mean, "bn.running_mean"), \
+                    _c(bn.running_var, "bn.running_var"), float(bn.eps)
+            else:
+                g = be = mu = var = None
+                eps = 0.0
+            cb = _c(conv_bias.detach(), "conv bias") if conv_bias is not None else None
+            lib().call("e4s_conv_prep_weights", _p(wt), _p(bias), _p(w), _p(g), _p(be), _p(mu), _p(var), eps, _p(cb), cout, cin, kh, kw, _stream())
+            self.key, self.wt, self.bias, self.shape = key, wt, bias, (cout, cin, kh, kw)
+        return self
+
+
+def conv2d(x: torch.Tensor, prepared: PreparedConv, stride: int = 1, pad: int = 0, *, x1: Optional[torch.Tensor] = None, in_norm=None,
+           prelu: Optional[torch.Tensor] = None, relu: bool = False, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``act(conv2d(cat(x, x1), W) + bias + residual)``; ``in_norm=(mean, rstd)`` applies InstanceNorm to the input on load."""
+    x = _c(x, "input")
+    cout, cin, kh, kw = prepared.shape
+    bs, c0, h, w = x.shape
+    if kh != kw:
+        raise NotImplementedError("square kernels only")
+    if x1 is not None:
+        x1 = _c(x1, "input (second half)")
+        if x1.shape[0] != bs or tuple(x1.shape[2:]) != (h, w):
+            raise ValueError("concatenated inputs must share batch and spatial size")
+    if c0 + (0 if x1 is None else x1.shape[1]) != cin:
+        raise ValueError(f"conv expects {cin} input channels, got {c0 + (0 if x1 is None else x1.shape[1])}")
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kh) // stride + 1
+    out = torch.empty((bs, cout, ho, wo), dtype=torch.float32, device=x.device)
+    mean = rstd = None
+    if in_norm is not None:
+        mean, rstd = _c(in_norm[0], "in_mean"), _c(in_norm[1], "in_rstd")
+    act = 2 if prelu is not None else (1 if relu else 0)
+    res = None
+    if residual is not None:
+        res = _c(residual, "residual")
+        if tuple(res.shape) != tuple(out.shape):
+            raise ValueError(f"residual shape {tuple(res.shape)} != output {tuple(out.shape)}")
+    ev = _timed(f"conv2d_kernel<{kh},{stride}>")
+    lib().call("e4s_conv2d", _p(out), _p(x), _p(x1), c0, _p(prepared.wt), _p(prepared.bias), _p(mean), _p(rstd),
+               _p(_c(prelu.detach(), "prelu")) if prelu is not None else None, _p(res), act, bs, cin, cout, h, w, kh, stride, pad, _stream())
+    if ev is not None:
+        ev.record()
+    return out
+
+
+def plane_stats(x: torch.Tensor, eps: Optional[float] = None, want_nmean: bool = False):
+    """Per-(b, c) mean [bs, C] (``eps=None``: mean only = global average pooling), or (mean, rstd[, nmean])."""
+    x = _c(x, "input")
+    bs, C = x.shape[:2]
+    hw = x[0, 0].numel()
+    mean = torch.empty((bs, C), dtype=torch.float32, device=x.device)
+    if eps is None:
+        lib().call("e4s_plane_stats", _p(mean), None, None, _p(x), bs * C, hw, 0.0, _stream())
+        return mean
+    rstd = torch.empty_like(mean)
+    nmean = torch.empty_like(mean) if want_nmean else None
+    lib().call("e4s_plane_stats", _p(mean), _p(rstd), _p(nmean), _p(x), bs * C, hw, float(eps), _stream())
+    return (mean, rstd, nmean) if want_nmean else (mean, rstd)
+
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 3
+
+
+def vec_fc(x: torch.Tensor, weight: torch.Tensor, bn=None, act: int = ACT_NONE) -> torch.Tensor:
+    """``act(bn(x @ W^T))`` for ``x [bs, cin]`` and a 1x1 conv weight ``[cout, cin, 1, 1]`` (or ``[cout, cin]``)."""
+    x = _c(x, "input")
+    w = _c(weight.detach(), "weight")
+    cout, cin = w.shape[0], w.shape[1]
+    bs = x.shape[0]
+    y = torch.empty((bs, cout), dtype=torch.float32, device=x.device)
+    if bn is not None:
+        if bn.training:
+            raise RuntimeError("BatchNorm2d must be in eval mode")
+        g, be, mu, var, eps = _c(bn.weight.detach(), "bn.weight"), _c(bn.bias.detach(), "bn.bias"), _c(bn.running_mean, "bn.running_mean"), \
+            _c(bn.running_var, "bn.running_var"), float(bn.eps)
+    else:
+        g = be = mu = var = None
+        eps = 0.0
+    lib().call("e4s_vec_fc", _p(y), _p(x), _p(w), _p(g), _p(be), _p(mu), _p(var), eps, act, bs, cin, cout, _stream())
+    return y
+
+
+def norm_gate_add(x, mean=None, rstd=None, gate=None, shortcut=None, sc_stats=None, sc_stride: int = 1, prelu=None) -> torch.Tensor:
+    x = _c(x, "input")
+    bs, C, h, w = x.shape
+    out = torch.empty_like(x)
+    sc = scm = scr = None
+    if shortcut is not None:
+        sc = _c(shortcut, "shortcut")
+        if tuple(sc.shape) != (bs, C, h * sc_stride, w * sc_stride):
+            raise ValueError(f"shortcut shape {tuple(sc.shape)} != {(bs, C, h * sc_stride, w * sc_stride)}")
+        if sc_stats is not None:
+            scm, scr = _c(sc_stats[0], "sc_mean"), _c(sc_stats[1], "sc_rstd")
+    lib().call("e4s_norm_gate_add", _p(out), _p(x), _p(mean), _p(rstd), _p(gate), _p(sc), _p(scm), _p(scr), sc_stride,
+               _p(_c(prelu.detach(), "prelu")) if prelu is not None else None, bs, C, h, w, _stream())
+    return out
+
+
+def masked_avg_pool(feats: torch.Tensor, labels: torch.Tensor, nreg: int) -> torch.Tensor:
+    feats = _c(feats, "features")
+    labels = _c(labels, "labels", torch.uint8)
+    bs, C, h, w = feats.shape
+    out = torch.empty((bs, nreg, C), dtype=torch.float32, device=feats.device)
+    lib().call("e4s_masked_avg_pool", _p(out), _p(feats), _p(labels), labels.shape[1], labels.shape[2], bs, C, h, w, nreg, _stream())
+    return out
+
+
+def bilinear_resize(x: torch.Tensor, size, align_corners: bool = False) -> torch.Tensor:
+    x = _c(x, "input")
+    bs, C, h, w = x.shape
+    out = torch.empty((bs, C, size[0], size[1]), dtype=torch.float32, device=x.device)
+    lib().call("e4s_bilinear_resize", _p(out), _p(x), bs * C, h, w, size[0], size[1], 1 if align_corners else 0, _stream())
+    return out
+
+
+def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
+    x = _c(x, "input")
+    bs, C, h, w = x.shape
+    out = torch.empty((bs, C, (h - 1) // 2 + 1, (w - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    lib().call("e4s_maxpool3x3s2", _p(out), _p(x), bs * C, h, w, _stream())
+    return out
+
+
+def gate_add_upsample(feat, gate=None, add_map=None, add_vec=None, up: int = 1) -> torch.Tensor:
+    feat = _c(feat, "feat")
+    bs, C, h, w = feat.shape
+    out = torch.empty((bs, C, h * up, w * up), dtype=torch.float32, device=feat.device)
+    am = _c(add_map, "add_map") if add_map is not None else None
+    if am is not None and tuple(am.shape) != tuple(feat.shape):
+        raise ValueError("add_map must have the shape of feat")
+    lib().call("e4s_gate_add_upsample", _p(out), _p(feat), _p(gate), _p(am), _p(add_vec), bs * C, h, w, up, _stream())
+    return out
+
+
+def bilinear_argmax(logits: torch.Tensor, size, lut: Optional[torch.Tensor] = None) -> torch.Tensor:
+    logits = _c(logits, "logits")
+    bs, ncls, h, w = logits.shape
+    out = torch.empty((bs, size[0], size[1]), dtype=torch.uint8, device=logits.device)
+    lib().call("e4s_bilinear_argmax", _p(out), _p(logits), _p(lut), bs, ncls, h, w, size[0], size[1], _stream())
+    return out
+
+
+def bicubic_down_normalize(img01: torch.Tensor, taps: torch.Tensor, factor: int, mean: Optional[torch.Tensor] = None,
+                           std: Optional[torch.Tensor] = None) -> torch.Tensor:
+    x = _c(img01, "image")
+    bs, C, h, w = x.shape
+    out = torch.empty((bs, C, h // factor, w // factor), dtype=torch.float32, device=x.device)
+    lib().call("e4s_bicubic_down_normalize", _p(out), _p(x), _p(_c(taps, "taps")) if taps is not None else None, _p(mean), _p(std), bs, C, h, w,
+               factor, _stream())
+    return out
 
 
 # ------------------------------------------------------------------------------------ a7

@@ -117,6 +117,76 @@ E4S_API int e4s_grouped_linear(float* out, int64_t out_stride_b, int64_t out_str
                        float scale, float bias_mul, int act, float slope,
                        int bs, int groups, int in_dim, int out_dim, void* stream);
 
+/* ------------------------------------------------------------------------------------ a8 / a9: plain convolutions
+ * Replaces the F.conv2d calls of the regional-style encoder (models/encoders/psp_encoders.py:334, helpers.py:128-139)
+ * and of BiSeNet / ResNet-18 (swap_face_fine/face_parsing/model.py:23-35, resnet.py:15-49) with one implicit-GEMM kernel on
+ * fp32 MFMA.  Weights are first re-laid out K-major (once per parameter version):
+ *   wt[ci][tap][co] = weight[co][ci][tap] * g[co];  bias_out[co] = beta - mean*g (+ conv_bias*g);  g = gamma/sqrt(var+eps)
+ * (BatchNorm2d in eval mode folds into the bias-free conv in front of it; pass bn_* = NULL for a plain conv). */
+E4S_API int e4s_conv_prep_weights(float* wt, float* bias_out, const float* weight,
+                                  const float* bn_gamma, const float* bn_beta, const float* bn_mean, const float* bn_var, float bn_eps,
+                                  const float* conv_bias, int cout, int cin, int kh, int kw, void* stream);
+
+/* out[bs,cout,ho,wo] = act( conv(x', wt) + bias + residual ),  ho = (h + 2*pad - ks)/stride + 1.
+ *   x0 / x1 : input channels [0,cin0) come from x0 [bs,cin0,h,w], [cin0,cin) from x1 [bs,cin-cin0,h,w] (x1 = NULL: all from x0) —
+ *             the channel concatenation of FeatureFusionModule (face_parsing/model.py:207) without a copy
+ *   in_mean / in_rstd : [bs,cin] or NULL — InstanceNorm2d of the INPUT applied while staging, x' = (x - mean)*rstd inside the
+ *             image and 0 in the padding (helpers.py:134: InstanceNorm2d -> Conv2d)
+ *   act : 0 none, 1 ReLU, 2 PReLU(prelu_slope[cout]);  residual : [bs,cout,ho,wo] added before the activation (resnet.py:46-48)
+ *   ks/stride : (3,1) (3,2) (1,1) (1,2) (7,2) */
+E4S_API int e4s_conv2d(float* out, const float* x0, const float* x1, int cin0, const float* wt, const float* bias,
+                       const float* in_mean, const float* in_rstd, const float* prelu_slope, const float* residual, int act,
+                       int bs, int cin, int cout, int h, int w, int ks, int stride, int pad, void* stream);
+
+/* Per-plane statistics of x [planes = bs*C, hw]: mean, rstd = 1/sqrt(biased var + eps) (InstanceNorm2d without affine / running
+ * stats, helpers.py:133,138), nmean = mean of the normalised plane (what SEModule's avg_pool sees, helpers.py:66).  rstd and nmean
+ * may be NULL (plain global average pooling: face_parsing/model.py:83, 116, 209). */
+E4S_API int e4s_plane_stats(float* mean, float* rstd, float* nmean, const float* x, int planes, int hw, float eps, void* stream);
+
+/* y[bs,cout] = act( bn( x[bs,cin] @ W[cout,cin]^T ) ), bn optional (eval BatchNorm), act: 0 none, 1 ReLU, 3 sigmoid.
+ * The 1x1 convolutions on pooled vectors: SEModule fc1/fc2 (helpers.py:67-71), ARM attention (face_parsing/model.py:84-86),
+ * FFM attention (:210-213), conv_avg (:117). */
+E4S_API int e4s_vec_fc(float* y, const float* x, const float* W, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
+                       const float* bn_var, float bn_eps, int act, int bs, int cin, int cout, void* stream);
+
+/* out = prelu( ((x - mean)*rstd) * gate + shortcut' ),  every modifier optional (NULL):
+ *   mean,rstd,gate,sc_mean,sc_rstd : [bs,C];  shortcut : [bs,C,h*sc_stride,w*sc_stride] sampled at (y*sc_stride, x*sc_stride)
+ *   (MaxPool2d(1,stride), helpers.py:126) and instance-normalised when sc_mean is given (helpers.py:128-131);  prelu : [C].
+ * Tail of bottleneck_IR_SE_Ours.forward (helpers.py:141-144) and InstanceNorm+PReLU of the input layer (psp_encoders.py:335-336). */
+E4S_API int e4s_norm_gate_add(float* out, const float* x, const float* mean, const float* rstd, const float* gate,
+                              const float* shortcut, const float* sc_mean, const float* sc_rstd, int sc_stride, const float* prelu,
+                              int bs, int C, int h, int w, void* stream);
+
+/* Masked average pooling per region (psp_encoders.py:355-375): out[bs,nreg,C] = mean of feats[bs,C,h,w] over the pixels whose
+ * label (uint8 [bs,lh,lw], sampled nearest at h x w) equals the region, zeros for an empty region. */
+E4S_API int e4s_masked_avg_pool(float* out, const float* feats, const uint8_t* labels, int lh, int lw,
+                                int bs, int C, int h, int w, int nreg, void* stream);
+
+/* F.interpolate(mode='bilinear', align_corners=...) on [planes, ih, iw] -> [planes, oh, ow], no antialias
+ * (models/networks.py:217 uses align_corners=False; face_parsing/model.py:257-259 uses True). */
+E4S_API int e4s_bilinear_resize(float* out, const float* in, int planes, int ih, int iw, int oh, int ow, int align_corners, void* stream);
+
+/* ------------------------------------------------------------------------------------ a9 / a10: parser glue */
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) on [planes,h,w] (resnet.py:65, 75). */
+E4S_API int e4s_maxpool3x3s2(float* out, const float* in, int planes, int h, int w, void* stream);
+
+/* out[p,Y,X] = feat[p,Y/up,X/up]*gate[p] + add_map[p,Y/up,X/up] + add_vec[p]  (gate/add_map/add_vec optional), planes = bs*C:
+ * ARM gating + context add + nearest upsample of ContextPath (face_parsing/model.py:118-128) and FFM's feat*atten+feat (:214-215). */
+E4S_API int e4s_gate_add_upsample(float* out, const float* feat, const float* gate, const float* add_map, const float* add_vec,
+                                  int planes, int h, int w, int up, void* stream);
+
+/* labels[bs,oh,ow] (uint8) = lut[ argmax_c bilinear_align_corners(logits[bs,ncls,ih,iw]) ] — fuses F.interpolate(..., align_corners=True)
+ * (face_parsing/model.py:257), torch.argmax (face_parsing_demo.py:170) and, through the optional 256-entry lut, the 19->12 remap
+ * (datasets/dataset.py:58-108).  First maximum wins ties. */
+E4S_API int e4s_bilinear_argmax(uint8_t* labels, const float* logits, const uint8_t* lut, int bs, int ncls, int ih, int iw, int oh, int ow,
+                                void* stream);
+
+/* BicubicDownSample(factor) + clamp(0,1) + (x-mean)/std of FaceParser.preprocess_img (face_parsing_demo.py:46-84, 151-156):
+ * in [bs,C,h,w] in [0,1] -> out [bs,C,h/factor,w/factor]; taps = the 4*factor normalised 1-D weights; mean/std [C] or NULL
+ * (NULL: plain down-sample, no clamp).  factor 2 or 4; factor 1 = clamp + normalise only (taps ignored). */
+E4S_API int e4s_bicubic_down_normalize(float* out, const float* in, const float* taps, const float* mean, const float* stdv,
+                                       int bs, int C, int h, int w, int factor, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

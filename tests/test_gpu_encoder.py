@@ -1,0 +1,152 @@
+"""GPU parity of the regional-style encoder path and of the generic fp32-MFMA convolution kernel."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, install_dropin
+from e4s2024_amd import seeded
+from oracle import e4s_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+
+
+def maxdiff(a, b):
+    return (a.detach().double().cpu() - torch.as_tensor(b).double()).abs().max().item()
+
+
+def rnd(key, shape, std=1.0):
+    return T(seeded.seeded_array(51, key, shape, 0.0, std, "normal"))
+
+
+CONV_CASES = [
+    # (bs, cin, cout, h, w, ks, stride, pad)
+    (2, 16, 24, 37, 41, 3, 1, 1),        # odd sizes, cout not a multiple of 4/32
+    (1, 64, 128, 64, 64, 3, 1, 1),       # 128x128 tile config
+    (1, 64, 64, 128, 128, 3, 1, 1),      # 64x256 tile config
+    (1, 128, 256, 64, 64, 3, 2, 1),      # stride 2 -> 32x32 (small-tile config)
+    (2, 512, 512, 16, 16, 3, 1, 1),      # 16-wide maps
+    (1, 256, 512, 32, 32, 3, 2, 1),      # -> 16x16
+    (1, 64, 128, 64, 64, 1, 2, 0),       # shortcut conv
+    (2, 256, 256, 64, 64, 1, 1, 0),      # FFM 1x1
+    (1, 256, 19, 64, 64, 1, 1, 0),       # classifier 1x1, cout = 19
+    (1, 3, 64, 128, 128, 7, 2, 3),       # ResNet stem
+    (1, 3, 64, 256, 256, 3, 1, 1),       # encoder input layer
+    (1, 10, 8, 9, 5, 3, 2, 1),           # tiny ragged
+]
+
+
+@pytest.mark.parametrize("bs,cin,cout,h,w,ks,stride,pad", CONV_CASES)
+def test_conv2d_vs_torch_cpu(bs, cin, cout, h, w, ks, stride, pad):
+    from e4s2024_amd import ops
+    x = rnd(f"cx{cin}{h}{ks}{stride}", (bs, cin, h, w))
+    wgt = rnd(f"cw{cin}{cout}{ks}", (cout, cin, ks, ks), (cin * ks * ks) ** -0.5)
+    ref = F.conv2d(x, wgt, stride=stride, padding=pad)
+    out = ops.conv2d(x.to(DEV), ops.PreparedConv().get(wgt.to(DEV)), stride, pad)
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert maxdiff(out, ref) <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_conv2d_fusions_vs_torch_cpu():
+    """instance-norm-on-load + PReLU; folded BatchNorm + residual + ReLU; channel-concatenated input."""
+    from e4s2024_amd import ops
+    x = rnd("fx", (2, 32, 40, 40)) * 3 + 1
+    wgt = rnd("fw", (48, 32, 3, 3), 0.06)
+    slope = rnd("fs", (48,), 0.1) + 0.25
+    ref = F.prelu(F.conv2d(O.instance_norm(x), wgt, padding=1), slope)
+    mean, rstd = ops.plane_stats(x.to(DEV), 1e-5)
+    assert maxdiff(mean, x.mean((2, 3))) <= 1e-5
+    assert maxdiff(rstd, 1 / torch.sqrt(x.var((2, 3), unbiased=False) + 1e-5)) <= 1e-5
+    out = ops.conv2d(x.to(DEV), ops.PreparedConv().get(wgt.to(DEV)), 1, 1, in_norm=(mean, rstd), prelu=slope.to(DEV))
+    assert maxdiff(out, ref) <= 5e-5
+    bn = torch.nn.BatchNorm2d(48).eval()
+    with torch.no_grad():
+        bn.weight.copy_(rnd("bg", (48,), 0.2) + 1); bn.bias.copy_(rnd("bb", (48,), 0.2))
+        bn.running_mean.copy_(rnd("bm", (48,), 0.2)); bn.running_var.copy_(rnd("bv", (48,), 0.2).abs() + 0.5)
+    res = rnd("fr", (2, 48, 20, 20))
+    ref2 = F.relu(res + bn(F.conv2d(x, wgt, stride=2, padding=1)))
+    out2 = ops.conv2d(x.to(DEV), ops.PreparedConv().get(wgt.to(DEV), bn.to(DEV)), 2, 1, residual=res.to(DEV), relu=True)
+    assert maxdiff(out2, ref2) <= 5e-5
+    xa, xb = x[:, :20].contiguous(), x[:, 20:].contiguous()
+    w1 = rnd("f1", (16, 32, 1, 1), 0.2)
+    out3 = ops.conv2d(xa.to(DEV), ops.PreparedConv().get(w1.to(DEV)), 1, 0, x1=xb.to(DEV))
+    assert maxdiff(out3, F.conv2d(x, w1)) <= 5e-5
+
+
+def test_bilinear_resize_both_modes():
+    from e4s2024_amd import ops
+    x = rnd("bl", (2, 3, 64, 48))
+    for size, ac in (((16, 12), False), ((37, 29), False), ((128, 96), True), ((100, 75), True), ((64, 48), False)):
+        ref = F.interpolate(x, size, mode="bilinear", align_corners=ac)
+        assert maxdiff(ops.bilinear_resize(x.to(DEV), size, ac), ref) <= 2e-6, (size, ac)
+
+
+def test_masked_avg_pool_edge_cases():
+    from e4s2024_amd import ops
+    feats = rnd("mp", (2, 20, 16, 16))
+    lab = seeded.iid_labels(3, 2, 12, 64)
+    lab[lab == 7] = 0                     # region 7 empty
+    lab[0] = 4                            # sample 0: one region covers everything
+    lab[1, 0, 0] = 11
+    mask = seeded.labels_to_onehot(lab, 12)
+    ref = O.masked_avg_pool(feats, mask)
+    out = ops.masked_avg_pool(feats.to(DEV), T(lab).to(DEV), 12)
+    assert maxdiff(out, ref) <= 1e-5
+    assert out[:, 7].abs().max().item() == 0 and out[0, 3].abs().max().item() == 0
+
+
+def test_encoder_units_vs_oracle(gpu_net3, net3_sd):
+    """One unit of each kind: conv shortcut + stride 2 (unit 0), identity shortcut (unit 1), MaxPool(1,2) shortcut (unit 21)."""
+    for idx, cin, depth, stride, hw in ((0, 64, 128, 2, 64), (1, 128, 128, 1, 32), (21, 512, 512, 2, 32)):
+        x = rnd(f"eu{idx}", (2, cin, hw, hw)) * 2 + 0.5
+        ref = O.encoder_unit(net3_sd, f"encoder.body.{idx}.", x, cin, depth, stride)
+        with torch.no_grad():
+            out = gpu_net3.encoder.body[idx](x.to(DEV))
+        assert tuple(out.shape) == tuple(ref.shape)
+        assert maxdiff(out, ref) <= 1e-4 * max(1.0, ref.abs().max().item()), idx
+
+
+def _g7_inputs():
+    lab = seeded.blocky_labels(3, 1, 12, 512, cells=16)
+    lab[lab == 9] = 0
+    lab[lab == 11] = 0
+    lab[0, 100:131, 57:300] = 5
+    return seeded.seeded_image(5, 1, 1024), seeded.labels_to_onehot(lab, 12)
+
+
+def test_g7_get_style_vectors_golden(gpu_net3):
+    g = load_golden("g7_style_vectors")
+    img, mask = _g7_inputs()
+    with torch.no_grad():
+        vec, struct = gpu_net3.get_style_vectors(img.to(DEV), mask.to(DEV))
+    assert tuple(vec.shape) == (1, 12, 1280) and tuple(struct.shape) == (1, 512, 16, 16) and struct.abs().max().item() == 0
+    d = maxdiff(vec, g["vectors"])
+    print(f"get_style_vectors: max-abs diff vs reference golden = {d:.3e} (|ref|max = {np.abs(g['vectors']).max():.3f})")
+    assert d <= 1e-3
+    assert vec[0, 9].abs().max().item() == 0 and vec[0, 11].abs().max().item() == 0
+
+
+def test_get_style_vectors_batch_vs_oracle(gpu_net3, net3_sd):
+    img = seeded.seeded_image(6, 2, 1024)
+    mask = seeded.labels_to_onehot(seeded.blocky_labels(8, 2, 12, 512, cells=8), 12)
+    ref, _ = O.get_style_vectors({k: v for k, v in net3_sd.items() if k.startswith("encoder.")}, img, mask)
+    with torch.no_grad():
+        vec, _ = gpu_net3.get_style_vectors(img.to(DEV), mask.to(DEV))
+        v0, _ = gpu_net3.get_style_vectors(img[:1].to(DEV), mask[:1].to(DEV).contiguous())
+    assert maxdiff(vec, ref) <= 1e-3
+    assert torch.equal(v0[0], vec[0])            # samples are independent, bit for bit
+
+
+def test_net3_forward_end_to_end(gpu_net3, net3_sd):
+    """Net3.forward = encode -> MLPs -> synthesis (models/networks.py:98-159) against the oracle chain."""
+    img, mask = _g7_inputs()
+    vec, _ = O.get_style_vectors({k: v for k, v in net3_sd.items() if k.startswith("encoder.")}, img, mask)
+    codes = O.cal_style_codes(net3_sd, vec, seeded.seeded_latent_avg(2, 18), 13)
+    ref_img, ref_feats = O.generator_forward(net3_sd, codes, mask, None)
+    with torch.no_grad():
+        out, feats = gpu_net3(img.to(DEV), mask.to(DEV), randomize_noise=False)
+        structure, style_codes = gpu_net3.get_style(img.to(DEV), mask.to(DEV))
+    assert maxdiff(style_codes, codes) <= 1e-3
+    assert maxdiff(out, ref_img) <= 1e-3 and maxdiff(feats, ref_feats) <= 1e-3
