@@ -148,7 +148,9 @@ def main():
         cpu = None
         if sd_cpu is not None:
             from oracle import e4s_oracle as O
-            torch.set_num_threads(os.cpu_count() or 1)
+            # 16 threads: measured best on the 256-thread EPYC 9575F GPU host (8: 5.0 s, 16: 3.4 s, 32: 3.7 s, 64: 5.7 s on a
+            # 256x256 generator; torch's default of all 256 threads took 370 s for one 1024x1024 face) — tools/cpu_threads_probe.py
+            torch.set_num_threads(min(16, os.cpu_count() or 1))
             c1, m1 = codes[:1].cpu(), mask[:1].cpu()
             t1 = time.perf_counter()
             with torch.no_grad():

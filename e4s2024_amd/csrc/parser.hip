@@ -180,3 +180,29 @@ extern "C" int e4s_bicubic_down_normalize(float* out, const float* in, const flo
         hipLaunchKernelGGL(bicubic_down_norm_kernel<4>, grid, dim3(256), 0, st, out, in, taps, mean, stdv, C, h, w, oh, ow, mean ? 1 : 0);
     return check_launch("bicubic_down_normalize");
 }
+
+// ------------------------------------------------------------------------------------ tensor2im
+// utils/torch_utils.py:64-76 of the reference on the device: ((x + 1) / 2) clamped to [0,1], * 255, TRUNCATED to uint8,
+// CHW float -> HWC uint8 (what PIL / the RCCL frame gather consume: 3 MB per 1024^2 frame instead of 12.6 MB).
+__global__ __launch_bounds__(256) void tensor2im_kernel(uint8_t* __restrict__ out, const float* __restrict__ img, int hw) {
+    const int b = blockIdx.y;
+    const float* p = img + (size_t)b * 3 * hw;
+    uint8_t* o = out + (size_t)b * 3 * hw;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = (p[(size_t)c * hw + i] + 1.0f) / 2.0f;
+            v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+            o[(size_t)i * 3 + c] = (uint8_t)(v * 255.0f);
+        }
+    }
+}
+
+extern "C" int e4s_tensor2im_u8(uint8_t* out, const float* img, int bs, int h, int w, void* stream) {
+    E4S_REQUIRE(out && img, "tensor2im_u8: null tensor");
+    E4S_REQUIRE(bs >= 0 && bs <= 65535 && h >= 1 && w >= 1, "tensor2im_u8: bad size");
+    if (bs == 0) return 0;
+    const int gx = cdiv(h * w, 256) < 1024 ? cdiv(h * w, 256) : 1024;
+    hipLaunchKernelGGL(tensor2im_kernel, dim3(gx, bs), dim3(256), 0, (hipStream_t)stream, out, img, h * w);
+    return check_launch("tensor2im_u8");
+}

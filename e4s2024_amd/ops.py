@@ -482,6 +482,17 @@ def bicubic_down_normalize(img01: torch.Tensor, taps: torch.Tensor, factor: int,
     return out
 
 
+def tensor2im_u8(img: torch.Tensor) -> torch.Tensor:
+    """``[bs, 3, H, W]`` float -> uint8 ``[bs, H, W, 3]`` with the reference's ``tensor2im`` arithmetic (truncating cast)."""
+    x = _c(img, "image")
+    bs, c, h, w = x.shape
+    if c != 3:
+        raise ValueError("tensor2im_u8 expects 3 channels")
+    out = torch.empty((bs, h, w, 3), dtype=torch.uint8, device=x.device)
+    lib().call("e4s_tensor2im_u8", _p(out), _p(x), bs, h, w, _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------ a7
 def grouped_linear(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Optional[Sequence[Optional[torch.Tensor]]], *, scale: float,
                    bias_mul: float = 1.0, act: int = 0, slope: float = 0.2, addend: Optional[torch.Tensor] = None,

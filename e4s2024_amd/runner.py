@@ -1,0 +1,124 @@
+"""Frame-sharded multi-GPU execution of the swap hot path.
+
+The reference processes a clip one frame at a time on one GPU (``face_swap_video_pipeline.py:337, 406``); frames are
+independent units, so they shard with no data-path dependency.  One process per GPU (``torch.distributed``, backend
+``nccl`` == RCCL over xGMI on ROCm; ``gloo`` in the CPU tests):
+
+* partition  — contiguous block of the frame index range per rank (frame ``i`` → rank ``i * N // n_frames``);
+* broadcast  — what is shared by the whole clip (the source identity's style vectors / W+ codes, 61–442 KB) goes from
+  rank 0 to every rank once per clip;
+* gather     — finished frames travel to rank 0 as **uint8 HWC** (``tensor2im`` semantics, 3 MB per 1024² frame instead of
+  12.6 MB fp32); with 8 GPUs that is ~1 GB/s into rank 0 over 7 dedicated links (≈153 GB/s each), i.e. negligible, so a
+  plain ``gather`` is used (shards are padded to the largest shard, at most one frame of padding per rank).
+
+Weights are replicated (each rank loads the same checkpoint / seed); there is no collective inside a frame.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """[start, stop) of the contiguous block owned by ``rank``: item i belongs to rank ``i * world // n_items``."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    # smallest i with i*world//n >= rank  ==  ceil(rank*n/world)
+    start = -((-rank * n_items) // world)
+    stop = -((-(rank + 1) * n_items) // world)
+    return start, stop
+
+
+class FrameShardRunner:
+    """Runs ``synth_fn`` over this rank's block of frames in batches and gathers the uint8 frames on rank 0.
+
+    ``synth_fn(shared, frame_inputs) -> uint8 [n, H, W, 3]`` is the per-batch compute (on the GPU box:
+    ``gen_img`` + ``ops.tensor2im_u8``); everything else here is host logic + collectives and is covered by the
+    world_size-2 gloo tests on CPU."""
+
+    def __init__(self, device: Optional[torch.device] = None, group=None):
+        self.group = group
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if self.distributed else 0
+        self.world = dist.get_world_size(group) if self.distributed else 1
+        self.device = device if device is not None else torch.device("cpu")
+
+    # ---- collectives ---------------------------------------------------------------------------------------------
+    def broadcast_shared(self, tensor: Optional[torch.Tensor], shape: Sequence[int], dtype=torch.float32, src: int = 0) -> torch.Tensor:
+        """Rank ``src`` provides ``tensor``; every rank returns its copy on ``self.device``."""
+        if self.rank == src:
+            if tensor is None or tuple(tensor.shape) != tuple(shape):
+                raise ValueError(f"source rank must provide a tensor of shape {tuple(shape)}")
+            buf = tensor.to(device=self.device, dtype=dtype).contiguous()
+        else:
+            buf = torch.empty(tuple(shape), dtype=dtype, device=self.device)
+        if self.distributed and self.world > 1:
+            dist.broadcast(buf, src=src, group=self.group)
+        return buf
+
+    def gather_frames(self, local: torch.Tensor, n_total: int, dst: int = 0) -> Optional[torch.Tensor]:
+        """``local`` = this rank's frames ``[n_local, ...]`` (block ``shard_range``); rank ``dst`` gets ``[n_total, ...]``
+        in frame order, the others ``None``."""
+        start, stop = shard_range(n_total, self.rank, self.world)
+        if local.shape[0] != stop - start:
+            raise ValueError(f"rank {self.rank} owns {stop - start} frames, got {local.shape[0]}")
+        if not self.distributed or self.world == 1:
+            return local
+        n_max = max(shard_range(n_total, r, self.world)[1] - shard_range(n_total, r, self.world)[0] for r in range(self.world))
+        pad = torch.zeros((n_max,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[: local.shape[0]] = local
+        if self.rank == dst:
+            bufs = [torch.empty_like(pad) for _ in range(self.world)]
+            dist.gather(pad, bufs, dst=dst, group=self.group)
+            parts = []
+            for r, b in enumerate(bufs):
+                s, e = shard_range(n_total, r, self.world)
+                parts.append(b[: e - s])
+            return torch.cat(parts, dim=0)
+        dist.gather(pad, None, dst=dst, group=self.group)
+        return None
+
+    def max_over_ranks(self, value: float) -> float:
+        if not self.distributed or self.world == 1:
+            return value
+        t = torch.tensor([value], dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+    def barrier(self):
+        if self.distributed and self.world > 1:
+            dist.barrier(group=self.group)
+
+    # ---- the clip loop -------------------------------------------------------------------------------------------
+    def run_clip(self, n_frames: int, shared: torch.Tensor, frame_inputs: Callable[[int, int], object],
+                 synth_fn: Callable[[torch.Tensor, object], torch.Tensor], batch: int = 4, dst: int = 0) -> Optional[torch.Tensor]:
+        """Synthesise frames ``[0, n_frames)``: this rank takes its block, walks it in batches of ``batch`` calling
+        ``synth_fn(shared, frame_inputs(lo, hi))`` and the uint8 results are gathered on rank ``dst``."""
+        start, stop = shard_range(n_frames, self.rank, self.world)
+        outs = []
+        for lo in range(start, stop, batch):
+            hi = min(lo + batch, stop)
+            frames = synth_fn(shared, frame_inputs(lo, hi))
+            if frames.dtype != torch.uint8 or frames.shape[0] != hi - lo:
+                raise ValueError("synth_fn must return uint8 frames [n, H, W, 3] for the requested block")
+            outs.append(frames)
+        if outs:
+            local = torch.cat(outs, dim=0)
+        else:  # a rank can own zero frames when n_frames < world: it still takes part in the gather
+            probe = synth_fn(shared, frame_inputs(0, min(1, n_frames)))
+            local = probe[:0]
+        return self.gather_frames(local, n_frames, dst=dst)
+
+
+def gen_img_frames(net, codes: torch.Tensor, labels: torch.Tensor, randomize_noise: bool = False) -> torch.Tensor:
+    """Per-batch compute for the MI355X path: ``Net3.gen_img`` on uint8 region maps ``[n, 512, 512]`` (or one-hot masks)
+    followed by the device-side ``tensor2im``.  ``codes`` is ``[1 or n, 12, 18, 512]`` (shared codes are expanded)."""
+    from . import ops
+    n = labels.shape[0]
+    if codes.shape[0] == 1 and n > 1:
+        codes = codes.expand(n, -1, -1, -1)
+    with torch.no_grad():
+        img, _, _ = net.gen_img(None, codes, labels, randomize_noise=randomize_noise)
+    return ops.tensor2im_u8(img)

@@ -187,6 +187,9 @@ E4S_API int e4s_bilinear_argmax(uint8_t* labels, const float* logits, const uint
 E4S_API int e4s_bicubic_down_normalize(float* out, const float* in, const float* taps, const float* mean, const float* stdv,
                                        int bs, int C, int h, int w, int factor, void* stream);
 
+/* tensor2im (utils/torch_utils.py:64-76): img [bs,3,h,w] in ~[-1,1] -> uint8 [bs,h,w,3] = trunc(clamp((x+1)/2, 0, 1) * 255). */
+E4S_API int e4s_tensor2im_u8(uint8_t* out, const float* img, int bs, int h, int w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

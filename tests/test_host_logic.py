@@ -1,0 +1,239 @@
+"""CPU-only tests: the C ABI loads and exports every declared symbol, argument validation (no launches), the drop-in
+module trees mirror the reference's state_dict layout, the seeded generator is frozen, frame sharding + collectives
+(gloo, world_size 2)."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, default_opts, install_dropin
+from e4s2024_amd import seeded
+
+
+# ------------------------------------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    from e4s2024_amd import _lib
+    L = _lib.lib()
+    declared = _lib.declared_symbols()
+    assert len(declared) >= 22 and len(set(declared)) == len(declared)
+    for name in declared:
+        assert hasattr(L.cdll, name), f"{name} declared in include/e4s_hip.h but not exported by {L.path}"
+    assert set(_lib._PROTOS) | {"e4s_abi_version", "e4s_last_error"} == set(declared)
+    assert L.cdll.e4s_abi_version() == 1
+    out = subprocess.run(["nm", "-D", "--defined-only", L.path], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert {s for s in exported if s.startswith("e4s_")} == set(declared)          # nothing undeclared leaks out either
+
+
+def test_abi_signatures_carry_no_torch_types():
+    import re
+    src = open(os.path.join(ROOT, "include", "e4s_hip.h")).read()
+    assert 'extern "C"' in src
+    code = re.sub(r"/\*.*?\*/", "", src, flags=re.S)            # declarations only, comments stripped
+    assert "torch" not in code.lower() and "at::" not in code and "Tensor" not in code and "#include <hip" not in code
+    for decl in re.findall(r"E4S_API\s+(?:int|const char\*)\s+e4s_\w+\([^;]+;", code):
+        for arg in decl[decl.index("(") + 1: decl.rindex(")")].split(","):
+            ty = " ".join(arg.split()[:-1])
+            assert ty in ("", "void", "int", "float", "int64_t", "void*", "float*", "const float*", "uint8_t*", "const uint8_t*", "int*",
+                          "const float* const*"), (decl.split("(")[0], arg)
+
+
+def test_argument_validation_without_gpu():
+    """Rejected arguments return E4S_ERR_ARG with a message before anything is launched."""
+    from e4s2024_amd._lib import lib
+    L = lib()
+    c = L.cdll
+    one = ctypes.c_void_p(16)          # non-null dummy pointers: validation fails before they are touched
+    assert c.e4s_upfirdn2d(one, one, one, 1, 4, 4, 40, 4, 1, 1, 1, 1, 0, 0, 0, 0, None) == -1
+    assert b"not in 1..32" in c.e4s_last_error()
+    assert c.e4s_upfirdn2d(one, one, one, 1, 4, 4, 4, 4, 0, 1, 1, 1, 0, 0, 0, 0, None) == -1
+    assert c.e4s_upfirdn2d(one, one, one, 1, 2, 2, 4, 4, 1, 1, 1, 1, 0, 0, 0, 0, None) == -1          # empty output
+    assert c.e4s_region_modconv3x3(one, one, one, one, None, None, 0, 0, None, 0, None, None, 0, 1, 8, 8, 4, 4, 12, 0, None) == -1
+    assert b"label map" in c.e4s_last_error()
+    assert c.e4s_region_modconv3x3(one, one, one, one, None, one, 4, 4, None, 0, None, None, 0, 1, 8, 8, 4, 4, 17, 0, None) == -1
+    assert c.e4s_conv2d(one, one, None, 0, one, None, None, None, None, None, 0, 1, 8, 8, 4, 4, 5, 1, 2, None) == -1
+    assert b"not supported" in c.e4s_last_error()
+    assert c.e4s_conv2d(one, one, None, 0, one, None, None, None, None, None, 0, 1, 8, 8, 4, 4, 3, 3, 1, None) == -1
+    assert c.e4s_modconv_prep_weights(one, None, one, None, 8, 8, 3, 1, None) == -1                   # up-conv without blur
+    assert c.e4s_onehot_to_labels(one, None, one, 1, 17, 4, 4, None) == -1
+    assert c.e4s_bicubic_down_normalize(one, one, one, None, None, 1, 3, 64, 64, 3, None) == -1
+    assert c.e4s_fused_bias_act(None, None, None, None, 3, 0, 0.2, 1.0, 0, 1, 0, None) == 0           # empty tensor: nothing to do
+    with pytest.raises(RuntimeError, match="e4s_upfirdn2d failed"):
+        L.call("e4s_upfirdn2d", one, one, one, 1, 4, 4, 40, 4, 1, 1, 1, 1, 0, 0, 0, 0, None)
+
+
+def test_ops_refuse_cpu_tensors_and_wrong_dtype():
+    from e4s2024_amd import ops
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        ops.fused_leaky_relu(torch.zeros(2, 3), torch.zeros(3))
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        ops.upfirdn2d(torch.zeros(1, 1, 4, 4), torch.ones(2, 2))
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        ops.mask_to_labels(torch.zeros(1, 12, 8, 8))
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        ops.plane_stats(torch.zeros(1, 4, 8, 8), 1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ drop-in trees
+def _meta(fn):
+    with torch.device("meta"):
+        return fn()
+
+
+def test_dropin_state_dicts_match_reference_manifests(manifest):
+    install_dropin()
+    from models.networks import Net3, Net, LocalMLP
+    from models.stylegan2.model import Generator
+    from swap_face_fine.face_parsing.model import BiSeNet
+    assert Net is Net3
+    for name, build in (("net3_1024_rli13", lambda: Net3(default_opts())),
+                        ("generator_64_rli5", lambda: Generator(64, 512, 8, split_layer_idx=5, remaining_layer_idx=5)),
+                        ("generator_256_rli13", lambda: Generator(256, 512, 8, split_layer_idx=5, remaining_layer_idx=13)),
+                        ("bisenet_19", lambda: BiSeNet(19))):
+        sd = _meta(build).state_dict()
+        ref = manifest[name]
+        keys = [k if not name.startswith("generator") else "G." + k for k in sd]
+        assert keys == list(ref.keys()), name                      # same keys in the same order
+        for k, kk in zip(sd, keys):
+            assert list(sd[k].shape) == ref[kk][0] and str(sd[k].dtype).replace("torch.", "") == ref[kk][1], (name, k)
+    net = _meta(lambda: Net3(default_opts()))
+    assert sorted(k for k, p in net.named_parameters() if not p.requires_grad) == manifest["net3_1024_rli13_requires_grad_false"]
+    net = _meta(lambda: Net3(default_opts(train_G=True)))
+    assert sorted(k for k, p in net.named_parameters() if not p.requires_grad) == manifest["net3_1024_rli13_trainG_requires_grad_false"]
+
+
+def test_dropin_api_surface():
+    """Names and signatures the unchanged callers touch."""
+    import inspect
+    install_dropin()
+    from models.networks import Net3
+    from models.stylegan2.model import Generator, StyledConv, ToRGB, ModulatedConv2d, EqualLinear
+    import models.stylegan2.op as op
+    from swap_face_fine.face_parsing.face_parsing_demo import init_faceParsing_pretrained_model, faceParsing_demo, vis_parsing_maps, FaceParser
+    from swap_face_fine.face_parsing.model import BiSeNet, seg_mean, seg_std
+    assert list(inspect.signature(Net3.gen_img).parameters) == ["self", "struc_codes", "style_codes", "mask", "randomize_noise", "noise", "return_latents"]
+    assert list(inspect.signature(Net3.get_style_vectors).parameters) == ["self", "img", "mask"]
+    assert list(inspect.signature(Net3.cal_style_codes).parameters) == ["self", "style_vectors"]
+    assert list(inspect.signature(Net3.forward).parameters) == ["self", "img", "mask", "resize", "randomize_noise", "return_latents"]
+    assert list(inspect.signature(Generator.forward).parameters) == ["self", "styles", "structure_feats", "mask", "return_latents", "inject_index",
+                                                                      "truncation", "truncation_latent", "input_is_latent", "noise",
+                                                                      "randomize_noise", "use_structure_code"]
+    assert list(inspect.signature(StyledConv.forward).parameters) == ["self", "input", "style", "mask", "noise"]
+    assert list(inspect.signature(ToRGB.forward).parameters) == ["self", "input", "style", "mask", "skip"]
+    assert list(inspect.signature(ModulatedConv2d.forward).parameters) == ["self", "input", "style"]
+    assert list(inspect.signature(op.fused_leaky_relu).parameters) == ["input", "bias", "negative_slope", "scale"]
+    assert list(inspect.signature(op.upfirdn2d).parameters) == ["input", "kernel", "up", "down", "pad"]
+    assert list(inspect.signature(faceParsing_demo).parameters) == ["model", "img", "convert_to_seg12"]
+    assert seg_mean.device.type == "cpu" and tuple(seg_std.shape) == (1, 3, 1, 1)
+    g = _meta(lambda: Generator(1024, 512, 8, split_layer_idx=5, remaining_layer_idx=13))
+    assert [c.mask_op for c in g.convs] == [True] * 12 + [False] * 4
+    assert [r.mask_op for r in g.to_rgbs] == [True] * 5 + [False] * 3 and g.conv1.mask_op and g.to_rgb1.mask_op
+    assert g.n_latent == 18 and g.num_layers == 17
+
+
+def test_install_only_overrides_hot_path_modules():
+    import e4s2024_amd
+    install_dropin()
+    import importlib
+    assert importlib.util.find_spec("models.encoders.model_irse") is None       # not ours: resolves from the reference tree when present
+    assert set(e4s2024_amd.OVERRIDES) == {"models.networks", "models.stylegan2.model", "models.stylegan2.op", "models.stylegan2.op.fused_act",
+                                          "models.stylegan2.op.upfirdn2d", "models.encoders.psp_encoders",
+                                          "swap_face_fine.face_parsing.model", "swap_face_fine.face_parsing.resnet",
+                                          "swap_face_fine.face_parsing.face_parsing_demo"}
+    import models.networks
+    assert models.networks.__file__.startswith(e4s2024_amd.DROPIN_DIR)
+
+
+def test_remap_lut_matches_oracle():
+    install_dropin()
+    from swap_face_fine.face_parsing.face_parsing_demo import remap_lut
+    from oracle import e4s_oracle as O
+    assert (remap_lut()[:19] == O.remap_19_to_12(np.arange(19, dtype=np.uint8))).all() and remap_lut()[19:].max() == 0
+
+
+# ------------------------------------------------------------------------------------------------ seeded generator
+def test_seeded_stream_is_frozen():
+    a = seeded.seeded_array(4, "G.conv1.conv.weight", (3, 5))
+    assert abs(float(a.sum()) - (-7.7163143)) < 1e-5 and a.dtype == np.float32, float(a.sum())
+    b = seeded.seeded_array(1, "codes", (2, 3), dist="normal")
+    assert abs(float(b[0, 0]) - 1.9986119) < 1e-6, float(b[0, 0])
+    lab = seeded.blocky_labels(3, 1, 12, 512, 16)
+    assert lab.shape == (1, 512, 512) and int(lab.astype(np.int64).sum()) == 1432576, int(lab.astype(np.int64).sum())
+    oh = seeded.labels_to_onehot(lab, 12)
+    assert oh.sum().item() == 512 * 512 and (oh.argmax(1).numpy() == lab).all()
+
+
+def test_bench_flop_accounting():
+    sys.path.insert(0, ROOT)
+    import bench
+    fl = bench.conv3x3_flops_per_face()
+    rgb = 2 * 3 * sum(c * r * r for c, r in ((512, 4), (512, 8), (512, 16), (512, 32), (512, 64), (256, 128), (128, 256), (64, 512), (32, 1024)))
+    assert abs((sum(fl.values()) + rgb) / 1e9 - 148.52) < 0.05
+
+
+# ------------------------------------------------------------------------------------------------ frame sharding (gloo, world 2)
+def test_shard_range_partitions_every_frame_once():
+    from e4s2024_amd.runner import shard_range
+    for n in (0, 1, 2, 5, 8, 255, 256, 257):
+        for world in (1, 2, 3, 4, 8):
+            seen = []
+            for r in range(world):
+                s, e = shard_range(n, r, world)
+                assert 0 <= s <= e <= n
+                seen += list(range(s, e))
+                for i in range(s, e):
+                    assert i * world // n == r
+            assert seen == list(range(n))
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[3])
+from e4s2024_amd.runner import FrameShardRunner, shard_range
+rank, world, n_frames = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[4])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[5], RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group("gloo", rank=rank, world_size=world)
+r = FrameShardRunner()
+shared = r.broadcast_shared(torch.arange(24, dtype=torch.float32).reshape(1, 2, 3, 4) if rank == 0 else None, (1, 2, 3, 4))
+calls = []
+def frame_inputs(lo, hi):
+    return torch.arange(lo, hi)
+def synth(shared, idx):
+    calls.append((int(idx[0]) if len(idx) else -1, len(idx)))
+    f = (idx.view(-1, 1, 1, 1) * 7 + shared.sum().long()) % 251
+    return f.to(torch.uint8).expand(-1, 4, 5, 3).contiguous()
+out = r.run_clip(n_frames, shared, frame_inputs, synth, batch=2)
+t = r.max_over_ranks(float(rank + 1))
+assert t == float(world)
+if rank == 0:
+    exp = ((torch.arange(n_frames).view(-1, 1, 1, 1) * 7 + 276) % 251).to(torch.uint8).expand(-1, 4, 5, 3)
+    assert out is not None and tuple(out.shape) == (n_frames, 4, 5, 3) and torch.equal(out, exp), (out.shape,)
+    print("RANK0_OK", n_frames)
+else:
+    assert out is None
+s, e = shard_range(n_frames, rank, world)
+assert sum(c[1] for c in calls if c[0] >= s) >= e - s
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("n_frames,port", [(7, 29611), (1, 29612), (8, 29613)])
+def test_run_clip_world2_gloo(tmp_path, n_frames, port):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", ROOT, str(n_frames), str(port)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert f"RANK0_OK {n_frames}" in outs[0]
+
+
+def test_run_clip_single_process_equals_sharded_result():
+    from e4s2024_amd.runner import FrameShardRunner
+    r = FrameShardRunner()
+    out = r.run_clip(5, torch.ones(1), lambda lo, hi: torch.arange(lo, hi), lambda sh, idx: idx.view(-1, 1, 1, 1).to(torch.uint8).expand(-1, 2, 2, 3).contiguous(), batch=4)
+    assert out[:, 0, 0, 0].tolist() == [0, 1, 2, 3, 4]
