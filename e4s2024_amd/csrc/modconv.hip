@@ -86,38 +86,85 @@ extern "C" int e4s_modconv_prep_weights(float* wt, float* wsq, const float* weig
 }
 
 // ============================================================================ style + demod tables
-// One wave per input channel: the channel's modulation row stays in registers (sdim/64 floats per lane) and is
-// dotted against every (sample, region) style vector with a wave-shuffle reduction.
+// style: one wave per (input channel, group of 8 (sample, region) rows): the channel's modulation row stays in registers and
+// is dotted against 8 style vectors with independent accumulators and wave-shuffle reductions.
+constexpr int STYLE_ROWS = 8;
+
 __global__ __launch_bounds__(256) void style_kernel(float* __restrict__ s, const float* __restrict__ styles, int64_t stride_b,
                                                     int64_t stride_r, const float* __restrict__ mod_weight,
-                                                    const float* __restrict__ mod_bias, int bs, int nreg, int cin, int sdim, float scale) {
+                                                    const float* __restrict__ mod_bias, int nbr, int nreg, int cin, int sdim, float scale) {
     const int lane = threadIdx.x & 63;
     const int ci = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ci >= cin) return;
+    const int br0 = blockIdx.y * STYLE_ROWS;
     const float* wrow = mod_weight + (size_t)ci * sdim;
     const float mb = mod_bias ? mod_bias[ci] : 0.f;
-    for (int br = 0; br < bs * nreg; ++br) {
-        const int b = br / nreg, r = br - b * nreg;
-        const float* sv = styles + b * stride_b + r * stride_r;
-        float a = 0.f;
-        for (int j = lane; j < sdim; j += 64) a += sv[j] * wrow[j];
-        a = wave_sum(a);
-        if (lane == 0) s[(size_t)br * cin + ci] = a * scale + mb;
+    float acc[STYLE_ROWS];
+#pragma unroll
+    for (int q = 0; q < STYLE_ROWS; ++q) acc[q] = 0.f;
+    const bool vec = (sdim & 3) == 0 && (stride_b & 3) == 0 && (stride_r & 3) == 0 && ((((uintptr_t)styles | (uintptr_t)mod_weight) & 15) == 0);
+    if (vec) {
+        for (int j = lane * 4; j < sdim; j += 256) {
+            const float4 w4 = *reinterpret_cast<const float4*>(wrow + j);
+#pragma unroll
+            for (int q = 0; q < STYLE_ROWS; ++q) {
+                const int br = br0 + q;
+                if (br < nbr) {
+                    const int b = br / nreg, r = br - b * nreg;
+                    const float4 v = *reinterpret_cast<const float4*>(styles + b * stride_b + r * stride_r + j);
+                    acc[q] += (v.x * w4.x + v.y * w4.y) + (v.z * w4.z + v.w * w4.w);
+                }
+            }
+        }
+    } else {
+        for (int j = lane; j < sdim; j += 64) {
+            const float wv = wrow[j];
+#pragma unroll
+            for (int q = 0; q < STYLE_ROWS; ++q) {
+                const int br = br0 + q;
+                if (br < nbr) {
+                    const int b = br / nreg, r = br - b * nreg;
+                    acc[q] += styles[b * stride_b + r * stride_r + j] * wv;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < STYLE_ROWS; ++q) {
+        const float a = wave_sum(acc[q]);
+        if (lane == 0 && br0 + q < nbr) s[(size_t)(br0 + q) * cin + ci] = a * scale + mb;
     }
 }
 
+// demod: block = (one (sample, region) row) x (64 output channels); the 4 waves split the input-channel range, lanes own
+// output channels (coalesced wsq rows), partial sums meet in LDS.
 __global__ __launch_bounds__(256) void demod_kernel(float* __restrict__ d, const float* __restrict__ s, const float* __restrict__ wsq,
-                                                    int nbr, int cin, int cout) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nbr * cout) return;
-    const int co = i % cout, br = i / cout;
+                                                    int cin, int cout) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int co = blockIdx.x * 64 + lane;
+    const int br = blockIdx.y;
     const float* sv = s + (size_t)br * cin;
-    float a = 0.f;
-    for (int ci = 0; ci < cin; ++ci) {
-        const float t = sv[ci];
-        a += t * t * wsq[(size_t)ci * cout + co];
+    const int per = (cin + 3) / 4;
+    const int c0 = wave * per, c1 = (c0 + per < cin) ? c0 + per : cin;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (co < cout) {
+        int ci = c0;
+        for (; ci + 3 < c1; ci += 4) {
+            const float t0 = sv[ci], t1 = sv[ci + 1], t2 = sv[ci + 2], t3 = sv[ci + 3];
+            a0 += t0 * t0 * wsq[(size_t)ci * cout + co];
+            a1 += t1 * t1 * wsq[(size_t)(ci + 1) * cout + co];
+            a2 += t2 * t2 * wsq[(size_t)(ci + 2) * cout + co];
+            a3 += t3 * t3 * wsq[(size_t)(ci + 3) * cout + co];
+        }
+        for (; ci < c1; ++ci) {
+            const float t = sv[ci];
+            a0 += t * t * wsq[(size_t)ci * cout + co];
+        }
     }
-    d[i] = rsqrtf(a + 1e-8f);
+    part[wave][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (wave == 0 && co < cout) d[(size_t)br * cout + co] = rsqrtf(((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) + 1e-8f);
 }
 
 extern "C" int e4s_style_demod(float* s, float* d, const float* styles, int64_t stride_b, int64_t stride_r, const float* mod_weight,
@@ -128,11 +175,12 @@ extern "C" int e4s_style_demod(float* s, float* d, const float* styles, int64_t 
     E4S_REQUIRE((d == nullptr) == (wsq == nullptr), "style_demod: d and wsq must both be given or both be NULL");
     if (bs == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(style_kernel, dim3(cdiv(cin, 4)), dim3(256), 0, st, s, styles, stride_b, stride_r, mod_weight, mod_bias, bs, nreg,
-                       cin, sdim, 1.0f / sqrtf((float)sdim));
+    const int nbr = bs * nreg;
+    hipLaunchKernelGGL(style_kernel, dim3(cdiv(cin, 4), cdiv(nbr, STYLE_ROWS)), dim3(256), 0, st, s, styles, stride_b, stride_r, mod_weight,
+                       mod_bias, nbr, nreg, cin, sdim, 1.0f / sqrtf((float)sdim));
     if (d) {
         E4S_REQUIRE(cout >= 1, "style_demod: bad cout");
-        hipLaunchKernelGGL(demod_kernel, dim3(cdiv(bs * nreg * cout, 256)), dim3(256), 0, st, d, s, wsq, bs * nreg, cin, cout);
+        hipLaunchKernelGGL(demod_kernel, dim3(cdiv(cout, 64), nbr), dim3(256), 0, st, d, s, wsq, cin, cout);
     }
     return check_launch("style_demod");
 }
@@ -154,6 +202,8 @@ struct ConvParams {
     int act;
     int bs, cin, cout, h, w, nreg, up;
     int tiles_x, tiles_y;
+    int ksplit, cin_per;   // split-K over input channels for small feature maps: block ks handles [ks*cin_per, (ks+1)*cin_per)
+    float* partial;        // [ksplit][bs][cout][ho*wo] raw accumulators when ksplit > 1
 };
 
 constexpr int CK = 8;  // input channels staged per K-chunk (K per chunk = 72)
@@ -188,8 +238,11 @@ __global__ __launch_bounds__(256) void region_modconv_kernel(const ConvParams p)
     const int wc = wave / WP, wp = wave % WP;
 
     const int ntile = p.tiles_x * p.tiles_y;
-    const int tile = blockIdx.x % ntile;
-    const int par = blockIdx.x / ntile;  // 0 when !up
+    const int npar = p.up ? 4 : 1;
+    const int ks = blockIdx.x / (ntile * npar);
+    const int bx = blockIdx.x - ks * ntile * npar;
+    const int tile = bx % ntile;
+    const int par = bx / ntile;  // 0 when !up
     const int pa = par >> 1, pb_ = par & 1;
     const int y0 = (tile / p.tiles_x) * C::TH, x0 = (tile % p.tiles_x) * C::TW;
     const int co0 = blockIdx.y * C::TN;
@@ -241,7 +294,9 @@ __global__ __launch_bounds__(256) void region_modconv_kernel(const ConvParams p)
 
     const bool wvec = (p.cout & 3) == 0;
 
-    for (int ci0 = 0; ci0 < p.cin; ci0 += CK) {
+    const int ci_begin = ks * p.cin_per;
+    const int ci_end = (ci_begin + p.cin_per < p.cin) ? ci_begin + p.cin_per : p.cin;
+    for (int ci0 = ci_begin; ci0 < ci_end; ci0 += CK) {
         __syncthreads();
         // stage x patch: CK channels x PATCH (zero padded)
 #pragma unroll
@@ -306,6 +361,25 @@ __global__ __launch_bounds__(256) void region_modconv_kernel(const ConvParams p)
         }
     }
 
+    if (p.ksplit > 1) {  // raw partial sums; modconv_finalize_kernel applies the epilogue after the K-slices are summed
+        float* part = p.partial + ((size_t)ks * p.bs + b) * p.cout * ho * wo;
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int pbk = wp * PB + q;
+            const int y = y0 + pbk * C::RPB + (l5 >> LOG_TW), x = x0 + (l5 & (C::TW - 1));
+            if (y >= p.h || x >= p.w) continue;
+            const size_t opix = (size_t)(p.up ? 2 * y + pa : y) * wo + (p.up ? 2 * x + pb_ : x);
+#pragma unroll
+            for (int i = 0; i < CB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + (wc * CB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    if (co < p.cout) part[(size_t)co * ho * wo + opix] = acc[i][q][r];
+                }
+        }
+        return;
+    }
+
     // ---- epilogue: demod table through LDS (overlays the weight stage), noise, bias, activation, store
     __syncthreads();
     float* dt = ws;  // [E4S_MAX_REGIONS][TN]
@@ -344,20 +418,63 @@ __global__ __launch_bounds__(256) void region_modconv_kernel(const ConvParams p)
     }
 }
 
+// Sum the K-slices in a fixed order and apply the StyledConv epilogue (demod, noise, bias, leaky-relu * sqrt2).
+__global__ __launch_bounds__(256) void modconv_finalize_kernel(const ConvParams p, int ho, int wo) {
+    const size_t ohw = (size_t)ho * wo;
+    const size_t per_b = (size_t)p.cout * ohw;
+    const size_t total = (size_t)p.bs * per_b;
+    const float nw = p.noise ? p.noise_weight[0] : 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int b = (int)(i / per_b);
+        const size_t r = i - (size_t)b * per_b;
+        const int co = (int)(r / ohw);
+        const size_t opix = r - (size_t)co * ohw;
+        const int oy = (int)(opix / wo), ox = (int)(opix - (size_t)oy * wo);
+        float a = 0.f;
+        for (int k = 0; k < p.ksplit; ++k) a += p.partial[(size_t)k * total + i];
+        int c = 0;
+        if (p.labels) c = p.labels[((size_t)b * p.lh + nearest_src(oy, p.lscale_y, p.lh)) * p.lw + nearest_src(ox, p.lscale_x, p.lw)];
+        float v = 0.f;
+        if (c < p.nreg) v = a * (p.d ? p.d[((size_t)b * p.nreg + c) * p.cout + co] : 1.f);
+        if (p.noise) v += nw * p.noise[(size_t)b * p.noise_bstride + opix];
+        if (p.act_bias) v += p.act_bias[co];
+        if (p.act) v = (v > 0.f ? v : v * 0.2f) * 1.41421356237309515f;
+        p.out[i] = v;
+    }
+}
+
 template <int CB, int PB, int WC, int WP, int LOG_TW>
-static int launch_conv(ConvParams& p, hipStream_t st) {
+static int launch_conv(ConvParams& p, hipStream_t st, float* workspace, int64_t workspace_floats) {
     using C = ConvCfg<CB, PB, WC, WP, LOG_TW>;
     p.tiles_x = cdiv(p.w, C::TW);
     p.tiles_y = cdiv(p.h, C::TH);
-    dim3 grid(p.tiles_x * p.tiles_y * (p.up ? 4 : 1), cdiv(p.cout, C::TN), p.bs);
+    const int npar = p.up ? 4 : 1;
+    const int64_t base = (int64_t)p.tiles_x * p.tiles_y * npar * cdiv(p.cout, C::TN) * p.bs;
+    const int ho = p.up ? 2 * p.h : p.h, wo = p.up ? 2 * p.w : p.w;
+    const int64_t out_floats = (int64_t)p.bs * p.cout * ho * wo;
+    int ksplit = 1;
+    if (workspace && base < 192) {  // too few workgroups for 256 CUs: split the reduction over input channels
+        const int chunks = cdiv(p.cin, CK);
+        while (ksplit < 16 && base * ksplit * 2 <= 512 && ksplit * 2 <= chunks && (int64_t)(ksplit * 2) * out_floats <= workspace_floats) ksplit *= 2;
+    }
+    p.ksplit = ksplit;
+    p.cin_per = cdiv(cdiv(p.cin, ksplit), CK) * CK;
+    p.partial = workspace;
+    dim3 grid(p.tiles_x * p.tiles_y * npar * ksplit, cdiv(p.cout, C::TN), p.bs);
     hipLaunchKernelGGL((region_modconv_kernel<CB, PB, WC, WP, LOG_TW>), grid, dim3(256), 0, st, p);
+    if (ksplit > 1) {
+        const int g = (int)(cdiv64(out_floats, 256) < 2048 ? cdiv64(out_floats, 256) : 2048);
+        hipLaunchKernelGGL(modconv_finalize_kernel, dim3(g), dim3(256), 0, st, p, ho, wo);
+    }
     return check_launch("region_modconv3x3");
 }
 
 extern "C" int e4s_region_modconv3x3(float* out, const float* x, const float* wt, const float* s, const float* d, const uint8_t* labels,
                                      int lh, int lw, const float* noise, int noise_bs, const float* noise_weight, const float* act_bias,
-                                     int act, int bs, int cin, int cout, int h, int w, int nreg, int up, void* stream) {
+                                     int act, int bs, int cin, int cout, int h, int w, int nreg, int up, float* workspace,
+                                     int64_t workspace_floats, void* stream) {
     E4S_REQUIRE(out && x && wt && s, "region_modconv3x3: null tensor");
+    E4S_REQUIRE(!workspace || workspace_floats >= 0, "region_modconv3x3: bad workspace size");
     E4S_REQUIRE(bs >= 0 && cin >= 1 && cout >= 1 && h >= 1 && w >= 1, "region_modconv3x3: bad size");
     E4S_REQUIRE(nreg >= 1 && nreg <= E4S_MAX_REGIONS, "region_modconv3x3: %d regions (max %d)", nreg, E4S_MAX_REGIONS);
     E4S_REQUIRE(labels || nreg == 1, "region_modconv3x3: nreg > 1 needs a label map");
@@ -374,19 +491,22 @@ extern "C" int e4s_region_modconv3x3(float* out, const float* x, const float* wt
     p.lscale_x = labels ? (float)lw / (float)wo : 1.f;
     p.noise_bstride = (noise && noise_bs > 1) ? ho * wo : 0;
     hipStream_t st = (hipStream_t)stream;
+    float* ws = workspace;
+    const int64_t wf = workspace_floats;
     if (w >= 32) {
-        if (cout > 64) return launch_conv<2, 2, 2, 2, 5>(p, st);   // 128 co x 128 px
-        if (cout > 32) return launch_conv<2, 2, 1, 4, 5>(p, st);   //  64 co x 256 px
-        return launch_conv<1, 2, 1, 4, 5>(p, st);                  //  32 co x 256 px
+        if (cout > 64) return launch_conv<2, 2, 2, 2, 5>(p, st, ws, wf);   // 128 co x 128 px
+        if (cout > 32) return launch_conv<2, 2, 1, 4, 5>(p, st, ws, wf);   //  64 co x 256 px
+        return launch_conv<1, 2, 1, 4, 5>(p, st, ws, wf);                  //  32 co x 256 px
     }
-    if (w >= 16) return launch_conv<2, 2, 2, 2, 4>(p, st);
-    if (w >= 8) return launch_conv<2, 1, 2, 2, 3>(p, st);
-    return launch_conv<2, 1, 2, 2, 2>(p, st);
+    if (w >= 16) return launch_conv<2, 2, 2, 2, 4>(p, st, ws, wf);
+    if (w >= 8) return launch_conv<2, 1, 2, 2, 3>(p, st, ws, wf);
+    return launch_conv<2, 1, 2, 2, 2>(p, st, ws, wf);
 }
 
 // ============================================================================ ToRGB
 // out[b,o,p] = sum_ci wt[ci][o] * s[b,c(p),ci] * x[b,ci,p] + bias[o] + upfirdn2d(skip, up=2, pad=(2,1))[p]
 // One thread per 4 consecutive pixels (float4 loads of x); the s table [nreg][cin] and wt [cin][3] sit in LDS.
+template <bool SINGLE>
 __global__ __launch_bounds__(256) void region_torgb_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ wt,
                                                            const float* __restrict__ s, const uint8_t* __restrict__ labels, int lh, int lw,
                                                            float lsy, float lsx, const float* __restrict__ bias,
@@ -398,7 +518,8 @@ __global__ __launch_bounds__(256) void region_torgb_kernel(float* __restrict__ o
     float* kf = wl + cin * 3;           // [16] flipped upsample taps
     const int b = blockIdx.y;
     for (int i = threadIdx.x; i < nreg * cin; i += 256) st[i] = s[(size_t)b * nreg * cin + i];
-    for (int i = threadIdx.x; i < cin * 3; i += 256) wl[i] = wt[i];
+    // single-region layers (the unmasked 256^2..1024^2 ToRGBs): fold the modulation into the weights once per block
+    for (int i = threadIdx.x; i < cin * 3; i += 256) wl[i] = SINGLE ? wt[i] * s[(size_t)b * cin + i / 3] : wt[i];
     if (threadIdx.x < 16) kf[threadIdx.x] = upk ? upk[15 - threadIdx.x] : 0.f;  // kf[ky*4+kx] = k[3-ky][3-kx]
     __syncthreads();
     const int hw = h * w;
@@ -417,14 +538,14 @@ __global__ __launch_bounds__(256) void region_torgb_kernel(float* __restrict__ o
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j][0] = acc[j][1] = acc[j][2] = 0.f;
     const float* xb = x + (size_t)b * cin * hw + pix;
-#pragma unroll 4
+#pragma unroll 8
     for (int ci = 0; ci < cin; ++ci) {
         const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)ci * hw);
         const float w0 = wl[ci * 3 + 0], w1 = wl[ci * 3 + 1], w2 = wl[ci * 3 + 2];
         const float xv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float t = cls[j] >= 0 ? xv[j] * st[cls[j] * cin + ci] : 0.f;
+            const float t = SINGLE ? xv[j] : (cls[j] >= 0 ? xv[j] * st[cls[j] * cin + ci] : 0.f);
             acc[j][0] += t * w0;
             acc[j][1] += t * w1;
             acc[j][2] += t * w2;
@@ -477,7 +598,11 @@ extern "C" int e4s_region_torgb(float* out, const float* x, const float* wt, con
     E4S_REQUIRE(shm <= 64 * 1024, "region_torgb: style table does not fit LDS (cin=%d nreg=%d)", cin, nreg);
     const float lsy = labels ? (float)lh / (float)h : 1.f, lsx = labels ? (float)lw / (float)w : 1.f;
     dim3 grid(cdiv(h * w / 4, 256), bs);
-    hipLaunchKernelGGL(region_torgb_kernel, grid, dim3(256), shm, (hipStream_t)stream, out, x, wt, s, labels, lh, lw, lsy, lsx, bias, skip,
-                       up_kernel, cin, h, w, nreg);
+    if (!labels && nreg == 1)
+        hipLaunchKernelGGL(region_torgb_kernel<true>, grid, dim3(256), shm, (hipStream_t)stream, out, x, wt, s, labels, lh, lw, lsy, lsx, bias,
+                           skip, up_kernel, cin, h, w, nreg);
+    else
+        hipLaunchKernelGGL(region_torgb_kernel<false>, grid, dim3(256), shm, (hipStream_t)stream, out, x, wt, s, labels, lh, lw, lsy, lsx, bias,
+                           skip, up_kernel, cin, h, w, nreg);
     return check_launch("region_torgb");
 }

@@ -264,6 +264,18 @@ def style_demod(styles: torch.Tensor, mod_weight: torch.Tensor, mod_bias: torch.
     return s, d
 
 
+_workspaces = {}
+SPLITK_MAX_OUT_FLOATS = 1 << 21   # only feature maps up to 8 MB of output (<= 32x32 at 512 ch, bs 4) are candidates for split-K
+
+
+def _workspace(device, floats: int) -> torch.Tensor:
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() < floats:
+        ws = torch.empty(floats, dtype=torch.float32, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
 def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: bool, cout: int, up: bool) -> torch.Tensor:
     x = _c(x, "input")
     bs, cin, h, w = x.shape
@@ -281,9 +293,14 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
         nbs = nz.shape[0]
         if nz.numel() != nbs * ho * wo:
             raise ValueError(f"noise shape {tuple(nz.shape)} does not match output {ho}x{wo}")
+    ws, wsn = None, 0
+    if out.numel() <= SPLITK_MAX_OUT_FLOATS:
+        wsn = 16 * out.numel()
+        ws = _workspace(x.device, wsn)
     ev = _timed(modconv_kernel_name(cout, w))
     lib().call("e4s_region_modconv3x3", _p(out), _p(x), _p(wt), _p(s), _p(d), _p(labels), lh, lw, _p(nz), nbs or 0,
-               _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, 1 if up else 0, _stream())
+               _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, 1 if up else 0,
+               _p(ws), wsn, _stream())
     if ev is not None:
         ev.record()
     return out

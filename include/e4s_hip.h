@@ -86,11 +86,15 @@ E4S_API int e4s_style_demod(float* s, float* d, const float* styles, int64_t str
  *   labels  : uint8 [bs, lh, lw] region map, sampled nearest at the OUTPUT pixel (model.py:389-391); NULL = every pixel is
  *             region 0 (unmasked layer, nreg must be 1)
  *   noise   : [noise_bs (1 or bs), 1, ho, wo] or NULL;  noise_weight: device pointer to the NoiseInjection scalar (model.py:335)
- *   act_bias: [cout] FusedLeakyReLU bias or NULL; act != 0 applies leaky_relu(0.2)*sqrt(2) (model.py:421) */
+ *   act_bias: [cout] FusedLeakyReLU bias or NULL; act != 0 applies leaky_relu(0.2)*sqrt(2) (model.py:421)
+ *   workspace: optional scratch of workspace_floats floats (NULL/0 = none).  Feature maps too small to fill 256 CUs (4x4..32x32)
+ *             are then reduced split-K over input channels: K-slices write raw partial sums to the workspace and a second
+ *             launch sums them in a fixed order and applies the epilogue (deterministic; 16*bs*cout*ho*wo floats is always enough) */
 E4S_API int e4s_region_modconv3x3(float* out, const float* x, const float* wt, const float* s, const float* d,
                           const uint8_t* labels, int lh, int lw,
                           const float* noise, int noise_bs, const float* noise_weight, const float* act_bias, int act,
-                          int bs, int cin, int cout, int h, int w, int nreg, int up, void* stream);
+                          int bs, int cin, int cout, int h, int w, int nreg, int up,
+                          float* workspace, int64_t workspace_floats, void* stream);
 
 /* ToRGB forward in one pass (model.py:439-479): 1x1 modulated conv without demodulation, + bias, + upsampled skip.
  *   x : [bs, cin, h, w]   wt : [cin, 3] from e4s_modconv_prep_weights(k=1)   s : [bs, nreg, cin]   bias : [3]

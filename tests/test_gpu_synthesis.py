@@ -121,8 +121,9 @@ def test_g6_gen_img_1024_iid_labels_golden(gpu_net3):
 
 
 def test_gen_img_batch4_properties(gpu_net3):
-    """BASELINE config 2 size (bs=4): samples are independent (sample b of the batch == the single-sample run, bit for
-    bit), the run is deterministic, and explicit noise == registered buffers."""
+    """BASELINE config 2 size (bs=4): samples are independent (sample b of the batch == the single-sample run up to the
+    re-association of the split-K reduction, whose slice count depends on the launch size), the run is bit-deterministic,
+    and explicit noise == registered buffers."""
     codes, mask = _config2_inputs(4)
     codes, mask = codes.to(DEV), mask.to(DEV)
     with torch.no_grad():
@@ -131,7 +132,7 @@ def test_gen_img_batch4_properties(gpu_net3):
         assert torch.equal(img4, img4b)
         for b in (0, 3):
             img1, _, f1 = gpu_net3.gen_img(None, codes[b:b + 1], mask[b:b + 1].contiguous(), randomize_noise=False)
-            assert torch.equal(img1[0], img4[b]) and torch.equal(f1[0], f4[b])
+            assert (img1[0] - img4[b]).abs().max().item() <= 1e-4 and (f1[0] - f4[b]).abs().max().item() <= 1e-4
         noise = [getattr(gpu_net3.G.noises, f"noise_{i}") for i in range(17)]
         img_n, _, _ = gpu_net3.gen_img(None, codes, mask, noise=noise)
         assert torch.equal(img_n, img4)

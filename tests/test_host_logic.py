@@ -52,9 +52,9 @@ def test_argument_validation_without_gpu():
     assert b"not in 1..32" in c.e4s_last_error()
     assert c.e4s_upfirdn2d(one, one, one, 1, 4, 4, 4, 4, 0, 1, 1, 1, 0, 0, 0, 0, None) == -1
     assert c.e4s_upfirdn2d(one, one, one, 1, 2, 2, 4, 4, 1, 1, 1, 1, 0, 0, 0, 0, None) == -1          # empty output
-    assert c.e4s_region_modconv3x3(one, one, one, one, None, None, 0, 0, None, 0, None, None, 0, 1, 8, 8, 4, 4, 12, 0, None) == -1
+    assert c.e4s_region_modconv3x3(one, one, one, one, None, None, 0, 0, None, 0, None, None, 0, 1, 8, 8, 4, 4, 12, 0, None, 0, None) == -1
     assert b"label map" in c.e4s_last_error()
-    assert c.e4s_region_modconv3x3(one, one, one, one, None, one, 4, 4, None, 0, None, None, 0, 1, 8, 8, 4, 4, 17, 0, None) == -1
+    assert c.e4s_region_modconv3x3(one, one, one, one, None, one, 4, 4, None, 0, None, None, 0, 1, 8, 8, 4, 4, 17, 0, None, 0, None) == -1
     assert c.e4s_conv2d(one, one, None, 0, one, None, None, None, None, None, 0, 1, 8, 8, 4, 4, 5, 1, 2, None) == -1
     assert b"not supported" in c.e4s_last_error()
     assert c.e4s_conv2d(one, one, None, 0, one, None, None, None, None, None, 0, 1, 8, 8, 4, 4, 3, 3, 1, None) == -1
