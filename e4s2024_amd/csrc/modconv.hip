@@ -584,19 +584,94 @@ __global__ __launch_bounds__(256) void region_torgb_kernel(float* __restrict__ o
     }
 }
 
+// Masked ToRGB at low resolution (<= 128^2, Cin 256..512): few pixels and a long reduction, so the block is 64 pixels wide and
+// its 4 waves split the input-channel range; partial RGB sums meet in LDS.
+__global__ __launch_bounds__(256) void region_torgb_splitc_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                                  const float* __restrict__ wt, const float* __restrict__ s,
+                                                                  const uint8_t* __restrict__ labels, int lh, int lw, float lsy, float lsx,
+                                                                  const float* __restrict__ bias, const float* __restrict__ skip,
+                                                                  const float* __restrict__ upk, int cin, int h, int w, int nreg) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* st = sm;                     // [nreg][cin]
+    float* wl = sm + nreg * cin;        // [cin][3]
+    float* kf = wl + cin * 3;           // [16]
+    float* red = kf + 16;               // [4][3][64]
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < nreg * cin; i += 256) st[i] = s[(size_t)b * nreg * cin + i];
+    for (int i = threadIdx.x; i < cin * 3; i += 256) wl[i] = wt[i];
+    if (threadIdx.x < 16) kf[threadIdx.x] = upk ? upk[15 - threadIdx.x] : 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hw = h * w;
+    const int pix = blockIdx.x * 64 + lane;
+    const bool ok = pix < hw;
+    const int y = ok ? pix / w : 0, xx = ok ? pix - (pix / w) * w : 0;
+    int c = 0;
+    if (labels && ok) c = labels[((size_t)b * lh + nearest_src(y, lsy, lh)) * lw + nearest_src(xx, lsx, lw)];
+    const int cls = c < nreg ? c : -1;
+    const int per = (cin + 3) / 4;
+    const int c0 = wave * per, c1 = (c0 + per < cin) ? c0 + per : cin;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if (ok && cls >= 0) {
+        const float* xb = x + (size_t)b * cin * hw + pix;
+        const float* sr = st + cls * cin;
+#pragma unroll 8
+        for (int ci = c0; ci < c1; ++ci) {
+            const float t = xb[(size_t)ci * hw] * sr[ci];
+            a0 += t * wl[ci * 3 + 0];
+            a1 += t * wl[ci * 3 + 1];
+            a2 += t * wl[ci * 3 + 2];
+        }
+    }
+    red[(wave * 3 + 0) * 64 + lane] = a0;
+    red[(wave * 3 + 1) * 64 + lane] = a1;
+    red[(wave * 3 + 2) * 64 + lane] = a2;
+    __syncthreads();
+    if (wave != 0 || !ok) return;
+    const int hs = h >> 1, wsk = w >> 1;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        float v = ((red[(0 * 3 + o) * 64 + lane] + red[(1 * 3 + o) * 64 + lane]) + (red[(2 * 3 + o) * 64 + lane] + red[(3 * 3 + o) * 64 + lane])) + bias[o];
+        if (skip) {
+            const int iy0 = (y - 1) >> 1, ix0 = (xx - 1) >> 1;
+            const int ky0 = 2 * iy0 + 2 - y, kx0 = 2 * ix0 + 2 - xx;
+            const float* sp = skip + ((size_t)b * 3 + o) * hs * wsk;
+            float u = 0.f;
+#pragma unroll
+            for (int ty = 0; ty < 2; ++ty) {
+                const int iy = iy0 + ty;
+                if (iy < 0 || iy >= hs) continue;
+#pragma unroll
+                for (int tx = 0; tx < 2; ++tx) {
+                    const int ix = ix0 + tx;
+                    if (ix < 0 || ix >= wsk) continue;
+                    u += sp[(size_t)iy * wsk + ix] * kf[(ky0 + 2 * ty) * 4 + kx0 + 2 * tx];
+                }
+            }
+            v += u;
+        }
+        out[((size_t)b * 3 + o) * hw + pix] = v;
+    }
+}
+
 extern "C" int e4s_region_torgb(float* out, const float* x, const float* wt, const float* s, const uint8_t* labels, int lh, int lw,
                                 const float* bias, const float* skip, const float* up_kernel, int bs, int cin, int h, int w, int nreg,
                                 void* stream) {
     E4S_REQUIRE(out && x && wt && s && bias, "region_torgb: null tensor");
-    E4S_REQUIRE(bs >= 0 && cin >= 1 && h >= 1 && w >= 4 && (w % 4) == 0, "region_torgb: width must be a multiple of 4");
+    E4S_REQUIRE(bs >= 0 && cin >= 1 && h >= 1 && w >= 1, "region_torgb: bad size");
     E4S_REQUIRE(nreg >= 1 && nreg <= E4S_MAX_REGIONS, "region_torgb: %d regions (max %d)", nreg, E4S_MAX_REGIONS);
     E4S_REQUIRE(labels || nreg == 1, "region_torgb: nreg > 1 needs a label map");
     E4S_REQUIRE(!skip || (up_kernel && (h % 2) == 0), "region_torgb: skip needs the 4x4 upsample kernel and even size");
     E4S_REQUIRE(bs <= 65535, "region_torgb: batch too large");
     if (bs == 0) return 0;
-    const size_t shm = ((size_t)nreg * cin + cin * 3 + 16) * sizeof(float);
+    const size_t shm = ((size_t)nreg * cin + cin * 3 + 16 + 4 * 3 * 64) * sizeof(float);
     E4S_REQUIRE(shm <= 64 * 1024, "region_torgb: style table does not fit LDS (cin=%d nreg=%d)", cin, nreg);
     const float lsy = labels ? (float)lh / (float)h : 1.f, lsx = labels ? (float)lw / (float)w : 1.f;
+    if ((w % 4) != 0 || (int64_t)h * w * bs < 262144) {  // small maps (or ragged widths): 64-pixel blocks, channels split over the waves
+        hipLaunchKernelGGL(region_torgb_splitc_kernel, dim3(cdiv(h * w, 64), bs), dim3(256), shm, (hipStream_t)stream, out, x, wt, s, labels, lh,
+                           lw, lsy, lsx, bias, skip, up_kernel, cin, h, w, nreg);
+        return check_launch("region_torgb");
+    }
     dim3 grid(cdiv(h * w / 4, 256), bs);
     if (!labels && nreg == 1)
         hipLaunchKernelGGL(region_torgb_kernel<true>, grid, dim3(256), shm, (hipStream_t)stream, out, x, wt, s, labels, lh, lw, lsy, lsx, bias,

@@ -1,0 +1,506 @@
+// a3/a4, fast path: region-aware 3x3 modulated conv on BF16 MFMA with SPLIT operands ("split-bf16").
+//
+// fp32 MFMA on gfx950 runs at 1/16 of the bf16 MFMA rate.  Every fp32 operand is therefore split into two bf16 numbers,
+//     a = a_hi + a_lo,   a_hi = bf16_rne(a),  a_lo = bf16_rne(a - a_hi)          (|a - a_hi - a_lo| <= 2^-17 |a|)
+// and a*b is evaluated as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with fp32 accumulation: three v_mfma_f32_32x32x16_bf16 per
+// 16-deep K step instead of eight v_mfma_f32_32x32x2_f32 — 5.3x less matrix-pipe time.  The dropped a_lo*b_lo term and the
+// representation error are ~2^-17 relative per product; measured end-to-end on the 1024x1024 generator (17 stacked layers,
+// tests/experiments/emulate_split_bf16.py): max-abs pixel error 8.2e-5 against the fp32 path, 12x inside the 1e-3 parity bar.
+//
+//   weights  : split once at preparation time into two K-major bf16 slabs  [par][Cin/16][tap][half][Cout][8]
+//   activation operand  B[k][pix] = x[ci][pix+tap] * s[region(pix)][ci] : multiplied in fp32 and split on the fly between
+//              the LDS read and the MFMA (4 VALU ops per element, hidden behind the 3 MFMAs it feeds)
+//   everything else (tiling, region lookup, split-K for small maps, epilogue) as in modconv.hip.
+//
+// Software pipeline: the global loads of chunk t+1 (x patch + both weight slabs) are issued into registers before chunk t
+// is computed and written to LDS after it, so HBM/L2 latency hides behind a whole chunk of MFMAs.
+#include <stdlib.h>
+
+#include "common.h"
+
+using namespace e4s;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int CKS = 16;  // input channels per K chunk (= one 16-deep MFMA step per tap)
+
+__device__ __forceinline__ unsigned pack_bf16_rne(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));  // v_cvt_pk_bf16_f32
+}
+// (t0, t1) -> packed hi pair, packed lo pair
+__device__ __forceinline__ void split2(float t0, float t1, unsigned& hi, unsigned& lo) {
+    hi = pack_bf16_rne(t0, t1);
+    const float h0 = __builtin_bit_cast(float, hi << 16);
+    const float h1 = __builtin_bit_cast(float, hi & 0xffff0000u);
+    lo = pack_bf16_rne(t0 - h0, t1 - h1);
+}
+
+// ============================================================================ weight preparation (split + re-layout)
+// whi/wlo[(((par*nchunk + chunk)*9 + tap)*2 + half)*cout + co][e]  <-  Weff[par][co][ci = chunk*16 + half*8 + e][tap] * scale
+__global__ __launch_bounds__(256) void prep_weights_sb_kernel(uint16_t* __restrict__ whi, uint16_t* __restrict__ wlo,
+                                                              const float* __restrict__ weight, const float* __restrict__ blur, int cout,
+                                                              int cin, int up, float scale) {
+    const int npar = up ? 4 : 1;
+    const int nchunk = (cin + CKS - 1) / CKS;
+    const int64_t total = (int64_t)npar * nchunk * 9 * 2 * cout * 8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int e = (int)(i & 7);
+        int64_t r = i >> 3;
+        const int co = (int)(r % cout); r /= cout;
+        const int half = (int)(r & 1); r >>= 1;
+        const int tap = (int)(r % 9); r /= 9;
+        const int chunk = (int)(r % nchunk);
+        const int par = (int)(r / nchunk);
+        const int ci = chunk * CKS + half * 8 + e;
+        float v = 0.f;
+        if (ci < cin) {
+            const float* w = weight + ((size_t)co * cin + ci) * 9;
+            if (!up) {
+                v = w[tap];
+            } else {  // transposed conv (stride 2) composed with the 4x4 blur: see modconv.hip / DESIGN.md §2
+                const int a = par >> 1, b = par & 1;
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int ty = ky + 2 * dy + 1 - a;
+                    if (ty < 0 || ty > 3) continue;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int tx = kx + 2 * dx + 1 - b;
+                        if (tx < 0 || tx > 3) continue;
+                        v += blur[(3 - ty) * 4 + (3 - tx)] * w[ky * 3 + kx];
+                    }
+                }
+            }
+            v *= scale;
+        }
+        const unsigned hp = pack_bf16_rne(v, 0.f) & 0xffffu;
+        const float hf = __builtin_bit_cast(float, hp << 16);
+        whi[i] = (uint16_t)hp;
+        wlo[i] = (uint16_t)(pack_bf16_rne(v - hf, 0.f) & 0xffffu);
+    }
+}
+
+__global__ __launch_bounds__(256) void wsq_sb_kernel(float* __restrict__ wsq, const float* __restrict__ weight, int cout, int cin, float scale) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cin * cout) return;
+    const int co = i % cout, ci = i / cout;
+    const float* w = weight + ((size_t)co * cin + ci) * 9;
+    float a = 0.f;
+    for (int t = 0; t < 9; ++t) {
+        const float v = w[t] * scale;
+        a += v * v;
+    }
+    wsq[i] = a;
+}
+
+extern "C" int e4s_modconv_prep_weights_sb(uint16_t* whi, uint16_t* wlo, float* wsq, const float* weight, const float* blur, int cout, int cin,
+                                           int up, void* stream) {
+    E4S_REQUIRE(whi && wlo && weight, "modconv_prep_weights_sb: null tensor");
+    E4S_REQUIRE(cout >= 1 && cin >= 1, "modconv_prep_weights_sb: bad channel counts");
+    E4S_REQUIRE(!up || blur, "modconv_prep_weights_sb: up-conv needs the 4x4 blur kernel");
+    const float scale = 1.0f / sqrtf((float)cin * 9.f);
+    const int64_t total = (int64_t)(up ? 4 : 1) * cdiv(cin, CKS) * 9 * 2 * cout * 8;
+    const int grid = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(prep_weights_sb_kernel, dim3(grid), dim3(256), 0, st, whi, wlo, weight, blur, cout, cin, up, scale);
+    if (wsq) hipLaunchKernelGGL(wsq_sb_kernel, dim3(cdiv(cin * cout, 256)), dim3(256), 0, st, wsq, weight, cout, cin, scale);
+    return check_launch("modconv_prep_weights_sb");
+}
+
+// ============================================================================ the conv kernel
+struct SbParams {
+    float* out;
+    const float* x;
+    const uint4* whi;  // bf16 x 8 per uint4
+    const uint4* wlo;
+    const float* s;
+    const float* d;
+    const uint8_t* labels;
+    const float* noise;
+    const float* noise_weight;
+    const float* act_bias;
+    int lh, lw;
+    float lscale_y, lscale_x;
+    int noise_bstride;
+    int act;
+    int bs, cin, cout, h, w, nreg, up;
+    int tiles_x, tiles_y;
+    int ksplit, chunks_per;  // split-K: block ks handles chunks [ks*chunks_per, (ks+1)*chunks_per)
+    float* partial;
+};
+
+template <int CB, int PB, int WC, int WP, int LOG_TW>
+struct SbCfg {
+    static constexpr int TN = WC * CB * 32;
+    static constexpr int NPB = WP * PB;
+    static constexpr int TW = 1 << LOG_TW;
+    static constexpr int RPB = 32 >> LOG_TW;
+    static constexpr int TH = NPB * RPB;
+    static constexpr int PW = TW + 2, PH = TH + 2;
+    static constexpr int PATCH = PH * PW;
+    static constexpr int EPT = (PATCH + 255) / 256;
+    static constexpr int XS_FLOATS = CKS * PATCH;
+    static constexpr int W4 = 2 * 9 * 2 * TN;               // uint4 per chunk: [hi/lo][tap][half][TN]
+    static constexpr int WPT = (W4 + 255) / 256;            // uint4 per thread
+    static constexpr int SS_FLOATS = E4S_MAX_REGIONS * CKS;
+    static constexpr int LDS_BYTES = XS_FLOATS * 4 + W4 * 16 + SS_FLOATS * 4;
+    static_assert(WC * WP == 4, "256-thread blocks");
+    static_assert(LDS_BYTES <= 64 * 1024, "static LDS limit");
+    static_assert(E4S_MAX_REGIONS * TN * 4 <= W4 * 16, "demod table overlays the weight stage");
+};
+
+// UNI = every output pixel of the launch has the same region (unmasked layers): x*s is then a property of the INPUT pixel, so it is
+// multiplied and split once while staging (each staged value feeds 9 taps) and kept in LDS as two bf16 planes [pixel][16 ch]; the
+// MFMA B operand is a single 16-byte LDS read per plane — no VALU in the main loop.  The two 16-byte halves of a pixel are swapped
+// on every other group of 8 pixels so that the ds_read_b128 of 16 consecutive pixels touches all 64 banks once.
+template <int CB, int PB, int WC, int WP, int LOG_TW, int MINW, bool UNI>
+__global__ __launch_bounds__(256, MINW) void region_modconv_sb_kernel(const SbParams p) {
+    using C = SbCfg<CB, PB, WC, WP, LOG_TW>;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[C::LDS_BYTES];
+    uint4* wsm = reinterpret_cast<uint4*>(lds_raw);                                   // [2][9][2][TN] uint4
+    float* xs = reinterpret_cast<float*>(lds_raw + C::W4 * 16);                       // [CKS][PATCH] fp32            (!UNI)
+    uint4* xh4 = reinterpret_cast<uint4*>(lds_raw + C::W4 * 16);                      // [PATCH][2] uint4 = 16 bf16   (UNI) hi plane
+    uint4* xl4 = xh4 + 2 * C::PATCH;                                                  //                                   lo plane
+    float* ss = xs + C::XS_FLOATS;                                                    // [MAX_REG][CKS]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l5 = lane & 31, khalf = lane >> 5;
+    const int wc = wave / WP, wp = wave % WP;
+
+    const int ntile = p.tiles_x * p.tiles_y;
+    const int npar = p.up ? 4 : 1;
+    const int ks = blockIdx.x / (ntile * npar);
+    const int bx = blockIdx.x - ks * ntile * npar;
+    const int tile = bx % ntile;
+    const int par = bx / ntile;
+    const int pa = par >> 1, pb_ = par & 1;
+    const int y0 = (tile / p.tiles_x) * C::TH, x0 = (tile % p.tiles_x) * C::TW;
+    const int co0 = blockIdx.y * C::TN;
+    const int b = blockIdx.z;
+    const int hw = p.h * p.w;
+    const int ho = p.up ? 2 * p.h : p.h, wo = p.up ? 2 * p.w : p.w;
+    const int nchunk = (p.cin + CKS - 1) / CKS;
+
+    int goff[C::EPT];
+    bool ginb[C::EPT];
+#pragma unroll
+    for (int j = 0; j < C::EPT; ++j) {
+        const int e = tid + j * 256;
+        const int py = e / C::PW, px = e - py * C::PW;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        ginb[j] = (e < C::PATCH) && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+        goff[j] = gy * p.w + gx;
+    }
+    const float* xb = p.x + (size_t)b * p.cin * hw;
+    const float* sb = p.s + (size_t)b * p.nreg * p.cin;
+
+    int xoff[PB], cls[PB];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int pbk = wp * PB + q;
+        const int ty = pbk * C::RPB + (l5 >> LOG_TW), tx = l5 & (C::TW - 1);
+        xoff[q] = ty * C::PW + tx;
+        const int y = y0 + ty, x = x0 + tx;
+        int c = 0;
+        if (p.labels) {
+            c = E4S_LABEL_NONE;
+            if (y < p.h && x < p.w) {
+                const int oy = p.up ? 2 * y + pa : y, ox = p.up ? 2 * x + pb_ : x;
+                c = p.labels[((size_t)b * p.lh + nearest_src(oy, p.lscale_y, p.lh)) * p.lw + nearest_src(ox, p.lscale_x, p.lw)];
+            }
+        }
+        cls[q] = (c < p.nreg) ? c : -1;
+    }
+
+    f32x16 acc[CB][PB];
+#pragma unroll
+    for (int i = 0; i < CB; ++i)
+#pragma unroll
+        for (int q = 0; q < PB; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.f;
+
+    // register stage of the NEXT chunk
+    float xr[CKS][C::EPT];
+    uint4 wr[C::WPT];
+    float sr = 0.f;
+
+    auto load_chunk = [&](int chunk) {
+        const int ci0 = chunk * CKS;
+#pragma unroll
+        for (int c = 0; c < CKS; ++c) {
+            const bool cok = ci0 + c < p.cin;
+            const float* xc = xb + (size_t)(ci0 + c) * hw;
+#pragma unroll
+            for (int j = 0; j < C::EPT; ++j) xr[c][j] = (cok && ginb[j]) ? xc[goff[j]] : 0.f;
+        }
+        const size_t wbase = ((size_t)par * nchunk + chunk) * 18 * p.cout;  // uint4 units: [tap][half][cout]
+#pragma unroll
+        for (int v = 0; v < C::WPT; ++v) {
+            const int idx = tid + v * 256;
+            uint4 val = make_uint4(0u, 0u, 0u, 0u);
+            if (idx < C::W4) {
+                const int hl = idx / (18 * C::TN);
+                const int rem = idx - hl * 18 * C::TN;
+                const int th = rem / C::TN, n = rem - th * C::TN;
+                if (co0 + n < p.cout) val = (hl ? p.wlo : p.whi)[wbase + (size_t)th * p.cout + co0 + n];
+            }
+            wr[v] = val;
+        }
+        if (tid < E4S_MAX_REGIONS * CKS) {
+            const int r = tid / CKS, c = tid % CKS;
+            sr = (r < p.nreg && ci0 + c < p.cin) ? sb[(size_t)r * p.cin + ci0 + c] : 0.f;
+        }
+    };
+    auto store_chunk = [&](int chunk) {
+        if constexpr (UNI) {
+            // s of the single region for the 16 channels of this chunk (wave-uniform loads)
+            float sc[CKS];
+#pragma unroll
+            for (int c = 0; c < CKS; ++c) sc[c] = (chunk * CKS + c < p.cin) ? sb[chunk * CKS + c] : 0.f;
+#pragma unroll
+            for (int j = 0; j < C::EPT; ++j) {
+                const int e = tid + j * 256;
+                if (e < C::PATCH) {
+                    unsigned h[8], l[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) split2(xr[2 * c][j] * sc[2 * c], xr[2 * c + 1][j] * sc[2 * c + 1], h[c], l[c]);
+                    const int sw = (e >> 3) & 1;
+                    xh4[e * 2 + (0 ^ sw)] = make_uint4(h[0], h[1], h[2], h[3]);
+                    xh4[e * 2 + (1 ^ sw)] = make_uint4(h[4], h[5], h[6], h[7]);
+                    xl4[e * 2 + (0 ^ sw)] = make_uint4(l[0], l[1], l[2], l[3]);
+                    xl4[e * 2 + (1 ^ sw)] = make_uint4(l[4], l[5], l[6], l[7]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CKS; ++c)
+#pragma unroll
+                for (int j = 0; j < C::EPT; ++j) {
+                    const int e = tid + j * 256;
+                    if (e < C::PATCH) xs[c * C::PATCH + e] = xr[c][j];
+                }
+        }
+#pragma unroll
+        for (int v = 0; v < C::WPT; ++v) {
+            const int idx = tid + v * 256;
+            if (idx < C::W4) wsm[idx] = wr[v];
+        }
+        if (!UNI && tid < E4S_MAX_REGIONS * CKS) ss[tid] = sr;
+    };
+
+    const int ch_begin = ks * p.chunks_per;
+    const int ch_end = (ch_begin + p.chunks_per < nchunk) ? ch_begin + p.chunks_per : nchunk;
+    if (ch_begin < ch_end) load_chunk(ch_begin);
+    for (int chunk = ch_begin; chunk < ch_end; ++chunk) {
+        __syncthreads();
+        store_chunk(chunk);
+        __syncthreads();
+        if (chunk + 1 < ch_end) load_chunk(chunk + 1);
+
+        // (!UNI) modulation of this lane's pixels for its 8 channels of the chunk: ci = 8*khalf + e
+        float sv[PB][8];
+        if constexpr (!UNI) {
+#pragma unroll
+            for (int q = 0; q < PB; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sv[q][e] = cls[q] >= 0 ? ss[cls[q] * CKS + khalf * 8 + e] : 0.f;
+        }
+        const float* xrow = xs + khalf * 8 * C::PATCH;
+        const uint4* whalf = wsm + khalf * C::TN + wc * CB * 32 + l5;   // + tap*2*TN, + 18*TN for the lo slab
+
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int toff = (tap / 3) * C::PW + (tap % 3);
+            uint4 bh[PB], bl[PB];
+#pragma unroll
+            for (int q = 0; q < PB; ++q) {
+                if constexpr (UNI) {
+                    const int e = xoff[q] + toff;
+                    const int slot = e * 2 + (khalf ^ ((e >> 3) & 1));
+                    bh[q] = xh4[slot];
+                    bl[q] = xl4[slot];
+                } else {
+                    float t[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = xrow[e * C::PATCH + xoff[q] + toff] * sv[q][e];
+                    split2(t[0], t[1], bh[q].x, bl[q].x);
+                    split2(t[2], t[3], bh[q].y, bl[q].y);
+                    split2(t[4], t[5], bh[q].z, bl[q].z);
+                    split2(t[6], t[7], bh[q].w, bl[q].w);
+                }
+            }
+            uint4 ah[CB], al[CB];
+#pragma unroll
+            for (int i = 0; i < CB; ++i) {
+                ah[i] = whalf[tap * 2 * C::TN + i * 32];
+                al[i] = whalf[18 * C::TN + tap * 2 * C::TN + i * 32];
+            }
+#pragma unroll
+            for (int i = 0; i < CB; ++i)
+#pragma unroll
+                for (int q = 0; q < PB; ++q)
+                    acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[q]), acc[i][q], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < CB; ++i)
+#pragma unroll
+                for (int q = 0; q < PB; ++q)
+                    acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[q]), acc[i][q], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < CB; ++i)
+#pragma unroll
+                for (int q = 0; q < PB; ++q)
+                    acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[q]), acc[i][q], 0, 0, 0);
+        }
+    }
+
+    if (p.ksplit > 1) {
+        float* part = p.partial + ((size_t)ks * p.bs + b) * p.cout * ho * wo;
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int pbk = wp * PB + q;
+            const int y = y0 + pbk * C::RPB + (l5 >> LOG_TW), x = x0 + (l5 & (C::TW - 1));
+            if (y >= p.h || x >= p.w) continue;
+            const size_t opix = (size_t)(p.up ? 2 * y + pa : y) * wo + (p.up ? 2 * x + pb_ : x);
+#pragma unroll
+            for (int i = 0; i < CB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + (wc * CB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    if (co < p.cout) part[(size_t)co * ho * wo + opix] = acc[i][q][r];
+                }
+        }
+        return;
+    }
+
+    __syncthreads();
+    float* dt = reinterpret_cast<float*>(lds_raw);  // [MAX_REG][TN] over the weight stage
+    for (int v = tid; v < E4S_MAX_REGIONS * C::TN; v += 256) {
+        const int r = v / C::TN, n = v % C::TN;
+        float val = 0.f;
+        if (r < p.nreg && co0 + n < p.cout) val = p.d ? p.d[((size_t)b * p.nreg + r) * p.cout + co0 + n] : 1.f;
+        dt[v] = val;
+    }
+    __syncthreads();
+    const float nw = p.noise ? p.noise_weight[0] : 0.f;
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int pbk = wp * PB + q;
+        const int y = y0 + pbk * C::RPB + (l5 >> LOG_TW), x = x0 + (l5 & (C::TW - 1));
+        if (y >= p.h || x >= p.w) continue;
+        const int oy = p.up ? 2 * y + pa : y, ox = p.up ? 2 * x + pb_ : x;
+        const size_t opix = (size_t)oy * wo + ox;
+        const float nz = p.noise ? nw * p.noise[(size_t)b * p.noise_bstride + opix] : 0.f;
+        const float* drow = dt + (cls[q] >= 0 ? cls[q] : 0) * C::TN;
+        const float dz = cls[q] >= 0 ? 1.f : 0.f;
+#pragma unroll
+        for (int i = 0; i < CB; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = (wc * CB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                const int co = co0 + n;
+                if (co < p.cout) {
+                    float v = acc[i][q][r] * drow[n] * dz + nz;
+                    if (p.act_bias) v += p.act_bias[co];
+                    if (p.act) v = (v > 0.f ? v : v * 0.2f) * 1.41421356237309515f;
+                    p.out[((size_t)b * p.cout + co) * ho * wo + opix] = v;
+                }
+            }
+        }
+    }
+}
+
+// Sum the K-slices in a fixed order and apply the StyledConv epilogue.
+__global__ __launch_bounds__(256) void modconv_sb_finalize_kernel(const SbParams p, int ho, int wo) {
+    const size_t ohw = (size_t)ho * wo;
+    const size_t per_b = (size_t)p.cout * ohw;
+    const size_t total = (size_t)p.bs * per_b;
+    const float nw = p.noise ? p.noise_weight[0] : 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int b = (int)(i / per_b);
+        const size_t r = i - (size_t)b * per_b;
+        const int co = (int)(r / ohw);
+        const size_t opix = r - (size_t)co * ohw;
+        const int oy = (int)(opix / wo), ox = (int)(opix - (size_t)oy * wo);
+        float a = 0.f;
+        for (int k = 0; k < p.ksplit; ++k) a += p.partial[(size_t)k * total + i];
+        int c = 0;
+        if (p.labels) c = p.labels[((size_t)b * p.lh + nearest_src(oy, p.lscale_y, p.lh)) * p.lw + nearest_src(ox, p.lscale_x, p.lw)];
+        float v = 0.f;
+        if (c < p.nreg) v = a * (p.d ? p.d[((size_t)b * p.nreg + c) * p.cout + co] : 1.f);
+        if (p.noise) v += nw * p.noise[(size_t)b * p.noise_bstride + opix];
+        if (p.act_bias) v += p.act_bias[co];
+        if (p.act) v = (v > 0.f ? v : v * 0.2f) * 1.41421356237309515f;
+        p.out[i] = v;
+    }
+}
+
+template <int CB, int PB, int WC, int WP, int LOG_TW>
+static int launch_sb(SbParams& p, hipStream_t st, float* workspace, int64_t workspace_floats) {
+    using C = SbCfg<CB, PB, WC, WP, LOG_TW>;
+    p.tiles_x = cdiv(p.w, C::TW);
+    p.tiles_y = cdiv(p.h, C::TH);
+    const int npar = p.up ? 4 : 1;
+    const int64_t base = (int64_t)p.tiles_x * p.tiles_y * npar * cdiv(p.cout, C::TN) * p.bs;
+    const int ho = p.up ? 2 * p.h : p.h, wo = p.up ? 2 * p.w : p.w;
+    const int64_t out_floats = (int64_t)p.bs * p.cout * ho * wo;
+    const int nchunk = cdiv(p.cin, CKS);
+    int ksplit = 1;
+    if (workspace && base < 384) {
+        while (ksplit < 16 && base * ksplit * 2 <= 1024 && ksplit * 2 <= nchunk && (int64_t)(ksplit * 2) * out_floats <= workspace_floats) ksplit *= 2;
+    }
+    p.ksplit = ksplit;
+    p.chunks_per = cdiv(nchunk, ksplit);
+    p.partial = workspace;
+    dim3 grid(p.tiles_x * p.tiles_y * npar * ksplit, cdiv(p.cout, C::TN), p.bs);
+    // tuning knob (A/B in one process): E4S_SB_MINWAVES=1 lets the register allocator use > 256 registers (1 wave/SIMD)
+    static const int minw = [] { const char* e = getenv("E4S_SB_MINWAVES"); return e ? atoi(e) : 2; }();
+    static const int uni_ok = [] { const char* e = getenv("E4S_SB_UNI"); return e ? atoi(e) : 1; }();
+    if (!p.labels && p.nreg == 1 && uni_ok)
+        hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, 2, true>), grid, dim3(256), 0, st, p);
+    else if (minw >= 2)
+        hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, 2, false>), grid, dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, 1, false>), grid, dim3(256), 0, st, p);
+    if (ksplit > 1) {
+        const int g = (int)(cdiv64(out_floats, 256) < 2048 ? cdiv64(out_floats, 256) : 2048);
+        hipLaunchKernelGGL(modconv_sb_finalize_kernel, dim3(g), dim3(256), 0, st, p, ho, wo);
+    }
+    return check_launch("region_modconv3x3_sb");
+}
+
+extern "C" int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16_t* whi, const uint16_t* wlo, const float* s, const float* d,
+                                        const uint8_t* labels, int lh, int lw, const float* noise, int noise_bs, const float* noise_weight,
+                                        const float* act_bias, int act, int bs, int cin, int cout, int h, int w, int nreg, int up,
+                                        float* workspace, int64_t workspace_floats, void* stream) {
+    E4S_REQUIRE(out && x && whi && wlo && s, "region_modconv3x3_sb: null tensor");
+    E4S_REQUIRE(bs >= 0 && cin >= 1 && cout >= 1 && h >= 1 && w >= 1, "region_modconv3x3_sb: bad size");
+    E4S_REQUIRE(nreg >= 1 && nreg <= E4S_MAX_REGIONS, "region_modconv3x3_sb: %d regions (max %d)", nreg, E4S_MAX_REGIONS);
+    E4S_REQUIRE(labels || nreg == 1, "region_modconv3x3_sb: nreg > 1 needs a label map");
+    E4S_REQUIRE(!labels || (lh >= 1 && lw >= 1), "region_modconv3x3_sb: bad label map size");
+    E4S_REQUIRE(!noise || (noise_weight && (noise_bs == 1 || noise_bs == bs)), "region_modconv3x3_sb: noise needs its weight and batch 1 or bs");
+    E4S_REQUIRE(bs <= 65535, "region_modconv3x3_sb: batch too large");
+    E4S_REQUIRE((((uintptr_t)whi | (uintptr_t)wlo) & 15) == 0, "region_modconv3x3_sb: weight slabs must be 16-byte aligned");
+    if (bs == 0) return 0;
+    SbParams p;
+    p.out = out; p.x = x; p.whi = reinterpret_cast<const uint4*>(whi); p.wlo = reinterpret_cast<const uint4*>(wlo); p.s = s; p.d = d;
+    p.labels = labels; p.noise = noise; p.noise_weight = noise_weight; p.act_bias = act_bias; p.lh = lh; p.lw = lw; p.act = act;
+    p.bs = bs; p.cin = cin; p.cout = cout; p.h = h; p.w = w; p.nreg = nreg; p.up = up ? 1 : 0;
+    const int ho = up ? 2 * h : h, wo = up ? 2 * w : w;
+    p.lscale_y = labels ? (float)lh / (float)ho : 1.f;
+    p.lscale_x = labels ? (float)lw / (float)wo : 1.f;
+    p.noise_bstride = (noise && noise_bs > 1) ? ho * wo : 0;
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = workspace;
+    const int64_t wf = workspace_floats;
+    if (w >= 32) {
+        if (cout > 32) return launch_sb<2, 2, 1, 4, 5>(p, st, ws, wf);   // 64 co x 256 px
+        return launch_sb<1, 2, 1, 4, 5>(p, st, ws, wf);                  // 32 co x 256 px
+    }
+    if (w >= 16) return launch_sb<1, 2, 2, 2, 4>(p, st, ws, wf);         // 64 co x 128 px (16 x 8)
+    if (w >= 8) return launch_sb<1, 1, 2, 2, 3>(p, st, ws, wf);          // 64 co x  64 px (8 x 8)
+    return launch_sb<1, 1, 2, 2, 2>(p, st, ws, wf);                      // 64 co x  64 px (4 x 16)
+}

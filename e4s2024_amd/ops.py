@@ -223,9 +223,15 @@ def mask_to_labels(mask: torch.Tensor, strict: Optional[bool] = None) -> torch.T
 
 
 # ------------------------------------------------------------------------- prepared weights
+# Arithmetic of the 3x3 modulated convolutions: "sb" = split-bf16 (3 bf16 MFMAs per fp32 product, fp32 accumulate; default),
+# "f32" = exact fp32 MFMA.  Both meet the 1e-3 pixel bar (sb: ~8e-5 end to end, f32: ~2e-5); f32 is ~3x slower.
+MODCONV_MODE = os.environ.get("E4S_MODCONV", "sb")
+
+
 class PreparedWeights:
     """K-major, scale-folded copy of a ModulatedConv2d weight (+ blur-composed parity kernels for up layers, + the
-    squared-sum table for demodulation).  Rebuilt when the parameter (or blur buffer) changes version or storage."""
+    squared-sum table for demodulation), as fp32 (``wt``) or as split-bf16 slabs (``wt = (whi, wlo)``).  Rebuilt when the
+    parameter (or blur buffer) changes version or storage, or the arithmetic mode changes."""
 
     __slots__ = ("key", "wt", "wsq")
 
@@ -233,17 +239,25 @@ class PreparedWeights:
         self.key, self.wt, self.wsq = None, None, None
 
     def get(self, weight: torch.Tensor, blur: Optional[torch.Tensor], up: bool, demodulate: bool):
-        key = (weight.data_ptr(), weight._version, weight.device, None if blur is None else (blur.data_ptr(), blur._version), up, demodulate)
+        sb = MODCONV_MODE == "sb" and weight.shape[-1] == 3
+        key = (weight.data_ptr(), weight._version, weight.device, None if blur is None else (blur.data_ptr(), blur._version), up, demodulate, sb)
         if key != self.key:
             w = _c(weight.detach(), "weight")
             _, cout, cin, k, _ = w.shape
             npar = 4 if up else 1
-            wt = torch.empty((npar, cin, k * k, cout), dtype=torch.float32, device=w.device)
             wsq = torch.empty((cin, cout), dtype=torch.float32, device=w.device) if demodulate else None
             bk = _c(blur, "blur kernel") if up else None
             if up and tuple(bk.shape) != (4, 4):
                 raise NotImplementedError(f"up-conv blur kernel must be 4x4, got {tuple(bk.shape)}")
-            lib().call("e4s_modconv_prep_weights", _p(wt), _p(wsq), _p(w), _p(bk), cout, cin, k, 1 if up else 0, _stream())
+            if sb:
+                shape = (npar, (cin + 15) // 16, 9, 2, cout, 8)
+                whi = torch.empty(shape, dtype=torch.int16, device=w.device)
+                wlo = torch.empty(shape, dtype=torch.int16, device=w.device)
+                lib().call("e4s_modconv_prep_weights_sb", _p(whi), _p(wlo), _p(wsq), _p(w), _p(bk), cout, cin, 1 if up else 0, _stream())
+                wt = (whi, wlo)
+            else:
+                wt = torch.empty((npar, cin, k * k, cout), dtype=torch.float32, device=w.device)
+                lib().call("e4s_modconv_prep_weights", _p(wt), _p(wsq), _p(w), _p(bk), cout, cin, k, 1 if up else 0, _stream())
             self.key, self.wt, self.wsq = key, wt, wsq
         return self.wt, self.wsq
 
@@ -297,10 +311,16 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
     if out.numel() <= SPLITK_MAX_OUT_FLOATS:
         wsn = 16 * out.numel()
         ws = _workspace(x.device, wsn)
-    ev = _timed(modconv_kernel_name(cout, w))
-    lib().call("e4s_region_modconv3x3", _p(out), _p(x), _p(wt), _p(s), _p(d), _p(labels), lh, lw, _p(nz), nbs or 0,
-               _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, 1 if up else 0,
-               _p(ws), wsn, _stream())
+    sb = isinstance(wt, tuple)
+    ev = _timed(modconv_kernel_name(cout, w, sb))
+    if sb:
+        lib().call("e4s_region_modconv3x3_sb", _p(out), _p(x), _p(wt[0]), _p(wt[1]), _p(s), _p(d), _p(labels), lh, lw, _p(nz), nbs or 0,
+                   _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, 1 if up else 0,
+                   _p(ws), wsn, _stream())
+    else:
+        lib().call("e4s_region_modconv3x3", _p(out), _p(x), _p(wt), _p(s), _p(d), _p(labels), lh, lw, _p(nz), nbs or 0,
+                   _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, 1 if up else 0,
+                   _p(ws), wsn, _stream())
     if ev is not None:
         ev.record()
     return out
@@ -575,8 +595,16 @@ def _timed(name: str):
     return b
 
 
-def modconv_kernel_name(cout: int, w: int) -> str:
-    """Template instantiation e4s_region_modconv3x3 dispatches to (mirrors the switch in csrc/modconv.hip)."""
+def modconv_kernel_name(cout: int, w: int, sb: Optional[bool] = None) -> str:
+    """Template instantiation the dispatch picks (mirrors the switches in csrc/modconv.hip and csrc/modconv_sb.hip)."""
+    if sb is None:
+        sb = MODCONV_MODE == "sb"
+    if sb:
+        if w >= 32:
+            cfg = "2,2,1,4,5" if cout > 32 else "1,2,1,4,5"
+        else:
+            cfg = "1,2,2,2,4" if w >= 16 else ("1,1,2,2,3" if w >= 8 else "1,1,2,2,2")
+        return f"region_modconv_sb_kernel<{cfg}>"
     if w >= 32:
         cfg = "2,2,2,2,5" if cout > 64 else ("2,2,1,4,5" if cout > 32 else "1,2,1,4,5")
     else:

@@ -96,6 +96,18 @@ E4S_API int e4s_region_modconv3x3(float* out, const float* x, const float* wt, c
                           int bs, int cin, int cout, int h, int w, int nreg, int up,
                           float* workspace, int64_t workspace_floats, void* stream);
 
+/* Split-bf16 variant of the two calls above (the default fast path; numerics in DESIGN.md §4): every fp32 operand is split into
+ * bf16 hi + bf16 lo and a*b is evaluated as hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation — 3 MFMAs at 16x the fp32
+ * MFMA rate.  whi / wlo : out, bf16 (as uint16) [npar][ceil(cin/16)][9][2][cout][8]: element (par, chunk, tap, half, co, e) holds input
+ * channel chunk*16 + half*8 + e (zero beyond cin).  k = 3 only.  All other arguments as e4s_modconv_prep_weights / e4s_region_modconv3x3. */
+E4S_API int e4s_modconv_prep_weights_sb(uint16_t* whi, uint16_t* wlo, float* wsq, const float* weight, const float* blur,
+                                        int cout, int cin, int up, void* stream);
+E4S_API int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16_t* whi, const uint16_t* wlo, const float* s, const float* d,
+                                     const uint8_t* labels, int lh, int lw,
+                                     const float* noise, int noise_bs, const float* noise_weight, const float* act_bias, int act,
+                                     int bs, int cin, int cout, int h, int w, int nreg, int up,
+                                     float* workspace, int64_t workspace_floats, void* stream);
+
 /* ToRGB forward in one pass (model.py:439-479): 1x1 modulated conv without demodulation, + bias, + upsampled skip.
  *   x : [bs, cin, h, w]   wt : [cin, 3] from e4s_modconv_prep_weights(k=1)   s : [bs, nreg, cin]   bias : [3]
  *   skip : previous RGB [bs, 3, h/2, w/2] or NULL; up_kernel : [4,4] FIR of Upsample (model.py:34-53; up=2, pad=(2,1))
