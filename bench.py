@@ -31,21 +31,26 @@ BATCH = 4
 
 
 def conv3x3_flops_per_face(size=1024):
-    """Algorithmic FLOPs of the 3x3 modulated convs per face, each counted once, keyed by kernel instantiation
-    (the transposed convs are counted per INPUT pixel)."""
+    """Algorithmic FLOPs of the 3x3 modulated convs per face, each counted once, keyed by the kernel that runs them
+    (the transposed convs are counted per INPUT pixel).  Layers up to 256x256 are masked (12 regions)."""
+    from e4s2024_amd import ops as _ops
     from e4s2024_amd.ops import modconv_kernel_name
     ch = {4: 512, 8: 512, 16: 512, 32: 512, 64: 512, 128: 256, 256: 128, 512: 64, 1024: 32}
     out = {}
 
-    def add(cout, w, fl):
-        k = modconv_kernel_name(cout, w)
+    def add(cout, w_in, fl, out_res, up):
+        masked = out_res <= 256
+        if up and not masked and _ops.MODCONV_MODE == "sb" and _ops.UP_TWO_STAGE:
+            k = "modconv_tconv_sb"
+        else:
+            k = modconv_kernel_name(cout, w_in, None, masked)
         out[k] = out.get(k, 0.0) + fl
-    add(512, 4, 2 * 512 * 512 * 9 * 16)
+    add(512, 4, 2 * 512 * 512 * 9 * 16, 4, False)
     cin, r = 512, 8
     while r <= size:
         co = ch[r]
-        add(co, r // 2, 2 * cin * co * 9 * (r // 2) ** 2)       # up-conv: launched on the input grid
-        add(co, r, 2 * co * co * 9 * r * r)
+        add(co, r // 2, 2 * cin * co * 9 * (r // 2) ** 2, r, True)      # up-conv: launched on the input grid
+        add(co, r, 2 * co * co * 9 * r * r, r, False)
         cin, r = co, r * 2
     return out
 

@@ -140,14 +140,15 @@ struct SbCfg {
     static constexpr int TH = NPB * RPB;
     static constexpr int PW = TW + 2, PH = TH + 2;
     static constexpr int PATCH = PH * PW;
-    static constexpr int EPT = (PATCH + 255) / 256;
+    static constexpr int NT = 64 * WC * WP;                 // threads per workgroup (256 or 512)
+    static constexpr int EPT = (PATCH + NT - 1) / NT;
     static constexpr int XS_FLOATS = CKS * PATCH;
     static constexpr int W4 = 2 * 9 * 2 * TN;               // uint4 per chunk: [hi/lo][tap][half][TN]
-    static constexpr int WPT = (W4 + 255) / 256;            // uint4 per thread
+    static constexpr int WPT = (W4 + NT - 1) / NT;          // uint4 per thread
     static constexpr int SS_FLOATS = E4S_MAX_REGIONS * CKS;
     static constexpr int LDS_BYTES = XS_FLOATS * 4 + W4 * 16 + SS_FLOATS * 4;
-    static_assert(WC * WP == 4, "256-thread blocks");
-    static_assert(LDS_BYTES <= 64 * 1024, "static LDS limit");
+    static_assert(WC * WP == 4 || WC * WP == 8, "256- or 512-thread workgroups");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS per CU");
     static_assert(E4S_MAX_REGIONS * TN * 4 <= W4 * 16, "demod table overlays the weight stage");
 };
 
@@ -155,10 +156,17 @@ struct SbCfg {
 // multiplied and split once while staging (each staged value feeds 9 taps) and kept in LDS as two bf16 planes [pixel][16 ch]; the
 // MFMA B operand is a single 16-byte LDS read per plane — no VALU in the main loop.  The two 16-byte halves of a pixel are swapped
 // on every other group of 8 pixels so that the ds_read_b128 of 16 consecutive pixels touches all 64 banks once.
-template <int CB, int PB, int WC, int WP, int LOG_TW, int MINW, bool UNI>
-__global__ __launch_bounds__(256, MINW) void region_modconv_sb_kernel(const SbParams p) {
+//
+// TCONV (single-region up layers only) = the stride-2 TRANSPOSED conv alone, at 1x its algorithmic MACs: the block's lanes sit on
+// an (h+1) x (w+1) grid of positions (a,b); tap (ky,kx) of the 3x3 kernel contributes W[ky][kx] * x[a-(ky>>1)][b-(kx>>1)] to the
+// pre-blur pixel z[2a+(ky&1)][2b+(kx&1)], so the 9 taps feed four accumulator sets (one per output parity) and the raw sums
+// are written to z [bs,cout,2h+1,2w+1]; e4s_blur_epilogue then applies blur, demodulation, noise, bias and activation.
+template <int CB, int PB, int WC, int WP, int LOG_TW, int MINW, bool UNI, bool TCONV>
+__global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(const SbParams p) {
+    static_assert(!TCONV || UNI, "the transposed-conv split is only built for single-region layers");
+    constexpr int NACC = TCONV ? 4 : 1;
     using C = SbCfg<CB, PB, WC, WP, LOG_TW>;
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[C::LDS_BYTES];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];           // C::LDS_BYTES, set at launch
     uint4* wsm = reinterpret_cast<uint4*>(lds_raw);                                   // [2][9][2][TN] uint4
     float* xs = reinterpret_cast<float*>(lds_raw + C::W4 * 16);                       // [CKS][PATCH] fp32            (!UNI)
     uint4* xh4 = reinterpret_cast<uint4*>(lds_raw + C::W4 * 16);                      // [PATCH][2] uint4 = 16 bf16   (UNI) hi plane
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(256, MINW) void region_modconv_sb_kernel(const SbPa
     bool ginb[C::EPT];
 #pragma unroll
     for (int j = 0; j < C::EPT; ++j) {
-        const int e = tid + j * 256;
+        const int e = tid + j * C::NT;
         const int py = e / C::PW, px = e - py * C::PW;
         const int gy = y0 - 1 + py, gx = x0 - 1 + px;
         ginb[j] = (e < C::PATCH) && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
@@ -215,13 +223,16 @@ __global__ __launch_bounds__(256, MINW) void region_modconv_sb_kernel(const SbPa
         cls[q] = (c < p.nreg) ? c : -1;
     }
 
-    f32x16 acc[CB][PB];
+    f32x16 accs[NACC][CB][PB];
 #pragma unroll
-    for (int i = 0; i < CB; ++i)
+    for (int a = 0; a < NACC; ++a)
 #pragma unroll
-        for (int q = 0; q < PB; ++q)
+        for (int i = 0; i < CB; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.f;
+            for (int q = 0; q < PB; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accs[a][i][q][r] = 0.f;
+    auto& acc = accs[0];
 
     // register stage of the NEXT chunk
     float xr[CKS][C::EPT];
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(256, MINW) void region_modconv_sb_kernel(const SbPa
         const size_t wbase = ((size_t)par * nchunk + chunk) * 18 * p.cout;  // uint4 units: [tap][half][cout]
 #pragma unroll
         for (int v = 0; v < C::WPT; ++v) {
-            const int idx = tid + v * 256;
+            const int idx = tid + v * C::NT;
             uint4 val = make_uint4(0u, 0u, 0u, 0u);
             if (idx < C::W4) {
                 const int hl = idx / (18 * C::TN);
@@ -263,7 +274,7 @@ __global__ __launch_bounds__(256, MINW) void region_modconv_sb_kernel(const SbPa
             for (int c = 0; c < CKS; ++c) sc[c] = (chunk * CKS + c < p.cin) ? sb[chunk * CKS + c] : 0.f;
 #pragma unroll
             for (int j = 0; j < C::EPT; ++j) {
-                const int e = tid + j * 256;
+                const int e = tid + j * C::NT;
                 if (e < C::PATCH) {
                     unsigned h[8], l[8];
 #pragma unroll
@@ -280,13 +291,13 @@ __global__ __launch_bounds__(256, MINW) void region_modconv_sb_kernel(const SbPa
             for (int c = 0; c < CKS; ++c)
 #pragma unroll
                 for (int j = 0; j < C::EPT; ++j) {
-                    const int e = tid + j * 256;
+                    const int e = tid + j * C::NT;
                     if (e < C::PATCH) xs[c * C::PATCH + e] = xr[c][j];
                 }
         }
 #pragma unroll
         for (int v = 0; v < C::WPT; ++v) {
-            const int idx = tid + v * 256;
+            const int idx = tid + v * C::NT;
             if (idx < C::W4) wsm[idx] = wr[v];
         }
         if (!UNI && tid < E4S_MAX_REGIONS * CKS) ss[tid] = sr;
@@ -314,7 +325,11 @@ __global__ __launch_bounds__(256, MINW) void region_modconv_sb_kernel(const SbPa
 
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int toff = (tap / 3) * C::PW + (tap % 3);
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int ky = tap / 3, kx = tap % 3;
+            const int toff = TCONV ? (1 - (ky >> 1)) * C::PW + (1 - (kx >> 1)) : ky * C::PW + kx;
+            const int ai = TCONV ? 2 * (ky & 1) + (kx & 1) : 0;
             uint4 bh[PB], bl[PB];
 #pragma unroll
             for (int q = 0; q < PB; ++q) {
@@ -343,18 +358,40 @@ __global__ __launch_bounds__(256, MINW) void region_modconv_sb_kernel(const SbPa
             for (int i = 0; i < CB; ++i)
 #pragma unroll
                 for (int q = 0; q < PB; ++q)
-                    acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[q]), acc[i][q], 0, 0, 0);
+                    accs[ai][i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[q]), accs[ai][i][q], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < CB; ++i)
 #pragma unroll
                 for (int q = 0; q < PB; ++q)
-                    acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[q]), acc[i][q], 0, 0, 0);
+                    accs[ai][i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[q]), accs[ai][i][q], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < CB; ++i)
 #pragma unroll
                 for (int q = 0; q < PB; ++q)
-                    acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[q]), acc[i][q], 0, 0, 0);
+                    accs[ai][i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[q]), accs[ai][i][q], 0, 0, 0);
         }
+    }
+
+    if constexpr (TCONV) {  // raw pre-blur sums: z[b][co][2a+i][2b+j], z is (2h+1) x (2w+1)
+        const int zh = 2 * p.h + 1, zw = 2 * p.w + 1;
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int pbk = wp * PB + q;
+            const int a = y0 + pbk * C::RPB + (l5 >> LOG_TW), bb = x0 + (l5 & (C::TW - 1));
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl) {
+                const int zy = 2 * a + (cl >> 1), zx = 2 * bb + (cl & 1);
+                if (zy >= zh || zx >= zw) continue;
+#pragma unroll
+                for (int i = 0; i < CB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = co0 + (wc * CB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                        if (co < p.cout) p.out[(((size_t)b * p.cout + co) * zh + zy) * zw + zx] = accs[cl][i][q][r];
+                    }
+            }
+        }
+        return;
     }
 
     if (p.ksplit > 1) {
@@ -378,7 +415,7 @@ __global__ __launch_bounds__(256, MINW) void region_modconv_sb_kernel(const SbPa
 
     __syncthreads();
     float* dt = reinterpret_cast<float*>(lds_raw);  // [MAX_REG][TN] over the weight stage
-    for (int v = tid; v < E4S_MAX_REGIONS * C::TN; v += 256) {
+    for (int v = tid; v < E4S_MAX_REGIONS * C::TN; v += C::NT) {
         const int r = v / C::TN, n = v % C::TN;
         float val = 0.f;
         if (r < p.nreg && co0 + n < p.cout) val = p.d ? p.d[((size_t)b * p.nreg + r) * p.cout + co0 + n] : 1.f;
@@ -439,6 +476,20 @@ __global__ __launch_bounds__(256) void modconv_sb_finalize_kernel(const SbParams
 }
 
 template <int CB, int PB, int WC, int WP, int LOG_TW>
+static int launch_sb_tconv(SbParams& p, hipStream_t st) {
+    using C = SbCfg<CB, PB, WC, WP, LOG_TW>;
+    p.tiles_x = cdiv(p.w + 1, C::TW);   // positions (a,b) run over (h+1) x (w+1)
+    p.tiles_y = cdiv(p.h + 1, C::TH);
+    p.up = 0;                            // one pass, no parity replication
+    p.ksplit = 1;
+    p.chunks_per = cdiv(p.cin, CKS);
+    p.partial = nullptr;
+    dim3 grid(p.tiles_x * p.tiles_y, cdiv(p.cout, C::TN), p.bs);
+    hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, 2, true, true>), grid, dim3(C::NT), C::LDS_BYTES, st, p);
+    return check_launch("modconv_tconv_sb");
+}
+
+template <int CB, int PB, int WC, int WP, int LOG_TW>
 static int launch_sb(SbParams& p, hipStream_t st, float* workspace, int64_t workspace_floats) {
     using C = SbCfg<CB, PB, WC, WP, LOG_TW>;
     p.tiles_x = cdiv(p.w, C::TW);
@@ -459,12 +510,19 @@ static int launch_sb(SbParams& p, hipStream_t st, float* workspace, int64_t work
     // tuning knob (A/B in one process): E4S_SB_MINWAVES=1 lets the register allocator use > 256 registers (1 wave/SIMD)
     static const int minw = [] { const char* e = getenv("E4S_SB_MINWAVES"); return e ? atoi(e) : 2; }();
     static const int uni_ok = [] { const char* e = getenv("E4S_SB_UNI"); return e ? atoi(e) : 1; }();
-    if (!p.labels && p.nreg == 1 && uni_ok)
-        hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, 2, true>), grid, dim3(256), 0, st, p);
+    constexpr bool BIG = C::LDS_BYTES > 64 * 1024;   // one workgroup per CU
+    constexpr int BIGW = C::NT / 256;                // waves per SIMD that workgroup provides
+    if (BIG) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, BIGW, false, false>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (attr != hipSuccess) return fail((int)attr, "region_modconv3x3_sb: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+        hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, BIGW, false, false>), grid, dim3(C::NT), C::LDS_BYTES, st, p);
+    } else if (!p.labels && p.nreg == 1 && uni_ok)
+        hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, 2, true, false>), grid, dim3(C::NT), C::LDS_BYTES, st, p);
     else if (minw >= 2)
-        hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, 2, false>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, 2, false, false>), grid, dim3(C::NT), C::LDS_BYTES, st, p);
     else
-        hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, 1, false>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, 1, false, false>), grid, dim3(C::NT), C::LDS_BYTES, st, p);
     if (ksplit > 1) {
         const int g = (int)(cdiv64(out_floats, 256) < 2048 ? cdiv64(out_floats, 256) : 2048);
         hipLaunchKernelGGL(modconv_sb_finalize_kernel, dim3(g), dim3(256), 0, st, p, ho, wo);
@@ -497,10 +555,104 @@ extern "C" int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16
     float* ws = workspace;
     const int64_t wf = workspace_floats;
     if (w >= 32) {
+        static const int wide = [] { const char* e = getenv("E4S_SB_WIDE"); return e ? atoi(e) : 1; }();
+        if (wide && labels && cout >= 128) return launch_sb<4, 1, 1, 8, 5>(p, st, ws, wf);   // 512 threads: 128 co x 256 px; on masked layers
+                                                                                              // the on-the-fly split of B feeds 12 MFMAs, not 6
         if (cout > 32) return launch_sb<2, 2, 1, 4, 5>(p, st, ws, wf);   // 64 co x 256 px
         return launch_sb<1, 2, 1, 4, 5>(p, st, ws, wf);                  // 32 co x 256 px
     }
     if (w >= 16) return launch_sb<1, 2, 2, 2, 4>(p, st, ws, wf);         // 64 co x 128 px (16 x 8)
     if (w >= 8) return launch_sb<1, 1, 2, 2, 3>(p, st, ws, wf);          // 64 co x  64 px (8 x 8)
     return launch_sb<1, 1, 2, 2, 2>(p, st, ws, wf);                      // 64 co x  64 px (4 x 16)
+}
+
+// ============================================================================ single-region up layer in two launches
+// (1) transposed conv only -> z [bs, cout, 2h+1, 2w+1] (raw sums, x already modulated by s);  whi/wlo from
+//     e4s_modconv_prep_weights_sb(..., up = 0) on the layer's 3x3 weight (NOT blur-composed).
+extern "C" int e4s_modconv_tconv_sb(float* z, const float* x, const uint16_t* whi, const uint16_t* wlo, const float* s, int bs, int cin, int cout,
+                                    int h, int w, void* stream) {
+    E4S_REQUIRE(z && x && whi && wlo && s, "modconv_tconv_sb: null tensor");
+    E4S_REQUIRE(bs >= 0 && bs <= 65535 && cin >= 1 && cout >= 1 && h >= 1 && w >= 1, "modconv_tconv_sb: bad size");
+    E4S_REQUIRE((((uintptr_t)whi | (uintptr_t)wlo) & 15) == 0, "modconv_tconv_sb: weight slabs must be 16-byte aligned");
+    if (bs == 0) return 0;
+    SbParams p;
+    memset(&p, 0, sizeof(p));
+    p.out = z; p.x = x; p.whi = reinterpret_cast<const uint4*>(whi); p.wlo = reinterpret_cast<const uint4*>(wlo); p.s = s;
+    p.bs = bs; p.cin = cin; p.cout = cout; p.h = h; p.w = w; p.nreg = 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (w + 1 > 16) {
+        if (cout > 32) return launch_sb_tconv<2, 1, 1, 4, 5>(p, st);   // 64 co x 128 positions, 4 parity accumulators
+        return launch_sb_tconv<1, 2, 1, 4, 5>(p, st);                  // 32 co x 256 positions
+    }
+    return launch_sb_tconv<1, 1, 2, 2, 4>(p, st);
+}
+
+// (2) out[b,co,p] = act( d[b,co] * sum_{ty,tx} z[b,co,py+ty-1,px+tx-1] * blur[3-ty][3-tx] + noise_w*noise[p] + bias[co] ),  zero padding:
+//     upfirdn2d(z, blur 4x4, pad (1,1)) of models/stylegan2/model.py:300 fused with the StyledConv epilogue (:419-421).
+// LDS-tiled: a block owns a 64 x 16 output tile of one (sample, channel) plane; the (16+3) x (64+3) pre-blur window is loaded
+// once with row-contiguous accesses (z rows are 2w+1 floats long, so nothing is 16-byte aligned in HBM) and each thread
+// produces 4 consecutive outputs from LDS.
+constexpr int BE_TW = 64, BE_TH = 16, BE_ZW = BE_TW + 3, BE_ZH = BE_TH + 3;
+
+__global__ __launch_bounds__(256) void blur_epilogue_kernel(float* __restrict__ out, const float* __restrict__ z, const float* __restrict__ blur,
+                                                            const float* __restrict__ d, const float* __restrict__ noise, int noise_bstride,
+                                                            const float* __restrict__ noise_weight, const float* __restrict__ act_bias, int act,
+                                                            int cout, int ho, int wo) {
+    __shared__ float kf[16];
+    __shared__ float zt[BE_ZH * BE_ZW];
+    if (threadIdx.x < 16) kf[threadIdx.x] = blur[15 - threadIdx.x];   // kf[ty*4+tx] = blur[3-ty][3-tx]
+    const int zh = ho + 1, zw = wo + 1;
+    const int plane = blockIdx.z;  // b*cout + co
+    const int b = plane / cout, co = plane - b * cout;
+    const int ox0 = blockIdx.x * BE_TW, oy0 = blockIdx.y * BE_TH;
+    const float* zp = z + (size_t)plane * zh * zw;
+    for (int e = threadIdx.x; e < BE_ZH * BE_ZW; e += 256) {
+        const int r = e / BE_ZW, c = e - r * BE_ZW;
+        const int zy = oy0 + r - 1, zx = ox0 + c - 1;
+        zt[e] = (zy >= 0 && zy < zh && zx >= 0 && zx < zw) ? zp[(size_t)zy * zw + zx] : 0.f;
+    }
+    __syncthreads();
+    const int lx = (threadIdx.x & 15) * 4, ly = threadIdx.x >> 4;
+    const int ox = ox0 + lx, oy = oy0 + ly;
+    if (ox >= wo || oy >= ho) return;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty) {
+        float row[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) row[j] = zt[(ly + ty) * BE_ZW + lx + j];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int tx = 0; tx < 4; ++tx) a[k] += row[k + tx] * kf[ty * 4 + tx];
+    }
+    const float dd = d ? d[plane] : 1.f;
+    const float nw = noise ? noise_weight[0] : 0.f;
+    const float bi = act_bias ? act_bias[co] : 0.f;
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float v = a[k] * dd + bi;
+        if (noise && ox + k < wo) v += nw * noise[(size_t)b * noise_bstride + (size_t)oy * wo + ox + k];
+        if (act) v = (v > 0.f ? v : v * 0.2f) * 1.41421356237309515f;
+        r[k] = v;
+    }
+    float* op = out + ((size_t)plane * ho + oy) * wo + ox;
+    if (ox + 3 < wo && (wo & 3) == 0) {
+        *reinterpret_cast<float4*>(op) = make_float4(r[0], r[1], r[2], r[3]);
+    } else {
+        for (int k = 0; k < 4 && ox + k < wo; ++k) op[k] = r[k];
+    }
+}
+
+extern "C" int e4s_blur_epilogue(float* out, const float* z, const float* blur, const float* d, const float* noise, int noise_bs,
+                                 const float* noise_weight, const float* act_bias, int act, int bs, int cout, int ho, int wo, void* stream) {
+    E4S_REQUIRE(out && z && blur, "blur_epilogue: null tensor");
+    E4S_REQUIRE(bs >= 0 && cout >= 1 && ho >= 1 && wo >= 1 && (int64_t)bs * cout <= 65535, "blur_epilogue: bad size");
+    E4S_REQUIRE(!noise || (noise_weight && (noise_bs == 1 || noise_bs == bs)), "blur_epilogue: noise needs its weight and batch 1 or bs");
+    if (bs == 0) return 0;
+    dim3 grid(cdiv(wo, BE_TW), cdiv(ho, BE_TH), bs * cout);
+    hipLaunchKernelGGL(blur_epilogue_kernel, grid, dim3(256), 0, (hipStream_t)stream, out, z, blur, d, noise, (noise && noise_bs > 1) ? ho * wo : 0,
+                       noise_weight, act_bias, act, cout, ho, wo);
+    return check_launch("blur_epilogue");
 }

@@ -132,6 +132,7 @@ class ModulatedConv2d(nn.Module):
         self.demodulate = demodulate
         self.fused = fused
         self._prepared = ops.PreparedWeights()
+        self._prepared_tconv = ops.PreparedWeights()
 
     def __repr__(self):
         return (f"{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, "
@@ -144,6 +145,13 @@ class ModulatedConv2d(nn.Module):
         return wt, s, d
 
     def forward_regions(self, input, styles, labels, noise=None, noise_weight=None, act_bias=None, act=False):
+        if self.upsample and labels is None and ops.MODCONV_MODE == "sb" and ops.UP_TWO_STAGE:
+            # single-region up layer: transposed conv at 1x its MACs into a pre-blur buffer, then blur + epilogue
+            wt, wsq = self._prepared_tconv.get(self.weight, None, False, self.demodulate, tconv=True)
+            s, d = ops.style_demod(styles, self.modulation.weight, self.modulation.bias, wsq, self.out_channel)
+            out = ops.modconv_up_single(input, wt, s, d, self.blur.kernel, noise, noise_weight, act_bias, act, self.out_channel)
+            return ops._attach("ModulatedConv2d", out, input, styles, self.weight, self.modulation.weight, self.modulation.bias, noise_weight,
+                               act_bias)
         wt, s, d = self.tables(styles)
         out = ops.region_modconv3x3(input, wt, s, d, labels, noise, noise_weight, act_bias, act, self.out_channel, self.upsample)
         return ops._attach("ModulatedConv2d", out, input, styles, self.weight, self.modulation.weight, self.modulation.bias, noise_weight,

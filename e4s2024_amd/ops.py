@@ -238,8 +238,11 @@ class PreparedWeights:
     def __init__(self):
         self.key, self.wt, self.wsq = None, None, None
 
-    def get(self, weight: torch.Tensor, blur: Optional[torch.Tensor], up: bool, demodulate: bool):
+    def get(self, weight: torch.Tensor, blur: Optional[torch.Tensor], up: bool, demodulate: bool, tconv: bool = False):
+        """``tconv``: slabs of the bare 3x3 weight of an up layer (for the transposed-conv + blur-epilogue pair)."""
         sb = MODCONV_MODE == "sb" and weight.shape[-1] == 3
+        if tconv:
+            up, blur = False, None
         key = (weight.data_ptr(), weight._version, weight.device, None if blur is None else (blur.data_ptr(), blur._version), up, demodulate, sb)
         if key != self.key:
             w = _c(weight.detach(), "weight")
@@ -260,6 +263,30 @@ class PreparedWeights:
                 lib().call("e4s_modconv_prep_weights", _p(wt), _p(wsq), _p(w), _p(bk), cout, cin, k, 1 if up else 0, _stream())
             self.key, self.wt, self.wsq = key, wt, wsq
         return self.wt, self.wsq
+
+
+UP_TWO_STAGE = os.environ.get("E4S_UP_TWO_STAGE", "1") != "0"
+
+
+def modconv_up_single(x, wt, s, d, blur, noise, noise_weight, act_bias, act: bool, cout: int) -> torch.Tensor:
+    """Single-region up layer: transposed conv (1x MACs) into a pre-blur buffer, then blur + demod + noise + bias + act."""
+    x = _c(x, "input")
+    bs, cin, h, w = x.shape
+    z = torch.empty((bs, cout, 2 * h + 1, 2 * w + 1), dtype=torch.float32, device=x.device)
+    out = torch.empty((bs, cout, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    nz = nbs = None
+    if noise is not None:
+        nz = _c(noise, "noise")
+        nbs = nz.shape[0]
+        if nz.numel() != nbs * 4 * h * w:
+            raise ValueError(f"noise shape {tuple(nz.shape)} does not match output {2 * h}x{2 * w}")
+    ev = _timed("modconv_tconv_sb")
+    lib().call("e4s_modconv_tconv_sb", _p(z), _p(x), _p(wt[0]), _p(wt[1]), _p(s), bs, cin, cout, h, w, _stream())
+    if ev is not None:
+        ev.record()
+    lib().call("e4s_blur_epilogue", _p(out), _p(z), _p(_c(blur, "blur kernel")), _p(d), _p(nz), nbs or 0,
+               _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cout, 2 * h, 2 * w, _stream())
+    return out
 
 
 def style_demod(styles: torch.Tensor, mod_weight: torch.Tensor, mod_bias: torch.Tensor, wsq: Optional[torch.Tensor], cout: int):
@@ -312,7 +339,7 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
         wsn = 16 * out.numel()
         ws = _workspace(x.device, wsn)
     sb = isinstance(wt, tuple)
-    ev = _timed(modconv_kernel_name(cout, w, sb))
+    ev = _timed(modconv_kernel_name(cout, w, sb, labels is not None))
     if sb:
         lib().call("e4s_region_modconv3x3_sb", _p(out), _p(x), _p(wt[0]), _p(wt[1]), _p(s), _p(d), _p(labels), lh, lw, _p(nz), nbs or 0,
                    _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, 1 if up else 0,
@@ -595,13 +622,14 @@ def _timed(name: str):
     return b
 
 
-def modconv_kernel_name(cout: int, w: int, sb: Optional[bool] = None) -> str:
+def modconv_kernel_name(cout: int, w: int, sb: Optional[bool] = None, masked: bool = True) -> str:
     """Template instantiation the dispatch picks (mirrors the switches in csrc/modconv.hip and csrc/modconv_sb.hip)."""
     if sb is None:
         sb = MODCONV_MODE == "sb"
     if sb:
         if w >= 32:
-            cfg = "2,2,1,4,5" if cout > 32 else "1,2,1,4,5"
+            wide = os.environ.get("E4S_SB_WIDE", "1") != "0"
+            cfg = "4,1,1,8,5" if (wide and masked and cout >= 128) else ("2,2,1,4,5" if cout > 32 else "1,2,1,4,5")
         else:
             cfg = "1,2,2,2,4" if w >= 16 else ("1,1,2,2,3" if w >= 8 else "1,1,2,2,2")
         return f"region_modconv_sb_kernel<{cfg}>"

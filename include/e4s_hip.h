@@ -108,6 +108,17 @@ E4S_API int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16_t*
                                      int bs, int cin, int cout, int h, int w, int nreg, int up,
                                      float* workspace, int64_t workspace_floats, void* stream);
 
+/* Single-region (unmasked) up layer at 1x the transposed conv's MACs, in two launches (the parity-composed kernel above spends 4x):
+ *   e4s_modconv_tconv_sb : z[bs,cout,2h+1,2w+1] = conv_transpose2d(x * s, W/sqrt(9 cin), stride 2)   (model.py:287-299; raw sums)
+ *                          whi/wlo from e4s_modconv_prep_weights_sb(up = 0) on the layer's 3x3 weight; s [bs,1,cin]
+ *   e4s_blur_epilogue    : out[bs,cout,ho,wo] = act( d * upfirdn2d(z, blur 4x4, pad (1,1)) + noise_weight*noise + act_bias )
+ *                          (model.py:300 + 419-421); d [bs,1,cout] or NULL; ho = 2h, wo = 2w */
+E4S_API int e4s_modconv_tconv_sb(float* z, const float* x, const uint16_t* whi, const uint16_t* wlo, const float* s,
+                                 int bs, int cin, int cout, int h, int w, void* stream);
+E4S_API int e4s_blur_epilogue(float* out, const float* z, const float* blur, const float* d,
+                              const float* noise, int noise_bs, const float* noise_weight, const float* act_bias, int act,
+                              int bs, int cout, int ho, int wo, void* stream);
+
 /* ToRGB forward in one pass (model.py:439-479): 1x1 modulated conv without demodulation, + bias, + upsampled skip.
  *   x : [bs, cin, h, w]   wt : [cin, 3] from e4s_modconv_prep_weights(k=1)   s : [bs, nreg, cin]   bias : [3]
  *   skip : previous RGB [bs, 3, h/2, w/2] or NULL; up_kernel : [4,4] FIR of Upsample (model.py:34-53; up=2, pad=(2,1))
