@@ -23,6 +23,7 @@ _PROTOS = {
     "e4s_onehot_to_labels": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_modconv_prep_weights": [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_style_demod": [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr],
+    "e4s_style_demod_batched": [c_ptr, c_int, c_int, c_int, c_ptr],
     "e4s_region_modconv3x3": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr, c_int] + [c_int] * 7 + [c_ptr, c_i64, c_ptr],
     "e4s_modconv_prep_weights_sb": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
     "e4s_region_modconv3x3_sb": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr, c_int] + [c_int] * 7 + [c_ptr, c_i64, c_ptr],
@@ -49,6 +50,12 @@ def declared_symbols(header: str = HEADER):
     """Names of every entry point declared in include/e4s_hip.h."""
     with open(header) as f:
         return re.findall(r"E4S_API\s+[\w\s\*]+?\b(e4s_\w+)\s*\(", f.read())
+
+
+class StyleJob(ctypes.Structure):
+    """Mirror of E4sStyleJob (include/e4s_hip.h)."""
+    _fields_ = [("s", c_ptr), ("d", c_ptr), ("styles", c_ptr), ("stride_b", c_i64), ("stride_r", c_i64), ("mod_weight", c_ptr),
+                ("mod_bias", c_ptr), ("wsq", c_ptr), ("nreg", c_int), ("cin", c_int), ("cout", c_int), ("_pad", c_int)]
 
 
 class _Lib:

@@ -185,6 +185,96 @@ extern "C" int e4s_style_demod(float* s, float* d, const float* styles, int64_t 
     return check_launch("style_demod");
 }
 
+// ---------------------------------------------------------------------------- all layers of a generator in two launches
+struct JobTable {
+    E4sStyleJob j[E4S_MAX_STYLE_JOBS];
+};
+
+__global__ __launch_bounds__(256) void style_batched_kernel(const JobTable t, int bs, int sdim, float scale) {
+    const E4sStyleJob& J = t.j[blockIdx.z];
+    const int lane = threadIdx.x & 63;
+    const int ci = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nbr = bs * J.nreg;
+    const int br0 = blockIdx.y * STYLE_ROWS;
+    if (ci >= J.cin || br0 >= nbr) return;
+    const float* wrow = J.mod_weight + (size_t)ci * sdim;
+    const float mb = J.mod_bias ? J.mod_bias[ci] : 0.f;
+    float acc[STYLE_ROWS];
+#pragma unroll
+    for (int q = 0; q < STYLE_ROWS; ++q) acc[q] = 0.f;
+    for (int j = lane; j < sdim; j += 64) {
+        const float wv = wrow[j];
+#pragma unroll
+        for (int q = 0; q < STYLE_ROWS; ++q) {
+            const int br = br0 + q;
+            if (br < nbr) {
+                const int b = br / J.nreg, r = br - b * J.nreg;
+                acc[q] += J.styles[b * J.stride_b + r * J.stride_r + j] * wv;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < STYLE_ROWS; ++q) {
+        const float a = wave_sum(acc[q]);
+        if (lane == 0 && br0 + q < nbr) J.s[(size_t)(br0 + q) * J.cin + ci] = a * scale + mb;
+    }
+}
+
+__global__ __launch_bounds__(256) void demod_batched_kernel(const JobTable t, int bs) {
+    const E4sStyleJob& J = t.j[blockIdx.z];
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int co = blockIdx.x * 64 + lane;
+    const int br = blockIdx.y;
+    if (!J.d || br >= bs * J.nreg || blockIdx.x * 64 >= J.cout) return;   // block-uniform exits
+    const float* sv = J.s + (size_t)br * J.cin;
+    const int per = (J.cin + 3) / 4;
+    const int c0 = wave * per, c1 = (c0 + per < J.cin) ? c0 + per : J.cin;
+    float a0 = 0.f, a1 = 0.f;
+    if (co < J.cout) {
+        int ci = c0;
+        for (; ci + 1 < c1; ci += 2) {
+            const float t0 = sv[ci], t1 = sv[ci + 1];
+            a0 += t0 * t0 * J.wsq[(size_t)ci * J.cout + co];
+            a1 += t1 * t1 * J.wsq[(size_t)(ci + 1) * J.cout + co];
+        }
+        if (ci < c1) {
+            const float t0 = sv[ci];
+            a0 += t0 * t0 * J.wsq[(size_t)ci * J.cout + co];
+        }
+    }
+    part[wave][lane] = a0 + a1;
+    __syncthreads();
+    if (wave == 0 && co < J.cout) J.d[(size_t)br * J.cout + co] = rsqrtf(((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) + 1e-8f);
+}
+
+extern "C" int e4s_style_demod_batched(const E4sStyleJob* jobs, int n_jobs, int bs, int sdim, void* stream) {
+    E4S_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= E4S_MAX_STYLE_JOBS, "style_demod_batched: 1..%d jobs", E4S_MAX_STYLE_JOBS);
+    E4S_REQUIRE(bs >= 0 && sdim >= 1, "style_demod_batched: bad size");
+    if (bs == 0) return 0;
+    JobTable t;
+    memset(&t, 0, sizeof(t));
+    int max_cin = 0, max_cout = 0, max_nbr = 0, any_d = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const E4sStyleJob& J = jobs[i];
+        E4S_REQUIRE(J.s && J.styles && J.mod_weight, "style_demod_batched: job %d has a null tensor", i);
+        E4S_REQUIRE(J.nreg >= 1 && J.nreg <= E4S_MAX_REGIONS && J.cin >= 1, "style_demod_batched: job %d has a bad size", i);
+        E4S_REQUIRE((J.d == nullptr) == (J.wsq == nullptr) && (!J.d || J.cout >= 1), "style_demod_batched: job %d: d and wsq go together", i);
+        t.j[i] = J;
+        max_cin = J.cin > max_cin ? J.cin : max_cin;
+        max_nbr = bs * J.nreg > max_nbr ? bs * J.nreg : max_nbr;
+        if (J.d) {
+            any_d = 1;
+            max_cout = J.cout > max_cout ? J.cout : max_cout;
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(style_batched_kernel, dim3(cdiv(max_cin, 4), cdiv(max_nbr, STYLE_ROWS), n_jobs), dim3(256), 0, st, t, bs, sdim,
+                       1.0f / sqrtf((float)sdim));
+    if (any_d) hipLaunchKernelGGL(demod_batched_kernel, dim3(cdiv(max_cout, 64), max_nbr, n_jobs), dim3(256), 0, st, t, bs);
+    return check_launch("style_demod_batched");
+}
+
 // ============================================================================ region-aware 3x3 modulated conv
 struct ConvParams {
     float* out;

@@ -168,7 +168,8 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
     using C = SbCfg<CB, PB, WC, WP, LOG_TW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];           // C::LDS_BYTES, set at launch
     uint4* wsm = reinterpret_cast<uint4*>(lds_raw);                                   // [2][9][2][TN] uint4
-    float* xs = reinterpret_cast<float*>(lds_raw + C::W4 * 16);                       // [CKS][PATCH] fp32            (!UNI)
+    float* xs = reinterpret_cast<float*>(lds_raw + C::W4 * 16);                       // (!UNI) [PATCH][16 ch] fp32, 16-B slots swizzled
+    float4* xf4 = reinterpret_cast<float4*>(lds_raw + C::W4 * 16);                    //        slot k (channels 4k..4k+3) of pixel e at e*4 + (k ^ ((e>>2)&3))
     uint4* xh4 = reinterpret_cast<uint4*>(lds_raw + C::W4 * 16);                      // [PATCH][2] uint4 = 16 bf16   (UNI) hi plane
     uint4* xl4 = xh4 + 2 * C::PATCH;                                                  //                                   lo plane
     float* ss = xs + C::XS_FLOATS;                                                    // [MAX_REG][CKS]
@@ -288,12 +289,14 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
             }
         } else {
 #pragma unroll
-            for (int c = 0; c < CKS; ++c)
+            for (int j = 0; j < C::EPT; ++j) {
+                const int e = tid + j * C::NT;
+                if (e < C::PATCH) {
+                    const int g = (e >> 2) & 3;
 #pragma unroll
-                for (int j = 0; j < C::EPT; ++j) {
-                    const int e = tid + j * C::NT;
-                    if (e < C::PATCH) xs[c * C::PATCH + e] = xr[c][j];
+                    for (int k = 0; k < 4; ++k) xf4[e * 4 + (k ^ g)] = make_float4(xr[4 * k][j], xr[4 * k + 1][j], xr[4 * k + 2][j], xr[4 * k + 3][j]);
                 }
+            }
         }
 #pragma unroll
         for (int v = 0; v < C::WPT; ++v) {
@@ -320,7 +323,6 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
 #pragma unroll
                 for (int e = 0; e < 8; ++e) sv[q][e] = cls[q] >= 0 ? ss[cls[q] * CKS + khalf * 8 + e] : 0.f;
         }
-        const float* xrow = xs + khalf * 8 * C::PATCH;
         const uint4* whalf = wsm + khalf * C::TN + wc * CB * 32 + l5;   // + tap*2*TN, + 18*TN for the lo slab
 
 #pragma unroll
@@ -339,13 +341,13 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
                     bh[q] = xh4[slot];
                     bl[q] = xl4[slot];
                 } else {
-                    float t[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) t[e] = xrow[e * C::PATCH + xoff[q] + toff] * sv[q][e];
-                    split2(t[0], t[1], bh[q].x, bl[q].x);
-                    split2(t[2], t[3], bh[q].y, bl[q].y);
-                    split2(t[4], t[5], bh[q].z, bl[q].z);
-                    split2(t[6], t[7], bh[q].w, bl[q].w);
+                    const int e = xoff[q] + toff;
+                    const int g = (e >> 2) & 3;
+                    const float4 x0 = xf4[e * 4 + ((2 * khalf) ^ g)], x1 = xf4[e * 4 + ((2 * khalf + 1) ^ g)];
+                    split2(x0.x * sv[q][0], x0.y * sv[q][1], bh[q].x, bl[q].x);
+                    split2(x0.z * sv[q][2], x0.w * sv[q][3], bh[q].y, bl[q].y);
+                    split2(x1.x * sv[q][4], x1.y * sv[q][5], bh[q].z, bl[q].z);
+                    split2(x1.z * sv[q][6], x1.w * sv[q][7], bh[q].w, bl[q].w);
                 }
             }
             uint4 ah[CB], al[CB];

@@ -138,21 +138,40 @@ class ModulatedConv2d(nn.Module):
         return (f"{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, "
                 f"upsample={self.upsample}, downsample={self.downsample})")
 
-    def tables(self, styles):
+    def _two_stage(self, masked):
+        return self.upsample and not masked and ops.MODCONV_MODE == "sb" and ops.UP_TWO_STAGE
+
+    def _weights(self, masked):
+        """Prepared weight slabs (+ the squared-sum table for demodulation) for the kernel this layer will run."""
+        if self._two_stage(masked):
+            return self._prepared_tconv.get(self.weight, None, False, self.demodulate, tconv=True)
+        return self._prepared.get(self.weight, self.blur.kernel if self.upsample else None, self.upsample, self.demodulate)
+
+    def table_job(self, styles, masked):
+        """Entry for ``ops.style_demod_plan``: this layer's (s, d) tables are then computed together with every other layer's."""
+        _, wsq = self._weights(masked)
+        return (id(self), styles, self.modulation.weight, self.modulation.bias, wsq, self.out_channel)
+
+    def _tables(self, styles, wsq):
+        planned = ops.style_demod_planned(id(self), styles)
+        if planned is not None:
+            return planned
+        return ops.style_demod(styles, self.modulation.weight, self.modulation.bias, wsq, self.out_channel)
+
+    def tables(self, styles, masked=True):
         """styles ``[bs, nreg, 512]`` → (wt, s, d) device tables for this layer."""
-        wt, wsq = self._prepared.get(self.weight, self.blur.kernel if self.upsample else None, self.upsample, self.demodulate)
-        s, d = ops.style_demod(styles, self.modulation.weight, self.modulation.bias, wsq, self.out_channel)
+        wt, wsq = self._weights(masked)
+        s, d = self._tables(styles, wsq)
         return wt, s, d
 
     def forward_regions(self, input, styles, labels, noise=None, noise_weight=None, act_bias=None, act=False):
-        if self.upsample and labels is None and ops.MODCONV_MODE == "sb" and ops.UP_TWO_STAGE:
+        if self._two_stage(labels is not None):
             # single-region up layer: transposed conv at 1x its MACs into a pre-blur buffer, then blur + epilogue
-            wt, wsq = self._prepared_tconv.get(self.weight, None, False, self.demodulate, tconv=True)
-            s, d = ops.style_demod(styles, self.modulation.weight, self.modulation.bias, wsq, self.out_channel)
+            wt, s, d = self.tables(styles, masked=False)
             out = ops.modconv_up_single(input, wt, s, d, self.blur.kernel, noise, noise_weight, act_bias, act, self.out_channel)
             return ops._attach("ModulatedConv2d", out, input, styles, self.weight, self.modulation.weight, self.modulation.bias, noise_weight,
                                act_bias)
-        wt, s, d = self.tables(styles)
+        wt, s, d = self.tables(styles, masked=labels is not None)
         out = ops.region_modconv3x3(input, wt, s, d, labels, noise, noise_weight, act_bias, act, self.out_channel, self.upsample)
         return ops._attach("ModulatedConv2d", out, input, styles, self.weight, self.modulation.weight, self.modulation.bias, noise_weight,
                            act_bias)
@@ -298,6 +317,27 @@ class Generator(nn.Module):
 
         self.n_latent = self.log_size * 2 - 2
 
+    def _table_jobs(self, latent):
+        """(layer, W+ slice) pairs in the order ``forward`` visits them — reference :661-690."""
+        rli = self.remaining_layer_idx
+
+        def job(layer, masked, idx):
+            st = latent[:, :, idx] if masked else latent[:, 0, idx][:, None, :]
+            return layer.conv.table_job(st, masked)
+        jobs = [job(self.conv1, True, 0), job(self.to_rgb1, True, 1)]
+        for j, to_rgb in enumerate(self.to_rgbs):
+            i = 2 * j + 1
+            per_region = i < rli
+            for conv, idx in ((self.convs[2 * j], i), (self.convs[2 * j + 1], i + 1)):
+                if conv.mask_op != per_region:
+                    return []          # inconsistent configuration (even remaining_layer_idx): let the per-layer path raise
+                jobs.append(job(conv, per_region, idx))
+            single = (not per_region) or (rli != 17 and i + 2 == rli)
+            if to_rgb.mask_op == single:
+                return []
+            jobs.append(job(to_rgb, not single, i + 2))
+        return jobs
+
     def make_noise(self):
         device = self.input.input.device
         noises = [torch.randn(1, 1, 2 ** 2, 2 ** 2, device=device)]
@@ -341,6 +381,8 @@ class Generator(nn.Module):
             latent = torch.cat([latent, latent2], 1)
 
         rli = self.remaining_layer_idx
+        if latent.ndim == 4 and latent.is_cuda:
+            ops.style_demod_plan(self._table_jobs(latent))     # every layer's modulation / demodulation table in two launches
         out = self.input(latent)
         out = self.conv1(out, latent[:, :, 0], mask, noise=noise[0])
         skip = self.to_rgb1(out, latent[:, :, 1], mask)
@@ -359,6 +401,7 @@ class Generator(nn.Module):
             single = (not per_region) or (rli != 17 and i + 2 == rli)   # reference :681-688
             skip = to_rgb(out, latent[:, 0, i + 2] if single else latent[:, :, i + 2], mask, skip)
 
+        ops._table_plan.clear()
         image = skip
         if return_latents:
             return image, latent, intermediate_feats

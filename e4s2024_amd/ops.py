@@ -289,6 +289,54 @@ def modconv_up_single(x, wt, s, d, blur, noise, noise_weight, act_bias, act: boo
     return out
 
 
+_table_plan = {}     # id(ModulatedConv2d) -> (styles data_ptr/shape/stride key, s, d); filled by style_demod_plan for one forward
+
+
+def style_demod_plan(jobs):
+    """jobs: list of (key, styles [bs,nreg,sdim], mod_weight, mod_bias, wsq or None, cout).  Computes every layer's (s, d) in two
+    launches and remembers them under ``key`` for the ``style_demod`` calls of the same forward pass."""
+    from ._lib import StyleJob
+    _table_plan.clear()
+    if not jobs:
+        return
+    bs, _, sdim = jobs[0][1].shape
+    dev = jobs[0][1].device
+    n_s = sum(bs * j[1].shape[1] * j[2].shape[0] for j in jobs)
+    n_d = sum(bs * j[1].shape[1] * j[5] for j in jobs if j[4] is not None)
+    sbuf = torch.empty(n_s, dtype=torch.float32, device=dev)
+    dbuf = torch.empty(max(n_d, 1), dtype=torch.float32, device=dev)
+    arr = (StyleJob * len(jobs))()
+    so = do = 0
+    keep = []
+    for i, (key, styles, mw, mb, wsq, cout) in enumerate(jobs):
+        _req(styles, "style")
+        if styles.stride(-1) != 1 or tuple(styles.shape[::2]) != (bs, sdim):
+            raise ValueError("style_demod_plan: all styles must be [bs, nreg, sdim] with unit inner stride")
+        nreg, cin = styles.shape[1], mw.shape[0]
+        mwc, mbc = _c(mw.detach(), "modulation.weight"), _c(mb.detach(), "modulation.bias")
+        keep += [mwc, mbc]
+        s_t = sbuf[so: so + bs * nreg * cin].view(bs, nreg, cin)
+        so += bs * nreg * cin
+        d_t = None
+        if wsq is not None:
+            d_t = dbuf[do: do + bs * nreg * cout].view(bs, nreg, cout)
+            do += bs * nreg * cout
+        arr[i] = StyleJob(s_t.data_ptr(), None if d_t is None else d_t.data_ptr(), styles.data_ptr(), styles.stride(0), styles.stride(1),
+                          mwc.data_ptr(), mbc.data_ptr(), None if wsq is None else wsq.data_ptr(), nreg, cin, cout, 0)
+        _table_plan[key] = ((styles.data_ptr(), tuple(styles.shape), styles.stride(), styles._version), s_t, d_t)
+    for i0 in range(0, len(jobs), 32):
+        n = min(32, len(jobs) - i0)
+        lib().call("e4s_style_demod_batched", ctypes.byref(arr, i0 * ctypes.sizeof(StyleJob)), n, bs, sdim, _stream())
+    del keep
+
+
+def style_demod_planned(key, styles):
+    ent = _table_plan.get(key)
+    if ent is not None and ent[0] == (styles.data_ptr(), tuple(styles.shape), styles.stride(), styles._version):
+        return ent[1], ent[2]
+    return None
+
+
 def style_demod(styles: torch.Tensor, mod_weight: torch.Tensor, mod_bias: torch.Tensor, wsq: Optional[torch.Tensor], cout: int):
     """styles ``[bs, nreg, sdim]`` (any batch/region strides, unit inner stride) → (s ``[bs,nreg,cin]``, d ``[bs,nreg,cout]`` or None)."""
     _req(styles, "style")

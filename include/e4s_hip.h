@@ -79,6 +79,22 @@ E4S_API int e4s_style_demod(float* s, float* d, const float* styles, int64_t str
                     const float* mod_weight, const float* mod_bias, const float* wsq,
                     int bs, int nreg, int cin, int cout, int sdim, void* stream);
 
+/* The same for up to E4S_MAX_STYLE_JOBS layers in two launches (all 26 modulated convs of a 1024x1024 generator: their W+ codes
+ * are known before the first layer runs).  jobs is a HOST array; every pointer inside is a device pointer with the meaning of the
+ * e4s_style_demod argument of the same name (d/wsq NULL for demodulate=False). */
+#define E4S_MAX_STYLE_JOBS 32
+typedef struct E4sStyleJob {
+    float* s;
+    float* d;
+    const float* styles;
+    int64_t stride_b, stride_r;
+    const float* mod_weight;
+    const float* mod_bias;
+    const float* wsq;
+    int nreg, cin, cout, _pad;
+} E4sStyleJob;
+E4S_API int e4s_style_demod_batched(const E4sStyleJob* jobs, int n_jobs, int bs, int sdim, void* stream);
+
 /* StyledConv forward in one pass (model.py:382-423): 3x3 modulated conv (same resolution, or x2 up-conv
  * + blur when up != 0) with per-pixel region modulation, demodulation, noise injection, bias, leaky-relu*sqrt2.
  *   x       : [bs, cin, h, w]            out : [bs, cout, ho, wo]  (ho = h, or 2h when up)
