@@ -129,6 +129,13 @@ struct SbParams {
     int tiles_x, tiles_y;
     int ksplit, chunks_per;  // split-K: block ks handles chunks [ks*chunks_per, (ks+1)*chunks_per)
     float* partial;
+    // optional fused single-region ToRGB (model.py:439-479) on this layer's output; needs the whole Cout in one workgroup
+    float* rgb_out;          // [bs,3,ho,wo]
+    const float* rgb_wt;     // [cout][3]  (e4s_modconv_prep_weights, k = 1)
+    const float* rgb_s;      // [bs][cout]
+    const float* rgb_bias;   // [3]
+    const float* rgb_skip;   // [bs,3,ho/2,wo/2] or NULL
+    const float* rgb_upk;    // [4,4]
 };
 
 template <int CB, int PB, int WC, int WP, int LOG_TW>
@@ -149,7 +156,7 @@ struct SbCfg {
     static constexpr int LDS_BYTES = XS_FLOATS * 4 + W4 * 16 + SS_FLOATS * 4;
     static_assert(WC * WP == 4 || WC * WP == 8, "256- or 512-thread workgroups");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS per CU");
-    static_assert(E4S_MAX_REGIONS * TN * 4 <= W4 * 16, "demod table overlays the weight stage");
+    static_assert((E4S_MAX_REGIONS + 3) * TN * 4 + 64 <= W4 * 16, "demod + ToRGB tables overlay the weight stage");
 };
 
 // UNI = every output pixel of the launch has the same region (unmasked layers): x*s is then a property of the INPUT pixel, so it is
@@ -161,7 +168,7 @@ struct SbCfg {
 // an (h+1) x (w+1) grid of positions (a,b); tap (ky,kx) of the 3x3 kernel contributes W[ky][kx] * x[a-(ky>>1)][b-(kx>>1)] to the
 // pre-blur pixel z[2a+(ky&1)][2b+(kx&1)], so the 9 taps feed four accumulator sets (one per output parity) and the raw sums
 // are written to z [bs,cout,2h+1,2w+1]; e4s_blur_epilogue then applies blur, demodulation, noise, bias and activation.
-template <int CB, int PB, int WC, int WP, int LOG_TW, int MINW, bool UNI, bool TCONV>
+template <int CB, int PB, int WC, int WP, int LOG_TW, int MINW, bool UNI, bool TCONV, bool RGB = false>
 __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(const SbParams p) {
     static_assert(!TCONV || UNI, "the transposed-conv split is only built for single-region layers");
     constexpr int NACC = TCONV ? 4 : 1;
@@ -423,29 +430,76 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
         if (r < p.nreg && co0 + n < p.cout) val = p.d ? p.d[((size_t)b * p.nreg + r) * p.cout + co0 + n] : 1.f;
         dt[v] = val;
     }
+    float* wsr = dt + E4S_MAX_REGIONS * C::TN;   // [TN][3]: ToRGB weight x its (single-region) modulation
+    float* kfr = wsr + 3 * C::TN;                // [16] flipped skip-upsample taps
+    if constexpr (RGB) {
+        for (int v = tid; v < 3 * C::TN; v += C::NT) {
+            const int n = v / 3;
+            wsr[v] = (co0 + n < p.cout) ? p.rgb_wt[(size_t)(co0 + n) * 3 + (v - n * 3)] * p.rgb_s[(size_t)b * p.cout + co0 + n] : 0.f;
+        }
+        if (tid < 16) kfr[tid] = p.rgb_upk ? p.rgb_upk[15 - tid] : 0.f;
+    }
     __syncthreads();
     const float nw = p.noise ? p.noise_weight[0] : 0.f;
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
         const int pbk = wp * PB + q;
         const int y = y0 + pbk * C::RPB + (l5 >> LOG_TW), x = x0 + (l5 & (C::TW - 1));
-        if (y >= p.h || x >= p.w) continue;
+        const bool pix_ok = y < p.h && x < p.w;
         const int oy = p.up ? 2 * y + pa : y, ox = p.up ? 2 * x + pb_ : x;
         const size_t opix = (size_t)oy * wo + ox;
-        const float nz = p.noise ? nw * p.noise[(size_t)b * p.noise_bstride + opix] : 0.f;
+        const float nz = (p.noise && pix_ok) ? nw * p.noise[(size_t)b * p.noise_bstride + opix] : 0.f;
         const float* drow = dt + (cls[q] >= 0 ? cls[q] : 0) * C::TN;
         const float dz = cls[q] >= 0 ? 1.f : 0.f;
+        float rgb0 = 0.f, rgb1 = 0.f, rgb2 = 0.f;
 #pragma unroll
         for (int i = 0; i < CB; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = (wc * CB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                 const int co = co0 + n;
-                if (co < p.cout) {
+                if (co < p.cout && pix_ok) {
                     float v = acc[i][q][r] * drow[n] * dz + nz;
                     if (p.act_bias) v += p.act_bias[co];
                     if (p.act) v = (v > 0.f ? v : v * 0.2f) * 1.41421356237309515f;
                     p.out[((size_t)b * p.cout + co) * ho * wo + opix] = v;
+                    if constexpr (RGB) {
+                        rgb0 += v * wsr[n * 3 + 0];
+                        rgb1 += v * wsr[n * 3 + 1];
+                        rgb2 += v * wsr[n * 3 + 2];
+                    }
+                }
+            }
+        }
+        if constexpr (RGB) {  // WC == 1: this wave holds every output channel of its pixels, split over the two half-waves
+            rgb0 += __shfl_xor(rgb0, 32, 64);
+            rgb1 += __shfl_xor(rgb1, 32, 64);
+            rgb2 += __shfl_xor(rgb2, 32, 64);
+            if (khalf == 0 && pix_ok) {
+                const int hs = ho >> 1, wsk = wo >> 1;
+                float rv[3] = {rgb0, rgb1, rgb2};
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    float v = rv[o] + p.rgb_bias[o];
+                    if (p.rgb_skip) {  // upfirdn2d(skip, up=2, pad=(2,1)) at (oy, ox): see region_torgb_kernel
+                        const int iy0 = (oy - 1) >> 1, ix0 = (ox - 1) >> 1;
+                        const int ky0 = 2 * iy0 + 2 - oy, kx0 = 2 * ix0 + 2 - ox;
+                        const float* sp = p.rgb_skip + ((size_t)b * 3 + o) * hs * wsk;
+                        float u = 0.f;
+#pragma unroll
+                        for (int ty = 0; ty < 2; ++ty) {
+                            const int iy = iy0 + ty;
+                            if (iy < 0 || iy >= hs) continue;
+#pragma unroll
+                            for (int tx = 0; tx < 2; ++tx) {
+                                const int ix = ix0 + tx;
+                                if (ix < 0 || ix >= wsk) continue;
+                                u += sp[(size_t)iy * wsk + ix] * kfr[(ky0 + 2 * ty) * 4 + kx0 + 2 * tx];
+                            }
+                        }
+                        v += u;
+                    }
+                    p.rgb_out[((size_t)b * 3 + o) * ho * wo + opix] = v;
                 }
             }
         }
@@ -505,6 +559,10 @@ static int launch_sb(SbParams& p, hipStream_t st, float* workspace, int64_t work
     if (workspace && base < 384) {
         while (ksplit < 16 && base * ksplit * 2 <= 1024 && ksplit * 2 <= nchunk && (int64_t)(ksplit * 2) * out_floats <= workspace_floats) ksplit *= 2;
     }
+    if (p.rgb_out) {
+        if (WC != 1 || p.cout > C::TN || p.up) return fail(E4S_ERR_ARG, "region_modconv3x3_sb: fused ToRGB needs all %d output channels in one workgroup tile", p.cout);
+        ksplit = 1;
+    }
     p.ksplit = ksplit;
     p.chunks_per = cdiv(nchunk, ksplit);
     p.partial = workspace;
@@ -512,6 +570,21 @@ static int launch_sb(SbParams& p, hipStream_t st, float* workspace, int64_t work
     // tuning knob (A/B in one process): E4S_SB_MINWAVES=1 lets the register allocator use > 256 registers (1 wave/SIMD)
     static const int minw = [] { const char* e = getenv("E4S_SB_MINWAVES"); return e ? atoi(e) : 2; }();
     static const int uni_ok = [] { const char* e = getenv("E4S_SB_UNI"); return e ? atoi(e) : 1; }();
+    if (p.rgb_out) {
+        if constexpr (WC == 1) {
+            constexpr int MW = C::NT / 256 >= 2 ? 2 : 2;
+            if (C::LDS_BYTES > 64 * 1024) {
+                static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, MW, false, false, true>),
+                                                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+                if (attr2 != hipSuccess) return fail((int)attr2, "region_modconv3x3_sb: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr2));
+            }
+            if (!p.labels && p.nreg == 1)
+                hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, MW, true, false, true>), grid, dim3(C::NT), C::LDS_BYTES, st, p);
+            else
+                hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, MW, false, false, true>), grid, dim3(C::NT), C::LDS_BYTES, st, p);
+            return check_launch("region_modconv3x3_sb");
+        }
+    }
     constexpr bool BIG = C::LDS_BYTES > 64 * 1024;   // one workgroup per CU
     constexpr int BIGW = C::NT / 256;                // waves per SIMD that workgroup provides
     if (BIG) {
@@ -535,8 +608,10 @@ static int launch_sb(SbParams& p, hipStream_t st, float* workspace, int64_t work
 extern "C" int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16_t* whi, const uint16_t* wlo, const float* s, const float* d,
                                         const uint8_t* labels, int lh, int lw, const float* noise, int noise_bs, const float* noise_weight,
                                         const float* act_bias, int act, int bs, int cin, int cout, int h, int w, int nreg, int up,
-                                        float* workspace, int64_t workspace_floats, void* stream) {
+                                        float* workspace, int64_t workspace_floats, float* rgb_out, const float* rgb_wt, const float* rgb_s,
+                                        const float* rgb_bias, const float* rgb_skip, const float* rgb_up_kernel, void* stream) {
     E4S_REQUIRE(out && x && whi && wlo && s, "region_modconv3x3_sb: null tensor");
+    E4S_REQUIRE(!rgb_out || (rgb_wt && rgb_s && rgb_bias && (!rgb_skip || rgb_up_kernel) && w >= 32 && !up), "region_modconv3x3_sb: incomplete fused-ToRGB arguments");
     E4S_REQUIRE(bs >= 0 && cin >= 1 && cout >= 1 && h >= 1 && w >= 1, "region_modconv3x3_sb: bad size");
     E4S_REQUIRE(nreg >= 1 && nreg <= E4S_MAX_REGIONS, "region_modconv3x3_sb: %d regions (max %d)", nreg, E4S_MAX_REGIONS);
     E4S_REQUIRE(labels || nreg == 1, "region_modconv3x3_sb: nreg > 1 needs a label map");
@@ -553,6 +628,7 @@ extern "C" int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16
     p.lscale_y = labels ? (float)lh / (float)ho : 1.f;
     p.lscale_x = labels ? (float)lw / (float)wo : 1.f;
     p.noise_bstride = (noise && noise_bs > 1) ? ho * wo : 0;
+    p.rgb_out = rgb_out; p.rgb_wt = rgb_wt; p.rgb_s = rgb_s; p.rgb_bias = rgb_bias; p.rgb_skip = rgb_skip; p.rgb_upk = rgb_up_kernel;
     hipStream_t st = (hipStream_t)stream;
     float* ws = workspace;
     const int64_t wf = workspace_floats;

@@ -164,7 +164,7 @@ class ModulatedConv2d(nn.Module):
         s, d = self._tables(styles, wsq)
         return wt, s, d
 
-    def forward_regions(self, input, styles, labels, noise=None, noise_weight=None, act_bias=None, act=False):
+    def forward_regions(self, input, styles, labels, noise=None, noise_weight=None, act_bias=None, act=False, rgb=None):
         if self._two_stage(labels is not None):
             # single-region up layer: transposed conv at 1x its MACs into a pre-blur buffer, then blur + epilogue
             wt, s, d = self.tables(styles, masked=False)
@@ -172,7 +172,10 @@ class ModulatedConv2d(nn.Module):
             return ops._attach("ModulatedConv2d", out, input, styles, self.weight, self.modulation.weight, self.modulation.bias, noise_weight,
                                act_bias)
         wt, s, d = self.tables(styles, masked=labels is not None)
-        out = ops.region_modconv3x3(input, wt, s, d, labels, noise, noise_weight, act_bias, act, self.out_channel, self.upsample)
+        out = ops.region_modconv3x3(input, wt, s, d, labels, noise, noise_weight, act_bias, act, self.out_channel, self.upsample, rgb=rgb)
+        if rgb is not None:
+            return tuple(ops._attach("ModulatedConv2d", o, input, styles, self.weight, self.modulation.weight, self.modulation.bias,
+                                     noise_weight, act_bias) for o in out)
         return ops._attach("ModulatedConv2d", out, input, styles, self.weight, self.modulation.weight, self.modulation.bias, noise_weight,
                            act_bias)
 
@@ -222,7 +225,9 @@ class StyledConv(nn.Module):
         self.activate = FusedLeakyReLU(out_channel)
         self.mask_op = mask_op
 
-    def forward(self, input, style, mask, noise=None):
+    def forward(self, input, style, mask, noise=None, _fused_rgb=None):
+        """``_fused_rgb=(to_rgb, rgb_style [bs,512], skip)`` (engine-internal, used by ``Generator.forward``) also evaluates that
+        single-region ToRGB in this layer's epilogue and returns ``(out, rgb)``."""
         bs, _, H, W = input.shape
         H_out, W_out = (H * 2, W * 2) if self.conv.upsample else (H, W)
         if noise is None:  # reference :331-333
@@ -237,7 +242,12 @@ class StyledConv(nn.Module):
                 raise ValueError(f"unmasked StyledConv expects style [bs, 512], got {tuple(style.shape)}")
             labels = None
             styles = style[:, None, :]
-        return self.conv.forward_regions(input, styles, labels, noise, self.noise.weight, self.activate.bias, act=True)
+        rgb = None
+        if _fused_rgb is not None:
+            to_rgb, rgb_style, skip = _fused_rgb
+            r_wt, r_s, _ = to_rgb.conv.tables(rgb_style[:, None, :])
+            rgb = (r_wt, r_s, to_rgb.bias, skip, to_rgb.upsample.kernel if skip is not None else None)
+        return self.conv.forward_regions(input, styles, labels, noise, self.noise.weight, self.activate.bias, act=True, rgb=rgb)
 
 
 class ToRGB(nn.Module):
@@ -397,9 +407,15 @@ class Generator(nn.Module):
                 if use_structure_code:
                     out = structure_feats
                 intermediate_feats = out
-            out = self.convs[2 * j + 1](out, code(i + 1), mask, noise=noise[2 + 2 * j])
             single = (not per_region) or (rli != 17 and i + 2 == rli)   # reference :681-688
-            skip = to_rgb(out, latent[:, 0, i + 2] if single else latent[:, :, i + 2], mask, skip)
+            conv2 = self.convs[2 * j + 1]
+            if (single and not to_rgb.mask_op and out.is_cuda and tuple(to_rgb.upsample.kernel.shape) == (4, 4)
+                    and ops.can_fuse_rgb(conv2.conv.out_channel, out.shape[-1], False, conv2.mask_op)):
+                # the single-region ToRGB rides in the conv's epilogue: the activation is not read back for the 1x1 conv
+                out, skip = conv2(out, code(i + 1), mask, noise=noise[2 + 2 * j], _fused_rgb=(to_rgb, latent[:, 0, i + 2], skip))
+            else:
+                out = conv2(out, code(i + 1), mask, noise=noise[2 + 2 * j])
+                skip = to_rgb(out, latent[:, 0, i + 2] if single else latent[:, :, i + 2], mask, skip)
 
         ops._table_plan.clear()
         image = skip

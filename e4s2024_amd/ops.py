@@ -365,7 +365,20 @@ def _workspace(device, floats: int) -> torch.Tensor:
     return ws
 
 
-def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: bool, cout: int, up: bool) -> torch.Tensor:
+# Fusing the single-region ToRGB into the preceding conv's epilogue is correct but measured neutral on MI355X (the longer epilogue
+# costs what the separate HBM-bound ToRGB launch costs), so it is off by default.
+FUSE_RGB = os.environ.get("E4S_FUSE_RGB", "0") != "0"
+
+
+def can_fuse_rgb(cout: int, w: int, up: bool, masked: bool) -> bool:
+    """Can the single-region ToRGB that follows a layer ride in its epilogue?  (the layer's Cout must fit one workgroup tile)"""
+    wide = os.environ.get("E4S_SB_WIDE", "1") != "0"
+    return FUSE_RGB and MODCONV_MODE == "sb" and not up and w >= 32 and (cout <= 64 or (masked and wide and cout == 128))
+
+
+def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: bool, cout: int, up: bool, rgb=None):
+    """``rgb = (wt_rgb [cout,3], s_rgb [bs,1,cout], bias [1,3,1,1], skip or None, up_kernel)`` fuses the following single-region
+    ToRGB; the call then returns ``(out, rgb_image)``."""
     x = _c(x, "input")
     bs, cin, h, w = x.shape
     nreg = s.shape[1]
@@ -388,17 +401,29 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
         ws = _workspace(x.device, wsn)
     sb = isinstance(wt, tuple)
     ev = _timed(modconv_kernel_name(cout, w, sb, labels is not None))
+    rgb_out = None
+    if rgb is not None:
+        if not sb:
+            raise RuntimeError("fused ToRGB needs the split-bf16 kernel")
+        r_wt, r_s, r_bias, r_skip, r_upk = rgb
+        rgb_out = torch.empty((bs, 3, ho, wo), dtype=torch.float32, device=x.device)
+        if r_skip is not None and tuple(r_skip.shape) != (bs, 3, ho // 2, wo // 2):
+            raise ValueError(f"skip shape {tuple(r_skip.shape)} != {(bs, 3, ho // 2, wo // 2)}")
+        rgb_args = (_p(rgb_out), _p(r_wt), _p(r_s), _p(_c(r_bias.detach(), "bias")), _p(_c(r_skip, "skip")) if r_skip is not None else None,
+                    _p(_c(r_upk, "upsample.kernel")) if r_skip is not None else None)
+    else:
+        rgb_args = (None,) * 6
     if sb:
         lib().call("e4s_region_modconv3x3_sb", _p(out), _p(x), _p(wt[0]), _p(wt[1]), _p(s), _p(d), _p(labels), lh, lw, _p(nz), nbs or 0,
                    _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, 1 if up else 0,
-                   _p(ws), wsn, _stream())
+                   _p(ws), wsn, *rgb_args, _stream())
     else:
         lib().call("e4s_region_modconv3x3", _p(out), _p(x), _p(wt), _p(s), _p(d), _p(labels), lh, lw, _p(nz), nbs or 0,
                    _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, 1 if up else 0,
                    _p(ws), wsn, _stream())
     if ev is not None:
         ev.record()
-    return out
+    return out if rgb is None else (out, rgb_out)
 
 
 def region_torgb(x, wt, s, labels, bias, skip, up_kernel) -> torch.Tensor:

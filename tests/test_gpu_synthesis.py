@@ -162,3 +162,21 @@ def test_g8_cal_style_codes(gpu_net3):
         c3 = gpu_net3.cal_style_codes(v.to(DEV))
     sd = {k: p.detach().cpu() for k, p in gpu_net3.state_dict().items() if k.startswith("MLPs.")}
     assert maxdiff(c3, O.cal_style_codes(sd, v, seeded.seeded_latent_avg(2, 18), 13)) <= 5e-5
+
+
+def test_fused_torgb_epilogue_matches_separate_launch(gpu_net3):
+    """The optional fusion of the single-region ToRGBs (256/512/1024) into the conv epilogue gives the same image."""
+    if _ops.MODCONV_MODE != "sb":
+        pytest.skip("fused ToRGB exists on the split-bf16 kernel only")
+    codes, mask = _config2_inputs(2)
+    codes, mask = codes.to(DEV), mask.to(DEV)
+    old = _ops.FUSE_RGB
+    try:
+        with torch.no_grad():
+            _ops.FUSE_RGB = False
+            a, _, _ = gpu_net3.gen_img(None, codes, mask, randomize_noise=False)
+            _ops.FUSE_RGB = True
+            b, _, _ = gpu_net3.gen_img(None, codes, mask, randomize_noise=False)
+    finally:
+        _ops.FUSE_RGB = old
+    assert (a - b).abs().max().item() <= 2e-5
