@@ -274,3 +274,342 @@ extern "C" int e4s_conv2d(float* out, const float* x0, const float* x1, int cin0
     if (ks == 7 && stride == 2) return dispatch2d<7, 2, 2>(p, st);
     return fail(E4S_ERR_ARG, "conv2d: kernel %dx%d stride %d not supported", ks, ks, stride);
 }
+
+// ====================================================================================================================
+// Split-bf16 variant (see modconv_sb.hip for the numerics): operands split into bf16 hi + lo, a*b = hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The activation operand does not depend on the output pixel here, so it is
+// transformed (InstanceNorm-on-load), split ONCE while staging and kept in LDS as two bf16 planes [patch pixel][16 channels];
+// the main loop is LDS reads + MFMAs only.  Weights are split at preparation time: [Cin/16][tap][half][Cout][8] bf16 x 2.
+// Used for every 3x3 / 1x1 convolution with Cin >= 16 (the 3-channel stems stay on the fp32 kernel above).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+constexpr int CKS2 = 16;
+
+__device__ __forceinline__ unsigned c2_pack_bf16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
+}
+__device__ __forceinline__ void c2_split2(float t0, float t1, unsigned& hi, unsigned& lo) {
+    hi = c2_pack_bf16(t0, t1);
+    lo = c2_pack_bf16(t0 - __builtin_bit_cast(float, hi << 16), t1 - __builtin_bit_cast(float, hi & 0xffff0000u));
+}
+
+__global__ __launch_bounds__(256) void conv_prep_sb_kernel(uint16_t* __restrict__ whi, uint16_t* __restrict__ wlo, float* __restrict__ bias_out,
+                                                           const float* __restrict__ weight, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ mean,
+                                                           const float* __restrict__ var, float eps, const float* __restrict__ conv_bias,
+                                                           int cout, int cin, int kk) {
+    const int nchunk = (cin + CKS2 - 1) / CKS2;
+    const int64_t total = (int64_t)nchunk * kk * 2 * cout * 8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int e = (int)(i & 7);
+        int64_t r = i >> 3;
+        const int co = (int)(r % cout); r /= cout;
+        const int half = (int)(r & 1); r >>= 1;
+        const int tap = (int)(r % kk);
+        const int chunk = (int)(r / kk);
+        const int ci = chunk * CKS2 + half * 8 + e;
+        float v = 0.f;
+        if (ci < cin) {
+            const float g = var ? gamma[co] / sqrtf(var[co] + eps) : 1.f;
+            v = weight[((size_t)co * cin + ci) * kk + tap] * g;
+        }
+        const unsigned hp = c2_pack_bf16(v, 0.f) & 0xffffu;
+        whi[i] = (uint16_t)hp;
+        wlo[i] = (uint16_t)(c2_pack_bf16(v - __builtin_bit_cast(float, hp << 16), 0.f) & 0xffffu);
+    }
+    if (bias_out) {
+        for (int co = blockIdx.x * 256 + threadIdx.x; co < cout; co += gridDim.x * 256) {
+            const float g = var ? gamma[co] / sqrtf(var[co] + eps) : 1.f;
+            float b = var ? beta[co] - mean[co] * g : 0.f;
+            if (conv_bias) b += conv_bias[co] * g;
+            bias_out[co] = b;
+        }
+    }
+}
+
+extern "C" int e4s_conv_prep_weights_sb(uint16_t* whi, uint16_t* wlo, float* bias_out, const float* weight, const float* bn_gamma,
+                                        const float* bn_beta, const float* bn_mean, const float* bn_var, float bn_eps, const float* conv_bias,
+                                        int cout, int cin, int kh, int kw, void* stream) {
+    E4S_REQUIRE(whi && wlo && weight, "conv_prep_weights_sb: null tensor");
+    E4S_REQUIRE(cout >= 1 && cin >= 1 && kh >= 1 && kw >= 1, "conv_prep_weights_sb: bad size");
+    const bool bn = bn_var != nullptr;
+    E4S_REQUIRE(!bn || (bn_gamma && bn_beta && bn_mean && bias_out), "conv_prep_weights_sb: BatchNorm fold needs gamma, beta, mean, var and bias_out");
+    E4S_REQUIRE(!conv_bias || bias_out, "conv_prep_weights_sb: conv bias needs bias_out");
+    const int64_t total = (int64_t)cdiv(cin, CKS2) * kh * kw * 2 * cout * 8;
+    const int grid = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
+    hipLaunchKernelGGL(conv_prep_sb_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, whi, wlo, bias_out, weight, bn_gamma, bn_beta, bn_mean,
+                       bn_var, bn_eps, conv_bias, cout, cin, kh * kw);
+    return check_launch("conv_prep_weights_sb");
+}
+
+struct Conv2dSbParams {
+    float* out;
+    const float* x0;
+    const float* x1;
+    const uint4* whi;
+    const uint4* wlo;
+    const float* bias;
+    const float* in_mean;
+    const float* in_rstd;
+    const float* slope;
+    const float* residual;
+    int act;
+    int bs, cin, cin0, cout, h, w, ho, wo, pad;
+    int tiles_x, tiles_y;
+};
+
+template <int KS, int S, int CB, int PB, int WC, int WP, int LOG_TW>
+struct C2SbCfg {
+    static constexpr int KK = KS * KS;
+    static constexpr int TN = WC * CB * 32;
+    static constexpr int NPB = WP * PB;
+    static constexpr int TW = 1 << LOG_TW;
+    static constexpr int RPB = 32 >> LOG_TW;
+    static constexpr int TH = NPB * RPB;
+    static constexpr int PW = (TW - 1) * S + KS, PH = (TH - 1) * S + KS;
+    static constexpr int PATCH = PH * PW;
+    static constexpr int EPT = (PATCH + 255) / 256;
+    static constexpr int W4 = 2 * KK * 2 * TN;       // uint4: [hi/lo][tap][half][TN]
+    static constexpr int WPT = (W4 + 255) / 256;
+    static constexpr int LDS_BYTES = W4 * 16 + PATCH * 64;
+    static_assert(WC * WP == 4, "256-thread blocks");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS per CU");
+};
+
+template <int KS, int S, int CB, int PB, int WC, int WP, int LOG_TW>
+__global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams p) {
+    using C = C2SbCfg<KS, S, CB, PB, WC, WP, LOG_TW>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint4* wsm = reinterpret_cast<uint4*>(lds_raw);                 // [2][KK][2][TN]
+    uint4* xh4 = reinterpret_cast<uint4*>(lds_raw + C::W4 * 16);    // [PATCH][2]: 16 bf16 (hi) per patch pixel, halves swizzled
+    uint4* xl4 = xh4 + 2 * C::PATCH;                                // lo plane
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l5 = lane & 31, khalf = lane >> 5;
+    const int wc = wave / WP, wp = wave % WP;
+    const int tile = blockIdx.x;
+    const int oy0 = (tile / p.tiles_x) * C::TH, ox0 = (tile % p.tiles_x) * C::TW;
+    const int co0 = blockIdx.y * C::TN;
+    const int b = blockIdx.z;
+    const int hw = p.h * p.w;
+    const int iy0 = oy0 * S - p.pad, ix0 = ox0 * S - p.pad;
+    const int nchunk = (p.cin + CKS2 - 1) / CKS2;
+
+    int goff[C::EPT];
+    bool ginb[C::EPT];
+#pragma unroll
+    for (int j = 0; j < C::EPT; ++j) {
+        const int e = tid + j * 256;
+        const int py = e / C::PW, px = e - py * C::PW;
+        const int gy = iy0 + py, gx = ix0 + px;
+        ginb[j] = (e < C::PATCH) && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+        goff[j] = gy * p.w + gx;
+    }
+    const int cin1 = p.cin - p.cin0;
+    const float* xb0 = p.x0 + (size_t)b * p.cin0 * hw;
+    const float* xb1 = p.x1 ? p.x1 + (size_t)b * cin1 * hw : nullptr;
+
+    int xoff[PB];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int pbk = wp * PB + q;
+        const int ty = pbk * C::RPB + (l5 >> LOG_TW), tx = l5 & (C::TW - 1);
+        xoff[q] = ty * S * C::PW + tx * S;
+    }
+
+    f32x16 acc[CB][PB];
+#pragma unroll
+    for (int i = 0; i < CB; ++i)
+#pragma unroll
+        for (int q = 0; q < PB; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.f;
+
+    float xr[CKS2][C::EPT];
+    uint4 wr[C::WPT];
+
+    auto load_chunk = [&](int chunk) {
+        const int ci0 = chunk * CKS2;
+#pragma unroll
+        for (int c = 0; c < CKS2; ++c) {
+            const int ci = ci0 + c;
+            const bool cok = ci < p.cin;
+            const float* xc = (ci < p.cin0) ? xb0 + (size_t)ci * hw : xb1 + (size_t)(ci - p.cin0) * hw;
+#pragma unroll
+            for (int j = 0; j < C::EPT; ++j) xr[c][j] = (cok && ginb[j]) ? xc[goff[j]] : 0.f;
+        }
+        const size_t wbase = (size_t)chunk * C::KK * 2 * p.cout;
+#pragma unroll
+        for (int v = 0; v < C::WPT; ++v) {
+            const int idx = tid + v * 256;
+            uint4 val = make_uint4(0u, 0u, 0u, 0u);
+            if (idx < C::W4) {
+                const int hl = idx / (C::KK * 2 * C::TN);
+                const int rem = idx - hl * C::KK * 2 * C::TN;
+                const int th = rem / C::TN, n = rem - th * C::TN;
+                if (co0 + n < p.cout) val = (hl ? p.wlo : p.whi)[wbase + (size_t)th * p.cout + co0 + n];
+            }
+            wr[v] = val;
+        }
+    };
+    auto store_chunk = [&](int chunk) {
+        const int ci0 = chunk * CKS2;
+        float mu[CKS2], rs[CKS2];
+#pragma unroll
+        for (int c = 0; c < CKS2; ++c) {
+            const bool on = p.in_mean && ci0 + c < p.cin;
+            mu[c] = on ? p.in_mean[(size_t)b * p.cin + ci0 + c] : 0.f;
+            rs[c] = on ? p.in_rstd[(size_t)b * p.cin + ci0 + c] : 1.f;
+        }
+#pragma unroll
+        for (int j = 0; j < C::EPT; ++j) {
+            const int e = tid + j * 256;
+            if (e < C::PATCH) {
+                unsigned h[8], l[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    // padding stays exactly 0: the normalisation applies to in-bounds pixels only
+                    const float t0 = ginb[j] ? (xr[2 * c][j] - mu[2 * c]) * rs[2 * c] : 0.f;
+                    const float t1 = ginb[j] ? (xr[2 * c + 1][j] - mu[2 * c + 1]) * rs[2 * c + 1] : 0.f;
+                    c2_split2(t0, t1, h[c], l[c]);
+                }
+                const int sw = (e >> 3) & 1;
+                xh4[e * 2 + (0 ^ sw)] = make_uint4(h[0], h[1], h[2], h[3]);
+                xh4[e * 2 + (1 ^ sw)] = make_uint4(h[4], h[5], h[6], h[7]);
+                xl4[e * 2 + (0 ^ sw)] = make_uint4(l[0], l[1], l[2], l[3]);
+                xl4[e * 2 + (1 ^ sw)] = make_uint4(l[4], l[5], l[6], l[7]);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < C::WPT; ++v) {
+            const int idx = tid + v * 256;
+            if (idx < C::W4) wsm[idx] = wr[v];
+        }
+    };
+
+    load_chunk(0);
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        __syncthreads();
+        store_chunk(chunk);
+        __syncthreads();
+        if (chunk + 1 < nchunk) load_chunk(chunk + 1);
+        const uint4* whalf = wsm + khalf * C::TN + wc * CB * 32 + l5;
+#pragma unroll
+        for (int tap = 0; tap < C::KK; ++tap) {
+            const int toff = (tap / KS) * C::PW + (tap % KS);
+            uint4 bh[PB], bl[PB];
+#pragma unroll
+            for (int q = 0; q < PB; ++q) {
+                const int e = xoff[q] + toff;
+                const int slot = e * 2 + (khalf ^ ((e >> 3) & 1));
+                bh[q] = xh4[slot];
+                bl[q] = xl4[slot];
+            }
+            uint4 ah[CB], al[CB];
+#pragma unroll
+            for (int i = 0; i < CB; ++i) {
+                ah[i] = whalf[tap * 2 * C::TN + i * 32];
+                al[i] = whalf[C::KK * 2 * C::TN + tap * 2 * C::TN + i * 32];
+            }
+#pragma unroll
+            for (int i = 0; i < CB; ++i)
+#pragma unroll
+                for (int q = 0; q < PB; ++q)
+                    acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[q]), acc[i][q], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < CB; ++i)
+#pragma unroll
+                for (int q = 0; q < PB; ++q)
+                    acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[q]), acc[i][q], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < CB; ++i)
+#pragma unroll
+                for (int q = 0; q < PB; ++q)
+                    acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[q]), acc[i][q], 0, 0, 0);
+        }
+    }
+
+    const size_t ohw = (size_t)p.ho * p.wo;
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int pbk = wp * PB + q;
+        const int oy = oy0 + pbk * C::RPB + (l5 >> LOG_TW), ox = ox0 + (l5 & (C::TW - 1));
+        if (oy >= p.ho || ox >= p.wo) continue;
+        const size_t opix = (size_t)oy * p.wo + ox;
+#pragma unroll
+        for (int i = 0; i < CB; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wc * CB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (co < p.cout) {
+                    const size_t o = ((size_t)b * p.cout + co) * ohw + opix;
+                    float v = acc[i][q][r];
+                    if (p.bias) v += p.bias[co];
+                    if (p.residual) v += p.residual[o];
+                    if (p.act == 1) v = fmaxf(v, 0.f);
+                    if (p.act == 2) v = v > 0.f ? v : v * p.slope[co];
+                    p.out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int KS, int S, int CB, int PB, int WC, int WP, int LOG_TW>
+static int launch2d_sb(Conv2dSbParams& p, hipStream_t st) {
+    using C = C2SbCfg<KS, S, CB, PB, WC, WP, LOG_TW>;
+    p.tiles_x = cdiv(p.wo, C::TW);
+    p.tiles_y = cdiv(p.ho, C::TH);
+    dim3 grid(p.tiles_x * p.tiles_y, cdiv(p.cout, C::TN), p.bs);
+    if (C::LDS_BYTES > 64 * 1024) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_sb_kernel<KS, S, CB, PB, WC, WP, LOG_TW>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (attr != hipSuccess) return fail((int)attr, "conv2d_sb: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+    }
+    hipLaunchKernelGGL((conv2d_sb_kernel<KS, S, CB, PB, WC, WP, LOG_TW>), grid, dim3(256), C::LDS_BYTES, st, p);
+    return check_launch("conv2d_sb");
+}
+
+static int64_t nblocks_sb(const Conv2dSbParams& p, int tn, int th, int tw) {
+    return (int64_t)cdiv(p.wo, tw) * cdiv(p.ho, th) * cdiv(p.cout, tn) * p.bs;
+}
+
+template <int KS, int S>
+static int dispatch2d_sb(Conv2dSbParams& p, hipStream_t st) {
+    constexpr int64_t FILL = 192;
+    if (p.wo >= 32) {
+        if (S == 1 && p.cout > 32 && nblocks_sb(p, 64, 8, 32) >= FILL) return launch2d_sb<KS, S, 2, 2, 1, 4, 5>(p, st);   // 64 co x 256 px
+        if (p.cout > 32 && nblocks_sb(p, 64, 4, 32) >= FILL) return launch2d_sb<KS, S, 2, 1, 1, 4, 5>(p, st);             // 64 co x 128 px
+        return launch2d_sb<KS, S, 1, 1, 2, 2, 5>(p, st);                                                                  // 64 co x  64 px
+    }
+    return launch2d_sb<KS, S, 1, 1, 2, 2, 4>(p, st);                                                                      // 64 co x 64 px (16 x 4)
+}
+
+extern "C" int e4s_conv2d_sb(float* out, const float* x0, const float* x1, int cin0, const uint16_t* whi, const uint16_t* wlo, const float* bias,
+                             const float* in_mean, const float* in_rstd, const float* prelu_slope, const float* residual, int act, int bs,
+                             int cin, int cout, int h, int w, int ks, int stride, int pad, void* stream) {
+    E4S_REQUIRE(out && x0 && whi && wlo, "conv2d_sb: null tensor");
+    E4S_REQUIRE(bs >= 0 && bs <= 65535 && cin >= 1 && cout >= 1 && h >= 1 && w >= 1, "conv2d_sb: bad size");
+    E4S_REQUIRE(stride == 1 || stride == 2, "conv2d_sb: stride %d not supported (1 or 2)", stride);
+    E4S_REQUIRE(pad >= 0 && pad <= ks, "conv2d_sb: bad padding");
+    E4S_REQUIRE(act >= 0 && act <= 2 && (act != 2 || prelu_slope), "conv2d_sb: bad activation");
+    E4S_REQUIRE((in_mean == nullptr) == (in_rstd == nullptr), "conv2d_sb: in_mean and in_rstd go together");
+    E4S_REQUIRE(x1 ? (cin0 >= 1 && cin0 < cin) : true, "conv2d_sb: bad channel split");
+    E4S_REQUIRE((((uintptr_t)whi | (uintptr_t)wlo) & 15) == 0, "conv2d_sb: weight slabs must be 16-byte aligned");
+    if (bs == 0) return 0;
+    Conv2dSbParams p;
+    p.out = out; p.x0 = x0; p.x1 = x1; p.whi = reinterpret_cast<const uint4*>(whi); p.wlo = reinterpret_cast<const uint4*>(wlo); p.bias = bias;
+    p.in_mean = in_mean; p.in_rstd = in_rstd; p.slope = prelu_slope; p.residual = residual; p.act = act;
+    p.bs = bs; p.cin = cin; p.cin0 = x1 ? cin0 : cin; p.cout = cout; p.h = h; p.w = w; p.pad = pad;
+    p.ho = (h + 2 * pad - ks) / stride + 1;
+    p.wo = (w + 2 * pad - ks) / stride + 1;
+    E4S_REQUIRE(p.ho >= 1 && p.wo >= 1, "conv2d_sb: empty output");
+    hipStream_t st = (hipStream_t)stream;
+    if (ks == 3 && stride == 1) return dispatch2d_sb<3, 1>(p, st);
+    if (ks == 3 && stride == 2) return dispatch2d_sb<3, 2>(p, st);
+    if (ks == 1 && stride == 1) return dispatch2d_sb<1, 1>(p, st);
+    if (ks == 1 && stride == 2) return dispatch2d_sb<1, 2>(p, st);
+    return fail(E4S_ERR_ARG, "conv2d_sb: kernel %dx%d stride %d not supported (3x3 / 1x1, stride 1 / 2)", ks, ks, stride);
+}

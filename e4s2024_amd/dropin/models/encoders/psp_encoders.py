@@ -98,6 +98,7 @@ class FSEncoder_PSP(Module):
             get_block(in_channel=512, depth=512, num_units=3),
         ]
         self.n_styles = 11
+        self.num_seg_cls = int(getattr(opts, "num_seg_cls", 12)) if opts is not None else 12
         self.input_layer = Sequential(Conv2d(3, 64, (3, 3), 1, 1, bias=False), InstanceNorm2d(64), PReLU(64))
         modules = []
         for block in blocks:
@@ -109,7 +110,9 @@ class FSEncoder_PSP(Module):
     def get_per_comp_styleCode(self, style_feats, segmap):
         """Masked average pooling per region (reference :355-375): the mask is sampled 'nearest' at the feature size; a region
         with no pixel gives a zero vector.  One launch, no host sync (the reference loops bs x n_cls times in Python)."""
-        return ops.masked_avg_pool(style_feats, ops.mask_to_labels(segmap), segmap.shape[1])
+        # segmap: one-hot float [bs, n_cls, H, W] (reference callers) or, engine extension, a uint8 region map [bs, H, W]
+        nreg = self.num_seg_cls if (segmap.dtype == torch.uint8 and segmap.dim() == 3) else segmap.shape[1]
+        return ops.masked_avg_pool(style_feats, ops.mask_to_labels(segmap), nreg)
 
     def forward(self, x, segmap):
         il = self.input_layer

@@ -43,7 +43,7 @@ class ConvBNReLU(nn.Module):
         self.conv = nn.Conv2d(in_chan, out_chan, kernel_size=ks, stride=stride, padding=padding, bias=False)
         self.bn = nn.BatchNorm2d(out_chan)
         self.stride, self.padding = stride, padding
-        self._w = ops.PreparedConv()
+        self._w = ops.PreparedConv(exact=ops.PARSER_EXACT)
         self.init_weight()
 
     def forward(self, x, x1=None):
@@ -65,7 +65,7 @@ class BiSeNetOutput(nn.Module):
         super(BiSeNetOutput, self).__init__()
         self.conv = ConvBNReLU(in_chan, mid_chan, ks=3, stride=1, padding=1)
         self.conv_out = nn.Conv2d(mid_chan, n_classes, kernel_size=1, bias=False)
-        self._w = ops.PreparedConv()
+        self._w = ops.PreparedConv(exact=ops.PARSER_EXACT)
         self.init_weight()
 
     def forward(self, x):

@@ -32,7 +32,7 @@ class BasicBlock(nn.Module):
         self.stride = stride
         if in_chan != out_chan or stride != 1:
             self.downsample = nn.Sequential(nn.Conv2d(in_chan, out_chan, kernel_size=1, stride=stride, bias=False), nn.BatchNorm2d(out_chan))
-        self._w = [ops.PreparedConv() for _ in range(3)]
+        self._w = [ops.PreparedConv(exact=ops.PARSER_EXACT) for _ in range(3)]
 
     def forward(self, x):
         _eval_only(self)
@@ -61,7 +61,7 @@ class Resnet18(nn.Module):
         self.layer2 = create_layer_basic(64, 128, bnum=2, stride=2)
         self.layer3 = create_layer_basic(128, 256, bnum=2, stride=2)
         self.layer4 = create_layer_basic(256, 512, bnum=2, stride=2)
-        self._w = ops.PreparedConv()
+        self._w = ops.PreparedConv(exact=ops.PARSER_EXACT)
 
     def forward(self, x):
         _eval_only(self)

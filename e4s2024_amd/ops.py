@@ -226,6 +226,8 @@ def mask_to_labels(mask: torch.Tensor, strict: Optional[bool] = None) -> torch.T
 # Arithmetic of the 3x3 modulated convolutions: "sb" = split-bf16 (3 bf16 MFMAs per fp32 product, fp32 accumulate; default),
 # "f32" = exact fp32 MFMA.  Both meet the 1e-3 pixel bar (sb: ~8e-5 end to end, f32: ~2e-5); f32 is ~3x slower.
 MODCONV_MODE = os.environ.get("E4S_MODCONV", "sb")
+CONV_MODE = os.environ.get("E4S_CONV", "sb")      # same switch for the plain convolutions of the regional-style encoder
+PARSER_EXACT = os.environ.get("E4S_PARSER_CONV", "f32") != "sb"   # BiSeNet stays on exact fp32 MFMA unless asked otherwise
 
 
 class PreparedWeights:
@@ -452,18 +454,30 @@ class PreparedConv:
     """K-major copy of a plain conv weight ``[cout, cin, k, k]`` (optionally with an eval-mode BatchNorm2d folded in),
     rebuilt when a parameter or BN buffer changes version or storage."""
 
-    __slots__ = ("key", "wt", "bias", "shape")
+    __slots__ = ("key", "wt", "bias", "shape", "exact")
 
-    def __init__(self):
-        self.key, self.wt, self.bias, self.shape = None, None, None, None
+    def __init__(self, exact: bool = False):
+        """``exact=True`` pins this convolution to the exact-fp32 MFMA kernel whatever ``CONV_MODE`` says (the face parser:
+        its argmax must match the reference pixel for pixel, and split-bf16's ~2e-5 relative logit error flips near-ties)."""
+        self.key, self.wt, self.bias, self.shape, self.exact = None, None, None, None, exact
+
+    def use_sb(self, cin: int, kh: int, kw: int) -> bool:
+        """Split-bf16 slabs (``wt = (whi, wlo)``) for 3x3 / 1x1 kernels with at least 16 input channels; the 3-channel stems
+        (7x7 ResNet stem, encoder input layer) stay on the exact-fp32 kernel."""
+        return CONV_MODE == "sb" and not self.exact and kh == kw and kh in (1, 3) and cin >= 16
 
     def get(self, weight: torch.Tensor, bn=None, conv_bias: Optional[torch.Tensor] = None):
         ts = [weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else []) + ([conv_bias] if conv_bias is not None else [])
-        key = tuple((t.data_ptr(), t._version) for t in ts) + (weight.device,)
+        key = tuple((t.data_ptr(), t._version) for t in ts) + (weight.device, CONV_MODE)
         if key != self.key:
             w = _c(weight.detach(), "weight")
             cout, cin, kh, kw = w.shape
-            wt = torch.empty((cin, kh * kw, cout), dtype=torch.float32, device=w.device)
+            sb = self.use_sb(cin, kh, kw)
+            if sb:
+                shape = ((cin + 15) // 16, kh * kw, 2, cout, 8)
+                wt = (torch.empty(shape, dtype=torch.int16, device=w.device), torch.empty(shape, dtype=torch.int16, device=w.device))
+            else:
+                wt = torch.empty((cin, kh * kw, cout), dtype=torch.float32, device=w.device)
             bias = torch.empty((cout,), dtype=torch.float32, device=w.device) if (bn is not None or conv_bias is not None) else None
             if bn is not None:
                 if bn.training:
@@ -474,7 +488,12 @@ class PreparedConv:
                 g = be = mu = var = None
                 eps = 0.0
             cb = _c(conv_bias.detach(), "conv bias") if conv_bias is not None else None
-            lib().call("e4s_conv_prep_weights", _p(wt), _p(bias), _p(w), _p(g), _p(be), _p(mu), _p(var), eps, _p(cb), cout, cin, kh, kw, _stream())
+            if sb:
+                lib().call("e4s_conv_prep_weights_sb", _p(wt[0]), _p(wt[1]), _p(bias), _p(w), _p(g), _p(be), _p(mu), _p(var), eps, _p(cb), cout,
+                           cin, kh, kw, _stream())
+            else:
+                lib().call("e4s_conv_prep_weights", _p(wt), _p(bias), _p(w), _p(g), _p(be), _p(mu), _p(var), eps, _p(cb), cout, cin, kh, kw,
+                           _stream())
             self.key, self.wt, self.bias, self.shape = key, wt, bias, (cout, cin, kh, kw)
         return self
 
@@ -504,9 +523,15 @@ def conv2d(x: torch.Tensor, prepared: PreparedConv, stride: int = 1, pad: int = 
         res = _c(residual, "residual")
         if tuple(res.shape) != tuple(out.shape):
             raise ValueError(f"residual shape {tuple(res.shape)} != output {tuple(out.shape)}")
-    ev = _timed(f"conv2d_kernel<{kh},{stride}>")
-    lib().call("e4s_conv2d", _p(out), _p(x), _p(x1), c0, _p(prepared.wt), _p(prepared.bias), _p(mean), _p(rstd),
-               _p(_c(prelu.detach(), "prelu")) if prelu is not None else None, _p(res), act, bs, cin, cout, h, w, kh, stride, pad, _stream())
+    sb = isinstance(prepared.wt, tuple)
+    ev = _timed(f"conv2d_{'sb_' if sb else ''}kernel<{kh},{stride}>")
+    pr = _p(_c(prelu.detach(), "prelu")) if prelu is not None else None
+    if sb:
+        lib().call("e4s_conv2d_sb", _p(out), _p(x), _p(x1), c0, _p(prepared.wt[0]), _p(prepared.wt[1]), _p(prepared.bias), _p(mean), _p(rstd),
+                   pr, _p(res), act, bs, cin, cout, h, w, kh, stride, pad, _stream())
+    else:
+        lib().call("e4s_conv2d", _p(out), _p(x), _p(x1), c0, _p(prepared.wt), _p(prepared.bias), _p(mean), _p(rstd), pr, _p(res), act, bs, cin,
+                   cout, h, w, kh, stride, pad, _stream())
     if ev is not None:
         ev.record()
     return out

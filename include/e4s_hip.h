@@ -187,6 +187,16 @@ E4S_API int e4s_conv2d(float* out, const float* x0, const float* x1, int cin0, c
                        const float* in_mean, const float* in_rstd, const float* prelu_slope, const float* residual, int act,
                        int bs, int cin, int cout, int h, int w, int ks, int stride, int pad, void* stream);
 
+/* Split-bf16 variants (3 bf16 MFMAs per fp32 product, fp32 accumulate) of the two calls above, for 3x3 / 1x1
+ * kernels.  whi / wlo: bf16 (as uint16) [ceil(cin/16)][kh*kw][2][cout][8] — element (chunk, tap, half, co, e) is input channel
+ * chunk*16 + half*8 + e.  Same fusions as e4s_conv2d. */
+E4S_API int e4s_conv_prep_weights_sb(uint16_t* whi, uint16_t* wlo, float* bias_out, const float* weight,
+                                     const float* bn_gamma, const float* bn_beta, const float* bn_mean, const float* bn_var, float bn_eps,
+                                     const float* conv_bias, int cout, int cin, int kh, int kw, void* stream);
+E4S_API int e4s_conv2d_sb(float* out, const float* x0, const float* x1, int cin0, const uint16_t* whi, const uint16_t* wlo, const float* bias,
+                          const float* in_mean, const float* in_rstd, const float* prelu_slope, const float* residual, int act,
+                          int bs, int cin, int cout, int h, int w, int ks, int stride, int pad, void* stream);
+
 /* Per-plane statistics of x [planes = bs*C, hw]: mean, rstd = 1/sqrt(biased var + eps) (InstanceNorm2d without affine / running
  * stats, helpers.py:133,138), nmean = mean of the normalised plane (what SEModule's avg_pool sees, helpers.py:66).  rstd and nmean
  * may be NULL (plain global average pooling: face_parsing/model.py:83, 116, 209). */

@@ -17,6 +17,11 @@ def maxdiff(a, b):
     return (a.detach().double().cpu() - torch.as_tensor(b).double()).abs().max().item()
 
 
+from e4s2024_amd import ops as _ops
+# plain convolutions default to split-bf16 arithmetic (~2^-16 relative per layer); E4S_CONV=f32 restores exact fp32 MFMA
+CONV_RTOL = 1e-4 if _ops.CONV_MODE == "sb" else 2e-5
+
+
 def rnd(key, shape, std=1.0):
     return T(seeded.seeded_array(51, key, shape, 0.0, std, "normal"))
 
@@ -46,7 +51,7 @@ def test_conv2d_vs_torch_cpu(bs, cin, cout, h, w, ks, stride, pad):
     ref = F.conv2d(x, wgt, stride=stride, padding=pad)
     out = ops.conv2d(x.to(DEV), ops.PreparedConv().get(wgt.to(DEV)), stride, pad)
     assert tuple(out.shape) == tuple(ref.shape)
-    assert maxdiff(out, ref) <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert maxdiff(out, ref) <= CONV_RTOL * max(1.0, ref.abs().max().item())
 
 
 def test_conv2d_fusions_vs_torch_cpu():
@@ -60,7 +65,7 @@ def test_conv2d_fusions_vs_torch_cpu():
     assert maxdiff(mean, x.mean((2, 3))) <= 1e-5
     assert maxdiff(rstd, 1 / torch.sqrt(x.var((2, 3), unbiased=False) + 1e-5)) <= 1e-5
     out = ops.conv2d(x.to(DEV), ops.PreparedConv().get(wgt.to(DEV)), 1, 1, in_norm=(mean, rstd), prelu=slope.to(DEV))
-    assert maxdiff(out, ref) <= 5e-5
+    assert maxdiff(out, ref) <= 5 * CONV_RTOL
     bn = torch.nn.BatchNorm2d(48).eval()
     with torch.no_grad():
         bn.weight.copy_(rnd("bg", (48,), 0.2) + 1); bn.bias.copy_(rnd("bb", (48,), 0.2))
@@ -68,11 +73,11 @@ def test_conv2d_fusions_vs_torch_cpu():
     res = rnd("fr", (2, 48, 20, 20))
     ref2 = F.relu(res + bn(F.conv2d(x, wgt, stride=2, padding=1)))
     out2 = ops.conv2d(x.to(DEV), ops.PreparedConv().get(wgt.to(DEV), bn.to(DEV)), 2, 1, residual=res.to(DEV), relu=True)
-    assert maxdiff(out2, ref2) <= 5e-5
+    assert maxdiff(out2, ref2) <= 5 * CONV_RTOL
     xa, xb = x[:, :20].contiguous(), x[:, 20:].contiguous()
     w1 = rnd("f1", (16, 32, 1, 1), 0.2)
     out3 = ops.conv2d(xa.to(DEV), ops.PreparedConv().get(w1.to(DEV)), 1, 0, x1=xb.to(DEV))
-    assert maxdiff(out3, F.conv2d(x, w1)) <= 5e-5
+    assert maxdiff(out3, F.conv2d(x, w1)) <= 5 * CONV_RTOL
 
 
 def test_bilinear_resize_both_modes():
@@ -105,7 +110,7 @@ def test_encoder_units_vs_oracle(gpu_net3, net3_sd):
         with torch.no_grad():
             out = gpu_net3.encoder.body[idx](x.to(DEV))
         assert tuple(out.shape) == tuple(ref.shape)
-        assert maxdiff(out, ref) <= 1e-4 * max(1.0, ref.abs().max().item()), idx
+        assert maxdiff(out, ref) <= 3e-4 * max(1.0, ref.abs().max().item()), idx
 
 
 def _g7_inputs():
