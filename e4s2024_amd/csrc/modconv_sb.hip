@@ -244,37 +244,43 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
 
     // register stage of the NEXT chunk
     float xr[CKS][C::EPT];
-    uint4 wr[C::WPT];
+    unsigned wr[C::WPT][4];   // scalar components: a uint4 array here ends up in scratch
     float sr = 0.f;
 
-    auto load_chunk = [&](int chunk) {
+    // Unconditional loads (no per-element branches, so the compiler issues them here and they really are a prefetch): out-of-image
+    // elements read a valid clamped address and are zeroed when the chunk is written to LDS; channels >= cin meet zero-padded
+    // weights; output-channel rows >= cout are computed but never stored.  The lambdas must be inlined or xr/wr live in scratch.
+    int goffs[C::EPT];
+#pragma unroll
+    for (int j = 0; j < C::EPT; ++j) goffs[j] = ginb[j] ? goff[j] : 0;
+    const ptrdiff_t wdelta = p.wlo - p.whi;
+    auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
         const int ci0 = chunk * CKS;
+        const int cmax = p.cin - 1 - ci0;
 #pragma unroll
         for (int c = 0; c < CKS; ++c) {
-            const bool cok = ci0 + c < p.cin;
-            const float* xc = xb + (size_t)(ci0 + c) * hw;
+            const float* xc = xb + (size_t)(ci0 + (c < cmax ? c : cmax)) * hw;
 #pragma unroll
-            for (int j = 0; j < C::EPT; ++j) xr[c][j] = (cok && ginb[j]) ? xc[goff[j]] : 0.f;
+            for (int j = 0; j < C::EPT; ++j) xr[c][j] = xc[goffs[j]];
         }
         const size_t wbase = ((size_t)par * nchunk + chunk) * 18 * p.cout;  // uint4 units: [tap][half][cout]
 #pragma unroll
         for (int v = 0; v < C::WPT; ++v) {
-            const int idx = tid + v * C::NT;
-            uint4 val = make_uint4(0u, 0u, 0u, 0u);
-            if (idx < C::W4) {
-                const int hl = idx / (18 * C::TN);
-                const int rem = idx - hl * 18 * C::TN;
-                const int th = rem / C::TN, n = rem - th * C::TN;
-                if (co0 + n < p.cout) val = (hl ? p.wlo : p.whi)[wbase + (size_t)th * p.cout + co0 + n];
-            }
-            wr[v] = val;
+            int idx = tid + v * C::NT;
+            idx = idx < C::W4 ? idx : C::W4 - 1;
+            const int hl = idx / (18 * C::TN);
+            const int rem = idx - hl * 18 * C::TN;
+            const int th = rem / C::TN, n = rem - th * C::TN;
+            const int co = (co0 + n < p.cout) ? co0 + n : p.cout - 1;
+            const uint4 t4 = p.whi[(ptrdiff_t)hl * wdelta + (ptrdiff_t)(wbase + (size_t)th * p.cout + co)];   // lo slab = hi slab + wdelta
+            wr[v][0] = t4.x; wr[v][1] = t4.y; wr[v][2] = t4.z; wr[v][3] = t4.w;
         }
         if (tid < E4S_MAX_REGIONS * CKS) {
             const int r = tid / CKS, c = tid % CKS;
             sr = (r < p.nreg && ci0 + c < p.cin) ? sb[(size_t)r * p.cin + ci0 + c] : 0.f;
         }
     };
-    auto store_chunk = [&](int chunk) {
+    auto store_chunk = [&](int chunk) __attribute__((always_inline)) {
         if constexpr (UNI) {
             // s of the single region for the 16 channels of this chunk (wave-uniform loads)
             float sc[CKS];
@@ -286,7 +292,8 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
                 if (e < C::PATCH) {
                     unsigned h[8], l[8];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) split2(xr[2 * c][j] * sc[2 * c], xr[2 * c + 1][j] * sc[2 * c + 1], h[c], l[c]);
+                    for (int c = 0; c < 8; ++c)
+                        split2(ginb[j] ? xr[2 * c][j] * sc[2 * c] : 0.f, ginb[j] ? xr[2 * c + 1][j] * sc[2 * c + 1] : 0.f, h[c], l[c]);
                     const int sw = (e >> 3) & 1;
                     xh4[e * 2 + (0 ^ sw)] = make_uint4(h[0], h[1], h[2], h[3]);
                     xh4[e * 2 + (1 ^ sw)] = make_uint4(h[4], h[5], h[6], h[7]);
@@ -301,14 +308,16 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
                 if (e < C::PATCH) {
                     const int g = (e >> 2) & 3;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) xf4[e * 4 + (k ^ g)] = make_float4(xr[4 * k][j], xr[4 * k + 1][j], xr[4 * k + 2][j], xr[4 * k + 3][j]);
+                    for (int k = 0; k < 4; ++k)
+                        xf4[e * 4 + (k ^ g)] = ginb[j] ? make_float4(xr[4 * k][j], xr[4 * k + 1][j], xr[4 * k + 2][j], xr[4 * k + 3][j])
+                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
         }
 #pragma unroll
         for (int v = 0; v < C::WPT; ++v) {
             const int idx = tid + v * C::NT;
-            if (idx < C::W4) wsm[idx] = wr[v];
+            if (idx < C::W4) wsm[idx] = make_uint4(wr[v][0], wr[v][1], wr[v][2], wr[v][3]);
         }
         if (!UNI && tid < E4S_MAX_REGIONS * CKS) ss[tid] = sr;
     };

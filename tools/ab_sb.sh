@@ -1,5 +1,5 @@
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_synthesis.py -m gpu -q --tb=short -s 2>&1 | grep -vE "^\s*$|amdgpu.ids" | tail -25
-for f in 1 0; do echo "== fuse_rgb=$f"; E4S_FUSE_RGB=$f timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep '^{' | python -c "
+timeout 900 python -m pytest tests/test_gpu_synthesis.py -m gpu -q --tb=short 2>&1 | tail -3
+timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-full-swap 2>&1 | grep '^{' | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['all_modconv3x3'])"; done
+d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['all_modconv3x3'])"
