@@ -428,33 +428,50 @@ __global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams 
             for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.f;
 
     float xr[CKS2][C::EPT];
-    uint4 wr[C::WPT];
+    unsigned wr[C::WPT][4];   // scalar components: an array of uint4 ends up in scratch
 
-    auto load_chunk = [&](int chunk) {
+    // Unconditional loads (no per-element branches, so they are issued here and really are a prefetch): out-of-image elements read
+    // a valid clamped address and are zeroed at conversion time; channels >= cin meet zero-padded weights; output-channel rows
+    // >= cout are computed but never stored.
+    int goffs[C::EPT];
+#pragma unroll
+    for (int j = 0; j < C::EPT; ++j) goffs[j] = ginb[j] ? goff[j] : 0;
+    const bool split_ok = (p.cin0 % CKS2) == 0;   // a chunk never straddles the two concatenated inputs
+    const ptrdiff_t wdelta = p.wlo - p.whi;
+    auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
         const int ci0 = chunk * CKS2;
+        if (split_ok) {
+            const float* xcb = (ci0 < p.cin0) ? xb0 + (size_t)ci0 * hw : xb1 + (size_t)(ci0 - p.cin0) * hw;
+            const int cmax = ((ci0 < p.cin0) ? p.cin0 : p.cin) - 1 - ci0;
 #pragma unroll
-        for (int c = 0; c < CKS2; ++c) {
-            const int ci = ci0 + c;
-            const bool cok = ci < p.cin;
-            const float* xc = (ci < p.cin0) ? xb0 + (size_t)ci * hw : xb1 + (size_t)(ci - p.cin0) * hw;
+            for (int c = 0; c < CKS2; ++c) {
+                const float* xc = xcb + (size_t)(c < cmax ? c : cmax) * hw;
 #pragma unroll
-            for (int j = 0; j < C::EPT; ++j) xr[c][j] = (cok && ginb[j]) ? xc[goff[j]] : 0.f;
+                for (int j = 0; j < C::EPT; ++j) xr[c][j] = xc[goffs[j]];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CKS2; ++c) {
+                const int ci = (ci0 + c < p.cin) ? ci0 + c : p.cin - 1;
+                const float* xc = (ci < p.cin0) ? xb0 + (size_t)ci * hw : xb1 + (size_t)(ci - p.cin0) * hw;
+#pragma unroll
+                for (int j = 0; j < C::EPT; ++j) xr[c][j] = xc[goffs[j]];
+            }
         }
         const size_t wbase = (size_t)chunk * C::KK * 2 * p.cout;
 #pragma unroll
         for (int v = 0; v < C::WPT; ++v) {
-            const int idx = tid + v * 256;
-            uint4 val = make_uint4(0u, 0u, 0u, 0u);
-            if (idx < C::W4) {
-                const int hl = idx / (C::KK * 2 * C::TN);
-                const int rem = idx - hl * C::KK * 2 * C::TN;
-                const int th = rem / C::TN, n = rem - th * C::TN;
-                if (co0 + n < p.cout) val = (hl ? p.wlo : p.whi)[wbase + (size_t)th * p.cout + co0 + n];
-            }
-            wr[v] = val;
+            int idx = tid + v * 256;
+            idx = idx < C::W4 ? idx : C::W4 - 1;
+            const int hl = idx / (C::KK * 2 * C::TN);
+            const int rem = idx - hl * C::KK * 2 * C::TN;
+            const int th = rem / C::TN, n = rem - th * C::TN;
+            const int co = (co0 + n < p.cout) ? co0 + n : p.cout - 1;
+            const uint4 t4 = p.whi[(ptrdiff_t)hl * wdelta + (ptrdiff_t)(wbase + (size_t)th * p.cout + co)];
+            wr[v][0] = t4.x; wr[v][1] = t4.y; wr[v][2] = t4.z; wr[v][3] = t4.w;
         }
     };
-    auto store_chunk = [&](int chunk) {
+    auto store_chunk = [&](int chunk) __attribute__((always_inline)) {
         const int ci0 = chunk * CKS2;
         float mu[CKS2], rs[CKS2];
 #pragma unroll
@@ -485,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams 
 #pragma unroll
         for (int v = 0; v < C::WPT; ++v) {
             const int idx = tid + v * 256;
-            if (idx < C::W4) wsm[idx] = wr[v];
+            if (idx < C::W4) wsm[idx] = make_uint4(wr[v][0], wr[v][1], wr[v][2], wr[v][3]);
         }
     };
 
