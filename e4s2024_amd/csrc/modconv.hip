@@ -202,14 +202,30 @@ __global__ __launch_bounds__(256) void style_batched_kernel(const JobTable t, in
     float acc[STYLE_ROWS];
 #pragma unroll
     for (int q = 0; q < STYLE_ROWS; ++q) acc[q] = 0.f;
-    for (int j = lane; j < sdim; j += 64) {
-        const float wv = wrow[j];
+    const bool vec = (sdim & 3) == 0 && (J.stride_b & 3) == 0 && (J.stride_r & 3) == 0 && ((((uintptr_t)J.styles | (uintptr_t)J.mod_weight) & 15) == 0);
+    if (vec) {
+        for (int j = lane * 4; j < sdim; j += 256) {
+            const float4 w4 = *reinterpret_cast<const float4*>(wrow + j);
 #pragma unroll
-        for (int q = 0; q < STYLE_ROWS; ++q) {
-            const int br = br0 + q;
-            if (br < nbr) {
-                const int b = br / J.nreg, r = br - b * J.nreg;
-                acc[q] += J.styles[b * J.stride_b + r * J.stride_r + j] * wv;
+            for (int q = 0; q < STYLE_ROWS; ++q) {
+                const int br = br0 + q;
+                if (br < nbr) {
+                    const int b = br / J.nreg, r = br - b * J.nreg;
+                    const float4 v = *reinterpret_cast<const float4*>(J.styles + b * J.stride_b + r * J.stride_r + j);
+                    acc[q] += (v.x * w4.x + v.y * w4.y) + (v.z * w4.z + v.w * w4.w);
+                }
+            }
+        }
+    } else {
+        for (int j = lane; j < sdim; j += 64) {
+            const float wv = wrow[j];
+#pragma unroll
+            for (int q = 0; q < STYLE_ROWS; ++q) {
+                const int br = br0 + q;
+                if (br < nbr) {
+                    const int b = br / J.nreg, r = br - b * J.nreg;
+                    acc[q] += J.styles[b * J.stride_b + r * J.stride_r + j] * wv;
+                }
             }
         }
     }

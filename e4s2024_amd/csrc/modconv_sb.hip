@@ -679,7 +679,7 @@ extern "C" int e4s_modconv_tconv_sb(float* z, const float* x, const uint16_t* wh
 // LDS-tiled: a block owns a 64 x 16 output tile of one (sample, channel) plane; the (16+3) x (64+3) pre-blur window is loaded
 // once with row-contiguous accesses (z rows are 2w+1 floats long, so nothing is 16-byte aligned in HBM) and each thread
 // produces 4 consecutive outputs from LDS.
-constexpr int BE_TW = 64, BE_TH = 16, BE_ZW = BE_TW + 3, BE_ZH = BE_TH + 3;
+constexpr int BE_TW = 128, BE_TH = 16, BE_ZW = BE_TW + 3, BE_ZH = BE_TH + 3;
 
 __global__ __launch_bounds__(256) void blur_epilogue_kernel(float* __restrict__ out, const float* __restrict__ z, const float* __restrict__ blur,
                                                             const float* __restrict__ d, const float* __restrict__ noise, int noise_bstride,
@@ -693,42 +693,59 @@ __global__ __launch_bounds__(256) void blur_epilogue_kernel(float* __restrict__ 
     const int b = plane / cout, co = plane - b * cout;
     const int ox0 = blockIdx.x * BE_TW, oy0 = blockIdx.y * BE_TH;
     const float* zp = z + (size_t)plane * zh * zw;
-    for (int e = threadIdx.x; e < BE_ZH * BE_ZW; e += 256) {
+    constexpr int NLD = (BE_ZH * BE_ZW + 255) / 256;
+    float ld[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {          // all loads first (independent, in flight together), then the LDS writes
+        const int e = threadIdx.x + k * 256;
         const int r = e / BE_ZW, c = e - r * BE_ZW;
         const int zy = oy0 + r - 1, zx = ox0 + c - 1;
-        zt[e] = (zy >= 0 && zy < zh && zx >= 0 && zx < zw) ? zp[(size_t)zy * zw + zx] : 0.f;
+        const bool ok = e < BE_ZH * BE_ZW && zy >= 0 && zy < zh && zx >= 0 && zx < zw;
+        const float v = zp[ok ? (size_t)zy * zw + zx : 0];
+        ld[k] = ok ? v : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int e = threadIdx.x + k * 256;
+        if (e < BE_ZH * BE_ZW) zt[e] = ld[k];
     }
     __syncthreads();
-    const int lx = (threadIdx.x & 15) * 4, ly = threadIdx.x >> 4;
-    const int ox = ox0 + lx, oy = oy0 + ly;
-    if (ox >= wo || oy >= ho) return;
-    float a[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ty = 0; ty < 4; ++ty) {
-        float row[7];
-#pragma unroll
-        for (int j = 0; j < 7; ++j) row[j] = zt[(ly + ty) * BE_ZW + lx + j];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int tx = 0; tx < 4; ++tx) a[k] += row[k + tx] * kf[ty * 4 + tx];
-    }
     const float dd = d ? d[plane] : 1.f;
     const float nw = noise ? noise_weight[0] : 0.f;
     const float bi = act_bias ? act_bias[co] : 0.f;
-    float r[4];
+    const int ly = threadIdx.x >> 4;
+    const int oy = oy0 + ly;
+    if (oy >= ho) return;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float v = a[k] * dd + bi;
-        if (noise && ox + k < wo) v += nw * noise[(size_t)b * noise_bstride + (size_t)oy * wo + ox + k];
-        if (act) v = (v > 0.f ? v : v * 0.2f) * 1.41421356237309515f;
-        r[k] = v;
-    }
-    float* op = out + ((size_t)plane * ho + oy) * wo + ox;
-    if (ox + 3 < wo && (wo & 3) == 0) {
-        *reinterpret_cast<float4*>(op) = make_float4(r[0], r[1], r[2], r[3]);
-    } else {
-        for (int k = 0; k < 4 && ox + k < wo; ++k) op[k] = r[k];
+    for (int half = 0; half < 2; ++half) {
+        const int lx = (threadIdx.x & 15) * 4 + half * 64;
+        const int ox = ox0 + lx;
+        if (ox >= wo) continue;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ty = 0; ty < 4; ++ty) {
+            float row[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) row[j] = zt[(ly + ty) * BE_ZW + lx + j];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int tx = 0; tx < 4; ++tx) a[k] += row[k + tx] * kf[ty * 4 + tx];
+        }
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v = a[k] * dd + bi;
+            if (noise && ox + k < wo) v += nw * noise[(size_t)b * noise_bstride + (size_t)oy * wo + ox + k];
+            if (act) v = (v > 0.f ? v : v * 0.2f) * 1.41421356237309515f;
+            r[k] = v;
+        }
+        float* op = out + ((size_t)plane * ho + oy) * wo + ox;
+        if (ox + 3 < wo && (wo & 3) == 0) {
+            *reinterpret_cast<float4*>(op) = make_float4(r[0], r[1], r[2], r[3]);
+        } else {
+            for (int k = 0; k < 4 && ox + k < wo; ++k) op[k] = r[k];
+        }
     }
 }
 
