@@ -1,0 +1,64 @@
+"""hipGraph capture of fixed-shape calls of the hot path.
+
+At batch 1 (the reference's frame-by-frame video loop, face_swap_video_pipeline.py:406) one full swap is ~900 short launches and
+the host cannot issue them as fast as the GPU retires them; capturing the whole call once and replaying it removes the Python /
+launch overhead (MI355X: ~3.5 us per eager launch vs ~10-16 us per whole-graph replay).  Everything the path launches goes to
+``torch.cuda.current_stream()``, which is the capture stream during capture, so the ctypes-launched HIP kernels are recorded like
+torch's own; outputs of ``torch.empty`` inside the call come from the graph's private pool.
+
+Requirements on ``fn``: fixed shapes, no host synchronisation (``ops.STRICT_MASK`` is switched off inside), no data-dependent
+control flow, and — for ``randomize_noise=True`` — torch's graph-safe RNG (works: the noise draws are torch ops).
+"""
+from __future__ import annotations
+
+from typing import Callable, Sequence
+
+import torch
+
+from . import ops
+
+
+class GraphedCall:
+    """``g = GraphedCall(fn, example_inputs); out = g(*new_inputs)`` — inputs are copied into static buffers, the captured graph is
+    replayed, the (static) output tensors are returned: clone them if they must survive the next call."""
+
+    def __init__(self, fn: Callable, example_inputs: Sequence[torch.Tensor], warmup: int = 2):
+        self.fn = fn
+        self.static_in = [t.clone() for t in example_inputs]
+        self._strict = ops.STRICT_MASK
+        ops.STRICT_MASK = False                       # the one-hot check reads a flag back to the host
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(warmup):                # builds the weight caches / split-K workspace outside the capture
+                    self.fn(*self.static_in)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph), torch.no_grad():
+                self.static_out = self.fn(*self.static_in)
+        finally:
+            ops.STRICT_MASK = self._strict
+
+    def __call__(self, *inputs: torch.Tensor):
+        if len(inputs) != len(self.static_in):
+            raise ValueError(f"expected {len(self.static_in)} inputs")
+        for dst, src in zip(self.static_in, inputs):
+            if dst.shape != src.shape or dst.dtype != src.dtype:
+                raise ValueError(f"graphed call was captured for {tuple(dst.shape)} {dst.dtype}, got {tuple(src.shape)} {src.dtype}")
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.static_out
+
+
+def graphed_gen_img(net, codes: torch.Tensor, labels: torch.Tensor, randomize_noise: bool = False) -> GraphedCall:
+    """``g(codes, labels) -> image`` for a fixed batch size; ``labels`` = uint8 region maps ``[bs, 512, 512]`` or one-hot masks."""
+    return GraphedCall(lambda c, m: net.gen_img(None, c, m, randomize_noise=randomize_noise)[0], [codes, labels])
+
+
+def graphed_swap(net, parser, driven: torch.Tensor, target: torch.Tensor, randomize_noise: bool = False) -> GraphedCall:
+    """``g(driven, target) -> (uint8 frames [bs,1024,1024,3], target region maps)`` — the whole full-swap unit as one graph."""
+    from . import pipeline
+    return GraphedCall(lambda d, t: pipeline.swap_batch(net, parser, d, t, randomize_noise=randomize_noise), [driven, target])

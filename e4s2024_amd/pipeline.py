@@ -16,14 +16,28 @@ from . import ops
 DEFAULT_COMP_INDICES = tuple(sorted(set(range(12)) - {0, 4, 11}))      # face_swap_video_pipeline.py:436: keep target background, hair, ear-rings
 
 
+_sel_cache = {}
+
+
+def _selector(device, comp_indices, n):
+    """bool [n] on ``device`` marking the components taken from the driven face; built once per (device, indices) so that no
+    host-to-device copy happens inside a hipGraph capture."""
+    key = (str(device), tuple(comp_indices), n)
+    sel = _sel_cache.get(key)
+    if sel is None:
+        m = torch.zeros(n, dtype=torch.bool)
+        m[list(comp_indices)] = True
+        sel = _sel_cache[key] = m.to(device)
+    return sel
+
+
 def mix_style_vectors(target_vec: torch.Tensor, driven_vec: torch.Tensor, comp_indices: Sequence[int] = DEFAULT_COMP_INDICES,
                       below_face_interpolation: bool = False) -> torch.Tensor:
     """``swap_comp_style_vector`` (swap_face_fine/swap_face_mask.py:336-367) for a batch, without host synchronisation:
     take the listed components from the driven face; ears (7) = mean of both; ear-rings (11) from the target; neck (8) optionally the
     mean; teeth (9) from the target when the driven face has none (its style vector sums to exactly 0)."""
-    out = target_vec.clone()
-    idx = list(comp_indices)
-    out[:, idx, :] = driven_vec[:, idx, :]
+    sel = _selector(target_vec.device, comp_indices, target_vec.shape[1])
+    out = torch.where(sel[None, :, None], driven_vec, target_vec)
     out[:, 7, :] = (target_vec[:, 7, :] + driven_vec[:, 7, :]) / 2
     out[:, 11, :] = target_vec[:, 11, :]
     if below_face_interpolation:
