@@ -43,7 +43,7 @@ def conv3x3_flops_per_face(size=1024):
     def add(cout, w_in, fl, out_res, up):
         masked = out_res <= 256
         if up and not masked and _ops.MODCONV_MODE == "sb" and _ops.UP_TWO_STAGE:
-            k = "modconv_tconv_sb"
+            k = "modconv_up_fused_sb" if _ops.UP_FUSED else "modconv_tconv_sb"
         else:
             k = modconv_kernel_name(cout, w_in, None, masked)
         out[k] = out.get(k, 0.0) + fl

@@ -1,0 +1,278 @@
+// a3/a4, single-region (unmasked) up layer in ONE launch: stride-2 transposed 3x3 conv on split-bf16 MFMA at 1x its algorithmic
+// MACs -> pre-blur tile in LDS -> 4x4 blur + demodulation + noise + bias + leaky-relu, written once.
+// Reference: ModulatedConv2d.forward upsample branch (models/stylegan2/model.py:287-301) + NoiseInjection/FusedLeakyReLU of
+// StyledConv.forward (:417-421).  Same arithmetic as e4s_modconv_tconv_sb + e4s_blur_epilogue (modconv_sb.hip) without the
+// [bs,cout,2h+1,2w+1] round trip through HBM (2 x 537 MB per step at 1024^2, batch 4).
+//
+// Geometry.  Lanes sit on a 16 x 16 tile of POSITIONS (a,b), a in [P0y, P0y+16): tap (ky,kx) adds W[ky][kx] * x[a-(ky>>1)][b-(kx>>1)]
+// to the pre-blur pixel z[2a+(ky&1)][2b+(kx&1)], so a tile owns z rows [2*P0y, 2*P0y+32) in four parity accumulators.  Output row
+// oy needs z rows oy-1..oy+2 (upfirdn2d pad (1,1)); with P0y = 14*t - 1 the tile yields the 28 output rows [28t, 28t+28)
+// from its own z rows only, so neighbouring tiles overlap by 2 positions (1.31x the MACs, nothing re-read from HBM but x's halo).
+// Positions outside [0,h] read zero x and give z = 0, which is exactly the blur's zero padding.
+#include <stdlib.h>
+
+#include "common.h"
+#include "sb_common.h"
+
+using namespace e4s;
+
+namespace {
+
+struct UpFusedParams {
+    float* out;
+    const float* x;
+    const uint4* whi;
+    const uint4* wlo;
+    const float* s;
+    const float* d;
+    const float* blur;
+    const float* noise;
+    const float* noise_weight;
+    const float* act_bias;
+    int noise_bstride;
+    int act;
+    int bs, cin, cout, h, w;
+    int tiles_x, tiles_y;
+};
+
+constexpr int UF_T = 16;                    // positions per tile side
+constexpr int UF_STEP = UF_T - 2;           // 14 new positions per tile
+constexpr int UF_OUT = 2 * UF_STEP;         // 28 output rows / columns per tile
+constexpr int UF_PW = UF_T + 1;             // x patch side (positions read x[a-1], x[a])
+constexpr int UF_PATCH = UF_PW * UF_PW;     // 289
+constexpr int UF_NT = 512;                  // 8 waves: wave v owns position rows 2v, 2v+1
+constexpr int UF_ZS = 34;                   // row stride of the pre-blur tile in LDS (32 + 2: float2-aligned, spreads banks)
+constexpr int UF_ZCO = 8;                   // output channels blurred per LDS pass
+
+template <int CB>
+struct UfCfg {
+    static constexpr int TN = CB * 32;
+    static constexpr int W4 = 2 * 9 * 2 * TN;                 // uint4 per chunk: [hi/lo][tap][half][TN]
+    static constexpr int WPT = (W4 + UF_NT - 1) / UF_NT;
+    static constexpr int MAIN_BYTES = W4 * 16 + UF_PATCH * 64;   // weights + x hi/lo planes
+    static constexpr int ZT_BYTES = UF_ZCO * 32 * UF_ZS * 4;
+    static constexpr int BODY = MAIN_BYTES > ZT_BYTES ? MAIN_BYTES : ZT_BYTES;
+    static constexpr int LDS_BYTES = BODY;
+};
+
+template <int CB, int MINW>
+__global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedParams p) {
+    using C = UfCfg<CB>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint4* wsm = reinterpret_cast<uint4*>(lds_raw);                       // [2][9][2][TN]
+    uint4* xh4 = reinterpret_cast<uint4*>(lds_raw + C::W4 * 16);          // [PATCH][2] uint4 = 16 bf16 (hi), halves swizzled
+    uint4* xl4 = xh4 + 2 * UF_PATCH;                                      // lo plane
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l5 = lane & 31, khalf = lane >> 5;
+
+    const int tyt = blockIdx.x / p.tiles_x, txt = blockIdx.x - tyt * p.tiles_x;
+    const int p0y = tyt * UF_STEP - 1, p0x = txt * UF_STEP - 1;
+    const int co0 = blockIdx.y * C::TN;
+    const int b = blockIdx.z;
+    const int hw = p.h * p.w;
+    const int nchunk = (p.cin + CKS - 1) / CKS;
+
+    // staging element of this thread (one patch pixel, 16 channels per chunk)
+    const int se_y = tid / UF_PW, se_x = tid - se_y * UF_PW;
+    const int sgy = p0y - 1 + se_y, sgx = p0x - 1 + se_x;
+    const bool s_in = tid < UF_PATCH && sgy >= 0 && sgy < p.h && sgx >= 0 && sgx < p.w;
+    const int sgoff = s_in ? sgy * p.w + sgx : 0;
+    const float* xb = p.x + (size_t)b * p.cin * hw;
+    const float* sb = p.s + (size_t)b * p.cin;
+
+    const int pty = 2 * wave + (l5 >> 4), ptx = l5 & 15;   // this lane's position inside the tile
+    const int xoff = pty * UF_PW + ptx;
+
+    f32x16 accs[4][CB];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int i = 0; i < CB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accs[a][i][r] = 0.f;
+
+    float xr[CKS];
+    unsigned wr[C::WPT][4];   // scalar components (a uint4 array would be placed in scratch)
+    const ptrdiff_t wdelta = p.wlo - p.whi;
+    auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
+        const int ci0 = chunk * CKS;
+        const int cmax = p.cin - 1 - ci0;
+#pragma unroll
+        for (int c = 0; c < CKS; ++c) xr[c] = xb[(size_t)(ci0 + (c < cmax ? c : cmax)) * hw + sgoff];
+        const size_t wbase = (size_t)chunk * 18 * p.cout;   // uint4 units: [tap][half][cout]
+#pragma unroll
+        for (int v = 0; v < C::WPT; ++v) {
+            int idx = tid + v * UF_NT;
+            idx = idx < C::W4 ? idx : C::W4 - 1;
+            const int hl = idx / (18 * C::TN);
+            const int rem = idx - hl * 18 * C::TN;
+            const int th = rem / C::TN, n = rem - th * C::TN;
+            const int co = (co0 + n < p.cout) ? co0 + n : p.cout - 1;
+            const uint4 t4 = p.whi[(ptrdiff_t)hl * wdelta + (ptrdiff_t)(wbase + (size_t)th * p.cout + co)];
+            wr[v][0] = t4.x; wr[v][1] = t4.y; wr[v][2] = t4.z; wr[v][3] = t4.w;
+        }
+    };
+    auto store_chunk = [&](int chunk) __attribute__((always_inline)) {
+        if (tid < UF_PATCH) {
+            unsigned hi[8], lo[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int c0 = chunk * CKS + 2 * c;
+                const float s0 = c0 < p.cin ? sb[c0] : 0.f, s1 = c0 + 1 < p.cin ? sb[c0 + 1] : 0.f;   // wave-uniform
+                split2(s_in ? xr[2 * c] * s0 : 0.f, s_in ? xr[2 * c + 1] * s1 : 0.f, hi[c], lo[c]);
+            }
+            const int sw = (tid >> 3) & 1;
+            xh4[tid * 2 + (0 ^ sw)] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            xh4[tid * 2 + (1 ^ sw)] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+            xl4[tid * 2 + (0 ^ sw)] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            xl4[tid * 2 + (1 ^ sw)] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+        }
+#pragma unroll
+        for (int v = 0; v < C::WPT; ++v) {
+            const int idx = tid + v * UF_NT;
+            if (idx < C::W4) wsm[idx] = make_uint4(wr[v][0], wr[v][1], wr[v][2], wr[v][3]);
+        }
+    };
+
+    load_chunk(0);
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        __syncthreads();
+        store_chunk(chunk);
+        __syncthreads();
+        if (chunk + 1 < nchunk) load_chunk(chunk + 1);
+        const uint4* whalf = wsm + khalf * C::TN + l5;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            const int e = xoff + (1 - (ky >> 1)) * UF_PW + (1 - (kx >> 1));
+            const int ai = 2 * (ky & 1) + (kx & 1);
+            const int slot = e * 2 + (khalf ^ ((e >> 3) & 1));
+            const uint4 bh = xh4[slot], bl = xl4[slot];
+            uint4 ah[CB], al[CB];
+#pragma unroll
+            for (int i = 0; i < CB; ++i) {
+                ah[i] = whalf[tap * 2 * C::TN + i * 32];
+                al[i] = whalf[18 * C::TN + tap * 2 * C::TN + i * 32];
+            }
+#pragma unroll
+            for (int i = 0; i < CB; ++i)
+                accs[ai][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh), accs[ai][i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < CB; ++i)
+                accs[ai][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl), accs[ai][i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < CB; ++i)
+                accs[ai][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh), accs[ai][i], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: 8 output channels at a time through LDS.  Blur item of this thread: one output column, 14 rows, one channel.
+    __syncthreads();
+    float* zt = reinterpret_cast<float*>(lds_raw);   // [8][32][ZS]
+    float kf[16];                                    // kf[ty*4+tx] = blur[3-ty][3-tx]  (uniform loads -> scalar registers)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) kf[t] = p.blur[15 - t];
+    const int ho = 2 * p.h, wo = 2 * p.w;
+    constexpr int NITEM = UF_ZCO * 2 * UF_OUT;       // 448
+    const int it_co = tid / (2 * UF_OUT);
+    const int it_rem = tid - it_co * 2 * UF_OUT;
+    const int it_rg = it_rem / UF_OUT, it_x = it_rem - it_rg * UF_OUT;
+    const int oy0 = tyt * UF_OUT + it_rg * UF_STEP, ox = txt * UF_OUT + it_x;
+    const bool it_ok = tid < NITEM && ox < wo && oy0 < ho;
+    const int nrow = it_ok ? (ho - oy0 < UF_STEP ? ho - oy0 : UF_STEP) : 0;   // valid output rows of this item
+    const float nw = p.noise ? p.noise_weight[0] : 0.f;
+    const float* nzb = p.noise ? p.noise + (size_t)b * p.noise_bstride : nullptr;   // uniform bases + 32-bit per-thread offsets
+    float* ob = p.out + (size_t)b * p.cout * ho * wo;
+    const unsigned pix0 = (unsigned)(oy0 * wo + ox);
+    const float* zc = zt + (it_co * 32 + it_rg * UF_STEP + 1) * UF_ZS + it_x + 1;   // z row (local) of output row r, tap t: r + 1 + t
+    const float* dp = p.d ? p.d + (size_t)b * p.cout : nullptr;
+
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int col = 4 * khalf + rr;   // channel (within the group of 8) held by register 4g+rr of this half-wave
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci)
+                    *reinterpret_cast<float2*>(&zt[(col * 32 + 2 * pty + ci) * UF_ZS + 2 * ptx]) =
+                        make_float2(accs[2 * ci][i][4 * g + rr], accs[2 * ci + 1][i][4 * g + rr]);
+            }
+            __syncthreads();
+            const int co = co0 + i * 32 + 8 * g + it_co;
+            if (nrow > 0 && co < p.cout) {
+                float a[UF_STEP];
+#pragma unroll
+                for (int r = 0; r < UF_STEP; ++r) a[r] = 0.f;
+#pragma unroll
+                for (int zr = 0; zr < UF_STEP + 3; ++zr) {
+                    const float z0 = zc[zr * UF_ZS], z1 = zc[zr * UF_ZS + 1], z2 = zc[zr * UF_ZS + 2], z3 = zc[zr * UF_ZS + 3];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int r = zr - t;
+                        if (r >= 0 && r < UF_STEP) {
+                            a[r] = __builtin_fmaf(z0, kf[t * 4], a[r]);
+                            a[r] = __builtin_fmaf(z1, kf[t * 4 + 1], a[r]);
+                            a[r] = __builtin_fmaf(z2, kf[t * 4 + 2], a[r]);
+                            a[r] = __builtin_fmaf(z3, kf[t * 4 + 3], a[r]);
+                        }
+                    }
+                }
+                const float dd = dp ? dp[co] : 1.f;
+                const float bi = p.act_bias ? p.act_bias[co] : 0.f;
+                const float neg = p.act ? 0.2f : 1.f, gain = p.act ? 1.41421356237309515f : 1.f;
+                const unsigned o0 = (unsigned)co * (unsigned)(ho * wo) + pix0;
+#pragma unroll
+                for (int r = 0; r < UF_STEP; ++r) {
+                    if (r < nrow) {
+                        float v = __builtin_fmaf(a[r], dd, bi);
+                        if (nzb) v = __builtin_fmaf(nw, nzb[pix0 + (unsigned)(r * wo)], v);
+                        v = fmaxf(v, v * neg) * gain;     // leaky relu 0.2 (max picks v for v >= 0, 0.2 v otherwise)
+                        ob[o0 + (unsigned)(r * wo)] = v;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int CB, int MINW>
+int launch_up_fused(UpFusedParams& p, hipStream_t st) {
+    using C = UfCfg<CB>;
+    dim3 grid(p.tiles_x * p.tiles_y, cdiv(p.cout, C::TN), p.bs);
+    if (C::LDS_BYTES > 64 * 1024) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&up_fused_sb_kernel<CB, MINW>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (attr != hipSuccess) return fail((int)attr, "modconv_up_fused_sb: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+    }
+    hipLaunchKernelGGL((up_fused_sb_kernel<CB, MINW>), grid, dim3(UF_NT), C::LDS_BYTES, st, p);
+    return check_launch("modconv_up_fused_sb");
+}
+
+}  // namespace
+
+extern "C" int e4s_modconv_up_fused_sb(float* out, const float* x, const uint16_t* whi, const uint16_t* wlo, const float* s, const float* d,
+                                       const float* blur, const float* noise, int noise_bs, const float* noise_weight, const float* act_bias,
+                                       int act, int bs, int cin, int cout, int h, int w, void* stream) {
+    E4S_REQUIRE(out && x && whi && wlo && s && blur, "modconv_up_fused_sb: null tensor");
+    E4S_REQUIRE(bs >= 0 && bs <= 65535 && cin >= 1 && cout >= 1 && h >= 1 && w >= 1, "modconv_up_fused_sb: bad size");
+    E4S_REQUIRE((int64_t)cout * 4 * h * w < ((int64_t)1 << 31) && (int64_t)cin * h * w < ((int64_t)1 << 31), "modconv_up_fused_sb: one sample must stay below 2^31 elements");
+    E4S_REQUIRE((((uintptr_t)whi | (uintptr_t)wlo) & 15) == 0, "modconv_up_fused_sb: weight slabs must be 16-byte aligned");
+    E4S_REQUIRE(!noise || (noise_weight && (noise_bs == 1 || noise_bs == bs)), "modconv_up_fused_sb: noise needs its weight and batch 1 or bs");
+    if (bs == 0) return 0;
+    UpFusedParams p;
+    p.out = out; p.x = x; p.whi = reinterpret_cast<const uint4*>(whi); p.wlo = reinterpret_cast<const uint4*>(wlo); p.s = s; p.d = d;
+    p.blur = blur; p.noise = noise; p.noise_weight = noise_weight; p.act_bias = act_bias;
+    p.noise_bstride = (noise && noise_bs > 1) ? 4 * h * w : 0;
+    p.act = act; p.bs = bs; p.cin = cin; p.cout = cout; p.h = h; p.w = w;
+    p.tiles_x = cdiv(2 * w, UF_OUT);
+    p.tiles_y = cdiv(2 * h, UF_OUT);
+    hipStream_t st = (hipStream_t)stream;
+    static const int cb2 = [] { const char* e = getenv("E4S_UPFUSED_CB2"); return e ? atoi(e) : 0; }();
+    if (cb2 && cout > 32) return launch_up_fused<2, 2>(p, st);   // 64 co per workgroup: x staged once, 1 workgroup per CU
+    return launch_up_fused<1, 4>(p, st);                          // 32 co per workgroup, 2 workgroups per CU
+}

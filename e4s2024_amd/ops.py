@@ -267,6 +267,7 @@ class PreparedWeights:
         return self.wt, self.wsq
 
 
+UP_FUSED = os.environ.get("E4S_UP_FUSED", "1") != "0"     # single-region up layers: one launch (blur in LDS) instead of tconv + blur epilogue
 UP_TWO_STAGE = os.environ.get("E4S_UP_TWO_STAGE", "1") != "0"
 
 
@@ -274,7 +275,6 @@ def modconv_up_single(x, wt, s, d, blur, noise, noise_weight, act_bias, act: boo
     """Single-region up layer: transposed conv (1x MACs) into a pre-blur buffer, then blur + demod + noise + bias + act."""
     x = _c(x, "input")
     bs, cin, h, w = x.shape
-    z = torch.empty((bs, cout, 2 * h + 1, 2 * w + 1), dtype=torch.float32, device=x.device)
     out = torch.empty((bs, cout, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
     nz = nbs = None
     if noise is not None:
@@ -282,6 +282,14 @@ def modconv_up_single(x, wt, s, d, blur, noise, noise_weight, act_bias, act: boo
         nbs = nz.shape[0]
         if nz.numel() != nbs * 4 * h * w:
             raise ValueError(f"noise shape {tuple(nz.shape)} does not match output {2 * h}x{2 * w}")
+    if UP_FUSED:
+        ev = _timed("modconv_up_fused_sb")
+        lib().call("e4s_modconv_up_fused_sb", _p(out), _p(x), _p(wt[0]), _p(wt[1]), _p(s), _p(d), _p(_c(blur, "blur kernel")), _p(nz), nbs or 0,
+                   _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, _stream())
+        if ev is not None:
+            ev.record()
+        return out
+    z = torch.empty((bs, cout, 2 * h + 1, 2 * w + 1), dtype=torch.float32, device=x.device)
     ev = _timed("modconv_tconv_sb")
     lib().call("e4s_modconv_tconv_sb", _p(z), _p(x), _p(wt[0]), _p(wt[1]), _p(s), bs, cin, cout, h, w, _stream())
     if ev is not None:

@@ -141,6 +141,12 @@ E4S_API int e4s_blur_epilogue(float* out, const float* z, const float* blur, con
                               const float* noise, int noise_bs, const float* noise_weight, const float* act_bias, int act,
                               int bs, int cout, int ho, int wo, void* stream);
 
+/* The same single-region up layer in ONE launch: the transposed conv's pre-blur tile stays in LDS and the 4x4 blur, demodulation,
+ * noise, bias and activation are applied before the only write (no [bs,cout,2h+1,2w+1] round trip).  Arguments as the pair above. */
+E4S_API int e4s_modconv_up_fused_sb(float* out, const float* x, const uint16_t* whi, const uint16_t* wlo, const float* s, const float* d,
+                                    const float* blur, const float* noise, int noise_bs, const float* noise_weight,
+                                    const float* act_bias, int act, int bs, int cin, int cout, int h, int w, void* stream);
+
 /* ToRGB forward in one pass (model.py:439-479): 1x1 modulated conv without demodulation, + bias, + upsampled skip.
  *   x : [bs, cin, h, w]   wt : [cin, 3] from e4s_modconv_prep_weights(k=1)   s : [bs, nreg, cin]   bias : [3]
  *   skip : previous RGB [bs, 3, h/2, w/2] or NULL; up_kernel : [4,4] FIR of Upsample (model.py:34-53; up=2, pad=(2,1))

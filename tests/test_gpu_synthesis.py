@@ -180,3 +180,38 @@ def test_fused_torgb_epilogue_matches_separate_launch(gpu_net3):
     finally:
         _ops.FUSE_RGB = old
     assert (a - b).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 20, 40, 9, 13), (1, 16, 24, 8, 8), (3, 48, 33, 30, 17), (1, 64, 32, 64, 64)])
+def test_up_fused_matches_two_stage_and_oracle(sg2, shape):
+    """Single-region up layer: the one-launch kernel (pre-blur tile kept in LDS) against the tconv + blur-epilogue pair and the
+    oracle's ModulatedConv2d upsample branch (model.py:287-301), incl. ragged sizes, cout not a multiple of 32, per-sample noise."""
+    if _ops.MODCONV_MODE != "sb":
+        pytest.skip("split-bf16 kernels only")
+    bs, cin, cout, h, w = shape
+    rs = np.random.RandomState(1234 + cin)
+    m = sg2.StyledConv(cin, cout, 3, 512, upsample=True, mask_op=False)
+    with torch.no_grad():
+        m.conv.weight.copy_(T(rs.standard_normal(m.conv.weight.shape).astype(np.float32)))
+        m.conv.modulation.weight.copy_(T(rs.standard_normal(m.conv.modulation.weight.shape).astype(np.float32)))
+        m.noise.weight.fill_(0.37)
+        m.activate.bias.copy_(T(0.1 * rs.standard_normal(cout).astype(np.float32)))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV)
+    x = T(rs.standard_normal((bs, cin, h, w)).astype(np.float32))
+    st = T(rs.standard_normal((bs, 512)).astype(np.float32))
+    nz = T(rs.standard_normal((bs, 1, 2 * h, 2 * w)).astype(np.float32))
+    old = _ops.UP_FUSED
+    try:
+        with torch.no_grad():
+            _ops.UP_FUSED = True
+            a = m(x.to(DEV), st.to(DEV), None, noise=nz.to(DEV))
+            _ops.UP_FUSED = False
+            b = m(x.to(DEV), st.to(DEV), None, noise=nz.to(DEV))
+    finally:
+        _ops.UP_FUSED = old
+    ref = O.styled_conv(sd, "", x, st, None, nz, masked=False, upsample=True)
+    scale = max(1.0, float(ref.abs().max()))
+    assert tuple(a.shape) == tuple(ref.shape)
+    assert (a - b).abs().max().item() <= 2e-5 * scale
+    assert maxdiff(a, ref) <= LAYER_TOL * scale
