@@ -11,7 +11,7 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "lib", "libe4s_hip.so")
+SO_PATH = os.environ.get("E4S_HIP_LIB") or os.path.join(HERE, "lib", "libe4s_hip.so")   # E4S_HIP_LIB: tuning builds only
 HEADER = os.path.join(os.path.dirname(HERE), "include", "e4s_hip.h")
 
 c_int, c_i64, c_f32, c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p

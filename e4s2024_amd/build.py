@@ -28,9 +28,13 @@ def _stale(obj, deps):
     return (not os.path.exists(obj)) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, phase_prof: bool = False) -> str:
+    """``phase_prof``: the tuning variant lib/libe4s_hip_prof.so (-DE4S_PHASE_PROF: per-workgroup phase timestamps, read by
+    tools/phase_prof.py through E4S_HIP_LIB); never loaded by default."""
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build_prof" if phase_prof else "build")
+    so = os.path.join(LIBDIR, "libe4s_hip_prof.so") if phase_prof else SO
+    flags = FLAGS + (["-DE4S_PHASE_PROF"] if phase_prof else [])
     os.makedirs(objdir, exist_ok=True)
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(os.path.dirname(HERE), "include", "e4s_hip.h")]
     objs, procs = [], []
@@ -38,20 +42,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + flags + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))
     for src, pr in procs:
         if pr.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    if force or procs or _stale(SO, objs):
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", SO] + objs
+    if force or procs or _stale(so, objs):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", so] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return SO
+    return so
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, phase_prof="--phase-prof" in sys.argv))

@@ -51,4 +51,29 @@ __device__ __forceinline__ int nearest_src(int dst, float scale, int in_size) {
     return s < in_size - 1 ? s : in_size - 1;
 }
 
+// Phase timestamps for kernel tuning (tools/phase_prof.py).  Only in the -DE4S_PHASE_PROF build (lib/libe4s_hip_prof.so); the
+// product library compiles these to nothing.
+#ifdef E4S_PHASE_PROF
+#define E4S_PROF_SLOTS 8
+#define E4S_PROF_BLOCKS (1 << 17)
+#define E4S_PROF_DECL(buf) __device__ long long buf[(size_t)E4S_PROF_BLOCKS * E4S_PROF_SLOTS];
+#define E4S_PROF_MARK(buf, slot)                                                                                     \
+    do {                                                                                                             \
+        if (threadIdx.x == 0) {                                                                                      \
+            const size_t lin_ = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);      \
+            if (lin_ < E4S_PROF_BLOCKS) {                                                                           \
+                buf[lin_ * E4S_PROF_SLOTS + (slot)] = (long long)wall_clock64();                                     \
+                if ((slot) == 0)   /* HW_ID (reg 4) | XCC_ID (reg 20) << 32: which CU this workgroup landed on */      \
+                    buf[lin_ * E4S_PROF_SLOTS + 7] = (long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) |  \
+                                                     ((long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32); \
+            }                                                                                                        \
+        }                                                                                                            \
+    } while (0)
+#define E4S_PROF_DRAIN() __builtin_amdgcn_s_waitcnt(0)
+#else
+#define E4S_PROF_DECL(buf)
+#define E4S_PROF_MARK(buf, slot) do { } while (0)
+#define E4S_PROF_DRAIN() do { } while (0)
+#endif
+
 }  // namespace e4s

@@ -197,7 +197,31 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const Conv2dParams p) {
         }
     }
 
+    // Epilogue in two passes: every global load (bias, residual, slope) first, then the stores.  gfx9 tracks loads and stores with
+    // one in-order counter (vmcnt), so a load issued after a store cannot complete its wait before that store has reached memory.
     const size_t ohw = (size_t)p.ho * p.wo;
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int pbk = wp * PB + q;
+        const int oy = oy0 + pbk * C::RPB + (l5 >> LOG_TW), ox = ox0 + (l5 & (C::TW - 1));
+        const bool pix_ok = oy < p.ho && ox < p.wo;
+        const size_t opix = (size_t)oy * p.wo + ox;
+#pragma unroll
+        for (int i = 0; i < CB; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wc * CB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (pix_ok && co < p.cout) {
+                    float v = acc[i][q][r];
+                    if (p.bias) v += p.bias[co];
+                    if (p.residual) v += p.residual[((size_t)b * p.cout + co) * ohw + opix];
+                    if (p.act == 1) v = fmaxf(v, 0.f);
+                    if (p.act == 2) v = v > 0.f ? v : v * p.slope[co];
+                    acc[i][q][r] = v;
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
         const int pbk = wp * PB + q;
@@ -209,15 +233,7 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const Conv2dParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + (wc * CB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                if (co < p.cout) {
-                    const size_t o = ((size_t)b * p.cout + co) * ohw + opix;
-                    float v = acc[i][q][r];
-                    if (p.bias) v += p.bias[co];
-                    if (p.residual) v += p.residual[o];
-                    if (p.act == 1) v = fmaxf(v, 0.f);
-                    if (p.act == 2) v = v > 0.f ? v : v * p.slope[co];
-                    p.out[o] = v;
-                }
+                if (co < p.cout) p.out[((size_t)b * p.cout + co) * ohw + opix] = acc[i][q][r];
             }
         }
     }
@@ -548,7 +564,31 @@ __global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams 
         }
     }
 
+    // Epilogue in two passes: every global load (bias, residual, slope) first, then the stores.  gfx9 tracks loads and stores with
+    // one in-order counter (vmcnt), so a load issued after a store cannot complete its wait before that store has reached memory.
     const size_t ohw = (size_t)p.ho * p.wo;
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int pbk = wp * PB + q;
+        const int oy = oy0 + pbk * C::RPB + (l5 >> LOG_TW), ox = ox0 + (l5 & (C::TW - 1));
+        const bool pix_ok = oy < p.ho && ox < p.wo;
+        const size_t opix = (size_t)oy * p.wo + ox;
+#pragma unroll
+        for (int i = 0; i < CB; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wc * CB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (pix_ok && co < p.cout) {
+                    float v = acc[i][q][r];
+                    if (p.bias) v += p.bias[co];
+                    if (p.residual) v += p.residual[((size_t)b * p.cout + co) * ohw + opix];
+                    if (p.act == 1) v = fmaxf(v, 0.f);
+                    if (p.act == 2) v = v > 0.f ? v : v * p.slope[co];
+                    acc[i][q][r] = v;
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
         const int pbk = wp * PB + q;
@@ -560,15 +600,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + (wc * CB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                if (co < p.cout) {
-                    const size_t o = ((size_t)b * p.cout + co) * ohw + opix;
-                    float v = acc[i][q][r];
-                    if (p.bias) v += p.bias[co];
-                    if (p.residual) v += p.residual[o];
-                    if (p.act == 1) v = fmaxf(v, 0.f);
-                    if (p.act == 2) v = v > 0.f ? v : v * p.slope[co];
-                    p.out[o] = v;
-                }
+                if (co < p.cout) p.out[((size_t)b * p.cout + co) * ohw + opix] = acc[i][q][r];
             }
         }
     }

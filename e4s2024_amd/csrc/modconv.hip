@@ -496,15 +496,17 @@ __global__ __launch_bounds__(256) void region_modconv_kernel(const ConvParams p)
         dt[v] = val;
     }
     __syncthreads();
+    // two passes: all global loads (noise, bias) before the first store — gfx9's single in-order vmcnt would otherwise make every
+    // load wait for the stores issued before it
     const float nw = p.noise ? p.noise_weight[0] : 0.f;
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
         const int pbk = wp * PB + q;
         const int y = y0 + pbk * C::RPB + (l5 >> LOG_TW), x = x0 + (l5 & (C::TW - 1));
-        if (y >= p.h || x >= p.w) continue;
+        const bool pix_ok = y < p.h && x < p.w;
         const int oy = p.up ? 2 * y + pa : y, ox = p.up ? 2 * x + pb_ : x;
         const size_t opix = (size_t)oy * wo + ox;
-        const float nz = p.noise ? nw * p.noise[(size_t)b * p.noise_bstride + opix] : 0.f;
+        const float nz = (p.noise && pix_ok) ? nw * p.noise[(size_t)b * p.noise_bstride + opix] : 0.f;
         const float* drow = dt + (cls[q] >= 0 ? cls[q] : 0) * C::TN;
         const float dz = cls[q] >= 0 ? 1.f : 0.f;
 #pragma unroll
@@ -513,12 +515,28 @@ __global__ __launch_bounds__(256) void region_modconv_kernel(const ConvParams p)
             for (int r = 0; r < 16; ++r) {
                 const int n = (wc * CB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                 const int co = co0 + n;
-                if (co < p.cout) {
+                if (pix_ok && co < p.cout) {
                     float v = acc[i][q][r] * drow[n] * dz + nz;
                     if (p.act_bias) v += p.act_bias[co];
                     if (p.act) v = (v > 0.f ? v : v * 0.2f) * 1.41421356237309515f;
-                    p.out[((size_t)b * p.cout + co) * ho * wo + opix] = v;
+                    acc[i][q][r] = v;
                 }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int pbk = wp * PB + q;
+        const int y = y0 + pbk * C::RPB + (l5 >> LOG_TW), x = x0 + (l5 & (C::TW - 1));
+        if (y >= p.h || x >= p.w) continue;
+        const int oy = p.up ? 2 * y + pa : y, ox = p.up ? 2 * x + pb_ : x;
+        const size_t opix = (size_t)oy * wo + ox;
+#pragma unroll
+        for (int i = 0; i < CB; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wc * CB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (co < p.cout) p.out[((size_t)b * p.cout + co) * ho * wo + opix] = acc[i][q][r];
             }
         }
     }
@@ -658,9 +676,9 @@ __global__ __launch_bounds__(256) void region_torgb_kernel(float* __restrict__ o
         }
     }
     const int hs = h >> 1, wsk = w >> 1;
+    float r[3][4];   // all skip loads before the first store (one in-order vmcnt for loads and stores)
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
-        float r[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float v = acc[j][o] + bias[o];
@@ -684,10 +702,12 @@ __global__ __launch_bounds__(256) void region_torgb_kernel(float* __restrict__ o
                 }
                 v += u;
             }
-            r[j] = v;
+            r[o][j] = v;
         }
-        *reinterpret_cast<float4*>(out + ((size_t)b * 3 + o) * hw + pix) = make_float4(r[0], r[1], r[2], r[3]);
     }
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+        *reinterpret_cast<float4*>(out + ((size_t)b * 3 + o) * hw + pix) = make_float4(r[o][0], r[o][1], r[o][2], r[o][3]);
 }
 
 // Masked ToRGB at low resolution (<= 128^2, Cin 256..512): few pixels and a long reduction, so the block is 64 pixels wide and

@@ -93,6 +93,19 @@ extern "C" int e4s_modconv_prep_weights_sb(uint16_t* whi, uint16_t* wlo, float* 
 }
 
 // ============================================================================ the conv kernel
+E4S_PROF_DECL(g_prof_sb)
+#ifdef E4S_PHASE_PROF
+extern "C" E4S_API int e4s_prof_read_sb(long long* host, int64_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prof_sb), (size_t)n * sizeof(long long), 0, hipMemcpyDeviceToHost);
+}
+extern "C" E4S_API int e4s_prof_clear_sb() {
+    void* ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_prof_sb));
+    if (e != hipSuccess) return (int)e;
+    return (int)hipMemset(ptr, 0, sizeof(long long) * (size_t)E4S_PROF_BLOCKS * E4S_PROF_SLOTS);
+}
+#endif
+
 struct SbParams {
     float* out;
     const float* x;
@@ -139,7 +152,7 @@ struct SbCfg {
     static constexpr int LDS_BYTES = XS_FLOATS * 4 + W4 * 16 + SS_FLOATS * 4;
     static_assert(WC * WP == 4 || WC * WP == 8, "256- or 512-thread workgroups");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS per CU");
-    static_assert((E4S_MAX_REGIONS + 3) * TN * 4 + 64 <= W4 * 16, "demod + ToRGB tables overlay the weight stage");
+    static_assert((E4S_MAX_REGIONS + 4) * TN * 4 + 64 <= W4 * 16, "demod + bias + ToRGB tables overlay the weight stage");
 };
 
 // UNI = every output pixel of the launch has the same region (unmasked layers): x*s is then a property of the INPUT pixel, so it is
@@ -168,6 +181,7 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
     const int lane = tid & 63, wave = tid >> 6;
     const int l5 = lane & 31, khalf = lane >> 5;
     const int wc = wave / WP, wp = wave % WP;
+    E4S_PROF_MARK(g_prof_sb, 0);
 
     const int ntile = p.tiles_x * p.tiles_y;
     const int npar = p.up ? 4 : 1;
@@ -312,6 +326,7 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
         __syncthreads();
         store_chunk(chunk);
         __syncthreads();
+        if (chunk == ch_begin) E4S_PROF_MARK(g_prof_sb, 1);
         if (chunk + 1 < ch_end) load_chunk(chunk + 1);
 
         // (!UNI) modulation of this lane's pixels for its 8 channels of the chunk: ci = 8*khalf + e
@@ -324,10 +339,9 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
         }
         const uint4* whalf = wsm + khalf * C::TN + wc * CB * 32 + l5;   // + tap*2*TN, + 18*TN for the lo slab
 
+        {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            constexpr int dummy = 0;
-            (void)dummy;
             const int ky = tap / 3, kx = tap % 3;
             const int toff = TCONV ? (1 - (ky >> 1)) * C::PW + (1 - (kx >> 1)) : ky * C::PW + kx;
             const int ai = TCONV ? 2 * (ky & 1) + (kx & 1) : 0;
@@ -371,8 +385,10 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
                 for (int q = 0; q < PB; ++q)
                     accs[ai][i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[q]), accs[ai][i][q], 0, 0, 0);
         }
+        }
     }
 
+    E4S_PROF_MARK(g_prof_sb, 2);
     if constexpr (TCONV) {  // raw pre-blur sums: z[b][co][2a+i][2b+j], z is (2h+1) x (2w+1)
         const int zh = 2 * p.h + 1, zw = 2 * p.w + 1;
 #pragma unroll
@@ -422,7 +438,9 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
         if (r < p.nreg && co0 + n < p.cout) val = p.d ? p.d[((size_t)b * p.nreg + r) * p.cout + co0 + n] : 1.f;
         dt[v] = val;
     }
-    float* wsr = dt + E4S_MAX_REGIONS * C::TN;   // [TN][3]: ToRGB weight x its (single-region) modulation
+    float* bt = dt + E4S_MAX_REGIONS * C::TN;    // [TN] activation bias
+    for (int v = tid; v < C::TN; v += C::NT) bt[v] = (p.act_bias && co0 + v < p.cout) ? p.act_bias[co0 + v] : 0.f;
+    float* wsr = bt + C::TN;                     // [TN][3]: ToRGB weight x its (single-region) modulation
     float* kfr = wsr + 3 * C::TN;                // [16] flipped skip-upsample taps
     if constexpr (RGB) {
         for (int v = tid; v < 3 * C::TN; v += C::NT) {
@@ -432,7 +450,18 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
         if (tid < 16) kfr[tid] = p.rgb_upk ? p.rgb_upk[15 - tid] : 0.f;
     }
     __syncthreads();
+    E4S_PROF_MARK(g_prof_sb, 3);
+    // Every global LOAD of the epilogue happens before the first store: gfx9 counts loads and stores in one in-order counter
+    // (vmcnt), so a load issued after a store cannot be waited for without also waiting for that store to reach memory.
     const float nw = p.noise ? p.noise_weight[0] : 0.f;
+    float nzq[PB];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int pbk = wp * PB + q;
+        const int y = y0 + pbk * C::RPB + (l5 >> LOG_TW), x = x0 + (l5 & (C::TW - 1));
+        const int oy = p.up ? 2 * y + pa : y, ox = p.up ? 2 * x + pb_ : x;
+        nzq[q] = (p.noise && y < p.h && x < p.w) ? nw * p.noise[(size_t)b * p.noise_bstride + (size_t)oy * wo + ox] : 0.f;
+    }
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
         const int pbk = wp * PB + q;
@@ -440,7 +469,7 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
         const bool pix_ok = y < p.h && x < p.w;
         const int oy = p.up ? 2 * y + pa : y, ox = p.up ? 2 * x + pb_ : x;
         const size_t opix = (size_t)oy * wo + ox;
-        const float nz = (p.noise && pix_ok) ? nw * p.noise[(size_t)b * p.noise_bstride + opix] : 0.f;
+        const float nz = nzq[q];
         const float* drow = dt + (cls[q] >= 0 ? cls[q] : 0) * C::TN;
         const float dz = cls[q] >= 0 ? 1.f : 0.f;
         float rgb0 = 0.f, rgb1 = 0.f, rgb2 = 0.f;
@@ -451,8 +480,7 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
                 const int n = (wc * CB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                 const int co = co0 + n;
                 if (co < p.cout && pix_ok) {
-                    float v = acc[i][q][r] * drow[n] * dz + nz;
-                    if (p.act_bias) v += p.act_bias[co];
+                    float v = acc[i][q][r] * drow[n] * dz + nz + bt[n];
                     if (p.act) v = (v > 0.f ? v : v * 0.2f) * 1.41421356237309515f;
                     p.out[((size_t)b * p.cout + co) * ho * wo + opix] = v;
                     if constexpr (RGB) {
@@ -496,6 +524,9 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
             }
         }
     }
+    E4S_PROF_MARK(g_prof_sb, 4);
+    E4S_PROF_DRAIN();
+    E4S_PROF_MARK(g_prof_sb, 5);
 }
 
 // Sum the K-slices in a fixed order and apply the StyledConv epilogue.
@@ -699,6 +730,14 @@ __global__ __launch_bounds__(256) void blur_epilogue_kernel(float* __restrict__ 
     const int ly = threadIdx.x >> 4;
     const int oy = oy0 + ly;
     if (oy >= ho) return;
+    float nzv[2][4];   // loads before stores (one in-order vmcnt for both on gfx9)
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ox = ox0 + (threadIdx.x & 15) * 4 + half * 64 + k;
+            nzv[half][k] = (noise && ox < wo) ? nw * noise[(size_t)b * noise_bstride + (size_t)oy * wo + ox] : 0.f;
+        }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int lx = (threadIdx.x & 15) * 4 + half * 64;
@@ -718,8 +757,7 @@ __global__ __launch_bounds__(256) void blur_epilogue_kernel(float* __restrict__ 
         float r[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            float v = a[k] * dd + bi;
-            if (noise && ox + k < wo) v += nw * noise[(size_t)b * noise_bstride + (size_t)oy * wo + ox + k];
+            float v = a[k] * dd + bi + nzv[half][k];
             if (act) v = (v > 0.f ? v : v * 0.2f) * 1.41421356237309515f;
             r[k] = v;
         }

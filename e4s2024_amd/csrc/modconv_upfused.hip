@@ -44,6 +44,8 @@ constexpr int UF_NT = 512;                  // 8 waves: wave v owns position row
 constexpr int UF_ZS = 34;                   // row stride of the pre-blur tile in LDS (32 + 2: float2-aligned, spreads banks)
 constexpr int UF_ZCO = 8;                   // output channels blurred per LDS pass
 
+E4S_PROF_DECL(g_prof_up)
+
 template <int CB>
 struct UfCfg {
     static constexpr int TN = CB * 32;
@@ -66,6 +68,7 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l5 = lane & 31, khalf = lane >> 5;
+    E4S_PROF_MARK(g_prof_up, 0);
 
     const int tyt = blockIdx.x / p.tiles_x, txt = blockIdx.x - tyt * p.tiles_x;
     const int p0y = tyt * UF_STEP - 1, p0x = txt * UF_STEP - 1;
@@ -141,6 +144,7 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
         __syncthreads();
         store_chunk(chunk);
         __syncthreads();
+        if (chunk == 0) E4S_PROF_MARK(g_prof_up, 1);
         if (chunk + 1 < nchunk) load_chunk(chunk + 1);
         const uint4* whalf = wsm + khalf * C::TN + l5;
 #pragma unroll
@@ -169,6 +173,7 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
     }
 
     // ---- epilogue: 8 output channels at a time through LDS.  Blur item of this thread: one output column, 14 rows, one channel.
+    E4S_PROF_MARK(g_prof_up, 2);
     __syncthreads();
     float* zt = reinterpret_cast<float*>(lds_raw);   // [8][32][ZS]
     float kf[16];                                    // kf[ty*4+tx] = blur[3-ty][3-tx]  (uniform loads -> scalar registers)
@@ -187,8 +192,21 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
     float* ob = p.out + (size_t)b * p.cout * ho * wo;
     const unsigned pix0 = (unsigned)(oy0 * wo + ox);
     const float* zc = zt + (it_co * 32 + it_rg * UF_STEP + 1) * UF_ZS + it_x + 1;   // z row (local) of output row r, tap t: r + 1 + t
-    const float* dp = p.d ? p.d + (size_t)b * p.cout : nullptr;
+    // All global loads of the epilogue are issued here, before the first store (gfx9's vmcnt orders loads behind earlier stores).
+    float ddr[CB][4], bir[CB][4], nz[UF_STEP];
+#pragma unroll
+    for (int i = 0; i < CB; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = co0 + i * 32 + 8 * g + it_co;
+            const bool ok = co < p.cout;
+            ddr[i][g] = (p.d && ok) ? p.d[(size_t)b * p.cout + co] : 1.f;
+            bir[i][g] = (p.act_bias && ok) ? p.act_bias[co] : 0.f;
+        }
+#pragma unroll
+    for (int r = 0; r < UF_STEP; ++r) nz[r] = (nzb && r < nrow) ? nw * nzb[pix0 + (unsigned)(r * wo)] : 0.f;
 
+    E4S_PROF_MARK(g_prof_up, 3);
 #pragma unroll
     for (int i = 0; i < CB; ++i) {
 #pragma unroll
@@ -221,15 +239,13 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
                         }
                     }
                 }
-                const float dd = dp ? dp[co] : 1.f;
-                const float bi = p.act_bias ? p.act_bias[co] : 0.f;
+                const float dd = ddr[i][g], bi = bir[i][g];
                 const float neg = p.act ? 0.2f : 1.f, gain = p.act ? 1.41421356237309515f : 1.f;
                 const unsigned o0 = (unsigned)co * (unsigned)(ho * wo) + pix0;
 #pragma unroll
                 for (int r = 0; r < UF_STEP; ++r) {
                     if (r < nrow) {
-                        float v = __builtin_fmaf(a[r], dd, bi);
-                        if (nzb) v = __builtin_fmaf(nw, nzb[pix0 + (unsigned)(r * wo)], v);
+                        float v = __builtin_fmaf(a[r], dd, bi) + nz[r];
                         v = fmaxf(v, v * neg) * gain;     // leaky relu 0.2 (max picks v for v >= 0, 0.2 v otherwise)
                         ob[o0 + (unsigned)(r * wo)] = v;
                     }
@@ -238,6 +254,9 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
             __syncthreads();
         }
     }
+    E4S_PROF_MARK(g_prof_up, 4);
+    E4S_PROF_DRAIN();
+    E4S_PROF_MARK(g_prof_up, 5);
 }
 
 template <int CB, int MINW>
@@ -254,6 +273,18 @@ int launch_up_fused(UpFusedParams& p, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef E4S_PHASE_PROF
+extern "C" E4S_API int e4s_prof_read_up(long long* host, int64_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prof_up), (size_t)n * sizeof(long long), 0, hipMemcpyDeviceToHost);
+}
+extern "C" E4S_API int e4s_prof_clear_up() {
+    void* ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_prof_up));
+    if (e != hipSuccess) return (int)e;
+    return (int)hipMemset(ptr, 0, sizeof(long long) * (size_t)E4S_PROF_BLOCKS * E4S_PROF_SLOTS);
+}
+#endif
 
 extern "C" int e4s_modconv_up_fused_sb(float* out, const float* x, const uint16_t* whi, const uint16_t* wlo, const float* s, const float* d,
                                        const float* blur, const float* noise, int noise_bs, const float* noise_weight, const float* act_bias,
