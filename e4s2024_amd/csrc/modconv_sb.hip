@@ -610,7 +610,7 @@ static int launch_sb(SbParams& p, hipStream_t st, float* workspace, int64_t work
     }
     constexpr bool BIG = C::LDS_BYTES > 64 * 1024;   // one workgroup per CU
     constexpr int BIGW = C::NT / 256;                // waves per SIMD that workgroup provides
-    if (BIG) {
+    if constexpr (BIG) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, BIGW, false, false>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (attr != hipSuccess) return fail((int)attr, "region_modconv3x3_sb: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
