@@ -1,0 +1,168 @@
+// f2 / f3: the integer mask surgery that sits between face parsing and synthesis, on the device.
+//   e4s_swap_head_mask   : swap_head_mask_hole_first            (swap_face_fine/swap_face_mask.py:194-333)
+//   e4s_foreground_masks : foreground mask + create_masks(..., 'expansion', radius)
+//                          (face_swap_video_pipeline.py:456-463, gradio_utils/face_swapping.py:203-221, utils/morphology.py:22-190)
+// uint8 label maps in, uint8 / {0,1} float maps out; every value is exact.  HBM-bound byte work: one coalesced pass per map.
+#include "common.h"
+
+using namespace e4s;
+
+namespace {
+
+__device__ __forceinline__ bool is_bg_class(int c) { return c == 4 || c == 0 || c == 8 || c == 7 || c == 11; }   // :210-220
+
+// One thread per column: top-most skin row of the target (rows >= 1; the reference's `target_skin * arange(H)` makes row 0
+// indistinguishable from "no skin", :282-286) and the lowest rows of the source's eyes / brows / nose (:234-239).
+__global__ __launch_bounds__(256) void swap_mask_scan_kernel(int* __restrict__ skin_top, int* __restrict__ lowest, const uint8_t* __restrict__ source,
+                                                             const uint8_t* __restrict__ target, int h, int w) {
+    const int b = blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    int top = h, m3 = -1, m2 = -1, m5 = -1;
+    if (x < w) {
+        const uint8_t* s = source + (size_t)b * h * w + x;
+        const uint8_t* t = target + (size_t)b * h * w + x;
+        for (int y = 0; y < h; ++y) {
+            const int sv = s[(size_t)y * w], tv = t[(size_t)y * w];
+            if (tv == 6 && y >= 1 && y < top) top = y;
+            if (sv == 3) m3 = y;
+            if (sv == 2) m2 = y;
+            if (sv == 5) m5 = y;
+        }
+        skin_top[(size_t)b * w + x] = top;
+    }
+    m3 = (int)wave_max((float)m3);   // rows < 2^24: exact in float
+    m2 = (int)wave_max((float)m2);
+    m5 = (int)wave_max((float)m5);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&lowest[b * 3 + 0], m3);
+        atomicMax(&lowest[b * 3 + 1], m2);
+        atomicMax(&lowest[b * 3 + 2], m5);
+    }
+}
+
+__global__ __launch_bounds__(256) void swap_mask_apply_kernel(uint8_t* __restrict__ res, uint8_t* __restrict__ hole, uint8_t* __restrict__ hole_map,
+                                                              int* __restrict__ lines, const uint8_t* __restrict__ source,
+                                                              const uint8_t* __restrict__ target, const int* __restrict__ skin_top,
+                                                              const int* __restrict__ lowest, int h, int w) {
+    const int b = blockIdx.y;
+    const int m3 = lowest[b * 3 + 0], m2 = lowest[b * 3 + 1], m5 = lowest[b * 3 + 2];
+    const int eye_line = m3 >= 0 ? m3 : (m2 >= 0 ? m2 : (int)(2.0 / 5.0 * (double)h));   // :232-237
+    const int nose_line = m5 >= 0 ? m5 : (int)(3.0 / 5.0 * (double)h);                   // :233, 238-239
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        lines[b * 2 + 0] = eye_line;
+        lines[b * 2 + 1] = nose_line;
+    }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= h * w) return;
+    const int y = i / w, x = i - y * w;
+    const size_t o = (size_t)b * h * w + i;
+    const int s = source[o], t = target[o];
+    bool hl = !is_bg_class(t) && is_bg_class(s);          // target face that the source face does not cover (:222-223)
+    if (y < eye_line) hl = false;                         // :243-244
+    int r = 0;
+    if (t == 0) r = 99;                                   // :247-251 (later assignments win, as in the reference)
+    if (t == 8) r = 8;
+    if (t == 7) r = 7;
+    if (t == 11) r = 11;
+    if (s == 1) r = 1;                                    // :263-269
+    if (s == 2) r = 2;
+    if (s == 4 && t == 2) r = 2;
+    if (s == 3) r = 3;
+    if (s == 5) r = 5;
+    if (s == 6) r = 6;
+    if (s == 9) r = 9;
+    const int top = skin_top[(size_t)b * w + x];
+    if (t == 0 && top != h && y <= top) r = 98;           // :287-301 target foreground above its skin (hats)
+    if (t == 4) r = 4;                                    // :304-305
+    if (t == 10) r = 10;
+    if (r == 0) r = 6;                                    // :310-312
+    if (r == 99 || r == 98) r = 0;
+    res[o] = (uint8_t)r;
+    hole[o] = hl ? 1 : 0;
+    hole_map[o] = hl ? 17 : (uint8_t)r;                   // :313-314
+}
+
+// foreground = not {background, ear-ring, ear, hair, neck} or hole; then flat (2r+1)^2 dilation / erosion that ignore pixels outside the
+// image ('geodesic' border).  For a {0,1} map: dilation = any foreground in the window, erosion = all in-image pixels foreground.
+constexpr int FM_T = 32;
+__global__ __launch_bounds__(256) void foreground_masks_kernel(float* __restrict__ content, float* __restrict__ border, float* __restrict__ full,
+                                                               const uint8_t* __restrict__ swapped, const uint8_t* __restrict__ hole, int h, int w,
+                                                               int radius) {
+    extern __shared__ unsigned char sm[];
+    const int pw = FM_T + 2 * radius;
+    unsigned char* fg = sm;                   // [pw][pw]: 1 foreground, 0 not, 2 outside the image
+    unsigned char* any_r = sm + pw * pw;      // [pw][FM_T] horizontal "any foreground"
+    unsigned char* all_r = any_r + pw * FM_T; // [pw][FM_T] horizontal "all foreground"
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * FM_T, y0 = blockIdx.y * FM_T;
+    for (int e = threadIdx.x; e < pw * pw; e += 256) {
+        const int py = e / pw, px = e - py * pw;
+        const int gy = y0 - radius + py, gx = x0 - radius + px;
+        unsigned char v = 2;
+        if (gy >= 0 && gy < h && gx >= 0 && gx < w) {
+            const size_t o = ((size_t)b * h + gy) * w + gx;
+            const int c = swapped[o];
+            const bool bgc = c == 0 || c == 11 || c == 7 || c == 4 || c == 8;
+            v = (!bgc || (hole && hole[o])) ? 1 : 0;
+        }
+        fg[e] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < pw * FM_T; e += 256) {
+        const int py = e / FM_T, lx = e - py * FM_T;
+        bool any = false, all = true;
+        for (int d = 0; d <= 2 * radius; ++d) {
+            const unsigned char v = fg[py * pw + lx + d];
+            any = any || v == 1;
+            all = all && v != 0;
+        }
+        any_r[e] = any;
+        all_r[e] = all;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < FM_T * FM_T; e += 256) {
+        const int ly = e / FM_T, lx = e - ly * FM_T;
+        const int gy = y0 + ly, gx = x0 + lx;
+        if (gy >= h || gx >= w) continue;
+        bool any = false, all = true;
+        for (int d = 0; d <= 2 * radius; ++d) {
+            any = any || any_r[(ly + d) * FM_T + lx];
+            all = all && all_r[(ly + d) * FM_T + lx];
+        }
+        const size_t o = ((size_t)b * h + gy) * w + gx;
+        const float dil = any ? 1.f : 0.f, ero = all ? 1.f : 0.f;
+        if (content) content[o] = fg[(ly + radius) * pw + lx + radius] == 1 ? 1.f : 0.f;
+        border[o] = fminf(fmaxf(dil - ero, 0.f), 1.f);
+        full[o] = dil;
+    }
+}
+
+}  // namespace
+
+extern "C" int e4s_swap_head_mask(uint8_t* res, uint8_t* hole_mask, uint8_t* hole_map, int32_t* lines, const uint8_t* source, const uint8_t* target,
+                                  int32_t* scratch, int bs, int h, int w, void* stream) {
+    E4S_REQUIRE(res && hole_mask && hole_map && lines && source && target && scratch, "swap_head_mask: null tensor");
+    E4S_REQUIRE(bs >= 0 && bs <= 65535 && h >= 1 && w >= 1 && (int64_t)h * w < ((int64_t)1 << 30), "swap_head_mask: bad size");
+    if (bs == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int* lowest = scratch;            // [bs][3]
+    int* skin_top = scratch + bs * 3; // [bs][w]
+    hipError_t e = hipMemsetAsync(lowest, 0xff, sizeof(int) * bs * 3, st);   // -1
+    if (e != hipSuccess) return fail((int)e, "swap_head_mask: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(swap_mask_scan_kernel, dim3(cdiv(w, 256), bs), dim3(256), 0, st, skin_top, lowest, source, target, h, w);
+    hipLaunchKernelGGL(swap_mask_apply_kernel, dim3(cdiv(h * w, 256), bs), dim3(256), 0, st, res, hole_mask, hole_map, lines, source, target, skin_top,
+                       lowest, h, w);
+    return check_launch("swap_head_mask");
+}
+
+extern "C" int e4s_foreground_masks(float* content, float* border, float* full, const uint8_t* swapped, const uint8_t* hole_mask, int bs, int h, int w,
+                                    int radius, void* stream) {
+    E4S_REQUIRE(border && full && swapped, "foreground_masks: null tensor");
+    E4S_REQUIRE(bs >= 0 && bs <= 65535 && h >= 1 && w >= 1 && radius >= 0 && radius <= 32, "foreground_masks: bad size (radius 0..32)");
+    if (bs == 0) return 0;
+    const int pw = FM_T + 2 * radius;
+    const size_t lds = (size_t)pw * pw + 2 * (size_t)pw * FM_T;
+    hipLaunchKernelGGL(foreground_masks_kernel, dim3(cdiv(w, FM_T), cdiv(h, FM_T), bs), dim3(256), lds, (hipStream_t)stream, content, border, full, swapped,
+                       hole_mask, h, w, radius);
+    return check_launch("foreground_masks");
+}

@@ -663,6 +663,51 @@ def tensor2im_u8(img: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# ------------------------------------------------------------------------------------ f2 / f3 (maskops.hip)
+def _labels_u8(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if t.dtype != torch.uint8 or t.dim() != 3:
+        raise ValueError(f"{name}: expected a uint8 [bs, H, W] label map, got {t.dtype} {tuple(t.shape)}")
+    return t.contiguous()
+
+
+def swap_head_mask(source: torch.Tensor, target: torch.Tensor):
+    """``swap_head_mask_hole_first`` (swap_face_fine/swap_face_mask.py:194-333) for a batch of 12-class maps on the device.
+    ``source`` = the driven face's map, ``target`` = the target frame's map, both uint8 ``[bs, H, W]``.
+    Returns ``(res, hole_mask, hole_map, lines)``: uint8 maps (``hole_mask`` in {0,1}) and int32 ``[bs, 2]`` = (eye_line, nose_line)."""
+    s, t = _labels_u8(source, "source"), _labels_u8(target, "target")
+    if s.shape != t.shape:
+        raise ValueError(f"source {tuple(s.shape)} and target {tuple(t.shape)} maps differ in shape")
+    bs, h, w = t.shape
+    res, hole, hole_map = torch.empty_like(t), torch.empty_like(t), torch.empty_like(t)
+    lines = torch.empty((bs, 2), dtype=torch.int32, device=t.device)
+    scratch = torch.empty((bs * (3 + w),), dtype=torch.int32, device=t.device)
+    if bs == 0:
+        return res, hole, hole_map, lines
+    lib().call("e4s_swap_head_mask", _p(res), _p(hole), _p(hole_map), _p(lines), _p(s), _p(t), _p(scratch), bs, h, w, _stream())
+    return res, hole, hole_map, lines
+
+
+def foreground_masks(swapped: torch.Tensor, hole_mask: Optional[torch.Tensor] = None, radius: int = 5):
+    """Foreground of a swapped map (everything but background / ear-ring / ear / hair / neck, plus the hole:
+    face_swap_video_pipeline.py:456-461) and ``create_masks(foreground, operation='expansion', radius)``
+    (gradio_utils/face_swapping.py:203-221).  Returns float32 ``[bs, 1, H, W]`` ``(content, border, full)``."""
+    m = _labels_u8(swapped, "swapped")
+    hm = _labels_u8(hole_mask, "hole_mask") if hole_mask is not None else None
+    if hm is not None and hm.shape != m.shape:
+        raise ValueError("hole_mask and swapped map differ in shape")
+    bs, h, w = m.shape
+    content = torch.empty((bs, 1, h, w), dtype=torch.float32, device=m.device)
+    border, full = torch.empty_like(content), torch.empty_like(content)
+    if bs == 0:
+        return content, border, full
+    lib().call("e4s_foreground_masks", _p(content), _p(border), _p(full), _p(m), _p(hm), bs, h, w, int(radius), _stream())
+    return content, border, full
+
+
 # ------------------------------------------------------------------------------------ a7
 def grouped_linear(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Optional[Sequence[Optional[torch.Tensor]]], *, scale: float,
                    bias_mul: float = 1.0, act: int = 0, slope: float = 0.2, addend: Optional[torch.Tensor] = None,

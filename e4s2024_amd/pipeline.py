@@ -1,9 +1,10 @@
 """Batched full-swap unit on the device: per face
     2 x parse (BiSeNet, 19 -> 12 classes) + 2 x get_style_vectors + style-vector mix + cal_style_codes + gen_img (+ tensor2im)
 which is what ``face_swap_video_pipeline.py`` does per frame between its CPU stages (:212-219 parsing, :332-354 style vectors,
-:429-443 mix + synthesis), here for a whole batch without leaving the GPU.  The numpy mask surgery of the reference
-(``swap_head_mask_hole_first``, swap_face_mask.py:194-333 — row f2, "next") is not part of this unit: the target's own region map
-drives the synthesis.
+:429-443 mix + synthesis), here for a whole batch without leaving the GPU.  With ``mask_surgery=True`` the synthesis is driven by
+``swap_head_mask_hole_first(driven_map, target_map)`` as at face_swap_video_pipeline.py:420 (row f2, ``ops.swap_head_mask``) and the
+paste-back masks of :456-463 (row f3, ``ops.foreground_masks``) are returned too; the default keeps BASELINE configs[2]'s unit of
+work, where the target's own region map drives the synthesis.
 """
 from __future__ import annotations
 
@@ -49,9 +50,11 @@ def mix_style_vectors(target_vec: torch.Tensor, driven_vec: torch.Tensor, comp_i
 
 @torch.no_grad()
 def swap_batch(net, parser, driven: torch.Tensor, target: torch.Tensor, comp_indices: Sequence[int] = DEFAULT_COMP_INDICES,
-               randomize_noise: bool = False, to_uint8: bool = True, timings: Optional[dict] = None):
+               randomize_noise: bool = False, to_uint8: bool = True, timings: Optional[dict] = None, mask_surgery: bool = False,
+               paste_radius: int = 5):
     """``driven`` / ``target``: ``[bs, 3, 1024, 1024]`` in [-1, 1] on the device.  Returns uint8 ``[bs, 1024, 1024, 3]`` frames
-    (or the float image) and the target's 12-class region maps."""
+    (or the float image) and the 12-class region maps the synthesis used; with ``mask_surgery`` a third value
+    ``{"hole_mask", "hole_map", "lines", "content", "border", "full"}`` (the reference's paste-back inputs, :456-463)."""
     def mark(name):
         if timings is not None:
             ev = torch.cuda.Event(enable_timing=True)
@@ -66,8 +69,15 @@ def swap_batch(net, parser, driven: torch.Tensor, target: torch.Tensor, comp_ind
     mark("encode_x2")
     codes = net.cal_style_codes(mix_style_vectors(vec_t, vec_d, comp_indices))
     mark("mix+mlps")
-    img, _, _ = net.gen_img(None, codes, lab_t, randomize_noise=randomize_noise)
+    extra = None
+    lab = lab_t
+    if mask_surgery:
+        lab, hole, hole_map, lines = ops.swap_head_mask(lab_d, lab_t)
+        content, border, full = ops.foreground_masks(lab, hole, paste_radius)
+        extra = {"hole_mask": hole, "hole_map": hole_map, "lines": lines, "content": content, "border": border, "full": full}
+        mark("mask_surgery")
+    img, _, _ = net.gen_img(None, codes, lab, randomize_noise=randomize_noise)
     mark("gen_img")
     out = ops.tensor2im_u8(img) if to_uint8 else img
     mark("tensor2im")
-    return out, lab_t
+    return (out, lab) if extra is None else (out, lab, extra)

@@ -255,6 +255,21 @@ E4S_API int e4s_bicubic_down_normalize(float* out, const float* in, const float*
 /* tensor2im (utils/torch_utils.py:64-76): img [bs,3,h,w] in ~[-1,1] -> uint8 [bs,h,w,3] = trunc(clamp((x+1)/2, 0, 1) * 255). */
 E4S_API int e4s_tensor2im_u8(uint8_t* out, const float* img, int bs, int h, int w, void* stream);
 
+/* ---- f2 / f3: mask surgery between face parsing and synthesis (integer maps, exact) --------------------------------------------
+ * e4s_swap_head_mask: swap_head_mask_hole_first(source, target) (swap_face_fine/swap_face_mask.py:194-333) for a batch.
+ *   source, target : uint8 [bs, h, w] 12-class maps (driven face, target face)
+ *   res            : uint8 [bs, h, w] swapped map;  hole_mask : uint8 {0,1};  hole_map : res with 17 on the hole
+ *   lines          : int32 [bs, 2] = (eye_line, nose_line) as computed at :232-239
+ *   scratch        : int32 [bs * (3 + w)] work buffer
+ * e4s_foreground_masks: foreground = not {0, 11, 7, 4, 8} or hole (face_swap_video_pipeline.py:456-461), then
+ *   create_masks(foreground, 'expansion', radius) (gradio_utils/face_swapping.py:203-221; flat (2r+1)^2 dilation / erosion with the
+ *   'geodesic' border of utils/morphology.py): content = foreground, full = dilation, border = clip(dilation - erosion, 0, 1).
+ *   content (may be NULL), border, full : float32 [bs, 1, h, w] in {0, 1};  hole_mask may be NULL. */
+E4S_API int e4s_swap_head_mask(uint8_t* res, uint8_t* hole_mask, uint8_t* hole_map, int32_t* lines, const uint8_t* source,
+                               const uint8_t* target, int32_t* scratch, int bs, int h, int w, void* stream);
+E4S_API int e4s_foreground_masks(float* content, float* border, float* full, const uint8_t* swapped, const uint8_t* hole_mask,
+                                 int bs, int h, int w, int radius, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

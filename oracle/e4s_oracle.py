@@ -458,3 +458,82 @@ def synthesis_flops(size: int = 1024) -> float:
         cin = co
         r *= 2
     return float(fl)
+
+
+# --------------------------------------------------------------------------- f2 / f3: mask surgery between parse and synthesis
+_BG_CLASSES = (4, 0, 8, 7, 11)      # hair, background, neck, ear, ear-ring  (swap_face_mask.py:210-220)
+
+
+def swap_head_mask_hole_first(source: np.ndarray, target: np.ndarray):
+    """``swap_head_mask_hole_first`` — swap_face_fine/swap_face_mask.py:194-333, vectorised but assignment for assignment
+    (later writes win).  ``source`` / ``target``: integer 12-class maps ``[H, W]``.  Returns
+    ``(res, hole_mask, hole_map, nose_line)`` like the reference, plus ``eye_line`` as a fifth value."""
+    source = np.asarray(source)
+    target = np.asarray(target)
+    H, W = target.shape
+    src_face = ~np.isin(source, _BG_CLASSES)                                             # :210-214
+    tgt_face = ~np.isin(target, _BG_CLASSES)                                             # :216-220
+    hole = np.logical_xor(np.logical_and(src_face, tgt_face), tgt_face)                  # :222-223
+    eye_line, nose_line = int(2 / 5 * H), int(3 / 5 * H)                                 # :232-233
+    if np.any(source == 3):
+        eye_line = int(np.where(source == 3)[0].max())                                   # :234-235
+    elif np.any(source == 2):
+        eye_line = int(np.where(source == 2)[0].max())                                   # :236-237
+    if np.any(source == 5):
+        nose_line = int(np.where(source == 5)[0].max())                                  # :238-239
+    if len(hole) >= eye_line:
+        hole[:eye_line, :] = False                                                       # :243-244
+    res = np.zeros_like(target)
+    res[target == 0] = 99                                                                # :247-251
+    res[target == 8] = 8
+    res[target == 7] = 7
+    res[target == 11] = 11
+    res[source == 1] = 1                                                                 # :263-269
+    res[source == 2] = 2
+    res[np.logical_and(source == 4, target == 2)] = 2
+    res[source == 3] = 3
+    res[source == 5] = 5
+    res[source == 6] = 6
+    res[source == 9] = 9
+    rows = np.arange(H)[:, None]
+    skin_rows = np.where(target == 6, rows, 0).astype(np.int64)                          # :282-285: skin in row 0 counts as "none"
+    skin_rows[skin_rows == 0] = H
+    skin_top = skin_rows.min(axis=0)                                                     # :286
+    fg = np.logical_and(target == 0, np.logical_and(rows <= skin_top[None, :], skin_top[None, :] != H))   # :287-299
+    res[fg] = 98                                                                         # :300-301
+    res[target == 4] = 4                                                                 # :304-305
+    res[target == 10] = 10
+    res[res == 0] = 6                                                                    # :310-312
+    res[res == 99] = 0
+    res[res == 98] = 0
+    hole_map = res.copy()
+    hole_map[hole] = 17                                                                  # :313-314
+    return res, hole, hole_map, nose_line, eye_line
+
+
+def _flat_morph(mask: np.ndarray, radius: int, op) -> np.ndarray:
+    """Flat (2r+1)^2 dilation / erosion with the 'geodesic' border of utils/morphology.py:76-81, 150-155: pixels outside the image
+    are ignored.  ``mask``: float ``[..., H, W]``."""
+    H, W = mask.shape[-2:]
+    pad_val = -np.inf if op is np.maximum else np.inf
+    p = np.pad(mask, [(0, 0)] * (mask.ndim - 2) + [(radius, radius), (radius, radius)], constant_values=pad_val)
+    out = np.full_like(mask, pad_val)
+    for dy in range(2 * radius + 1):
+        for dx in range(2 * radius + 1):
+            out = op(out, p[..., dy:dy + H, dx:dx + W])
+    return out
+
+
+def create_masks_expansion(mask: np.ndarray, radius: int):
+    """``create_masks(mask, operation='expansion', radius)`` — gradio_utils/face_swapping.py:203-221:
+    ``(content, border, full) = (mask, clip(dilate(mask) - erode(mask), 0, 1), dilate(mask))``."""
+    mask = np.asarray(mask, dtype=np.float32)
+    full = _flat_morph(mask, radius, np.maximum)
+    ero = _flat_morph(mask, radius, np.minimum)
+    return mask, np.clip(full - ero, 0, 1), full
+
+
+def foreground_mask(swapped: np.ndarray, hole: np.ndarray) -> np.ndarray:
+    """face_swap_video_pipeline.py:456-461: everything except background / ear-ring / ear / hair / neck, plus the hole."""
+    fg = ~np.isin(swapped, (0, 11, 7, 4, 8))
+    return np.logical_or(fg, hole).astype(np.float32)

@@ -339,6 +339,77 @@ def g11():
     save("g11_helpers", img=v, im=im, lab=lab, onehot=oh)
 
 
+def _face_like_labels(rs, h, w, classes, n_blobs=14):
+    """Integer label map with rectangular blobs of the given classes on background (a crude face layout is enough: the functions
+    under test are per-pixel logic plus row/column reductions)."""
+    lab = np.zeros((h, w), np.uint8)
+    for _ in range(n_blobs):
+        c = classes[rs.randint(len(classes))]
+        y0, x0 = rs.randint(0, h - 2), rs.randint(0, w - 2)
+        y1, x1 = min(h, y0 + rs.randint(2, h // 2 + 2)), min(w, x0 + rs.randint(2, w // 2 + 2))
+        lab[y0:y1, x0:x1] = c
+    return lab
+
+
+def g12():
+    print("G12 mask surgery: swap_head_mask_hole_first (swap_face_fine/swap_face_mask.py:194-333), create_masks (gradio_utils/face_swapping.py:203-221)")
+    shim.install()
+    import ast
+    import copy
+    import types
+    if not hasattr(np, "long"):
+        np.long = np.int64          # swap_face_mask.py:281 uses the alias numpy removed in 1.24 (the reference pins numpy 1.23.5)
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    import importlib
+    sfm = importlib.import_module("swap_face_fine.swap_face_mask")
+    morph = importlib.import_module("utils.morphology")
+    # create_masks lives in a module that imports dlib-based alignment code at module scope; run the reference's own text of just
+    # that function (parsed from where it lies, nothing is copied) against the reference's dilation / erosion.
+    src = open(os.path.join(shim.REF, "gradio_utils", "face_swapping.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "create_masks"]
+    ns = {"copy": copy, "torch": torch, "dilation": morph.dilation, "erosion": morph.erosion}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), "face_swapping.py:create_masks", "exec"), ns)
+    create_masks = ns["create_masks"]
+
+    rs = np.random.RandomState(21)
+    allc = list(range(12))
+    cases = {
+        "generic": (_face_like_labels(rs, 64, 64, allc), _face_like_labels(rs, 64, 64, allc)),
+        "ragged": (_face_like_labels(rs, 48, 80, allc), _face_like_labels(rs, 48, 80, allc)),
+        "no_eyes": (_face_like_labels(rs, 64, 64, [c for c in allc if c != 3]), _face_like_labels(rs, 64, 64, allc)),
+        "no_eyes_no_brows_no_nose": (_face_like_labels(rs, 40, 56, [1, 4, 6, 7, 8, 9]), _face_like_labels(rs, 40, 56, allc)),
+        "iid": (rs.randint(0, 12, (33, 47)).astype(np.uint8), rs.randint(0, 12, (33, 47)).astype(np.uint8)),
+        "target_all_bg": (_face_like_labels(rs, 32, 32, allc), np.zeros((32, 32), np.uint8)),
+    }
+    t = _face_like_labels(rs, 64, 64, allc)
+    t[0, :] = 6            # skin in row 0 is treated as "no skin" by the column scan (:283-285)
+    t[1:9, 10:20] = 0
+    cases["skin_row0"] = (_face_like_labels(rs, 64, 64, allc), t)
+    out = {}
+    for name, (src_m, tgt_m) in cases.items():
+        res, hole, hole_map, nose_line = sfm.swap_head_mask_hole_first(src_m.copy(), tgt_m.copy())
+        o = O.swap_head_mask_hole_first(src_m, tgt_m)
+        assert (res == o[0]).all() and (hole == o[1]).all() and (hole_map == o[2]).all() and nose_line == o[3], name
+        fgm = O.foreground_mask(res, hole)
+        content, border, full = create_masks(T(fgm[None, None]), operation="expansion", radius=5)
+        oc, ob, of = O.create_masks_expansion(fgm[None, None], 5)
+        assert (content.numpy() == oc).all() and (border.numpy() == ob).all() and (full.numpy() == of).all(), name
+        out.update({f"{name}.source": src_m, f"{name}.target": tgt_m, f"{name}.res": res, f"{name}.hole": hole.astype(np.uint8),
+                    f"{name}.hole_map": hole_map, f"{name}.lines": np.array([o[4], nose_line], np.int32),
+                    f"{name}.border": border.numpy()[0, 0].astype(np.uint8), f"{name}.full": full.numpy()[0, 0].astype(np.uint8)})
+        print(f"  {name:28s} {src_m.shape}: eye_line {o[4]} nose_line {nose_line} hole px {int(hole.sum())} border px {int(border.sum())}  restatement == reference")
+    # radius sweep of the morphology on a random binary mask (incl. radius 0 and a radius larger than the image edge distance)
+    m = (rs.rand(2, 1, 20, 27) > 0.7).astype(np.float32)
+    for r in (0, 1, 3, 7):
+        content, border, full = create_masks(T(m), operation="expansion", radius=r)
+        oc, ob, of = O.create_masks_expansion(m, r)
+        assert (border.numpy() == ob).all() and (full.numpy() == of).all(), r
+        out[f"morph.r{r}.border"] = border.numpy().astype(np.uint8)
+        out[f"morph.r{r}.full"] = full.numpy().astype(np.uint8)
+    out["morph.mask"] = m.astype(np.uint8)
+    save("g12_mask_surgery", **out)
+
+
 def g0(Net3, sg2):
     """state_dict manifests (key -> shape, dtype) of the reference modules: pure data."""
     import argparse as ap
@@ -388,6 +459,7 @@ def main():
     if want("g678"): g678(Net3)
     if want("g9"): g9_10()
     if want("g11"): g11()
+    if want("g12"): g12()
 
 
 if __name__ == "__main__":

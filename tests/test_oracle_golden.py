@@ -157,3 +157,21 @@ def test_g11_helpers():
 
 def test_synthesis_flop_count():
     assert abs(O.synthesis_flops(1024) / 1e9 - 148.52) < 0.05
+
+
+G12_CASES = ("generic", "ragged", "no_eyes", "no_eyes_no_brows_no_nose", "iid", "target_all_bg", "skin_row0")
+
+
+def test_g12_mask_surgery():
+    """f2/f3: swap_head_mask_hole_first and create_masks('expansion') restated in numpy vs the reference's own outputs (integer, exact)."""
+    g = load_golden("g12_mask_surgery")
+    for name in G12_CASES:
+        res, hole, hole_map, nose_line, eye_line = O.swap_head_mask_hole_first(g[f"{name}.source"], g[f"{name}.target"])
+        assert (res == g[f"{name}.res"]).all() and (hole == g[f"{name}.hole"].astype(bool)).all() and (hole_map == g[f"{name}.hole_map"]).all(), name
+        assert [eye_line, nose_line] == g[f"{name}.lines"].tolist(), name
+        _, border, full = O.create_masks_expansion(O.foreground_mask(res, hole)[None, None], 5)
+        assert (border[0, 0] == g[f"{name}.border"]).all() and (full[0, 0] == g[f"{name}.full"]).all(), name
+    m = g["morph.mask"].astype(np.float32)
+    for r in (0, 1, 3, 7):
+        _, border, full = O.create_masks_expansion(m, r)
+        assert (border == g[f"morph.r{r}.border"]).all() and (full == g[f"morph.r{r}.full"]).all(), r
