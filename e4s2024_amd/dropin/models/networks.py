@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from e4s2024_amd import ops
+from e4s2024_amd import ops, torch_ref
 from models.stylegan2.model import EqualLinear, Generator
 from models.encoders.psp_encoders import FSEncoder_PSP
 
@@ -41,7 +41,12 @@ def local_mlps(mlps, x, addend=None):
     h = ops.grouped_linear(x, [l.weight for l in l0], [l.bias for l in l0], scale=l0[0].scale, bias_mul=l0[0].lr_mul, act=1, slope=slope)
     out = ops.grouped_linear(h, [l.weight for l in l2], [l.bias for l in l2], scale=l2[0].scale, bias_mul=l2[0].lr_mul, act=0, addend=addend)
     deps = [x] + [p for l in l0 + l2 for p in (l.weight, l.bias)]
-    return ops._attach("LocalMLP", out, *deps)
+    n = len(mlps)
+
+    def ref(xr, *ps):     # ps: (w, b) of the n first layers, then of the n second layers
+        return torch_ref.local_mlps(xr, ps[0:2 * n:2], ps[1:2 * n:2], ps[2 * n::2], ps[2 * n + 1::2], l0[0].scale, l2[0].scale, l0[0].lr_mul,
+                                    l2[0].lr_mul, slope, addend)
+    return ops._attach("LocalMLP", out, *deps, ref=ref)
 
 
 class Net3(nn.Module):

@@ -16,7 +16,7 @@ import random
 import torch
 from torch import nn
 
-from e4s2024_amd import ops
+from e4s2024_amd import ops, torch_ref
 from models.stylegan2.op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 
 
@@ -91,7 +91,8 @@ class EqualLinear(nn.Module):
         out = ops.grouped_linear(x, [self.weight], None if self.bias is None else [self.bias], scale=self.scale, bias_mul=self.lr_mul,
                                  act=2 if self.activation else 0, slope=0.2)
         out = out.reshape(*shp[:-1], self.weight.shape[0])
-        return ops._attach("EqualLinear", out, input, self.weight, self.bias)
+        return ops._attach("EqualLinear", out, input, self.weight, self.bias,
+                           ref=lambda x, w, b: torch_ref.equal_linear(x, w, b, self.scale, self.lr_mul, bool(self.activation)))
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]})"
@@ -170,20 +171,33 @@ class ModulatedConv2d(nn.Module):
             wt, s, d = self.tables(styles, masked=False)
             out = ops.modconv_up_single(input, wt, s, d, self.blur.kernel, noise, noise_weight, act_bias, act, self.out_channel)
             return ops._attach("ModulatedConv2d", out, input, styles, self.weight, self.modulation.weight, self.modulation.bias, noise_weight,
-                               act_bias)
+                               act_bias, ref=self._torch_ref(labels, noise, act))
         wt, s, d = self.tables(styles, masked=labels is not None)
         out = ops.region_modconv3x3(input, wt, s, d, labels, noise, noise_weight, act_bias, act, self.out_channel, self.upsample, rgb=rgb)
         if rgb is not None:
             return tuple(ops._attach("ModulatedConv2d", o, input, styles, self.weight, self.modulation.weight, self.modulation.bias,
                                      noise_weight, act_bias) for o in out)
         return ops._attach("ModulatedConv2d", out, input, styles, self.weight, self.modulation.weight, self.modulation.bias, noise_weight,
-                           act_bias)
+                           act_bias, ref=self._torch_ref(labels, noise, act))
+
+    def _torch_ref(self, labels, noise, act):
+        """The differentiable PyTorch form of ``forward_regions`` for the backward pass (torch_ref.styled_conv)."""
+        blur = self.blur.kernel if self.upsample else None
+        mod = self.modulation
+
+        def ref(x, styles, weight, mod_w, mod_b, noise_weight, act_bias):
+            return torch_ref.styled_conv(x, styles, weight, mod_w, mod_b, noise_weight, act_bias, labels=labels, noise=noise, act=act,
+                                         upsample=self.upsample, blur=blur, demodulate=self.demodulate, mod_scale=mod.scale, mod_lr=mod.lr_mul)
+        return ref
 
     def forward(self, input, style):
         if self.kernel_size == 1:
             wt, s, _ = self.tables(style[:, None, :])
             out = ops.region_torgb(input, wt, s, None, torch.zeros(3, device=input.device), None, None)
-            return ops._attach("ModulatedConv2d", out, input, style, self.weight, self.modulation.weight, self.modulation.bias)
+            mod = self.modulation
+            return ops._attach("ModulatedConv2d", out, input, style, self.weight, self.modulation.weight, self.modulation.bias,
+                               ref=lambda x, st, w, mw, mb: torch_ref.to_rgb(x, st[:, None, :], None, w, mw, mb, 0.0, labels=None, up_kernel=None,
+                                                                              mod_scale=mod.scale, mod_lr=mod.lr_mul))
         return self.forward_regions(input, style[:, None, :], None)
 
 
@@ -275,7 +289,16 @@ class ToRGB(nn.Module):
         out = ops.region_torgb(input, wt, s, labels, self.bias, skip if fuse_skip else None, self.upsample.kernel if fuse_skip else None)
         if skip is not None and not fuse_skip:
             out = out + self.upsample(skip)
-        return ops._attach("ToRGB", out, input, style, skip, self.conv.weight, self.conv.modulation.weight, self.conv.modulation.bias, self.bias)
+        mod = self.conv.modulation
+        up_kernel = self.upsample.kernel if skip is not None else None
+        if skip is not None and (tuple(up_kernel.shape) != (4, 4) or self.upsample.factor != 2):
+            raise NotImplementedError("ToRGB backward is written for the 4x4, factor-2 skip upsample")
+
+        def ref(x, st, sk, w, mw, mb, bias):
+            return torch_ref.to_rgb(x, st if self.mask_op else st[:, None, :], sk, w, mw, mb, bias, labels=labels, up_kernel=up_kernel,
+                                    mod_scale=mod.scale, mod_lr=mod.lr_mul)
+        return ops._attach("ToRGB", out, input, style, skip, self.conv.weight, self.conv.modulation.weight, self.conv.modulation.bias, self.bias,
+                           ref=ref)
 
 
 class Generator(nn.Module):

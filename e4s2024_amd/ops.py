@@ -59,8 +59,46 @@ class _ForwardOnly(torch.autograd.Function):
             f"backward of {ctx.name} is not built yet (SURVEY §8 f1); run the fused synthesis path under torch.no_grad()")
 
 
-def _attach(name: str, out: torch.Tensor, *deps: Optional[torch.Tensor]) -> torch.Tensor:
+class _TorchBackward(torch.autograd.Function):
+    """Forward: the fused HIP kernel's result.  Backward: re-evaluates ``ref(*deps)`` — the same layer written with stock PyTorch
+    ops (``torch_ref.py``) — under autograd on the saved inputs and back-propagates ``grad`` through it (interim:
+    native forward, PyTorch gradients)."""
+
+    @staticmethod
+    def forward(ctx, ref, out, *deps):
+        ctx.ref = ref
+        ctx.is_tensor = [isinstance(d, torch.Tensor) for d in deps]
+        ctx.save_for_backward(*[d for d in deps if isinstance(d, torch.Tensor)])
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, grad):
+        saved = iter(ctx.saved_tensors)
+        needs = ctx.needs_input_grad[2:]
+        ins, wanted = [], []
+        for flag, need in zip(ctx.is_tensor, needs):
+            if not flag:
+                ins.append(None)
+                continue
+            t = next(saved).detach()
+            if need:
+                t = t.requires_grad_(True)
+                wanted.append(t)
+            ins.append(t)
+        with torch.enable_grad():
+            ref_out = ctx.ref(*ins)
+            grads = torch.autograd.grad(ref_out, wanted, grad, allow_unused=True)
+        it = iter(grads)
+        res = [next(it) if (flag and need) else None for flag, need in zip(ctx.is_tensor, needs)]
+        return (None, None, *res)
+
+
+def _attach(name: str, out: torch.Tensor, *deps: Optional[torch.Tensor], ref=None) -> torch.Tensor:
+    """Put a fused kernel's output into the autograd graph of its inputs.  With ``ref`` (a differentiable PyTorch form of the same
+    computation taking ``*deps``) a backward pass works through ``_TorchBackward``; without, it fails loudly."""
     if torch.is_grad_enabled() and any(d is not None and d.requires_grad for d in deps):
+        if ref is not None:
+            return _TorchBackward.apply(ref, out, *deps)
         return _ForwardOnly.apply(name, out, *[d for d in deps if d is not None and d.requires_grad])
     return out
 

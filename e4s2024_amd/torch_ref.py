@@ -1,0 +1,103 @@
+"""Differentiable stock-PyTorch (ROCm ATen/MIOpen) forms of the fused synthesis layers, used ONLY for the backward pass.
+
+SURVEY §8 row f1: the HIP kernels of rows a3-a7 are forward kernels.  Until their dgrad / wgrad kernels exist, a backward through
+the drop-in modules (PTI tuning, ``training/video_swap_ft_coach.py:242-299``; W-optimisation, ``optimization.py:321-349``) re-evaluates
+the layer with the functions below under autograd (``ops._attach(..., ref=...)``) and back-propagates through that — the forward that
+produced the activations is still the fused HIP kernel, the gradients are PyTorch's.  Each function states the reference lines it
+evaluates; none of this runs under ``torch.no_grad()`` inference.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+SQRT2 = math.sqrt(2.0)
+
+
+def fir_resample(x: torch.Tensor, kernel: torch.Tensor, up: int = 1, pad=(0, 0)) -> torch.Tensor:
+    """``upfirdn2d(x, kernel, up=up, down=1, pad=pad)`` (op/upfirdn2d.py:85-147) with ATen ops: zero-insert, pad, correlate with the
+    flipped kernel, every channel on its own."""
+    bs, ch, h, w = x.shape
+    if up > 1:
+        z = x.new_zeros(bs, ch, h, up, w, up)
+        z[:, :, :, 0, :, 0] = x
+        x = z.reshape(bs, ch, h * up, w * up)
+    p0, p1 = pad
+    x = F.pad(x, (max(p0, 0), max(p1, 0), max(p0, 0), max(p1, 0)))
+    if p0 < 0 or p1 < 0:
+        x = x[:, :, max(-p0, 0): x.shape[2] - max(-p1, 0), max(-p0, 0): x.shape[3] - max(-p1, 0)]
+    k = torch.flip(kernel, (0, 1)).to(x.dtype)[None, None].expand(ch, 1, -1, -1)
+    return F.conv2d(x, k, groups=ch)
+
+
+def equal_linear(x, weight, bias, scale: float, lr_mul: float, activation: bool):
+    """``EqualLinear.forward`` (model.py:150-161)."""
+    if activation:
+        out = F.linear(x, weight * scale)
+        return F.leaky_relu(out + (bias * lr_mul if bias is not None else 0.0), 0.2) * SQRT2
+    return F.linear(x, weight * scale, None if bias is None else bias * lr_mul)
+
+
+def local_mlps(x, w0: Sequence[torch.Tensor], b0, w2, b2, scale0: float, scale2: float, lr0: float, lr2: float, slope: float, addend=None):
+    """The per-region ``LocalMLP`` stack of ``Net3.cal_style_codes`` (networks.py:23-49, 236-244): ``x [bs, n, dim]`` -> ``[bs, n, out]``."""
+    outs = []
+    for g in range(len(w0)):
+        h = F.leaky_relu(F.linear(x[:, g], w0[g] * scale0, b0[g] * lr0), slope)
+        o = F.linear(h, w2[g] * scale2, b2[g] * lr2)
+        outs.append(o if addend is None else o + addend)
+    return torch.stack(outs, dim=1)
+
+
+def _modulated(x, s, weight, demodulate: bool, upsample: bool, blur: Optional[torch.Tensor], eps: float = 1e-8):
+    """One region's ``ModulatedConv2d`` fused branch (model.py:276-320): ``s [bs, cin]`` is the modulation output."""
+    bs, cin, h, w = x.shape
+    cout, k = weight.shape[1], weight.shape[-1]
+    wm = (weight * (1.0 / math.sqrt(cin * k * k))) * s.view(bs, 1, cin, 1, 1)
+    if demodulate:
+        wm = wm * torch.rsqrt(wm.pow(2).sum((2, 3, 4), keepdim=True) + eps)
+    xin = x.reshape(1, bs * cin, h, w)
+    if upsample:
+        y = F.conv_transpose2d(xin, wm.transpose(1, 2).reshape(bs * cin, cout, k, k), stride=2, padding=0, groups=bs)
+        return fir_resample(y.view(bs, cout, y.shape[-2], y.shape[-1]), blur, pad=(1, 1))
+    y = F.conv2d(xin, wm.reshape(bs * cout, cin, k, k), padding=k // 2, groups=bs)
+    return y.view(bs, cout, h, w)
+
+
+def _region_sum(x, styles, labels, weight, mod_w, mod_b, mod_scale, mod_lr, demodulate, upsample, blur):
+    """Σ_c modconv(x, style_c) ⊙ [label == c]  (StyledConv.forward :389-398 / ToRGB.forward :447-454); ``labels`` None = one region."""
+    out = None
+    for c in range(styles.shape[1]):
+        s = F.linear(styles[:, c], mod_w * mod_scale, mod_b * mod_lr)
+        y = _modulated(x, s, weight, demodulate, upsample, blur)
+        if labels is not None:
+            lab = labels
+            if lab.shape[-2:] != y.shape[-2:]:   # nearest resize of the region map to this layer's resolution (F.interpolate, :391)
+                lab = F.interpolate(lab[:, None].float(), size=y.shape[-2:], mode="nearest")[:, 0].to(labels.dtype)
+            y = y * (lab == c)[:, None].to(y.dtype)
+        out = y if out is None else out + y
+    return out
+
+
+def styled_conv(x, styles, weight, mod_w, mod_b, noise_weight, act_bias, *, labels, noise, act: bool, upsample: bool, blur, demodulate: bool,
+                mod_scale: float, mod_lr: float):
+    """``StyledConv.forward`` (model.py:382-423): region sum + noise injection (:335) + FusedLeakyReLU (:421)."""
+    out = _region_sum(x, styles, labels, weight, mod_w, mod_b, mod_scale, mod_lr, demodulate, upsample, blur)
+    if noise is not None and noise_weight is not None:
+        out = out + noise_weight * noise
+    if act_bias is not None:
+        out = out + act_bias.view(1, -1, 1, 1)
+    if act:
+        out = F.leaky_relu(out, 0.2) * SQRT2
+    return out
+
+
+def to_rgb(x, styles, skip, weight, mod_w, mod_b, bias, *, labels, up_kernel, mod_scale: float, mod_lr: float):
+    """``ToRGB.forward`` (model.py:439-479): 1x1 modulated conv without demodulation, + bias, + upsampled skip (Upsample :34-53)."""
+    out = _region_sum(x, styles, labels, weight, mod_w, mod_b, mod_scale, mod_lr, False, False, None)
+    out = out + bias
+    if skip is not None:
+        out = out + fir_resample(skip, up_kernel, up=2, pad=(2, 1))
+    return out

@@ -1,0 +1,86 @@
+"""Row f1 (interim): gradients through the drop-in modules on the GPU — fused HIP forward, stock-PyTorch backward
+(ops._TorchBackward + torch_ref.py) — against autograd through the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import install_dropin, template_from_manifest
+from e4s2024_amd import seeded
+from oracle import e4s_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+
+
+@pytest.fixture(scope="module")
+def sg2():
+    install_dropin()
+    from models.stylegan2 import model
+    return model
+
+
+def test_generator64_parameter_and_code_gradients(sg2, manifest):
+    """One PTI-style backward through Generator(64, remaining_layer_idx=5): d(loss)/d(codes) and d(loss)/d(every parameter)
+    equal the oracle's autograd results (the trainable set of a PTI step, training/video_swap_ft_coach.py:297-299)."""
+    size, rli, ncls, bs = 64, 5, 5, 2
+    lab = seeded.blocky_labels(22, bs, ncls, 64, cells=8)
+    n_latent = int(np.log2(size)) * 2 - 2
+    codes = seeded.seeded_codes(23, bs, ncls, n_latent, seeded.seeded_latent_avg(2, n_latent))
+    sd = seeded.seeded_state_dict(template_from_manifest(manifest["generator_64_rli5"]), 21, "net3")
+    mask = seeded.labels_to_onehot(lab, ncls)
+    wgt = T(np.random.RandomState(5).standard_normal((bs, 3, size, size)).astype(np.float32))
+
+    # oracle autograd on CPU
+    sd_o = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "noises" not in k and "kernel" not in k else v) for k, v in sd.items()}
+    codes_o = codes.clone().requires_grad_(True)
+    img_o, _ = O.generator_forward(sd_o, codes_o, mask, None, size=size, remaining_layer_idx=rli, split_layer_idx=5)
+    (img_o * wgt).sum().backward()
+
+    gen = sg2.Generator(size, 512, 8, split_layer_idx=5, remaining_layer_idx=rli)
+    gen.load_state_dict({k[2:]: v for k, v in sd.items()})
+    gen = gen.to(DEV).train()
+    codes_g = codes.clone().to(DEV).requires_grad_(True)
+    img, _, _ = gen([codes_g], None, mask.to(DEV), input_is_latent=True, randomize_noise=False)
+    assert (img.detach().cpu() - img_o.detach()).abs().max().item() <= 5e-4
+    (img * wgt.to(DEV)).sum().backward()
+
+    # Tolerances: this random-weight network is ill-conditioned for gradients (a 1e-5 change of an activation flips leaky-relu branches
+    # further down): the fp32 oracle itself is 1e-3..8e-3 (2e-2 on a cancelling scalar sum) away from an fp64 evaluation of the same
+    # graph.  The tight per-layer gradient checks are in tests/test_backward_cpu.py; this test pins the wiring of every parameter.
+    def rel(a, b):
+        return (a.cpu() - b).abs().max().item() / max(1e-6, b.abs().max().item())
+    assert rel(codes_g.grad, codes_o.grad) <= 3e-2
+    scalar_scale = max(v.grad.abs().max().item() for k, v in sd_o.items() if k.endswith("noise.weight") and getattr(v, "grad", None) is not None)
+    checked = 0
+    for name, p in gen.named_parameters():
+        go = sd_o["G." + name].grad
+        if go is None:          # not on the path (e.g. the 8-layer style MLP when input_is_latent=True)
+            assert p.grad is None or p.grad.abs().max().item() == 0
+            continue
+        assert p.grad is not None, name
+        if go.numel() == 1:     # noise weights: sum of +/- terms, compare on the scale of the largest of them
+            assert (p.grad.cpu() - go).abs().item() <= 3e-2 * scalar_scale, (name, p.grad.item(), go.item())
+        else:
+            assert rel(p.grad, go) <= 3e-2, (name, rel(p.grad, go))
+        checked += 1
+    assert checked >= 40
+
+
+def test_local_mlp_gradients():
+    install_dropin()
+    from models.networks import LocalMLP
+    rs = np.random.RandomState(7)
+    m = LocalMLP(dim_component=24, dim_style=16, num_w_layers=3)
+    x = T(rs.standard_normal((4, 24)).astype(np.float32))
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    h = torch.nn.functional.leaky_relu(O.equal_linear(x, sd["mlp.0.weight"], sd["mlp.0.bias"]), 0.01)
+    ref = O.equal_linear(h, sd["mlp.2.weight"], sd["mlp.2.bias"]).view(-1, 3, 16)
+    g = T(rs.standard_normal(tuple(ref.shape)).astype(np.float32))
+    (ref * g).sum().backward()
+    m = m.to(DEV)
+    out = m(x.to(DEV))
+    assert (out.detach().cpu() - ref.detach()).abs().max().item() <= 1e-4
+    (out * g.to(DEV)).sum().backward()
+    for k, p in m.named_parameters():
+        assert (p.grad.cpu() - sd[k].grad).abs().max().item() <= 1e-4 * max(1.0, sd[k].grad.abs().max().item()), k

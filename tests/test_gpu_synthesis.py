@@ -64,11 +64,18 @@ def test_g4_masked_layers_incl_empty_region(sg2):
 
 
 def test_forward_only_kernels_refuse_backward(sg2):
-    m = sg2.StyledConv(16, 24, 3, 512, mask_op=False).to(DEV)
-    x = torch.randn(1, 16, 8, 8, device=DEV, requires_grad=True)
-    y = m(x, torch.randn(1, 512, device=DEV), None, noise=torch.zeros(1, 1, 8, 8, device=DEV))
+    """The encoder's fused units have no backward of any kind yet and must fail loudly; the synthesis layers back-propagate through
+    the stock-PyTorch form (tests/test_gpu_backward.py)."""
+    install_dropin()
+    from models.encoders.psp_encoders import SEModule
+    m = SEModule(32, 16).to(DEV)
+    x = torch.randn(1, 32, 8, 8, device=DEV, requires_grad=True)
     with pytest.raises(NotImplementedError):
-        y.sum().backward()
+        m(x).sum().backward()
+    c = sg2.StyledConv(16, 24, 3, 512, mask_op=False).to(DEV)
+    x = torch.randn(1, 16, 8, 8, device=DEV, requires_grad=True)
+    c(x, torch.randn(1, 512, device=DEV), None, noise=torch.zeros(1, 1, 8, 8, device=DEV)).sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
 
 
 @pytest.mark.parametrize("tag,man", [("s64", "generator_64_rli5"), ("s256", "generator_256_rli13")])
