@@ -57,6 +57,20 @@ def conv3x3_flops_per_face(size=1024):
     return out
 
 
+def _pmc_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate runs, tools/final_prof.sh -> profiles/r01_traffic.json); None if no pass covers that kernel.
+    bench.py cannot collect counters itself — a --pmc run is a separate process around it."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    ent = t.get(kernel_key)
+    return None if ent is None else ent.get("hbm_bytes_per_launch")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,7 +195,7 @@ def main():
             # is a third of the dense bf16 MFMA peak; exact mode is priced against the fp32 MFMA peak.
             peak = BF16_MATRIX_PEAK_TFLOPS / 3.0 if sb else FP32_MATRIX_PEAK_TFLOPS
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None,
+                    "frac": round(ach / peak, 4), "traffic": _pmc_traffic(dom),
                     "peak_basis": ("dense bf16 MFMA 2500 TFLOP/s / 3 MFMAs per fp32-accurate product (split-bf16)" if sb else "fp32 MFMA 157.3 TFLOP/s"),
                     "vs_fp32_mfma_peak": round(ach / FP32_MATRIX_PEAK_TFLOPS, 3),
                     "launches_per_step": calls // args.steps, "avg_launch_ms": round(avg_ms, 4),

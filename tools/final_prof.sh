@@ -1,4 +1,21 @@
-export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out; cd /tmp
+# Round-end evidence: GPU test suite, default bench line, kernel-trace stats of the bench and of the full swap, two PMC passes.
+# Everything lands as small text/JSON under gpurun_out/; the result databases are deleted on the box.
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out; cd $R
+timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -3 > gpurun_out/final_gpu_tests.txt; cat gpurun_out/final_gpu_tests.txt
+timeout 900 python bench.py 2> gpurun_out/final_bench.err | grep '^{' > gpurun_out/final_bench.json; cut -c1-400 gpurun_out/final_bench.json
+cd /tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench -o bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-full-swap > $R/gpurun_out/prof_bench.log 2>&1
+grep '^{' $R/gpurun_out/prof_bench.log > $R/gpurun_out/final_bench_under_rocprof.json
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_swap -o swap -- python3 $R/tools/time_swap.py 8 6 > $R/gpurun_out/prof_swap.log 2>&1
-tail -7 $R/gpurun_out/prof_swap.log
+cd $R
+python tools/rocpd_summary.py gpurun_out/prof_bench/bench_results.db | cut -c1-260 > gpurun_out/final_bench_kernel_stats.txt
+python tools/rocpd_summary.py gpurun_out/prof_swap/swap_results.db | cut -c1-260 > gpurun_out/final_swap_kernel_stats.txt
+tail -7 gpurun_out/prof_swap.log > gpurun_out/final_swap_timing.txt
+rm -rf gpurun_out/prof_bench gpurun_out/prof_swap
+bash tools/pmc_pass.sh "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" pmc_sq
+cd $R; python tools/rocpd_pmc.py gpurun_out/pmc_sq/pmc_results.db region_modconv > gpurun_out/final_pmc_sq.txt; python tools/rocpd_pmc.py gpurun_out/pmc_sq/pmc_results.db up_fused >> gpurun_out/final_pmc_sq.txt; rm -rf gpurun_out/pmc_sq
+bash tools/pmc_pass.sh "FETCH_SIZE" pmc_fetch
+cd $R; python tools/rocpd_pmc.py gpurun_out/pmc_fetch/pmc_results.db > gpurun_out/final_pmc_fetch.txt; rm -rf gpurun_out/pmc_fetch
+bash tools/pmc_pass.sh "WRITE_SIZE" pmc_write
+cd $R; python tools/rocpd_pmc.py gpurun_out/pmc_write/pmc_results.db > gpurun_out/final_pmc_write.txt; rm -rf gpurun_out/pmc_write
+head -12 gpurun_out/final_bench_kernel_stats.txt; head -20 gpurun_out/final_pmc_sq.txt
