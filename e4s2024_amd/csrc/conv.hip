@@ -6,6 +6,8 @@
 // Fusions: InstanceNorm of the INPUT applied while staging ((x-mean)*rstd for in-bounds pixels, padding stays 0),
 // channel-concatenated input (two source tensors), folded-BatchNorm bias, residual add, ReLU / PReLU epilogue.
 // Tile shape is chosen per launch so that small feature maps (32x32, 16x16) still put >= ~200 workgroups on the chip.
+#include <stdlib.h>
+
 #include "common.h"
 
 using namespace e4s;
@@ -393,7 +395,7 @@ struct C2SbCfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS per CU");
 };
 
-template <int KS, int S, int CB, int PB, int WC, int WP, int LOG_TW>
+template <int KS, int S, int CB, int PB, int WC, int WP, int LOG_TW, int PF = 1>
 __global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams p) {
     using C = C2SbCfg<KS, S, CB, PB, WC, WP, LOG_TW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -443,8 +445,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.f;
 
-    float xr[CKS2][C::EPT];
-    unsigned wr[C::WPT][4];   // scalar components: an array of uint4 ends up in scratch
+    // Register stages of the NEXT TWO chunks (set 0 / set 1 alternate): with one or two workgroups per CU a single chunk of MFMAs
+    // (~1 us) does not cover a cold HBM/L2 miss (2-4 us) on the weight slabs, so loads run two chunks ahead.  The per-channel
+    // InstanceNorm statistics of a chunk travel with it (they used to be fetched at conversion time, on the critical path).
+    // (PF = 1 keeps one stage where the second would spill: the 64 co x 256 px tile and the large stride-2 patches.)
+    float xr[PF][CKS2][C::EPT];
+    unsigned wr[PF][C::WPT][4];   // scalar components: an array of uint4 ends up in scratch
+    float mu[PF][CKS2], rs[PF][CKS2];
 
     // Unconditional loads (no per-element branches, so they are issued here and really are a prefetch): out-of-image elements read
     // a valid clamped address and are zeroed at conversion time; channels >= cin meet zero-padded weights; output-channel rows
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams 
     for (int j = 0; j < C::EPT; ++j) goffs[j] = ginb[j] ? goff[j] : 0;
     const bool split_ok = (p.cin0 % CKS2) == 0;   // a chunk never straddles the two concatenated inputs
     const ptrdiff_t wdelta = p.wlo - p.whi;
-    auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
+    auto load_chunk = [&](int chunk, float (&xs)[CKS2][C::EPT], unsigned (&ws)[C::WPT][4], float (&m)[CKS2], float (&r)[CKS2]) __attribute__((always_inline)) {
         const int ci0 = chunk * CKS2;
         if (split_ok) {
             const float* xcb = (ci0 < p.cin0) ? xb0 + (size_t)ci0 * hw : xb1 + (size_t)(ci0 - p.cin0) * hw;
@@ -463,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams 
             for (int c = 0; c < CKS2; ++c) {
                 const float* xc = xcb + (size_t)(c < cmax ? c : cmax) * hw;
 #pragma unroll
-                for (int j = 0; j < C::EPT; ++j) xr[c][j] = xc[goffs[j]];
+                for (int j = 0; j < C::EPT; ++j) xs[c][j] = xc[goffs[j]];
             }
         } else {
 #pragma unroll
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams 
                 const int ci = (ci0 + c < p.cin) ? ci0 + c : p.cin - 1;
                 const float* xc = (ci < p.cin0) ? xb0 + (size_t)ci * hw : xb1 + (size_t)(ci - p.cin0) * hw;
 #pragma unroll
-                for (int j = 0; j < C::EPT; ++j) xr[c][j] = xc[goffs[j]];
+                for (int j = 0; j < C::EPT; ++j) xs[c][j] = xc[goffs[j]];
             }
         }
         const size_t wbase = (size_t)chunk * C::KK * 2 * p.cout;
@@ -484,18 +491,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams 
             const int th = rem / C::TN, n = rem - th * C::TN;
             const int co = (co0 + n < p.cout) ? co0 + n : p.cout - 1;
             const uint4 t4 = p.whi[(ptrdiff_t)hl * wdelta + (ptrdiff_t)(wbase + (size_t)th * p.cout + co)];
-            wr[v][0] = t4.x; wr[v][1] = t4.y; wr[v][2] = t4.z; wr[v][3] = t4.w;
+            ws[v][0] = t4.x; ws[v][1] = t4.y; ws[v][2] = t4.z; ws[v][3] = t4.w;
         }
-    };
-    auto store_chunk = [&](int chunk) __attribute__((always_inline)) {
-        const int ci0 = chunk * CKS2;
-        float mu[CKS2], rs[CKS2];
 #pragma unroll
         for (int c = 0; c < CKS2; ++c) {
             const bool on = p.in_mean && ci0 + c < p.cin;
-            mu[c] = on ? p.in_mean[(size_t)b * p.cin + ci0 + c] : 0.f;
-            rs[c] = on ? p.in_rstd[(size_t)b * p.cin + ci0 + c] : 1.f;
+            m[c] = on ? p.in_mean[(size_t)b * p.cin + ci0 + c] : 0.f;
+            r[c] = on ? p.in_rstd[(size_t)b * p.cin + ci0 + c] : 1.f;
         }
+    };
+    auto store_chunk = [&](const float (&xs)[CKS2][C::EPT], const unsigned (&ws)[C::WPT][4], const float (&m)[CKS2], const float (&r)[CKS2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < C::EPT; ++j) {
             const int e = tid + j * 256;
@@ -504,8 +509,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams 
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     // padding stays exactly 0: the normalisation applies to in-bounds pixels only
-                    const float t0 = ginb[j] ? (xr[2 * c][j] - mu[2 * c]) * rs[2 * c] : 0.f;
-                    const float t1 = ginb[j] ? (xr[2 * c + 1][j] - mu[2 * c + 1]) * rs[2 * c + 1] : 0.f;
+                    const float t0 = ginb[j] ? (xs[2 * c][j] - m[2 * c]) * r[2 * c] : 0.f;
+                    const float t1 = ginb[j] ? (xs[2 * c + 1][j] - m[2 * c + 1]) * r[2 * c + 1] : 0.f;
                     c2_split2(t0, t1, h[c], l[c]);
                 }
                 const int sw = (e >> 3) & 1;
@@ -518,16 +523,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams 
 #pragma unroll
         for (int v = 0; v < C::WPT; ++v) {
             const int idx = tid + v * 256;
-            if (idx < C::W4) wsm[idx] = make_uint4(wr[v][0], wr[v][1], wr[v][2], wr[v][3]);
+            if (idx < C::W4) wsm[idx] = make_uint4(ws[v][0], ws[v][1], ws[v][2], ws[v][3]);
         }
     };
-
-    load_chunk(0);
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-        __syncthreads();
-        store_chunk(chunk);
-        __syncthreads();
-        if (chunk + 1 < nchunk) load_chunk(chunk + 1);
+    auto compute_chunk = [&]() __attribute__((always_inline)) {
         const uint4* whalf = wsm + khalf * C::TN + wc * CB * 32 + l5;
 #pragma unroll
         for (int tap = 0; tap < C::KK; ++tap) {
@@ -561,6 +560,34 @@ __global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams 
 #pragma unroll
                 for (int q = 0; q < PB; ++q)
                     acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[q]), acc[i][q], 0, 0, 0);
+        }
+    };
+
+    if constexpr (PF == 2) {
+        load_chunk(0, xr[0], wr[0], mu[0], rs[0]);
+        if (nchunk > 1) load_chunk(1, xr[1], wr[1], mu[1], rs[1]);
+        for (int chunk = 0; chunk < nchunk; chunk += 2) {
+            __syncthreads();
+            store_chunk(xr[0], wr[0], mu[0], rs[0]);
+            __syncthreads();
+            if (chunk + 2 < nchunk) load_chunk(chunk + 2, xr[0], wr[0], mu[0], rs[0]);
+            compute_chunk();
+            if (chunk + 1 < nchunk) {
+                __syncthreads();
+                store_chunk(xr[1], wr[1], mu[1], rs[1]);
+                __syncthreads();
+                if (chunk + 3 < nchunk) load_chunk(chunk + 3, xr[1], wr[1], mu[1], rs[1]);
+                compute_chunk();
+            }
+        }
+    } else {
+        load_chunk(0, xr[0], wr[0], mu[0], rs[0]);
+        for (int chunk = 0; chunk < nchunk; ++chunk) {
+            __syncthreads();
+            store_chunk(xr[0], wr[0], mu[0], rs[0]);
+            __syncthreads();
+            if (chunk + 1 < nchunk) load_chunk(chunk + 1, xr[0], wr[0], mu[0], rs[0]);
+            compute_chunk();
         }
     }
 
@@ -608,16 +635,18 @@ __global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams 
 
 template <int KS, int S, int CB, int PB, int WC, int WP, int LOG_TW>
 static int launch2d_sb(Conv2dSbParams& p, hipStream_t st) {
+    // two chunks of register prefetch wherever both stages fit in 256 registers without spilling (measured with hipcc 7.2)
+    constexpr int PF = (CB * PB <= 2 && (S == 1 || KS == 1)) ? 2 : 1;
     using C = C2SbCfg<KS, S, CB, PB, WC, WP, LOG_TW>;
     p.tiles_x = cdiv(p.wo, C::TW);
     p.tiles_y = cdiv(p.ho, C::TH);
     dim3 grid(p.tiles_x * p.tiles_y, cdiv(p.cout, C::TN), p.bs);
     if (C::LDS_BYTES > 64 * 1024) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_sb_kernel<KS, S, CB, PB, WC, WP, LOG_TW>),
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_sb_kernel<KS, S, CB, PB, WC, WP, LOG_TW, PF>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (attr != hipSuccess) return fail((int)attr, "conv2d_sb: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
     }
-    hipLaunchKernelGGL((conv2d_sb_kernel<KS, S, CB, PB, WC, WP, LOG_TW>), grid, dim3(256), C::LDS_BYTES, st, p);
+    hipLaunchKernelGGL((conv2d_sb_kernel<KS, S, CB, PB, WC, WP, LOG_TW, PF>), grid, dim3(256), C::LDS_BYTES, st, p);
     return check_launch("conv2d_sb");
 }
 
@@ -627,7 +656,7 @@ static int64_t nblocks_sb(const Conv2dSbParams& p, int tn, int th, int tw) {
 
 template <int KS, int S>
 static int dispatch2d_sb(Conv2dSbParams& p, hipStream_t st) {
-    constexpr int64_t FILL = 192;
+    constexpr int64_t FILL = 512;   // two workgroups per CU before a larger tile is chosen (measured: 192 -> 512 = -6 % on the encoder)
     if (p.wo >= 32) {
         if (S == 1 && p.cout > 32 && nblocks_sb(p, 64, 8, 32) >= FILL) return launch2d_sb<KS, S, 2, 2, 1, 4, 5>(p, st);   // 64 co x 256 px
         if (p.cout > 32 && nblocks_sb(p, 64, 4, 32) >= FILL) return launch2d_sb<KS, S, 2, 1, 1, 4, 5>(p, st);             // 64 co x 128 px
