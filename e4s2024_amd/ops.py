@@ -85,9 +85,12 @@ class _TorchBackward(torch.autograd.Function):
                 t = t.requires_grad_(True)
                 wanted.append(t)
             ins.append(t)
+        ev = _timed("backward:" + getattr(ctx.ref, "__qualname__", "ref").split(".")[0] + f"{tuple(grad.shape[1:])}")
         with torch.enable_grad():
             ref_out = ctx.ref(*ins)
             grads = torch.autograd.grad(ref_out, wanted, grad, allow_unused=True)
+        if ev is not None:
+            ev.record()
         it = iter(grads)
         res = [next(it) if (flag and need) else None for flag, need in zip(ctx.is_tensor, needs)]
         return (None, None, *res)

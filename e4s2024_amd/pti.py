@@ -19,18 +19,70 @@ def trainable_parameters(net):
     return [p for p in net.parameters() if p.requires_grad]
 
 
+def _loss(net, style_vectors, mask, target, foreground_mask, l2_lambda, extra_loss, randomize_noise):
+    codes = net.cal_style_codes(style_vectors)
+    recon, _, _ = net.gen_img(None, codes, mask, randomize_noise=randomize_noise)
+    a, b = (recon, target) if foreground_mask is None else (recon * foreground_mask, target * foreground_mask)
+    loss = l2_lambda * F.mse_loss(a, b)                                      # calc_loss :196-199 (loss_l2)
+    if extra_loss is not None:
+        loss = loss + extra_loss(recon, target)
+    return loss, recon
+
+
+class GraphedPTIStep:
+    """The whole optimiser step (forward, backward, Adam update) captured once as a hipGraph and replayed per frame: at batch 1 the
+    eager step issues several thousand short launches and is bound by the host (~0.12 s) rather than by the GPU.
+
+    ``optimizer`` must be capture-safe (``torch.optim.Adam(..., capturable=True)``); shapes are fixed by the example inputs;
+    ``mask`` must be a uint8 region map ``[bs, 512, 512]`` (the one-hot check of a float mask reads a flag back to the host).
+    The ``warmup`` eager steps that precede the capture are real optimiser steps on the example frame.  Weight re-layout kernels are
+    part of the captured step (the parameters change under them), so every replay prepares its weights from their current values."""
+
+    def __init__(self, net, optimizer, style_vectors, mask, target, foreground_mask=None, l2_lambda: float = 1.0, extra_loss=None,
+                 randomize_noise: bool = True, warmup: int = 3):
+        if mask.dtype != torch.uint8:
+            raise TypeError("GraphedPTIStep needs the uint8 region map (ops.mask_to_labels(onehot)), not a float mask")
+        self.static = [style_vectors.clone(), mask.clone(), target.clone()] + ([foreground_mask.clone()] if foreground_mask is not None else [])
+        fg = self.static[3] if foreground_mask is not None else None
+        args = (net, self.static[0], self.static[1], self.static[2], fg, l2_lambda, extra_loss, randomize_noise)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                optimizer.zero_grad(set_to_none=True)
+                loss, _ = _loss(*args)
+                loss.backward()
+                optimizer.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss, self.recon = _loss(*args)
+            self.loss.backward()
+            optimizer.step()
+
+    def __call__(self, style_vectors, mask, target, foreground_mask=None):
+        """Copies the frame into the static buffers and replays the step; returns the (static) loss and reconstruction tensors."""
+        new = [style_vectors, mask, target] + ([foreground_mask] if foreground_mask is not None else [])
+        if len(new) != len(self.static):
+            raise ValueError("foreground_mask must be given iff the step was captured with one")
+        for dst, src in zip(self.static, new):
+            if dst.shape != src.shape or dst.dtype != src.dtype:
+                raise ValueError(f"captured for {tuple(dst.shape)} {dst.dtype}, got {tuple(src.shape)} {src.dtype}")
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.loss, self.recon
+
+
 def pti_step(net, optimizer: torch.optim.Optimizer, style_vectors: torch.Tensor, mask: torch.Tensor, target: torch.Tensor,
              foreground_mask: Optional[torch.Tensor] = None, l2_lambda: float = 1.0,
              extra_loss: Optional[Callable[[torch.Tensor, torch.Tensor], torch.Tensor]] = None):
     """One optimiser step.  ``style_vectors [bs, 12, 1280]``, ``mask`` one-hot ``[bs, 12, 512, 512]`` (or uint8 labels),
     ``target [bs, 3, 1024, 1024]`` in [-1, 1]; ``foreground_mask [bs, 1, 1024, 1024]`` restricts the loss as at :283-288.
     Returns ``(loss value, reconstruction)``."""
-    codes = net.cal_style_codes(style_vectors)
-    recon, _, _ = net.gen_img(None, codes, mask, randomize_noise=True)      # the coach calls gen_img with its default, fresh noise
-    a, b = (recon, target) if foreground_mask is None else (recon * foreground_mask, target * foreground_mask)
-    loss = l2_lambda * F.mse_loss(a, b)                                      # calc_loss :196-199 (loss_l2)
-    if extra_loss is not None:
-        loss = loss + extra_loss(recon, target)
+    loss, recon = _loss(net, style_vectors, mask, target, foreground_mask, l2_lambda, extra_loss, True)   # the coach calls gen_img with fresh noise
     optimizer.zero_grad()
     loss.backward()
     optimizer.step()

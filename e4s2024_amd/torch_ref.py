@@ -67,17 +67,56 @@ def _modulated(x, s, weight, demodulate: bool, upsample: bool, blur: Optional[to
 
 
 def _region_sum(x, styles, labels, weight, mod_w, mod_b, mod_scale, mod_lr, demodulate, upsample, blur):
-    """Σ_c modconv(x, style_c) ⊙ [label == c]  (StyledConv.forward :389-398 / ToRGB.forward :447-454); ``labels`` None = one region."""
-    out = None
-    for c in range(styles.shape[1]):
-        s = F.linear(styles[:, c], mod_w * mod_scale, mod_b * mod_lr)
-        y = _modulated(x, s, weight, demodulate, upsample, blur)
-        if labels is not None:
-            lab = labels
-            if lab.shape[-2:] != y.shape[-2:]:   # nearest resize of the region map to this layer's resolution (F.interpolate, :391)
-                lab = F.interpolate(lab[:, None].float(), size=y.shape[-2:], mode="nearest")[:, 0].to(labels.dtype)
-            y = y * (lab == c)[:, None].to(y.dtype)
-        out = y if out is None else out + y
+    """Σ_c modconv(x, style_c) ⊙ [label == c]  (StyledConv.forward :389-398 / ToRGB.forward :447-454).  ``labels`` None = one region
+    (plain modulated conv).  With a region map the sum is evaluated in its ONE-PASS form so that autograd sees one
+    GEMM per layer instead of twelve convolutions: ``out[b,o,p] = d[b,c(p),o] · Σ_{i,k} Ws[o,i,k] · s[b,c(p),i] · x[b,i,p+k]``."""
+    if labels is None:
+        s = F.linear(styles[:, 0], mod_w * mod_scale, mod_b * mod_lr)
+        return _modulated(x, s, weight, demodulate, upsample, blur)
+    bs, cin, h, w = x.shape
+    cout, k = weight.shape[1], weight.shape[-1]
+    nreg = styles.shape[1]
+    s = F.linear(styles, mod_w * mod_scale, mod_b * mod_lr)                       # [bs, nreg, cin]
+    ws = weight[0] * (1.0 / math.sqrt(cin * k * k))                               # [cout, cin, k, k]
+    d = None
+    if demodulate:                                                                # :280 on the modulated 3x3 weight
+        d = torch.rsqrt(torch.einsum("bri,oi->bro", s * s, (ws * ws).sum((2, 3))) + 1e-8)
+    ho, wo = (2 * h, 2 * w) if upsample else (h, w)
+    lab = labels
+    if lab.shape[-2:] != (ho, wo):                                                # nearest resize of the region map (:391)
+        lab = F.interpolate(lab[:, None].float(), size=(ho, wo), mode="nearest")[:, 0]
+    lab = lab.long()
+    valid = (lab < nreg)
+    lab = lab.clamp(max=nreg - 1)
+
+    def per_pixel(table, lab_flat):          # table [bs, nreg, C] -> [bs, C, P] rows picked by each pixel's region
+        return torch.gather(table.transpose(1, 2), 2, lab_flat[:, None, :].expand(-1, table.shape[2], -1))
+
+    xu = F.unfold(x, k, padding=k // 2).view(bs, cin, k * k, h * w)               # x[b, i, p + tap]
+    if not upsample:
+        lf = lab.reshape(bs, -1)
+        y = torch.matmul(ws.reshape(cout, cin * k * k), (xu * per_pixel(s, lf)[:, :, None, :]).reshape(bs, cin * k * k, h * w))
+        if d is not None:
+            y = y * per_pixel(d, lf)
+        return (y * valid.reshape(bs, 1, -1).to(y.dtype)).view(bs, cout, h, w)
+    # stride-2 transposed conv followed by the 4x4 blur = four 3x3 correlations over the input grid, one per output parity (a, b):
+    # Weff[a,b][dy,dx] = C2[2-2dy+a][2-2dx+b] with C2 the full 2-D convolution of the 3x3 weight with the blur kernel (6x6).
+    # (as one small GEMM: C2[o,i,m,n] = Σ_{ky,kx} blur[m-ky][n-kx] · Ws[o,i,ky,kx])
+    shift = blur.new_zeros(6, 6, 3, 3)
+    for ky in range(3):
+        for kx in range(3):
+            shift[ky:ky + 4, kx:kx + 4, ky, kx] = blur
+    c2 = torch.einsum("mnkl,oikl->oimn", shift.to(x.dtype), ws)
+    out = x.new_zeros(bs, cout, ho, wo)
+    for a in (0, 1):
+        for b in (0, 1):
+            weff = c2[:, :, a::2, b::2].flip(2, 3)                                  # rows (4+a, 2+a, a), columns likewise: [cout, cin, 3(dy), 3(dx)]
+            lf = lab[:, a::2, b::2].reshape(bs, -1)
+            y = torch.matmul(weff.reshape(cout, cin * 9), (xu * per_pixel(s, lf)[:, :, None, :]).reshape(bs, cin * 9, h * w))
+            if d is not None:
+                y = y * per_pixel(d, lf)
+            y = y * valid[:, a::2, b::2].reshape(bs, 1, -1).to(y.dtype)
+            out[:, :, a::2, b::2] = y.view(bs, cout, h, w)
     return out
 
 

@@ -84,3 +84,55 @@ def test_local_mlp_gradients():
     (out * g.to(DEV)).sum().backward()
     for k, p in m.named_parameters():
         assert (p.grad.cpu() - sd[k].grad).abs().max().item() <= 1e-4 * max(1.0, sd[k].grad.abs().max().item()), k
+
+
+def test_pti_step_eager_and_graph_agree():
+    """pti.pti_step (eager) and pti.GraphedPTIStep (the same step captured as one hipGraph) walk the same loss trajectory on a small
+    Net3 (64x64 generator), and the loss goes down."""
+    import types
+    install_dropin()
+    from models.networks import Net3
+    from e4s2024_amd import pti, ops
+    opts = types.SimpleNamespace(fsencoder_type="psp", remaining_layer_idx=5, num_seg_cls=12, out_size=64, train_G=True,
+                                 start_from_latent_avg=True, learn_in_w=False)
+    vec = T(seeded.seeded_array(41, "vec", (1, 12, 1280), dist="normal")).to(DEV)
+    lab = T(seeded.blocky_labels(3, 1, 12, 64, 8)).to(DEV)
+    target = torch.tanh(T(seeded.seeded_array(5, "img", (1, 3, 64, 64), dist="normal"))).to(DEV)
+
+    def make():
+        torch.manual_seed(0)
+        net = Net3(opts)
+        seeded.apply_seeded(net, 4, "net3")
+        net = net.to(DEV).train()
+        net.latent_avg = seeded.seeded_latent_avg(2, 10).to(DEV)
+        return net
+
+    net_a = make()
+    opt_a = torch.optim.Adam(pti.trainable_parameters(net_a), lr=1e-3)
+    losses_a = []
+    for _ in range(6):
+        torch.manual_seed(1)          # same noise draw every step in both variants
+        loss, _ = pti.pti_step(net_a, opt_a, vec, lab, target)
+        losses_a.append(loss.item())
+    assert losses_a[-1] < losses_a[0]
+
+    net_b = make()
+    opt_b = torch.optim.Adam(pti.trainable_parameters(net_b), lr=1e-3, capturable=True)
+    step = pti.GraphedPTIStep(net_b, opt_b, vec, lab, target, randomize_noise=False, warmup=2)
+    net_c = make()
+    opt_c = torch.optim.Adam(pti.trainable_parameters(net_c), lr=1e-3)
+    losses_b, losses_c = [], []
+    for _ in range(2):                # the two warm-up steps of the capture, eagerly, for the comparison run
+        codes = net_c.cal_style_codes(vec)
+        rec, _, _ = net_c.gen_img(None, codes, lab, randomize_noise=False)
+        l = torch.nn.functional.mse_loss(rec, target)
+        opt_c.zero_grad(); l.backward(); opt_c.step()
+    for _ in range(4):
+        lb, _ = step(vec, lab, target)
+        losses_b.append(lb.item())
+        codes = net_c.cal_style_codes(vec)
+        rec, _, _ = net_c.gen_img(None, codes, lab, randomize_noise=False)
+        l = torch.nn.functional.mse_loss(rec, target)
+        opt_c.zero_grad(); l.backward(); opt_c.step()
+        losses_c.append(l.item())
+    assert np.allclose(losses_b, losses_c, rtol=2e-3), (losses_b, losses_c)
