@@ -8,6 +8,7 @@ work, where the target's own region map drives the synthesis.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -17,7 +18,20 @@ from . import ops
 DEFAULT_COMP_INDICES = tuple(sorted(set(range(12)) - {0, 4, 11}))      # face_swap_video_pipeline.py:436: keep target background, hair, ear-rings
 
 
+TWO_STREAMS = os.environ.get("E4S_SWAP_TWO_STREAMS", "1") != "0"
 _sel_cache = {}
+_side = {}
+
+
+SWAP_CHAINS = int(os.environ.get("E4S_SWAP_CHAINS", "2"))     # 2 = driven | target; 4 = each additionally split into half batches
+
+
+def _side_stream(device, idx=0):
+    key = (str(device), idx)
+    st = _side.get(key)
+    if st is None:
+        st = _side[key] = torch.cuda.Stream(device=device)
+    return st
 
 
 def _selector(device, comp_indices, n):
@@ -51,7 +65,7 @@ def mix_style_vectors(target_vec: torch.Tensor, driven_vec: torch.Tensor, comp_i
 @torch.no_grad()
 def swap_batch(net, parser, driven: torch.Tensor, target: torch.Tensor, comp_indices: Sequence[int] = DEFAULT_COMP_INDICES,
                randomize_noise: bool = False, to_uint8: bool = True, timings: Optional[dict] = None, mask_surgery: bool = False,
-               paste_radius: int = 5):
+               paste_radius: int = 5, two_streams: bool = TWO_STREAMS):
     """``driven`` / ``target``: ``[bs, 3, 1024, 1024]`` in [-1, 1] on the device.  Returns uint8 ``[bs, 1024, 1024, 3]`` frames
     (or the float image) and the 12-class region maps the synthesis used; with ``mask_surgery`` a third value
     ``{"hole_mask", "hole_map", "lines", "content", "border", "full"}`` (the reference's paste-back inputs, :456-463)."""
@@ -61,12 +75,41 @@ def swap_batch(net, parser, driven: torch.Tensor, target: torch.Tensor, comp_ind
             ev.record()
             timings.setdefault("_events", []).append((name, ev))
     mark("start")
-    lab_d = parser.parse_batch((driven + 1) / 2, seg12=True)          # uint8 [bs, 512, 512]
-    lab_t = parser.parse_batch((target + 1) / 2, seg12=True)
-    mark("parse_x2")
-    vec_d, _ = net.get_style_vectors(driven, lab_d)
-    vec_t, _ = net.get_style_vectors(target, lab_t)
-    mark("encode_x2")
+    if two_streams:
+        # The driven and the target face are independent until the style-vector mix: run the parse -> encode chains on separate HIP
+        # streams so that the launch-bound glue kernels and short-K convolutions of one fill the idle CUs of the others.
+        main = torch.cuda.current_stream()
+        bs = driven.shape[0]
+        halves = SWAP_CHAINS // 2 if (SWAP_CHAINS >= 4 and bs % (SWAP_CHAINS // 2) == 0) else 1
+        step = bs // halves
+        jobs = [(img, i * step, (i + 1) * step) for img in (driven, target) for i in range(halves)]
+        outs = []
+        for j, (img, lo, hi) in enumerate(jobs):
+            st = main if j == len(jobs) - 1 else _side_stream(driven.device, j)
+            if st is not main:
+                st.wait_stream(main)
+            with torch.cuda.stream(st):
+                part = img[lo:hi]
+                lab = parser.parse_batch((part + 1) / 2, seg12=True)
+                vec, _ = net.get_style_vectors(part, lab)
+            outs.append((lab, vec, st))
+        for lab, vec, st in outs:
+            if st is not main:
+                main.wait_stream(st)
+                lab.record_stream(main)
+                vec.record_stream(main)
+        lab_d = torch.cat([o[0] for o in outs[:halves]]) if halves > 1 else outs[0][0]
+        vec_d = torch.cat([o[1] for o in outs[:halves]]) if halves > 1 else outs[0][1]
+        lab_t = torch.cat([o[0] for o in outs[halves:]]) if halves > 1 else outs[1][0]
+        vec_t = torch.cat([o[1] for o in outs[halves:]]) if halves > 1 else outs[1][1]
+        mark("parse+encode_x2")
+    else:
+        lab_d = parser.parse_batch((driven + 1) / 2, seg12=True)          # uint8 [bs, 512, 512]
+        lab_t = parser.parse_batch((target + 1) / 2, seg12=True)
+        mark("parse_x2")
+        vec_d, _ = net.get_style_vectors(driven, lab_d)
+        vec_t, _ = net.get_style_vectors(target, lab_t)
+        mark("encode_x2")
     codes = net.cal_style_codes(mix_style_vectors(vec_t, vec_d, comp_indices))
     mark("mix+mlps")
     extra = None

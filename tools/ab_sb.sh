@@ -1,2 +1,2 @@
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_backward.py -m gpu -q --tb=short -x 2>&1 | tail -12
+for v in 2 4 8; do echo "== E4S_SWAP_CHAINS=$v"; E4S_SWAP_CHAINS=$v timeout 300 python tools/time_swap.py 8 8 2>&1 | tail -5; done
