@@ -138,36 +138,64 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const Conv2dParams p) {
 
     const bool wvec = (p.cout & 3) == 0;
 
-    for (int ci0 = 0; ci0 < p.cin; ci0 += CKK) {
-        __syncthreads();
+    // Register stage of the NEXT K chunk: global loads are unconditional (clamped addresses, masked when written to LDS) and issued
+    // before the current chunk's MFMAs, so their latency hides behind the matrix work instead of sitting between two barriers.
+    // Same arithmetic, same order as before — results are bit-identical.
+    constexpr int NV = CKK * C::KK * C::TN / 4;
+    constexpr int WPT = (NV + 255) / 256;
+    float xr[CKK][C::EPT];
+    float wr[WPT][4];
+    float mur[CKK], rsr[CKK];
+    int goffs[C::EPT];
+#pragma unroll
+    for (int j = 0; j < C::EPT; ++j) goffs[j] = ginb[j] ? goff[j] : 0;
+    auto load_chunk = [&](int ci0) __attribute__((always_inline)) {
 #pragma unroll
         for (int c = 0; c < CKK; ++c) {
-            const int ci = ci0 + c;
-            const bool cok = ci < p.cin;
+            const int ci = (ci0 + c < p.cin) ? ci0 + c : p.cin - 1;
             const float* xc = (ci < p.cin0) ? xb0 + (size_t)ci * hw : xb1 + (size_t)(ci - p.cin0) * hw;
-            float mu = 0.f, rs = 1.f;
-            if (p.in_mean && cok) {
-                mu = p.in_mean[(size_t)b * p.cin + ci];
-                rs = p.in_rstd[(size_t)b * p.cin + ci];
+#pragma unroll
+            for (int j = 0; j < C::EPT; ++j) xr[c][j] = xc[goffs[j]];
+            mur[c] = p.in_mean ? p.in_mean[(size_t)b * p.cin + ci] : 0.f;
+            rsr[c] = p.in_mean ? p.in_rstd[(size_t)b * p.cin + ci] : 1.f;
+        }
+        if (wvec) {
+#pragma unroll
+            for (int v = 0; v < WPT; ++v) {
+                int idx = tid + v * 256;
+                idx = idx < NV ? idx : NV - 1;
+                const int n4 = idx % (C::TN / 4);
+                int ct = idx / (C::TN / 4);
+                const int ctmax = (p.cin - ci0) * C::KK - 1;            // last valid (channel, tap) row of this chunk
+                ct = ct < ctmax ? ct : ctmax;
+                const int co = (co0 + n4 * 4 < p.cout) ? co0 + n4 * 4 : 0;
+                const float4 t4 = *reinterpret_cast<const float4*>(p.wt + ((size_t)ci0 * C::KK + ct) * p.cout + co);
+                wr[v][0] = t4.x; wr[v][1] = t4.y; wr[v][2] = t4.z; wr[v][3] = t4.w;
             }
+        }
+    };
+    auto store_chunk = [&](int ci0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < CKK; ++c) {
+            const bool cok = ci0 + c < p.cin;
 #pragma unroll
             for (int j = 0; j < C::EPT; ++j) {
                 const int e = tid + j * 256;
-                if (e < C::PATCH) xs[c * C::PATCH + e] = (cok && ginb[j]) ? (xc[goff[j]] - mu) * rs : 0.f;
+                if (e < C::PATCH) xs[c * C::PATCH + e] = (cok && ginb[j]) ? (xr[c][j] - mur[c]) * rsr[c] : 0.f;
             }
         }
         if (wvec) {
-            constexpr int NV = CKK * C::KK * C::TN / 4;
-            for (int v = tid; v < NV; v += 256) {
-                const int n4 = v % (C::TN / 4);
-                const int ct = v / (C::TN / 4);
-                const int c = ct / C::KK;
-                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ci0 + c < p.cin && co0 + n4 * 4 < p.cout)
-                    val = *reinterpret_cast<const float4*>(p.wt + ((size_t)ci0 * C::KK + ct) * p.cout + co0 + n4 * 4);
-                *reinterpret_cast<float4*>(ws + ct * C::TN + n4 * 4) = val;
+#pragma unroll
+            for (int v = 0; v < WPT; ++v) {
+                const int idx = tid + v * 256;
+                if (idx < NV) {
+                    const int n4 = idx % (C::TN / 4);
+                    const int ct = idx / (C::TN / 4);
+                    const bool ok = ci0 + ct / C::KK < p.cin && co0 + n4 * 4 < p.cout;
+                    *reinterpret_cast<float4*>(ws + ct * C::TN + n4 * 4) = ok ? make_float4(wr[v][0], wr[v][1], wr[v][2], wr[v][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
-        } else {
+        } else {   // cout not a multiple of 4 (the 19-class heads): small layers, staged straight from global memory
             constexpr int NS = CKK * C::KK * C::TN;
             for (int v = tid; v < NS; v += 256) {
                 const int n = v % C::TN;
@@ -176,7 +204,14 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const Conv2dParams p) {
                 ws[v] = (ci0 + c < p.cin && co0 + n < p.cout) ? p.wt[((size_t)ci0 * C::KK + ct) * p.cout + co0 + n] : 0.f;
             }
         }
+    };
+
+    load_chunk(0);
+    for (int ci0 = 0; ci0 < p.cin; ci0 += CKK) {
         __syncthreads();
+        store_chunk(ci0);
+        __syncthreads();
+        if (ci0 + CKK < p.cin) load_chunk(ci0 + CKK);
 
 #pragma unroll
         for (int cp = 0; cp < CKK / 2; ++cp) {
