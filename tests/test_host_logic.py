@@ -237,3 +237,29 @@ def test_run_clip_single_process_equals_sharded_result():
     r = FrameShardRunner()
     out = r.run_clip(5, torch.ones(1), lambda lo, hi: torch.arange(lo, hi), lambda sh, idx: idx.view(-1, 1, 1, 1).to(torch.uint8).expand(-1, 2, 2, 3).contiguous(), batch=4)
     assert out[:, 0, 0, 0].tolist() == [0, 1, 2, 3, 4]
+
+
+def test_handoff_files_roundtrip(tmp_path):
+    """Row f4: a clip dumped with the reference's file names / encodings reads back exactly (masks, style vectors) or to the uint8
+    quantisation of ``tensor2im`` (images)."""
+    import numpy as np
+    import torch
+    from e4s2024_amd import handoff
+    rs = np.random.RandomState(0)
+    n = 3
+    clip = handoff.ClipBatch(
+        driven=torch.from_numpy(rs.uniform(-1, 1, (n, 3, 32, 32)).astype(np.float32)),
+        target=torch.from_numpy(rs.uniform(-1, 1, (n, 3, 32, 32)).astype(np.float32)),
+        driven_mask=torch.from_numpy(rs.randint(0, 12, (n, 16, 16)).astype(np.uint8)),
+        target_mask=torch.from_numpy(rs.randint(0, 12, (n, 16, 16)).astype(np.uint8)),
+        driven_style=torch.from_numpy(rs.standard_normal((n, 12, 1280)).astype(np.float32)),
+        target_style=torch.from_numpy(rs.standard_normal((n, 12, 1280)).astype(np.float32)))
+    handoff.dump(clip, str(tmp_path), first_index=5)
+    assert sorted(os.listdir(tmp_path / "mask"))[0] == "D_mask_0005.png" and (tmp_path / "styleVec" / "T_style_vec_0007.pt").exists()
+    back = handoff.load(str(tmp_path), first_index=5, size=32)
+    assert len(back) == n
+    assert torch.equal(back.driven_mask, clip.driven_mask) and torch.equal(back.target_mask, clip.target_mask)
+    assert torch.equal(back.driven_style, clip.driven_style) and torch.equal(back.target_style, clip.target_style)
+    q = (((clip.target.clamp(-1, 1) + 1) / 2 * 255).to(torch.uint8).float() / 255 - 0.5) / 0.5
+    assert torch.allclose(back.target, q, atol=1e-6)
+    assert torch.load(tmp_path / "styleVec" / "D_style_vec_0005.pt").shape == (1, 12, 1280)
