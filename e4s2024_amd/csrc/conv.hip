@@ -422,16 +422,30 @@ struct C2SbCfg {
     static constexpr int TH = NPB * RPB;
     static constexpr int PW = (TW - 1) * S + KS, PH = (TH - 1) * S + KS;
     static constexpr int PATCH = PH * PW;
-    static constexpr int EPT = (PATCH + 255) / 256;
+    static constexpr int NT = 64 * WC * WP;          // threads per workgroup (256 or 512)
+    static constexpr int EPT = (PATCH + NT - 1) / NT;
     static constexpr int W4 = 2 * KK * 2 * TN;       // uint4: [hi/lo][tap][half][TN]
-    static constexpr int WPT = (W4 + 255) / 256;
+    static constexpr int WPT = (W4 + NT - 1) / NT;
     static constexpr int LDS_BYTES = W4 * 16 + PATCH * 64;
-    static_assert(WC * WP == 4, "256-thread blocks");
+    static_assert(WC * WP == 4 || WC * WP == 8, "256- or 512-thread workgroups");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS per CU");
 };
 
+E4S_PROF_DECL(g_prof_conv)
+#ifdef E4S_PHASE_PROF
+extern "C" E4S_API int e4s_prof_read_conv(long long* host, int64_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prof_conv), (size_t)n * sizeof(long long), 0, hipMemcpyDeviceToHost);
+}
+extern "C" E4S_API int e4s_prof_clear_conv() {
+    void* ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_prof_conv));
+    if (e != hipSuccess) return (int)e;
+    return (int)hipMemset(ptr, 0, sizeof(long long) * (size_t)E4S_PROF_BLOCKS * E4S_PROF_SLOTS);
+}
+#endif
+
 template <int KS, int S, int CB, int PB, int WC, int WP, int LOG_TW, int PF = 1>
-__global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams p) {
+__global__ __launch_bounds__(64 * WC * WP, 2) void conv2d_sb_kernel(const Conv2dSbParams p) {
     using C = C2SbCfg<KS, S, CB, PB, WC, WP, LOG_TW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint4* wsm = reinterpret_cast<uint4*>(lds_raw);                 // [2][KK][2][TN]
@@ -439,6 +453,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams 
     uint4* xl4 = xh4 + 2 * C::PATCH;                                // lo plane
 
     const int tid = threadIdx.x;
+    E4S_PROF_MARK(g_prof_conv, 0);
     const int lane = tid & 63, wave = tid >> 6;
     const int l5 = lane & 31, khalf = lane >> 5;
     const int wc = wave / WP, wp = wave % WP;
@@ -454,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams 
     bool ginb[C::EPT];
 #pragma unroll
     for (int j = 0; j < C::EPT; ++j) {
-        const int e = tid + j * 256;
+        const int e = tid + j * C::NT;
         const int py = e / C::PW, px = e - py * C::PW;
         const int gy = iy0 + py, gx = ix0 + px;
         ginb[j] = (e < C::PATCH) && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
@@ -519,7 +534,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams 
         const size_t wbase = (size_t)chunk * C::KK * 2 * p.cout;
 #pragma unroll
         for (int v = 0; v < C::WPT; ++v) {
-            int idx = tid + v * 256;
+            int idx = tid + v * C::NT;
             idx = idx < C::W4 ? idx : C::W4 - 1;
             const int hl = idx / (C::KK * 2 * C::TN);
             const int rem = idx - hl * C::KK * 2 * C::TN;
@@ -538,7 +553,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams 
     auto store_chunk = [&](const float (&xs)[CKS2][C::EPT], const unsigned (&ws)[C::WPT][4], const float (&m)[CKS2], const float (&r)[CKS2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < C::EPT; ++j) {
-            const int e = tid + j * 256;
+            const int e = tid + j * C::NT;
             if (e < C::PATCH) {
                 unsigned h[8], l[8];
 #pragma unroll
@@ -557,7 +572,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams 
         }
 #pragma unroll
         for (int v = 0; v < C::WPT; ++v) {
-            const int idx = tid + v * 256;
+            const int idx = tid + v * C::NT;
             if (idx < C::W4) wsm[idx] = make_uint4(ws[v][0], ws[v][1], ws[v][2], ws[v][3]);
         }
     };
@@ -621,11 +636,14 @@ __global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams 
             __syncthreads();
             store_chunk(xr[0], wr[0], mu[0], rs[0]);
             __syncthreads();
+            if (chunk == 0) E4S_PROF_MARK(g_prof_conv, 1);
             if (chunk + 1 < nchunk) load_chunk(chunk + 1, xr[0], wr[0], mu[0], rs[0]);
             compute_chunk();
         }
     }
 
+    E4S_PROF_MARK(g_prof_conv, 2);
+    E4S_PROF_MARK(g_prof_conv, 3);
     // Epilogue in two passes: every global load (bias, residual, slope) first, then the stores.  gfx9 tracks loads and stores with
     // one in-order counter (vmcnt), so a load issued after a store cannot complete its wait before that store has reached memory.
     const size_t ohw = (size_t)p.ho * p.wo;
@@ -666,6 +684,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_sb_kernel(const Conv2dSbParams 
             }
         }
     }
+    E4S_PROF_MARK(g_prof_conv, 4);
+    E4S_PROF_DRAIN();
+    E4S_PROF_MARK(g_prof_conv, 5);
 }
 
 template <int KS, int S, int CB, int PB, int WC, int WP, int LOG_TW>
@@ -681,7 +702,7 @@ static int launch2d_sb(Conv2dSbParams& p, hipStream_t st) {
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (attr != hipSuccess) return fail((int)attr, "conv2d_sb: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
     }
-    hipLaunchKernelGGL((conv2d_sb_kernel<KS, S, CB, PB, WC, WP, LOG_TW, PF>), grid, dim3(256), C::LDS_BYTES, st, p);
+    hipLaunchKernelGGL((conv2d_sb_kernel<KS, S, CB, PB, WC, WP, LOG_TW, PF>), grid, dim3(C::NT), C::LDS_BYTES, st, p);
     return check_launch("conv2d_sb");
 }
 
@@ -693,6 +714,7 @@ template <int KS, int S>
 static int dispatch2d_sb(Conv2dSbParams& p, hipStream_t st) {
     constexpr int64_t FILL = 512;   // two workgroups per CU before a larger tile is chosen (measured: 192 -> 512 = -6 % on the encoder)
     if (p.wo >= 32) {
+        // (a 512-thread 128 co x 256 px tile, <KS,S,4,1,1,8,5>, measured the same as two 64 co x 256 px workgroups per CU: not dispatched)
         if (S == 1 && p.cout > 32 && nblocks_sb(p, 64, 8, 32) >= FILL) return launch2d_sb<KS, S, 2, 2, 1, 4, 5>(p, st);   // 64 co x 256 px
         if (p.cout > 32 && nblocks_sb(p, 64, 4, 32) >= FILL) return launch2d_sb<KS, S, 2, 1, 1, 4, 5>(p, st);             // 64 co x 128 px
         return launch2d_sb<KS, S, 1, 1, 2, 2, 5>(p, st);                                                                  // 64 co x  64 px

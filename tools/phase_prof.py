@@ -100,7 +100,22 @@ def run_up_fused(cin, cout, h, bs=4):
     report(f"fused up {cin}->{cout} @{h}^2 bs{bs}", read(1 << 17, "up"), a.elapsed_time(b))
 
 
+def run_conv(cin, cout, h, bs=8):
+    x = torch.randn(bs, cin, h, h, device=dev); w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+    mean = torch.zeros(bs, cin, device=dev); rstd = torch.ones(bs, cin, device=dev); slope = torch.full((cout,), 0.25, device=dev)
+    pc = ops.PreparedConv(); pc.get(w)
+    for _ in range(3):
+        ops.conv2d(x, pc, stride=1, pad=1, in_norm=(mean, rstd), prelu=slope)
+    clear("conv")
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); ops.conv2d(x, pc, stride=1, pad=1, in_norm=(mean, rstd), prelu=slope); b.record(); torch.cuda.synchronize()
+    report(f"encoder conv {cin}->{cout} @{h}^2 bs{bs}", read(1 << 17, "conv"), a.elapsed_time(b))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "conv":
+        run_conv(256, 256, 64); run_conv(128, 128, 128); run_conv(64, 64, 256); run_conv(512, 512, 32)
+        sys.exit(0)
     run_same(32, 32, 1024)
     run_same(64, 64, 512)
     run_same(512, 512, 64, masked=True)
