@@ -54,7 +54,8 @@ struct UfCfg {
     static constexpr int MAIN_BYTES = W4 * 16 + UF_PATCH * 64;   // weights + x hi/lo planes
     static constexpr int ZT_BYTES = UF_ZCO * 32 * UF_ZS * 4;
     static constexpr int BODY = MAIN_BYTES > ZT_BYTES ? MAIN_BYTES : ZT_BYTES;
-    static constexpr int LDS_BYTES = BODY;
+    static constexpr int EP_FLOATS = 2 * TN + UF_OUT * UF_OUT;   // epilogue operands fetched at kernel start: d, bias, noise_weight * noise tile
+    static constexpr int LDS_BYTES = BODY + EP_FLOATS * 4;
 };
 
 template <int CB, int MINW>
@@ -64,6 +65,9 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
     uint4* wsm = reinterpret_cast<uint4*>(lds_raw);                       // [2][9][2][TN]
     uint4* xh4 = reinterpret_cast<uint4*>(lds_raw + C::W4 * 16);          // [PATCH][2] uint4 = 16 bf16 (hi), halves swizzled
     uint4* xl4 = xh4 + 2 * UF_PATCH;                                      // lo plane
+    float* ep_d = reinterpret_cast<float*>(lds_raw + C::BODY);            // [TN] demodulation
+    float* ep_b = ep_d + C::TN;                                           // [TN] activation bias
+    float* ep_n = ep_b + C::TN;                                           // [28][28] noise_weight * noise of this tile's outputs
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -139,10 +143,36 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
         }
     };
 
+    // Epilogue operands: fetched now, next to the first chunk's loads, and parked in LDS when that chunk is staged — the epilogue then
+    // has no global loads at all (they used to cost ~10 us per workgroup there, and a load behind a store drains the store first).
+    const int ho = 2 * p.h, wo = 2 * p.w;
+    float ep_r[4] = {1.f, 0.f, 0.f, 0.f};
+    {
+        const int co = co0 + tid;
+        if (tid < C::TN && co < p.cout) {
+            if (p.d) ep_r[0] = p.d[(size_t)b * p.cout + co];
+            if (p.act_bias) ep_r[1] = p.act_bias[co];
+        }
+        if (p.noise) {
+            const float nw0 = p.noise_weight[0];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int e = tid + k * UF_NT;
+                const int ny = tyt * UF_OUT + e / UF_OUT, nx = txt * UF_OUT + e % UF_OUT;
+                if (e < UF_OUT * UF_OUT && ny < ho && nx < wo) ep_r[2 + k] = nw0 * p.noise[(size_t)b * p.noise_bstride + (size_t)ny * wo + nx];
+            }
+        }
+    }
     load_chunk(0);
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         __syncthreads();
         store_chunk(chunk);
+        if (chunk == 0) {
+            if (tid < C::TN) { ep_d[tid] = ep_r[0]; ep_b[tid] = ep_r[1]; }
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (tid + k * UF_NT < UF_OUT * UF_OUT) ep_n[tid + k * UF_NT] = ep_r[2 + k];
+        }
         __syncthreads();
         if (chunk == 0) E4S_PROF_MARK(g_prof_up, 1);
         if (chunk + 1 < nchunk) load_chunk(chunk + 1);
@@ -179,7 +209,6 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
     float kf[16];                                    // kf[ty*4+tx] = blur[3-ty][3-tx]  (uniform loads -> scalar registers)
 #pragma unroll
     for (int t = 0; t < 16; ++t) kf[t] = p.blur[15 - t];
-    const int ho = 2 * p.h, wo = 2 * p.w;
     constexpr int NITEM = UF_ZCO * 2 * UF_OUT;       // 448
     const int it_co = tid / (2 * UF_OUT);
     const int it_rem = tid - it_co * 2 * UF_OUT;
@@ -187,24 +216,12 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
     const int oy0 = tyt * UF_OUT + it_rg * UF_STEP, ox = txt * UF_OUT + it_x;
     const bool it_ok = tid < NITEM && ox < wo && oy0 < ho;
     const int nrow = it_ok ? (ho - oy0 < UF_STEP ? ho - oy0 : UF_STEP) : 0;   // valid output rows of this item
-    const float nw = p.noise ? p.noise_weight[0] : 0.f;
-    const float* nzb = p.noise ? p.noise + (size_t)b * p.noise_bstride : nullptr;   // uniform bases + 32-bit per-thread offsets
     float* ob = p.out + (size_t)b * p.cout * ho * wo;
     const unsigned pix0 = (unsigned)(oy0 * wo + ox);
     const float* zc = zt + (it_co * 32 + it_rg * UF_STEP + 1) * UF_ZS + it_x + 1;   // z row (local) of output row r, tap t: r + 1 + t
-    // All global loads of the epilogue are issued here, before the first store (gfx9's vmcnt orders loads behind earlier stores).
-    float ddr[CB][4], bir[CB][4], nz[UF_STEP];
+    float nz[UF_STEP];
 #pragma unroll
-    for (int i = 0; i < CB; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int co = co0 + i * 32 + 8 * g + it_co;
-            const bool ok = co < p.cout;
-            ddr[i][g] = (p.d && ok) ? p.d[(size_t)b * p.cout + co] : 1.f;
-            bir[i][g] = (p.act_bias && ok) ? p.act_bias[co] : 0.f;
-        }
-#pragma unroll
-    for (int r = 0; r < UF_STEP; ++r) nz[r] = (nzb && r < nrow) ? nw * nzb[pix0 + (unsigned)(r * wo)] : 0.f;
+    for (int r = 0; r < UF_STEP; ++r) nz[r] = (tid < NITEM) ? ep_n[(it_rg * UF_STEP + r) * UF_OUT + it_x] : 0.f;
 
     E4S_PROF_MARK(g_prof_up, 3);
 #pragma unroll
@@ -239,7 +256,7 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
                         }
                     }
                 }
-                const float dd = ddr[i][g], bi = bir[i][g];
+                const float dd = ep_d[i * 32 + 8 * g + it_co], bi = ep_b[i * 32 + 8 * g + it_co];
                 const float neg = p.act ? 0.2f : 1.f, gain = p.act ? 1.41421356237309515f : 1.f;
                 const unsigned o0 = (unsigned)co * (unsigned)(ho * wo) + pix0;
 #pragma unroll
