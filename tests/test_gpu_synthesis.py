@@ -222,3 +222,56 @@ def test_up_fused_matches_two_stage_and_oracle(sg2, shape):
     assert tuple(a.shape) == tuple(ref.shape)
     assert (a - b).abs().max().item() <= 2e-5 * scale
     assert maxdiff(a, ref) <= LAYER_TOL * scale
+
+
+RAGGED = [  # (bs, cin, cout, h, w, nreg, label_h, label_w)
+    (1, 7, 5, 5, 9, 3, 5, 9),            # tiny, channels far from any tile multiple
+    (2, 20, 40, 13, 21, 12, 32, 32),     # label map at another resolution, non-integer nearest ratio
+    (1, 48, 33, 40, 35, 7, 64, 64),      # crosses a 32-wide tile boundary, Cout = 32 + 1
+    (3, 130, 70, 6, 6, 2, 6, 6),         # small map with a long K (split-K path), Cin not a multiple of 16
+    (1, 16, 136, 34, 70, 12, 70, 140),   # Cout > 128 on a wide map (the 512-thread masked tile + a channel tail)
+]
+
+
+@pytest.mark.parametrize("shape", RAGGED)
+@pytest.mark.parametrize("upsample", [False, True])
+def test_masked_layers_ragged_shapes_against_oracle(sg2, shape, upsample):
+    """StyledConv (masked, same / up) and ToRGB on ragged sizes: odd spatial sizes, channel tails, few regions, pixels that belong to
+    no region (label 255 -> zero, like the reference's masked sum), label maps at a different resolution than the features."""
+    bs, cin, cout, h, w, nreg, lh, lw = shape
+    rs = np.random.RandomState(100 * cin + h + (7 if upsample else 0))
+    lab = rs.randint(0, nreg, (bs, lh, lw)).astype(np.uint8)
+    lab[:, : max(1, lh // 7), : max(1, lw // 5)] = 255                       # a corner that belongs to no region
+    onehot = torch.zeros(bs, nreg, lh, lw)
+    for c in range(nreg):
+        onehot[:, c] = T((lab == c).astype(np.float32))
+    m = sg2.StyledConv(cin, cout, 3, 512, upsample=upsample, mask_op=True)
+    with torch.no_grad():
+        m.conv.weight.copy_(T(rs.standard_normal(m.conv.weight.shape).astype(np.float32)))
+        m.conv.modulation.weight.copy_(T(rs.standard_normal(m.conv.modulation.weight.shape).astype(np.float32)))
+        m.noise.weight.fill_(0.21)
+        m.activate.bias.copy_(T(0.1 * rs.standard_normal(cout).astype(np.float32)))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = T(rs.standard_normal((bs, cin, h, w)).astype(np.float32))
+    st = T(rs.standard_normal((bs, nreg, 512)).astype(np.float32))
+    ho, wo = (2 * h, 2 * w) if upsample else (h, w)
+    nz = T(rs.standard_normal((bs, 1, ho, wo)).astype(np.float32))
+    m = m.to(DEV)
+    with torch.no_grad():
+        y = m(x.to(DEV), st.to(DEV), T(lab).to(DEV), noise=nz.to(DEV))
+    ref = O.styled_conv(sd, "", x, st, onehot, nz, masked=True, upsample=upsample)
+    scale = max(1.0, float(ref.abs().max()))
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert maxdiff(y, ref) <= LAYER_TOL * scale, (shape, upsample, maxdiff(y, ref), scale)
+    if not upsample:
+        rgb = sg2.ToRGB(cin, 512, upsample=False, mask_op=True)
+        with torch.no_grad():
+            rgb.conv.weight.copy_(T(rs.standard_normal(rgb.conv.weight.shape).astype(np.float32)))
+            rgb.conv.modulation.weight.copy_(T(rs.standard_normal(rgb.conv.modulation.weight.shape).astype(np.float32)))
+            rgb.bias.copy_(T(0.1 * rs.standard_normal((1, 3, 1, 1)).astype(np.float32)))
+        sdr = {k: v.detach().clone() for k, v in rgb.state_dict().items()}
+        rgb = rgb.to(DEV)
+        with torch.no_grad():
+            yr = rgb(x.to(DEV), st.to(DEV), T(lab).to(DEV), None)
+        refr = O.to_rgb(sdr, "", x, st, onehot, None, masked=True)
+        assert maxdiff(yr, refr) <= 3e-5 * max(1.0, float(refr.abs().max()))
