@@ -462,6 +462,37 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
         const int oy = p.up ? 2 * y + pa : y, ox = p.up ? 2 * x + pb_ : x;
         nzq[q] = (p.noise && y < p.h && x < p.w) ? nw * p.noise[(size_t)b * p.noise_bstride + (size_t)oy * wo + ox] : 0.f;
     }
+    float rgbadd[PB][3];   // fused ToRGB: bias + FIR-upsampled skip of this lane's pixels, also fetched before any store
+    if constexpr (RGB) {
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int pbk = wp * PB + q;
+            const int oy = y0 + pbk * C::RPB + (l5 >> LOG_TW), ox = x0 + (l5 & (C::TW - 1));   // fused ToRGB runs on same-resolution layers only
+            const bool ok = oy < p.h && ox < p.w;
+            const int hs = ho >> 1, wsk = wo >> 1;
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                float u = p.rgb_bias[o];
+                if (p.rgb_skip && ok) {  // upfirdn2d(skip, up=2, pad=(2,1)) at (oy, ox): see region_torgb_kernel
+                    const int iy0 = (oy - 1) >> 1, ix0 = (ox - 1) >> 1;
+                    const int ky0 = 2 * iy0 + 2 - oy, kx0 = 2 * ix0 + 2 - ox;
+                    const float* sp = p.rgb_skip + ((size_t)b * 3 + o) * hs * wsk;
+#pragma unroll
+                    for (int ty = 0; ty < 2; ++ty) {
+                        const int iy = iy0 + ty;
+                        if (iy < 0 || iy >= hs) continue;
+#pragma unroll
+                        for (int tx = 0; tx < 2; ++tx) {
+                            const int ix = ix0 + tx;
+                            if (ix < 0 || ix >= wsk) continue;
+                            u += sp[(size_t)iy * wsk + ix] * kfr[(ky0 + 2 * ty) * 4 + kx0 + 2 * tx];
+                        }
+                    }
+                }
+                rgbadd[q][o] = u;
+            }
+        }
+    }
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
         const int pbk = wp * PB + q;
@@ -496,31 +527,9 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
             rgb1 += __shfl_xor(rgb1, 32, 64);
             rgb2 += __shfl_xor(rgb2, 32, 64);
             if (khalf == 0 && pix_ok) {
-                const int hs = ho >> 1, wsk = wo >> 1;
-                float rv[3] = {rgb0, rgb1, rgb2};
-#pragma unroll
-                for (int o = 0; o < 3; ++o) {
-                    float v = rv[o] + p.rgb_bias[o];
-                    if (p.rgb_skip) {  // upfirdn2d(skip, up=2, pad=(2,1)) at (oy, ox): see region_torgb_kernel
-                        const int iy0 = (oy - 1) >> 1, ix0 = (ox - 1) >> 1;
-                        const int ky0 = 2 * iy0 + 2 - oy, kx0 = 2 * ix0 + 2 - ox;
-                        const float* sp = p.rgb_skip + ((size_t)b * 3 + o) * hs * wsk;
-                        float u = 0.f;
-#pragma unroll
-                        for (int ty = 0; ty < 2; ++ty) {
-                            const int iy = iy0 + ty;
-                            if (iy < 0 || iy >= hs) continue;
-#pragma unroll
-                            for (int tx = 0; tx < 2; ++tx) {
-                                const int ix = ix0 + tx;
-                                if (ix < 0 || ix >= wsk) continue;
-                                u += sp[(size_t)iy * wsk + ix] * kfr[(ky0 + 2 * ty) * 4 + kx0 + 2 * tx];
-                            }
-                        }
-                        v += u;
-                    }
-                    p.rgb_out[((size_t)b * 3 + o) * ho * wo + opix] = v;
-                }
+                p.rgb_out[((size_t)b * 3 + 0) * ho * wo + opix] = rgb0 + rgbadd[q][0];
+                p.rgb_out[((size_t)b * 3 + 1) * ho * wo + opix] = rgb1 + rgbadd[q][1];
+                p.rgb_out[((size_t)b * 3 + 2) * ho * wo + opix] = rgb2 + rgbadd[q][2];
             }
         }
     }

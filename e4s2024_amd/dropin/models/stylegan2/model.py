@@ -432,7 +432,10 @@ class Generator(nn.Module):
                 intermediate_feats = out
             single = (not per_region) or (rli != 17 and i + 2 == rli)   # reference :681-688
             conv2 = self.convs[2 * j + 1]
-            if (single and not to_rgb.mask_op and out.is_cuda and tuple(to_rgb.upsample.kernel.shape) == (4, 4)
+            # (inference only: the fused pair has no backward form — under autograd the two layers run separately)
+            needs_grad = torch.is_grad_enabled() and (out.requires_grad or latent.requires_grad or any(p.requires_grad for p in conv2.parameters())
+                                                      or any(p.requires_grad for p in to_rgb.parameters()))
+            if (single and not needs_grad and not to_rgb.mask_op and out.is_cuda and tuple(to_rgb.upsample.kernel.shape) == (4, 4)
                     and ops.can_fuse_rgb(conv2.conv.out_channel, out.shape[-1], False, conv2.mask_op)):
                 # the single-region ToRGB rides in the conv's epilogue: the activation is not read back for the 1x1 conv
                 out, skip = conv2(out, code(i + 1), mask, noise=noise[2 + 2 * j], _fused_rgb=(to_rgb, latent[:, 0, i + 2], skip))

@@ -418,7 +418,7 @@ def _workspace(device, floats: int) -> torch.Tensor:
 
 # Fusing the single-region ToRGB into the preceding conv's epilogue is correct but measured neutral on MI355X (the longer epilogue
 # costs what the separate HBM-bound ToRGB launch costs), so it is off by default.
-FUSE_RGB = os.environ.get("E4S_FUSE_RGB", "0") != "0"
+FUSE_RGB = os.environ.get("E4S_FUSE_RGB", "1") != "0"
 
 
 def can_fuse_rgb(cout: int, w: int, up: bool, masked: bool) -> bool:
