@@ -513,7 +513,7 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
                 if (co < p.cout && pix_ok) {
                     float v = acc[i][q][r] * drow[n] * dz + nz + bt[n];
                     if (p.act) v = (v > 0.f ? v : v * 0.2f) * 1.41421356237309515f;
-                    p.out[((size_t)b * p.cout + co) * ho * wo + opix] = v;
+                    if (!RGB || p.out) p.out[((size_t)b * p.cout + co) * ho * wo + opix] = v;   // out == NULL: only the fused RGB is wanted
                     if constexpr (RGB) {
                         rgb0 += v * wsr[n * 3 + 0];
                         rgb1 += v * wsr[n * 3 + 1];
@@ -642,7 +642,7 @@ extern "C" int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16
                                         const float* act_bias, int act, int bs, int cin, int cout, int h, int w, int nreg, int up,
                                         float* workspace, int64_t workspace_floats, float* rgb_out, const float* rgb_wt, const float* rgb_s,
                                         const float* rgb_bias, const float* rgb_skip, const float* rgb_up_kernel, void* stream) {
-    E4S_REQUIRE(out && x && whi && wlo && s, "region_modconv3x3_sb: null tensor");
+    E4S_REQUIRE((out || rgb_out) && x && whi && wlo && s, "region_modconv3x3_sb: null tensor");
     E4S_REQUIRE(!rgb_out || (rgb_wt && rgb_s && rgb_bias && (!rgb_skip || rgb_up_kernel) && w >= 32 && !up), "region_modconv3x3_sb: incomplete fused-ToRGB arguments");
     E4S_REQUIRE(bs >= 0 && cin >= 1 && cout >= 1 && h >= 1 && w >= 1, "region_modconv3x3_sb: bad size");
     E4S_REQUIRE(nreg >= 1 && nreg <= E4S_MAX_REGIONS, "region_modconv3x3_sb: %d regions (max %d)", nreg, E4S_MAX_REGIONS);

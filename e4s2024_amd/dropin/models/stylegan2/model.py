@@ -165,7 +165,7 @@ class ModulatedConv2d(nn.Module):
         s, d = self._tables(styles, wsq)
         return wt, s, d
 
-    def forward_regions(self, input, styles, labels, noise=None, noise_weight=None, act_bias=None, act=False, rgb=None):
+    def forward_regions(self, input, styles, labels, noise=None, noise_weight=None, act_bias=None, act=False, rgb=None, want_out=True):
         if self._two_stage(labels is not None):
             # single-region up layer: transposed conv at 1x its MACs into a pre-blur buffer, then blur + epilogue
             wt, s, d = self.tables(styles, masked=False)
@@ -173,10 +173,11 @@ class ModulatedConv2d(nn.Module):
             return ops._attach("ModulatedConv2d", out, input, styles, self.weight, self.modulation.weight, self.modulation.bias, noise_weight,
                                act_bias, ref=self._torch_ref(labels, noise, act))
         wt, s, d = self.tables(styles, masked=labels is not None)
-        out = ops.region_modconv3x3(input, wt, s, d, labels, noise, noise_weight, act_bias, act, self.out_channel, self.upsample, rgb=rgb)
+        out = ops.region_modconv3x3(input, wt, s, d, labels, noise, noise_weight, act_bias, act, self.out_channel, self.upsample, rgb=rgb,
+                                    want_out=want_out)
         if rgb is not None:
-            return tuple(ops._attach("ModulatedConv2d", o, input, styles, self.weight, self.modulation.weight, self.modulation.bias,
-                                     noise_weight, act_bias) for o in out)
+            return tuple(None if o is None else ops._attach("ModulatedConv2d", o, input, styles, self.weight, self.modulation.weight,
+                                                            self.modulation.bias, noise_weight, act_bias) for o in out)
         return ops._attach("ModulatedConv2d", out, input, styles, self.weight, self.modulation.weight, self.modulation.bias, noise_weight,
                            act_bias, ref=self._torch_ref(labels, noise, act))
 
@@ -239,7 +240,7 @@ class StyledConv(nn.Module):
         self.activate = FusedLeakyReLU(out_channel)
         self.mask_op = mask_op
 
-    def forward(self, input, style, mask, noise=None, _fused_rgb=None):
+    def forward(self, input, style, mask, noise=None, _fused_rgb=None, _want_out=True):
         """``_fused_rgb=(to_rgb, rgb_style [bs,512], skip)`` (engine-internal, used by ``Generator.forward``) also evaluates that
         single-region ToRGB in this layer's epilogue and returns ``(out, rgb)``."""
         bs, _, H, W = input.shape
@@ -261,7 +262,8 @@ class StyledConv(nn.Module):
             to_rgb, rgb_style, skip = _fused_rgb
             r_wt, r_s, _ = to_rgb.conv.tables(rgb_style[:, None, :])
             rgb = (r_wt, r_s, to_rgb.bias, skip, to_rgb.upsample.kernel if skip is not None else None)
-        return self.conv.forward_regions(input, styles, labels, noise, self.noise.weight, self.activate.bias, act=True, rgb=rgb)
+        return self.conv.forward_regions(input, styles, labels, noise, self.noise.weight, self.activate.bias, act=True, rgb=rgb,
+                                         want_out=_want_out or rgb is None)
 
 
 class ToRGB(nn.Module):
@@ -438,7 +440,9 @@ class Generator(nn.Module):
             if (single and not needs_grad and not to_rgb.mask_op and out.is_cuda and tuple(to_rgb.upsample.kernel.shape) == (4, 4)
                     and ops.can_fuse_rgb(conv2.conv.out_channel, out.shape[-1], False, conv2.mask_op)):
                 # the single-region ToRGB rides in the conv's epilogue: the activation is not read back for the 1x1 conv
-                out, skip = conv2(out, code(i + 1), mask, noise=noise[2 + 2 * j], _fused_rgb=(to_rgb, latent[:, 0, i + 2], skip))
+                # (the last layer's own activation is consumed by nothing but this ToRGB: it is not written)
+                out, skip = conv2(out, code(i + 1), mask, noise=noise[2 + 2 * j], _fused_rgb=(to_rgb, latent[:, 0, i + 2], skip),
+                                  _want_out=j + 1 < len(self.to_rgbs))
             else:
                 out = conv2(out, code(i + 1), mask, noise=noise[2 + 2 * j])
                 skip = to_rgb(out, latent[:, 0, i + 2] if single else latent[:, :, i + 2], mask, skip)

@@ -427,14 +427,17 @@ def can_fuse_rgb(cout: int, w: int, up: bool, masked: bool) -> bool:
     return FUSE_RGB and MODCONV_MODE == "sb" and not up and w >= 32 and (cout <= 64 or (masked and wide and cout == 128))
 
 
-def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: bool, cout: int, up: bool, rgb=None):
+def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: bool, cout: int, up: bool, rgb=None, want_out: bool = True):
     """``rgb = (wt_rgb [cout,3], s_rgb [bs,1,cout], bias [1,3,1,1], skip or None, up_kernel)`` fuses the following single-region
-    ToRGB; the call then returns ``(out, rgb_image)``."""
+    ToRGB; the call then returns ``(out, rgb_image)``.  ``want_out=False`` (with ``rgb``) skips writing the layer's own activation
+    and returns ``(None, rgb_image)``."""
     x = _c(x, "input")
     bs, cin, h, w = x.shape
     nreg = s.shape[1]
     ho, wo = (2 * h, 2 * w) if up else (h, w)
-    out = torch.empty((bs, cout, ho, wo), dtype=torch.float32, device=x.device)
+    if not want_out and rgb is None:
+        raise ValueError("want_out=False only makes sense together with a fused ToRGB")
+    out = torch.empty((bs, cout, ho, wo), dtype=torch.float32, device=x.device) if want_out else None
     lh = lw = 0
     if labels is not None:
         lh, lw = labels.shape[1:]
@@ -447,8 +450,8 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
         if nz.numel() != nbs * ho * wo:
             raise ValueError(f"noise shape {tuple(nz.shape)} does not match output {ho}x{wo}")
     ws, wsn = None, 0
-    if out.numel() <= SPLITK_MAX_OUT_FLOATS:
-        wsn = 16 * out.numel()
+    if bs * cout * ho * wo <= SPLITK_MAX_OUT_FLOATS:
+        wsn = 16 * bs * cout * ho * wo
         ws = _workspace(x.device, wsn)
     sb = isinstance(wt, tuple)
     ev = _timed(modconv_kernel_name(cout, w, sb, labels is not None))

@@ -128,7 +128,9 @@ E4S_API int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16_t*
 /* rgb_* (all NULL = off): fuse the single-region ToRGB that follows this layer (model.py:439-479) into the epilogue — allowed for
  * same-resolution layers of width >= 32 whose Cout fits one workgroup tile (<= 64, or <= 128 on masked layers): rgb_out [bs,3,h,w] =
  * sum_co out[co] * rgb_wt[co][o] * rgb_s[b][co] + rgb_bias[o] + upfirdn2d(rgb_skip, rgb_up_kernel, up=2, pad=(2,1)), so the layer's
- * output is not read back for the 1x1 conv.  rgb_wt from e4s_modconv_prep_weights(k=1), rgb_s = the ToRGB's s table [bs,1,cout]. */
+ * output is not read back for the 1x1 conv.  rgb_wt from e4s_modconv_prep_weights(k=1), rgb_s = the ToRGB's s table [bs,1,cout].
+ * With rgb_out given, out may be NULL: the layer's own activation is then not written at all (the last layer of the generator, whose
+ * output only feeds its ToRGB). */
 
 /* Single-region (unmasked) up layer at 1x the transposed conv's MACs, in two launches (the parity-composed kernel above spends 4x):
  *   e4s_modconv_tconv_sb : z[bs,cout,2h+1,2w+1] = conv_transpose2d(x * s, W/sqrt(9 cin), stride 2)   (model.py:287-299; raw sums)
