@@ -87,3 +87,16 @@ def pti_step(net, optimizer: torch.optim.Optimizer, style_vectors: torch.Tensor,
     loss.backward()
     optimizer.step()
     return loss.detach(), recon.detach()
+
+
+def style_vector_step(net, optimizer: torch.optim.Optimizer, latent: torch.Tensor, mask: torch.Tensor, target: torch.Tensor,
+                      l2_lambda: float = 1.0, extra_loss: Optional[Callable[[torch.Tensor, torch.Tensor], torch.Tensor]] = None,
+                      randomize_noise: bool = True):
+    """One step of the reference's W-optimisation (``Optimizer.optim_W_online``, optimization.py:321-349): the per-region style
+    vectors ``latent [bs, 12, 1280]`` (``requires_grad``, held by ``optimizer``) are tuned so that ``gen_img(cal_style_codes(latent))``
+    matches ``target``; the network's own parameters are left alone (they are not in ``optimizer``)."""
+    optimizer.zero_grad()
+    loss, recon = _loss(net, latent, mask, target, None, l2_lambda, extra_loss, randomize_noise)
+    loss.backward()
+    optimizer.step()
+    return loss.detach(), recon.detach()

@@ -136,3 +136,26 @@ def test_pti_step_eager_and_graph_agree():
         opt_c.zero_grad(); l.backward(); opt_c.step()
         losses_c.append(l.item())
     assert np.allclose(losses_b, losses_c, rtol=2e-3), (losses_b, losses_c)
+
+
+def test_style_vector_optimisation_reduces_the_loss():
+    """W-optimisation (optimization.py:321-349): gradient steps on the style vectors alone, network frozen."""
+    import types
+    install_dropin()
+    from models.networks import Net3
+    from e4s2024_amd import pti
+    opts = types.SimpleNamespace(fsencoder_type="psp", remaining_layer_idx=5, num_seg_cls=12, out_size=64, train_G=False,
+                                 start_from_latent_avg=True, learn_in_w=False)
+    net = Net3(opts)
+    seeded.apply_seeded(net, 4, "net3")
+    net = net.to(DEV).eval()
+    net.latent_avg = seeded.seeded_latent_avg(2, 10).to(DEV)
+    before = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    latent = T(seeded.seeded_array(41, "vec", (1, 12, 1280), dist="normal")).to(DEV).requires_grad_(True)
+    lab = T(seeded.blocky_labels(3, 1, 12, 64, 8)).to(DEV)
+    target = torch.tanh(T(seeded.seeded_array(5, "img", (1, 3, 64, 64), dist="normal"))).to(DEV)
+    opt = torch.optim.Adam([latent], lr=0.05)
+    losses = [pti.style_vector_step(net, opt, latent, lab, target, randomize_noise=False)[0].item() for _ in range(8)]
+    assert losses[-1] < 0.9 * losses[0], losses
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, before[k]), k          # the network did not move
