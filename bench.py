@@ -182,7 +182,7 @@ def main():
         p50 = times[len(times) // 2]
         full_swap = {"p50_ms_per_frame": round(p50 / SWAP_BATCH, 3), "p50_ms_per_batch": round(p50, 3), "batch": SWAP_BATCH, "frames": 13 * SWAP_BATCH,
                      "swaps_per_s": round(SWAP_BATCH / p50 * 1e3, 1),
-                     "unit_of_work": "2 x BiSeNet parse (exact fp32) + 2 x get_style_vectors + style mix + cal_style_codes + gen_img + tensor2im, "
+                     "unit_of_work": "2 x BiSeNet parse (three-way bf16 split, fp32-class) + 2 x get_style_vectors + style mix + cal_style_codes + gen_img + tensor2im, "
                                      "inputs resident in HBM (BASELINE configs[2])"}
         del parser, drv, tgt, frames
 

@@ -36,7 +36,9 @@ _PROTOS = {
     "e4s_conv_prep_weights": [c_ptr] * 7 + [c_f32, c_ptr, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_conv2d": [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int] + [c_int] * 8 + [c_ptr],
     "e4s_conv_prep_weights_sb": [c_ptr] * 8 + [c_f32, c_ptr, c_int, c_int, c_int, c_int, c_ptr],
+    "e4s_conv_prep_weights_sb3": [c_ptr] * 9 + [c_f32, c_ptr, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_conv2d_sb": [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int] + [c_int] * 8 + [c_ptr],
+    "e4s_conv2d_sb3": [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int] + [c_int] * 8 + [c_ptr],
     "e4s_plane_stats": [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_f32, c_ptr],
     "e4s_vec_fc": [c_ptr] * 7 + [c_f32, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_norm_gate_add": [c_ptr] * 8 + [c_int, c_ptr, c_int, c_int, c_int, c_int, c_ptr],

@@ -347,7 +347,7 @@ __device__ __forceinline__ void c2_split2(float t0, float t1, unsigned& hi, unsi
     lo = c2_pack_bf16(t0 - __builtin_bit_cast(float, hi << 16), t1 - __builtin_bit_cast(float, hi & 0xffff0000u));
 }
 
-__global__ __launch_bounds__(256) void conv_prep_sb_kernel(uint16_t* __restrict__ whi, uint16_t* __restrict__ wlo, float* __restrict__ bias_out,
+__global__ __launch_bounds__(256) void conv_prep_sb_kernel(uint16_t* __restrict__ whi, uint16_t* __restrict__ wlo, uint16_t* __restrict__ wlo2, float* __restrict__ bias_out,
                                                            const float* __restrict__ weight, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ mean,
                                                            const float* __restrict__ var, float eps, const float* __restrict__ conv_bias,
@@ -369,7 +369,10 @@ __global__ __launch_bounds__(256) void conv_prep_sb_kernel(uint16_t* __restrict_
         }
         const unsigned hp = c2_pack_bf16(v, 0.f) & 0xffffu;
         whi[i] = (uint16_t)hp;
-        wlo[i] = (uint16_t)(c2_pack_bf16(v - __builtin_bit_cast(float, hp << 16), 0.f) & 0xffffu);
+        const float r1 = v - __builtin_bit_cast(float, hp << 16);
+        const unsigned mp = c2_pack_bf16(r1, 0.f) & 0xffffu;
+        wlo[i] = (uint16_t)mp;
+        if (wlo2) wlo2[i] = (uint16_t)(c2_pack_bf16(r1 - __builtin_bit_cast(float, mp << 16), 0.f) & 0xffffu);   // third term of the 3-way split
     }
     if (bias_out) {
         for (int co = blockIdx.x * 256 + threadIdx.x; co < cout; co += gridDim.x * 256) {
@@ -391,17 +394,32 @@ extern "C" int e4s_conv_prep_weights_sb(uint16_t* whi, uint16_t* wlo, float* bia
     E4S_REQUIRE(!conv_bias || bias_out, "conv_prep_weights_sb: conv bias needs bias_out");
     const int64_t total = (int64_t)cdiv(cin, CKS2) * kh * kw * 2 * cout * 8;
     const int grid = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
-    hipLaunchKernelGGL(conv_prep_sb_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, whi, wlo, bias_out, weight, bn_gamma, bn_beta, bn_mean,
-                       bn_var, bn_eps, conv_bias, cout, cin, kh * kw);
+    hipLaunchKernelGGL(conv_prep_sb_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, whi, wlo, (uint16_t*)nullptr, bias_out, weight, bn_gamma,
+                       bn_beta, bn_mean, bn_var, bn_eps, conv_bias, cout, cin, kh * kw);
     return check_launch("conv_prep_weights_sb");
+}
+
+// Three-way split: w = w0 + w1 + w2 (each bf16, RNE of the running residual) represents an fp32 weight to ~2^-25.
+extern "C" int e4s_conv_prep_weights_sb3(uint16_t* w0, uint16_t* w1, uint16_t* w2, float* bias_out, const float* weight, const float* bn_gamma,
+                                         const float* bn_beta, const float* bn_mean, const float* bn_var, float bn_eps, const float* conv_bias,
+                                         int cout, int cin, int kh, int kw, void* stream) {
+    E4S_REQUIRE(w0 && w1 && w2 && weight, "conv_prep_weights_sb3: null tensor");
+    E4S_REQUIRE(cout >= 1 && cin >= 1 && kh >= 1 && kw >= 1, "conv_prep_weights_sb3: bad size");
+    const bool bn = bn_var != nullptr;
+    E4S_REQUIRE(!bn || (bn_gamma && bn_beta && bn_mean && bias_out), "conv_prep_weights_sb3: BatchNorm fold needs gamma, beta, mean, var and bias_out");
+    E4S_REQUIRE(!conv_bias || bias_out, "conv_prep_weights_sb3: conv bias needs bias_out");
+    const int64_t total = (int64_t)cdiv(cin, CKS2) * kh * kw * 2 * cout * 8;
+    const int grid = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
+    hipLaunchKernelGGL(conv_prep_sb_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w0, w1, w2, bias_out, weight, bn_gamma, bn_beta, bn_mean,
+                       bn_var, bn_eps, conv_bias, cout, cin, kh * kw);
+    return check_launch("conv_prep_weights_sb3");
 }
 
 struct Conv2dSbParams {
     float* out;
     const float* x0;
     const float* x1;
-    const uint4* whi;
-    const uint4* wlo;
+    const uint4* wsl[3];   // weight slabs: hi, lo (, lo2 for the three-way split)
     const float* bias;
     const float* in_mean;
     const float* in_rstd;
@@ -412,7 +430,10 @@ struct Conv2dSbParams {
     int tiles_x, tiles_y;
 };
 
-template <int KS, int S, int CB, int PB, int WC, int WP, int LOG_TW>
+// NS = number of bf16 terms per operand.  NS = 2: a*b ~ a0*b0 + a0*b1 + a1*b0 (3 MFMAs per 16-deep step, ~2^-17 per product).
+// NS = 3: a0*b0 + a0*b1 + a1*b0 + a0*b2 + a2*b0 + a1*b1 (6 MFMAs, ~2^-24: fp32-class, for the face parser whose argmax must not move)
+// — still 2.7x less matrix-pipe time than the 8 fp32 MFMAs of the exact kernel.
+template <int KS, int S, int CB, int PB, int WC, int WP, int LOG_TW, int NS = 2>
 struct C2SbCfg {
     static constexpr int KK = KS * KS;
     static constexpr int TN = WC * CB * 32;
@@ -424,9 +445,9 @@ struct C2SbCfg {
     static constexpr int PATCH = PH * PW;
     static constexpr int NT = 64 * WC * WP;          // threads per workgroup (256 or 512)
     static constexpr int EPT = (PATCH + NT - 1) / NT;
-    static constexpr int W4 = 2 * KK * 2 * TN;       // uint4: [hi/lo][tap][half][TN]
+    static constexpr int W4 = NS * KK * 2 * TN;      // uint4: [term][tap][half][TN]
     static constexpr int WPT = (W4 + NT - 1) / NT;
-    static constexpr int LDS_BYTES = W4 * 16 + PATCH * 64;
+    static constexpr int LDS_BYTES = W4 * 16 + PATCH * 32 * NS;
     static_assert(WC * WP == 4 || WC * WP == 8, "256- or 512-thread workgroups");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS per CU");
 };
@@ -444,13 +465,12 @@ extern "C" E4S_API int e4s_prof_clear_conv() {
 }
 #endif
 
-template <int KS, int S, int CB, int PB, int WC, int WP, int LOG_TW, int PF = 1>
+template <int KS, int S, int CB, int PB, int WC, int WP, int LOG_TW, int PF = 1, int NS = 2>
 __global__ __launch_bounds__(64 * WC * WP, 2) void conv2d_sb_kernel(const Conv2dSbParams p) {
-    using C = C2SbCfg<KS, S, CB, PB, WC, WP, LOG_TW>;
+    using C = C2SbCfg<KS, S, CB, PB, WC, WP, LOG_TW, NS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    uint4* wsm = reinterpret_cast<uint4*>(lds_raw);                 // [2][KK][2][TN]
-    uint4* xh4 = reinterpret_cast<uint4*>(lds_raw + C::W4 * 16);    // [PATCH][2]: 16 bf16 (hi) per patch pixel, halves swizzled
-    uint4* xl4 = xh4 + 2 * C::PATCH;                                // lo plane
+    uint4* wsm = reinterpret_cast<uint4*>(lds_raw);                 // [NS][KK][2][TN]
+    uint4* xpl = reinterpret_cast<uint4*>(lds_raw + C::W4 * 16);    // NS planes of [PATCH][2]: 16 bf16 per patch pixel, halves swizzled
 
     const int tid = threadIdx.x;
     E4S_PROF_MARK(g_prof_conv, 0);
@@ -510,7 +530,6 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void conv2d_sb_kernel(const Conv2d
 #pragma unroll
     for (int j = 0; j < C::EPT; ++j) goffs[j] = ginb[j] ? goff[j] : 0;
     const bool split_ok = (p.cin0 % CKS2) == 0;   // a chunk never straddles the two concatenated inputs
-    const ptrdiff_t wdelta = p.wlo - p.whi;
     auto load_chunk = [&](int chunk, float (&xs)[CKS2][C::EPT], unsigned (&ws)[C::WPT][4], float (&m)[CKS2], float (&r)[CKS2]) __attribute__((always_inline)) {
         const int ci0 = chunk * CKS2;
         if (split_ok) {
@@ -540,7 +559,8 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void conv2d_sb_kernel(const Conv2d
             const int rem = idx - hl * C::KK * 2 * C::TN;
             const int th = rem / C::TN, n = rem - th * C::TN;
             const int co = (co0 + n < p.cout) ? co0 + n : p.cout - 1;
-            const uint4 t4 = p.whi[(ptrdiff_t)hl * wdelta + (ptrdiff_t)(wbase + (size_t)th * p.cout + co)];
+            const uint4* slab = hl == 0 ? p.wsl[0] : (hl == 1 ? p.wsl[1] : p.wsl[2]);
+            const uint4 t4 = slab[wbase + (size_t)th * p.cout + co];
             ws[v][0] = t4.x; ws[v][1] = t4.y; ws[v][2] = t4.z; ws[v][3] = t4.w;
         }
 #pragma unroll
@@ -555,19 +575,29 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void conv2d_sb_kernel(const Conv2d
         for (int j = 0; j < C::EPT; ++j) {
             const int e = tid + j * C::NT;
             if (e < C::PATCH) {
-                unsigned h[8], l[8];
+                unsigned h[8], l[8], l2[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     // padding stays exactly 0: the normalisation applies to in-bounds pixels only
                     const float t0 = ginb[j] ? (xs[2 * c][j] - m[2 * c]) * r[2 * c] : 0.f;
                     const float t1 = ginb[j] ? (xs[2 * c + 1][j] - m[2 * c + 1]) * r[2 * c + 1] : 0.f;
                     c2_split2(t0, t1, h[c], l[c]);
+                    if (NS == 3) {   // third term: what the first two leave over
+                        const float q0 = (t0 - __builtin_bit_cast(float, h[c] << 16)) - __builtin_bit_cast(float, l[c] << 16);
+                        const float q1 = (t1 - __builtin_bit_cast(float, h[c] & 0xffff0000u)) - __builtin_bit_cast(float, l[c] & 0xffff0000u);
+                        l2[c] = c2_pack_bf16(q0, q1);
+                    }
                 }
                 const int sw = (e >> 3) & 1;
-                xh4[e * 2 + (0 ^ sw)] = make_uint4(h[0], h[1], h[2], h[3]);
-                xh4[e * 2 + (1 ^ sw)] = make_uint4(h[4], h[5], h[6], h[7]);
-                xl4[e * 2 + (0 ^ sw)] = make_uint4(l[0], l[1], l[2], l[3]);
-                xl4[e * 2 + (1 ^ sw)] = make_uint4(l[4], l[5], l[6], l[7]);
+                uint4* x0p = xpl, *x1p = xpl + 2 * C::PATCH, *x2p = xpl + 4 * C::PATCH;
+                x0p[e * 2 + (0 ^ sw)] = make_uint4(h[0], h[1], h[2], h[3]);
+                x0p[e * 2 + (1 ^ sw)] = make_uint4(h[4], h[5], h[6], h[7]);
+                x1p[e * 2 + (0 ^ sw)] = make_uint4(l[0], l[1], l[2], l[3]);
+                x1p[e * 2 + (1 ^ sw)] = make_uint4(l[4], l[5], l[6], l[7]);
+                if (NS == 3) {
+                    x2p[e * 2 + (0 ^ sw)] = make_uint4(l2[0], l2[1], l2[2], l2[3]);
+                    x2p[e * 2 + (1 ^ sw)] = make_uint4(l2[4], l2[5], l2[6], l2[7]);
+                }
             }
         }
 #pragma unroll
@@ -581,35 +611,30 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void conv2d_sb_kernel(const Conv2d
 #pragma unroll
         for (int tap = 0; tap < C::KK; ++tap) {
             const int toff = (tap / KS) * C::PW + (tap % KS);
-            uint4 bh[PB], bl[PB];
+            uint4 bt[NS][PB];
 #pragma unroll
             for (int q = 0; q < PB; ++q) {
                 const int e = xoff[q] + toff;
                 const int slot = e * 2 + (khalf ^ ((e >> 3) & 1));
-                bh[q] = xh4[slot];
-                bl[q] = xl4[slot];
+#pragma unroll
+                for (int t = 0; t < NS; ++t) bt[t][q] = xpl[t * 2 * C::PATCH + slot];
             }
-            uint4 ah[CB], al[CB];
+            uint4 at[NS][CB];
 #pragma unroll
-            for (int i = 0; i < CB; ++i) {
-                ah[i] = whalf[tap * 2 * C::TN + i * 32];
-                al[i] = whalf[C::KK * 2 * C::TN + tap * 2 * C::TN + i * 32];
-            }
+            for (int t = 0; t < NS; ++t)
 #pragma unroll
-            for (int i = 0; i < CB; ++i)
+                for (int i = 0; i < CB; ++i) at[t][i] = whalf[t * C::KK * 2 * C::TN + tap * 2 * C::TN + i * 32];
+            // products in order of magnitude: (0,0) (0,1) (1,0) [ (0,2) (2,0) (1,1) ]
+            constexpr int NPROD = NS == 3 ? 6 : 3;
+            constexpr int TA[6] = {0, 0, 1, 0, 2, 1};
+            constexpr int TB[6] = {0, 1, 0, 2, 0, 1};
 #pragma unroll
-                for (int q = 0; q < PB; ++q)
-                    acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[q]), acc[i][q], 0, 0, 0);
+            for (int pr = 0; pr < NPROD; ++pr)
 #pragma unroll
-            for (int i = 0; i < CB; ++i)
+                for (int i = 0; i < CB; ++i)
 #pragma unroll
-                for (int q = 0; q < PB; ++q)
-                    acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[q]), acc[i][q], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < CB; ++i)
-#pragma unroll
-                for (int q = 0; q < PB; ++q)
-                    acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[q]), acc[i][q], 0, 0, 0);
+                    for (int q = 0; q < PB; ++q)
+                        acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, at[TA[pr]][i]), __builtin_bit_cast(bf16x8, bt[TB[pr]][q]), acc[i][q], 0, 0, 0);
         }
     };
 
@@ -689,20 +714,20 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void conv2d_sb_kernel(const Conv2d
     E4S_PROF_MARK(g_prof_conv, 5);
 }
 
-template <int KS, int S, int CB, int PB, int WC, int WP, int LOG_TW>
+template <int KS, int S, int CB, int PB, int WC, int WP, int LOG_TW, int NS = 2>
 static int launch2d_sb(Conv2dSbParams& p, hipStream_t st) {
     // two chunks of register prefetch wherever both stages fit in 256 registers without spilling (measured with hipcc 7.2)
-    constexpr int PF = (CB * PB <= 2 && (S == 1 || KS == 1)) ? 2 : 1;
-    using C = C2SbCfg<KS, S, CB, PB, WC, WP, LOG_TW>;
+    constexpr int PF = (NS == 2 && CB * PB <= 2 && (S == 1 || KS == 1)) ? 2 : 1;
+    using C = C2SbCfg<KS, S, CB, PB, WC, WP, LOG_TW, NS>;
     p.tiles_x = cdiv(p.wo, C::TW);
     p.tiles_y = cdiv(p.ho, C::TH);
     dim3 grid(p.tiles_x * p.tiles_y, cdiv(p.cout, C::TN), p.bs);
     if (C::LDS_BYTES > 64 * 1024) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_sb_kernel<KS, S, CB, PB, WC, WP, LOG_TW, PF>),
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_sb_kernel<KS, S, CB, PB, WC, WP, LOG_TW, PF, NS>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (attr != hipSuccess) return fail((int)attr, "conv2d_sb: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
     }
-    hipLaunchKernelGGL((conv2d_sb_kernel<KS, S, CB, PB, WC, WP, LOG_TW, PF>), grid, dim3(C::NT), C::LDS_BYTES, st, p);
+    hipLaunchKernelGGL((conv2d_sb_kernel<KS, S, CB, PB, WC, WP, LOG_TW, PF, NS>), grid, dim3(C::NT), C::LDS_BYTES, st, p);
     return check_launch("conv2d_sb");
 }
 
@@ -722,29 +747,61 @@ static int dispatch2d_sb(Conv2dSbParams& p, hipStream_t st) {
     return launch2d_sb<KS, S, 1, 1, 2, 2, 4>(p, st);                                                                      // 64 co x 64 px (16 x 4)
 }
 
-extern "C" int e4s_conv2d_sb(float* out, const float* x0, const float* x1, int cin0, const uint16_t* whi, const uint16_t* wlo, const float* bias,
-                             const float* in_mean, const float* in_rstd, const float* prelu_slope, const float* residual, int act, int bs,
-                             int cin, int cout, int h, int w, int ks, int stride, int pad, void* stream) {
-    E4S_REQUIRE(out && x0 && whi && wlo, "conv2d_sb: null tensor");
+// three-way split: the 64 co x 128 px tile is the largest whose three planes + three slabs leave room for two workgroups per CU
+template <int KS, int S>
+static int dispatch2d_sb3(Conv2dSbParams& p, hipStream_t st) {
+    if (p.wo >= 32) {
+        if (p.cout > 32 && nblocks_sb(p, 64, 4, 32) >= 256) return launch2d_sb<KS, S, 2, 1, 1, 4, 5, 3>(p, st);           // 64 co x 128 px
+        return launch2d_sb<KS, S, 1, 1, 2, 2, 5, 3>(p, st);                                                                // 64 co x  64 px
+    }
+    return launch2d_sb<KS, S, 1, 1, 2, 2, 4, 3>(p, st);                                                                    // 64 co x 64 px (16 x 4)
+}
+
+static int conv2d_sb_common(int nterms, float* out, const float* x0, const float* x1, int cin0, const uint16_t* w0, const uint16_t* w1, const uint16_t* w2,
+                            const float* bias, const float* in_mean, const float* in_rstd, const float* prelu_slope, const float* residual, int act,
+                            int bs, int cin, int cout, int h, int w, int ks, int stride, int pad, void* stream) {
+    E4S_REQUIRE(out && x0 && w0 && w1 && (nterms == 2 || w2), "conv2d_sb: null tensor");
     E4S_REQUIRE(bs >= 0 && bs <= 65535 && cin >= 1 && cout >= 1 && h >= 1 && w >= 1, "conv2d_sb: bad size");
     E4S_REQUIRE(stride == 1 || stride == 2, "conv2d_sb: stride %d not supported (1 or 2)", stride);
     E4S_REQUIRE(pad >= 0 && pad <= ks, "conv2d_sb: bad padding");
     E4S_REQUIRE(act >= 0 && act <= 2 && (act != 2 || prelu_slope), "conv2d_sb: bad activation");
     E4S_REQUIRE((in_mean == nullptr) == (in_rstd == nullptr), "conv2d_sb: in_mean and in_rstd go together");
     E4S_REQUIRE(x1 ? (cin0 >= 1 && cin0 < cin) : true, "conv2d_sb: bad channel split");
-    E4S_REQUIRE((((uintptr_t)whi | (uintptr_t)wlo) & 15) == 0, "conv2d_sb: weight slabs must be 16-byte aligned");
+    E4S_REQUIRE((((uintptr_t)w0 | (uintptr_t)w1 | (uintptr_t)w2) & 15) == 0, "conv2d_sb: weight slabs must be 16-byte aligned");
     if (bs == 0) return 0;
     Conv2dSbParams p;
-    p.out = out; p.x0 = x0; p.x1 = x1; p.whi = reinterpret_cast<const uint4*>(whi); p.wlo = reinterpret_cast<const uint4*>(wlo); p.bias = bias;
+    p.out = out; p.x0 = x0; p.x1 = x1; p.bias = bias;
+    p.wsl[0] = reinterpret_cast<const uint4*>(w0); p.wsl[1] = reinterpret_cast<const uint4*>(w1); p.wsl[2] = reinterpret_cast<const uint4*>(w2 ? w2 : w1);
     p.in_mean = in_mean; p.in_rstd = in_rstd; p.slope = prelu_slope; p.residual = residual; p.act = act;
     p.bs = bs; p.cin = cin; p.cin0 = x1 ? cin0 : cin; p.cout = cout; p.h = h; p.w = w; p.pad = pad;
     p.ho = (h + 2 * pad - ks) / stride + 1;
     p.wo = (w + 2 * pad - ks) / stride + 1;
     E4S_REQUIRE(p.ho >= 1 && p.wo >= 1, "conv2d_sb: empty output");
     hipStream_t st = (hipStream_t)stream;
-    if (ks == 3 && stride == 1) return dispatch2d_sb<3, 1>(p, st);
-    if (ks == 3 && stride == 2) return dispatch2d_sb<3, 2>(p, st);
-    if (ks == 1 && stride == 1) return dispatch2d_sb<1, 1>(p, st);
-    if (ks == 1 && stride == 2) return dispatch2d_sb<1, 2>(p, st);
+    if (nterms == 3) {
+        if (ks == 3 && stride == 1) return dispatch2d_sb3<3, 1>(p, st);
+        if (ks == 3 && stride == 2) return dispatch2d_sb3<3, 2>(p, st);
+        if (ks == 1 && stride == 1) return dispatch2d_sb3<1, 1>(p, st);
+        if (ks == 1 && stride == 2) return dispatch2d_sb3<1, 2>(p, st);
+    } else {
+        if (ks == 3 && stride == 1) return dispatch2d_sb<3, 1>(p, st);
+        if (ks == 3 && stride == 2) return dispatch2d_sb<3, 2>(p, st);
+        if (ks == 1 && stride == 1) return dispatch2d_sb<1, 1>(p, st);
+        if (ks == 1 && stride == 2) return dispatch2d_sb<1, 2>(p, st);
+    }
     return fail(E4S_ERR_ARG, "conv2d_sb: kernel %dx%d stride %d not supported (3x3 / 1x1, stride 1 / 2)", ks, ks, stride);
+}
+
+extern "C" int e4s_conv2d_sb(float* out, const float* x0, const float* x1, int cin0, const uint16_t* whi, const uint16_t* wlo, const float* bias,
+                             const float* in_mean, const float* in_rstd, const float* prelu_slope, const float* residual, int act, int bs,
+                             int cin, int cout, int h, int w, int ks, int stride, int pad, void* stream) {
+    return conv2d_sb_common(2, out, x0, x1, cin0, whi, wlo, nullptr, bias, in_mean, in_rstd, prelu_slope, residual, act, bs, cin, cout, h, w, ks, stride,
+                            pad, stream);
+}
+
+extern "C" int e4s_conv2d_sb3(float* out, const float* x0, const float* x1, int cin0, const uint16_t* w0, const uint16_t* w1, const uint16_t* w2,
+                              const float* bias, const float* in_mean, const float* in_rstd, const float* prelu_slope, const float* residual, int act,
+                              int bs, int cin, int cout, int h, int w, int ks, int stride, int pad, void* stream) {
+    return conv2d_sb_common(3, out, x0, x1, cin0, w0, w1, w2, bias, in_mean, in_rstd, prelu_slope, residual, act, bs, cin, cout, h, w, ks, stride, pad,
+                            stream);
 }

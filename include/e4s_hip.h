@@ -204,6 +204,16 @@ E4S_API int e4s_conv_prep_weights_sb(uint16_t* whi, uint16_t* wlo, float* bias_o
 E4S_API int e4s_conv2d_sb(float* out, const float* x0, const float* x1, int cin0, const uint16_t* whi, const uint16_t* wlo, const float* bias,
                           const float* in_mean, const float* in_rstd, const float* prelu_slope, const float* residual, int act,
                           int bs, int cin, int cout, int h, int w, int ks, int stride, int pad, void* stream);
+/* Three-way split (w = w0 + w1 + w2, x likewise; 6 bf16 MFMAs per 16-deep step: a0b0 + a0b1 + a1b0 + a0b2 + a2b0 + a1b1, fp32
+ * accumulate): fp32-class error (~2^-24 per product) at 2.7x less matrix-pipe time than the exact fp32 kernel.  Meant for the face
+ * parser (swap_face_fine/face_parsing/model.py:20-260), whose argmax must not move.  Slabs from e4s_conv_prep_weights_sb3. */
+E4S_API int e4s_conv_prep_weights_sb3(uint16_t* w0, uint16_t* w1, uint16_t* w2, float* bias_out, const float* weight,
+                                      const float* bn_gamma, const float* bn_beta, const float* bn_mean, const float* bn_var,
+                                      float bn_eps, const float* conv_bias, int cout, int cin, int kh, int kw, void* stream);
+E4S_API int e4s_conv2d_sb3(float* out, const float* x0, const float* x1, int cin0, const uint16_t* w0, const uint16_t* w1,
+                           const uint16_t* w2, const float* bias, const float* in_mean, const float* in_rstd,
+                           const float* prelu_slope, const float* residual, int act, int bs, int cin, int cout, int h, int w,
+                           int ks, int stride, int pad, void* stream);
 
 /* Per-plane statistics of x [planes = bs*C, hw]: mean, rstd = 1/sqrt(biased var + eps) (InstanceNorm2d without affine / running
  * stats, helpers.py:133,138), nmean = mean of the normalised plane (what SEModule's avg_pool sees, helpers.py:66).  rstd and nmean
