@@ -31,6 +31,10 @@ _PROTOS = {
     "e4s_modconv_up_fused_sb": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_swap_head_mask": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
     "e4s_foreground_masks": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr],
+    "e4s_mconv_unfold": [c_ptr] * 4 + [c_int] * 7 + [c_ptr],
+    "e4s_mconv_scale": [c_ptr] * 9 + [c_int, c_ptr, c_ptr] + [c_int] * 8 + [c_ptr],
+    "e4s_unfold2d": [c_ptr, c_ptr] + [c_int] * 9 + [c_ptr],
+    "e4s_mconv_fold": [c_ptr] * 6 + [c_int] * 8 + [c_ptr],
     "e4s_blur_epilogue": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_region_torgb": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr] + [c_int] * 5 + [c_ptr],
     "e4s_conv_prep_weights": [c_ptr] * 7 + [c_f32, c_ptr, c_int, c_int, c_int, c_int, c_ptr],

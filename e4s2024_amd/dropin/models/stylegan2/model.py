@@ -186,9 +186,11 @@ class ModulatedConv2d(nn.Module):
         blur = self.blur.kernel if self.upsample else None
         mod = self.modulation
 
-        def ref(x, styles, weight, mod_w, mod_b, noise_weight, act_bias):
+        def ref(x, styles, weight, mod_w, mod_b, noise_weight, act_bias, fwd_out=None):
             return torch_ref.styled_conv(x, styles, weight, mod_w, mod_b, noise_weight, act_bias, labels=labels, noise=noise, act=act,
-                                         upsample=self.upsample, blur=blur, demodulate=self.demodulate, mod_scale=mod.scale, mod_lr=mod.lr_mul)
+                                         upsample=self.upsample, blur=blur, demodulate=self.demodulate, mod_scale=mod.scale, mod_lr=mod.lr_mul,
+                                         fwd_out=fwd_out)
+        ref.takes_fwd_out = True      # the backward differentiates from the kernel's own output: the layer is not re-evaluated
         return ref
 
     def forward(self, input, style):

@@ -68,12 +68,15 @@ class _TorchBackward(torch.autograd.Function):
     def forward(ctx, ref, out, *deps):
         ctx.ref = ref
         ctx.is_tensor = [isinstance(d, torch.Tensor) for d in deps]
-        ctx.save_for_backward(*[d for d in deps if isinstance(d, torch.Tensor)])
+        ctx.with_out = bool(getattr(ref, "takes_fwd_out", False))       # a ref that differentiates from the forward value (no re-evaluation)
+        ctx.save_for_backward(*[d for d in deps if isinstance(d, torch.Tensor)], *([out] if ctx.with_out else []))
         return out.view_as(out)
 
     @staticmethod
     def backward(ctx, grad):
-        saved = iter(ctx.saved_tensors)
+        tensors = ctx.saved_tensors
+        extra = {"fwd_out": tensors[-1]} if ctx.with_out else {}
+        saved = iter(tensors)
         needs = ctx.needs_input_grad[2:]
         ins, wanted = [], []
         for flag, need in zip(ctx.is_tensor, needs):
@@ -87,7 +90,7 @@ class _TorchBackward(torch.autograd.Function):
             ins.append(t)
         ev = _timed("backward:" + getattr(ctx.ref, "__qualname__", "ref").split(".")[0] + f"{tuple(grad.shape[1:])}")
         with torch.enable_grad():
-            ref_out = ctx.ref(*ins)
+            ref_out = ctx.ref(*ins, **extra)
             grads = torch.autograd.grad(ref_out, wanted, grad, allow_unused=True)
         if ev is not None:
             ev.record()
@@ -765,6 +768,240 @@ def foreground_masks(swapped: torch.Tensor, hole_mask: Optional[torch.Tensor] = 
         return content, border, full
     lib().call("e4s_foreground_masks", _p(content), _p(border), _p(full), _p(m), _p(hm), bs, h, w, int(radius), _stream())
     return content, border, full
+
+
+# ------------------------------------------------------------------------------------ f1: native gradients of the masked conv
+NATIVE_BWD = os.environ.get("E4S_NATIVE_BWD", "1") != "0"
+_FOLD_CHUNK_PX = 4096
+_SCALE_CHUNK_PX = 8192
+
+
+def _mconv_unfold(x, s, lab, ks: int, up: int = 1):
+    bs, cin, h, w = x.shape
+    cols = torch.empty((up * up, bs, cin * ks * ks, h * w), dtype=torch.float32, device=x.device)
+    lib().call("e4s_mconv_unfold", _p(cols), _p(x), _p(s), _p(lab), bs, cin, h, w, ks, s.shape[1], up, _stream())
+    return cols
+
+
+def _mconv_scale(gy, out, d, lab, nreg: int, up: int = 1, want_q: bool = False, noise=None, noise_weight=None, act_bias=None, act: bool = False,
+                 want_sums: bool = False):
+    """-> gz [up*up, bs, cout, h*w], q [bs, nreg, cout] | None, dbias [bs, cout] | None, dnw [bs, cout] | None  (csrc/modconv_bwd.hip)"""
+    bs, cout, ho, wo = gy.shape
+    h, w = ho // up, wo // up
+    nchunk = -(-(ho * wo) // _SCALE_CHUNK_PX)
+    gz = torch.empty((up * up, bs, cout, h * w), dtype=torch.float32, device=gy.device)
+    q = torch.empty((nchunk, bs, nreg, cout), dtype=torch.float32, device=gy.device) if want_q else None
+    dbias = torch.empty((nchunk, bs, cout), dtype=torch.float32, device=gy.device) if want_sums else None
+    dnw = torch.empty((nchunk, bs, cout), dtype=torch.float32, device=gy.device) if want_sums and noise is not None else None
+    lib().call("e4s_mconv_scale", _p(gz), _p(q), _p(dbias), _p(dnw), _p(gy), _p(out), _p(d), _p(lab), _p(noise), 0 if noise is None else noise.shape[0],
+               _p(noise_weight), _p(act_bias), int(act), bs, cout, h, w, nreg, up, _SCALE_CHUNK_PX, _stream())
+    return (gz,) + tuple(None if t is None else (t.sum(0) if nchunk > 1 else t[0]) for t in (q, dbias, dnw))
+
+
+def _gemm_nt(a, b):
+    """``a [..., M, K] @ b [..., N, K]ᵀ``.  A long reduction (K = all the pixels of a layer) with a small M x N goes to the library as a
+    batch of K-chunks — a single GEMM would use a handful of workgroups (measured: 1.13 -> 0.36 ms for 32 x 1M x 288)."""
+    k = a.shape[-1]
+    kc = 8192
+    if k < 65536 or k % kc:
+        return torch.matmul(a, b.transpose(-1, -2))
+    a = a.reshape(*a.shape[:-1], k // kc, kc).transpose(-2, -3)                      # [..., nb, M, kc] (views)
+    b = b.reshape(*b.shape[:-1], k // kc, kc).transpose(-2, -3)
+    return torch.matmul(a, b.transpose(-1, -2)).sum(-3)
+
+
+def unfold2d(x, ks: int, stride: int, pad: int, ho: int, wo: int):
+    """``cols [bs, C*ks*ks, ho*wo] = x[bs, C, stride*q + k - pad]`` (``e4s_unfold2d``)."""
+    x = _c(x, "x")
+    bs, ch, hi, wi = x.shape
+    cols = torch.empty((bs, ch * ks * ks, ho * wo), dtype=torch.float32, device=x.device)
+    lib().call("e4s_unfold2d", _p(cols), _p(x), bs, ch, hi, wi, ho, wo, ks, stride, pad, _stream())
+    return cols
+
+
+def _mconv_input_grads(gz, wg, x, s, lab, up: int, need_x: bool, need_s: bool, need_w: bool):
+    """The part of the backward that follows ``gz``: U_g = W_gᵀ gz_g (library GEMM), dx / ds from one pass over U (``e4s_mconv_fold``), and
+    dW_g = gz_g cols_gᵀ (unfold kernel + library GEMM)."""
+    bs, cin, h, w = x.shape
+    G, cout, ks, nreg = wg.shape[0], wg.shape[1], wg.shape[-1], s.shape[1]
+    dx = ds = dw = None
+    if need_x or need_s:
+        u = torch.matmul(wg.reshape(G, 1, cout, cin * ks * ks).transpose(2, 3), gz)                  # [G, bs, cin*KK, P]
+        dx = torch.empty_like(x) if need_x else None
+        nchunk = -(-(h * w) // _FOLD_CHUNK_PX)
+        part = torch.empty((nchunk, bs, nreg, cin), dtype=torch.float32, device=x.device) if need_s else None
+        lib().call("e4s_mconv_fold", _p(dx), _p(part), _p(u), _p(x), _p(s), _p(lab), bs, cin, h, w, ks, nreg, up, _FOLD_CHUNK_PX, _stream())
+        del u
+        if need_s:
+            ds = part.sum(0) if nchunk > 1 else part[0]
+    if need_w:
+        cols = _mconv_unfold(x, s, lab, ks, up)
+        dw = _gemm_nt(gz, cols).sum(1).view_as(wg)
+    return dx, ds, dw
+
+
+def _check_mconv(x, wg, s, d, lab, up):
+    bs, cin, h, w = x.shape
+    G, cout, ks = wg.shape[0], wg.shape[1], wg.shape[-1]
+    if wg.shape != (up * up, cout, cin, ks, ks) or s.dim() != 3 or s.shape[0] != bs or s.shape[2] != cin or lab.shape != (bs, up * h, up * w):
+        raise ValueError(f"masked conv: x {tuple(x.shape)}, w {tuple(wg.shape)}, s {tuple(s.shape)}, labels {tuple(lab.shape)}, up {up} do not fit")
+    if d is not None and d.shape != (bs, s.shape[1], cout):
+        raise ValueError(f"masked conv: d {tuple(d.shape)} is not [bs, nreg, cout]")
+
+
+class _MaskedConvCore(torch.autograd.Function):
+    """``y[b,o,p] = d[b,c(p),o] · Σ_{i,k} W[o,i,k] · s[b,c(p),i] · x[b,i,p+k-pad]`` evaluated AND differentiated with the kernels of
+    ``csrc/modconv_bwd.hip`` and fp32 library GEMMs — the differentiable core ``torch_ref._region_sum`` uses on the
+    device when a backward pass has to re-evaluate a masked layer (ToRGB).  The inference forward is the fused MFMA kernel, not this.
+
+    ``x [bs,cin,h,w]``, ``w [cout,cin,ks,ks]`` (already scaled), ``s [bs,nreg,cin]``, ``d [bs,nreg,cout]`` or None, ``lab`` uint8 ``[bs,h,w]``."""
+
+    @staticmethod
+    def forward(ctx, x, w, s, d, lab):
+        x, wg, s = _c(x, "x"), _c(w, "w")[None], _c(s, "s")
+        d = _c(d, "d") if d is not None else None
+        lab = _labels_u8(lab, "labels")
+        _check_mconv(x, wg, s, d, lab, 1)
+        bs, cin, h, wd = x.shape
+        cout = wg.shape[1]
+        z = torch.matmul(wg.reshape(1, 1, cout, -1), _mconv_unfold(x, s, lab, wg.shape[-1])).view(bs, cout, h, wd)
+        y = _mconv_scale(z, None, d, lab, s.shape[1])[0].view(bs, cout, h, wd)        # y = z * d[c(p)], zero where the label is no region
+        ctx.save_for_backward(x, wg, s, d, lab, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, wg, s, d, lab, y = ctx.saved_tensors
+        need_x, need_w, need_s, need_d = ctx.needs_input_grad[:4]
+        gz, q, _, _ = _mconv_scale(gy.contiguous(), y, d, lab, s.shape[1], want_q=d is not None and need_d)
+        dx, ds, dw = _mconv_input_grads(gz, wg, x, s, lab, 1, need_x, need_s, need_w)
+        return dx, None if dw is None else dw[0], ds, None if q is None else q / d, None
+
+
+def masked_conv_core(x, w, s, d, lab):
+    return _MaskedConvCore.apply(x, w, s, d, lab)
+
+
+class _MaskedStyledConvGrad(torch.autograd.Function):
+    """A masked ``StyledConv`` whose forward value is already known (``out``, from the fused MFMA kernel) and whose gradients come from
+    ``csrc/modconv_bwd.hip`` + fp32 library GEMMs — no re-evaluation of the layer:
+
+        out = leaky_relu(d[c(p)] · Σ W_g · s[c(p)] · x  +  noise_weight · noise  +  act_bias) · √2
+
+    ``wg [G,cout,cin,ks,ks]``: G = 1 (plain layer) or 4 (up-sampling layer: the composed weight of each output parity, labels at the output
+    resolution).  Differentiable inputs: x, wg, s, d, noise_weight, act_bias."""
+
+    @staticmethod
+    def forward(ctx, x, wg, s, d, noise_weight, act_bias, lab, noise, act, out):
+        x, wg, s = _c(x, "x"), _c(wg, "w"), _c(s, "s")
+        d = _c(d, "d") if d is not None else None
+        lab = _labels_u8(lab, "labels")
+        up = {1: 1, 4: 2}[wg.shape[0]]
+        _check_mconv(x, wg, s, d, lab, up)
+        out = _c(out, "out")
+        if out.shape != (x.shape[0], wg.shape[1], up * x.shape[2], up * x.shape[3]):
+            raise ValueError(f"masked conv: forward output {tuple(out.shape)} does not fit")
+        if noise is not None:
+            noise = _c(noise, "noise").reshape(noise.shape[0], -1)
+            if noise_weight is None or noise.shape[1] != out.shape[2] * out.shape[3] or noise.shape[0] not in (1, x.shape[0]):
+                raise ValueError("masked conv: noise must be [1 or bs, 1, H, W] of the output and come with its weight")
+        ctx.save_for_backward(x, wg, s, d, noise_weight, act_bias, lab, noise, out)
+        ctx.act, ctx.up = bool(act), up
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, wg, s, d, nw, bias, lab, noise, out = ctx.saved_tensors
+        need_x, need_w, need_s, need_d, need_nw, need_b = ctx.needs_input_grad[:6]
+        gz, q, dbias, dnw = _mconv_scale(grad.contiguous(), out, d, lab, s.shape[1], ctx.up, want_q=d is not None and need_d, noise=noise,
+                                         noise_weight=None if nw is None else nw.reshape(-1), act_bias=None if bias is None else bias.reshape(-1),
+                                         act=ctx.act, want_sums=True)
+        dx, ds, dw = _mconv_input_grads(gz, wg, x, s, lab, ctx.up, need_x, need_s, need_w)
+        g_nw = dnw.sum().view_as(nw) if (need_nw and dnw is not None) else None
+        g_b = dbias.sum(0).view_as(bias) if (need_b and bias is not None) else None
+        return dx, dw, ds, None if q is None else q / d, g_nw, g_b, None, None, None, None
+
+
+def masked_styled_conv_grad(x, wg, s, d, noise_weight, act_bias, lab, noise, act, out):
+    return _MaskedStyledConvGrad.apply(x, wg, s, d, noise_weight, act_bias, lab, noise, act, out)
+
+
+class _SingleStyledConvGrad(torch.autograd.Function):
+    """A single-region ``StyledConv`` (the layers past ``remaining_layer_idx``) whose forward value ``out`` is already known: gradients
+    without re-evaluating the layer.  ``wmod [bs,cout,cin,k,k]`` is the modulated (and demodulated) weight, built under autograd by the
+    caller from the tiny style tensors, so this only has to return dL/dx and dL/dwmod:
+
+        out = leaky_relu(conv(x, wmod)  [or blur(conv_transpose(x, wmod, stride 2)) for the up-sampling layers]  + nw·noise + bias) · √2
+
+    g' = dL/dout · act'(out), Σ g', Σ g'·noise come from ``e4s_mconv_scale``; the blur's transpose is the same FIR kernel
+    (``e4s_upfirdn2d``); the data / weight gradients of the convolution itself are MIOpen's (``aten.convolution_backward``)."""
+
+    @staticmethod
+    def forward(ctx, x, wmod, noise_weight, act_bias, noise, act, blur, out):
+        bs, cin, h, w = x.shape
+        up = 1 if blur is None else 2
+        if wmod.dim() != 5 or wmod.shape[0] != bs or wmod.shape[2] != cin or out.shape != (bs, wmod.shape[1], up * h, up * w):
+            raise ValueError(f"single-region conv: x {tuple(x.shape)}, wmod {tuple(wmod.shape)}, out {tuple(out.shape)} do not fit")
+        if noise is not None:
+            noise = _c(noise, "noise").reshape(noise.shape[0], -1)
+        ctx.save_for_backward(_c(x, "x"), wmod, noise_weight, act_bias, noise, blur, _c(out, "out"))
+        ctx.act = bool(act)
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, wmod, nw, bias, noise, blur, out = ctx.saved_tensors
+        need_x, need_w, need_nw, need_b = ctx.needs_input_grad[:4]
+        bs, cin, h, w = x.shape
+        cout, k = wmod.shape[1], wmod.shape[-1]
+        gz, _, dbias, dnw = _mconv_scale(grad.contiguous(), out, None, None, 1, 1, noise=noise, noise_weight=None if nw is None else nw.reshape(-1),
+                                         act_bias=None if bias is None else bias.reshape(-1), act=ctx.act, want_sums=True)
+        g = gz.view(bs, cout, out.shape[2], out.shape[3])
+        xin = x.view(1, bs * cin, h, w)
+        conv_bwd = torch.ops.aten.convolution_backward
+        dx = dw = None
+        if blur is not None:
+            # out = fir(conv_transpose(x), pad (1,1)): the FIR's transpose is the FIR with the flipped kernel and pad (2,2)
+            g = upfirdn2d_raw(g.view(bs * cout, 1, out.shape[2], out.shape[3]), torch.flip(blur, (0, 1)), (1, 1), (1, 1), (2, 2, 2, 2))
+            g = g.view(bs, cout, 2 * h + 1, 2 * w + 1)
+        if need_x:
+            # data gradient on the MFMA conv kernel (three-way bf16 split: fp32-class), one sample at a time (its weights are per sample):
+            # a 3x3 correlation of g with the transposed + flipped weight, or — for the transposed conv — a stride-2 correlation of g
+            wd = wmod.detach().transpose(1, 2)                                     # [bs, cin, cout, k, k]
+            if blur is None:
+                wd = wd.flip(3, 4)
+            if cout >= 16 and k in (1, 3):
+                dx = torch.cat([conv2d(g[b:b + 1], PreparedConv(exact="sb3").get(wd[b].contiguous()), 1 if blur is None else 2,
+                                       k // 2 if blur is None else 0) for b in range(bs)])
+        if need_w and k in (1, 3):
+            # weight gradient = one unfold + one library GEMM per sample group: dW[o,(i,k)] = Σ_p g'[o,p] · x[i,p+k-pad], or for the
+            # transposed conv dWt[i,(o,k)] = Σ_q x[i,q] · gT[o,2q+k]
+            if blur is None:
+                dw = _gemm_nt(g.reshape(bs, cout, h * w), unfold2d(x, k, 1, k // 2, h, w)).view(bs, cout, cin, k, k)
+            else:
+                dw = _gemm_nt(x.reshape(bs, cin, h * w), unfold2d(g, k, 2, 0, h, w)).view(bs, cin, cout, k, k).transpose(1, 2)
+        want_dx, want_dw = need_x and dx is None, need_w and dw is None
+        if want_dx or want_dw:                                  # shapes the kernels above do not cover: MIOpen
+            g1 = g.reshape(1, bs * cout, g.shape[2], g.shape[3])
+            if blur is None:
+                dxm, dwm, _ = conv_bwd(g1, xin, wmod.reshape(bs * cout, cin, k, k), None, [1, 1], [k // 2, k // 2], [1, 1], False, [0, 0], bs,
+                                       [bool(want_dx), bool(want_dw), False])
+                if dwm is not None:
+                    dwm = dwm.view(bs, cout, cin, k, k)
+            else:
+                dxm, dwm, _ = conv_bwd(g1, xin, wmod.transpose(1, 2).reshape(bs * cin, cout, k, k), None, [2, 2], [0, 0], [1, 1], True, [0, 0], bs,
+                                       [bool(want_dx), bool(want_dw), False])
+                if dwm is not None:
+                    dwm = dwm.view(bs, cin, cout, k, k).transpose(1, 2)
+            dx = dxm if want_dx else dx
+            dw = dwm if want_dw else dw
+        g_nw = dnw.sum().view_as(nw) if (need_nw and dnw is not None) else None
+        g_b = dbias.sum(0).view_as(bias) if (need_b and bias is not None) else None
+        return None if dx is None else dx.view_as(x), dw, g_nw, g_b, None, None, None, None
+
+
+def single_styled_conv_grad(x, wmod, noise_weight, act_bias, noise, act, blur, out):
+    return _SingleStyledConvGrad.apply(x, wmod, noise_weight, act_bias, noise, act, blur, out)
 
 
 # ------------------------------------------------------------------------------------ a7

@@ -66,6 +66,15 @@ def _modulated(x, s, weight, demodulate: bool, upsample: bool, blur: Optional[to
     return y.view(bs, cout, h, w)
 
 
+def _composed_up_weights(ws, blur, dtype):
+    """C2[o,i,m,n] = Σ_{ky,kx} blur[m-ky][n-kx] · Ws[o,i,ky,kx]: the full 2-D convolution of the 3x3 weight with the 4x4 blur (6x6)."""
+    shift = blur.new_zeros(6, 6, 3, 3)
+    for ky in range(3):
+        for kx in range(3):
+            shift[ky:ky + 4, kx:kx + 4, ky, kx] = blur
+    return torch.einsum("mnkl,oikl->oimn", shift.to(dtype), ws)
+
+
 def _region_sum(x, styles, labels, weight, mod_w, mod_b, mod_scale, mod_lr, demodulate, upsample, blur):
     """Σ_c modconv(x, style_c) ⊙ [label == c]  (StyledConv.forward :389-398 / ToRGB.forward :447-454).  ``labels`` None = one region
     (plain modulated conv).  With a region map the sum is evaluated in its ONE-PASS form so that autograd sees one
@@ -76,15 +85,21 @@ def _region_sum(x, styles, labels, weight, mod_w, mod_b, mod_scale, mod_lr, demo
     bs, cin, h, w = x.shape
     cout, k = weight.shape[1], weight.shape[-1]
     nreg = styles.shape[1]
-    s = F.linear(styles, mod_w * mod_scale, mod_b * mod_lr)                       # [bs, nreg, cin]
-    ws = weight[0] * (1.0 / math.sqrt(cin * k * k))                               # [cout, cin, k, k]
-    d = None
-    if demodulate:                                                                # :280 on the modulated 3x3 weight
-        d = torch.rsqrt(torch.einsum("bri,oi->bro", s * s, (ws * ws).sum((2, 3))) + 1e-8)
+    s, ws, d = _tables(x, styles, weight, mod_w, mod_b, mod_scale, mod_lr, demodulate)
     ho, wo = (2 * h, 2 * w) if upsample else (h, w)
-    lab = labels
-    if lab.shape[-2:] != (ho, wo):                                                # nearest resize of the region map (:391)
-        lab = F.interpolate(lab[:, None].float(), size=(ho, wo), mode="nearest")[:, 0]
+    lab = _labels_at(labels, ho, wo)
+    if x.is_cuda:
+        from . import ops
+        if ops.NATIVE_BWD:                                                        # §8 f1: HIP gradient kernels + two library GEMMs
+            lab8 = lab.to(torch.uint8)
+            if not upsample:
+                return ops.masked_conv_core(x, ws, s, d, lab8)
+            c2 = _composed_up_weights(ws, blur, x.dtype)
+            out = x.new_zeros(bs, cout, ho, wo)
+            for a in (0, 1):
+                for b in (0, 1):
+                    out[:, :, a::2, b::2] = ops.masked_conv_core(x, c2[:, :, a::2, b::2].flip(2, 3), s, d, lab8[:, a::2, b::2])
+            return out
     lab = lab.long()
     valid = (lab < nreg)
     lab = lab.clamp(max=nreg - 1)
@@ -102,11 +117,7 @@ def _region_sum(x, styles, labels, weight, mod_w, mod_b, mod_scale, mod_lr, demo
     # stride-2 transposed conv followed by the 4x4 blur = four 3x3 correlations over the input grid, one per output parity (a, b):
     # Weff[a,b][dy,dx] = C2[2-2dy+a][2-2dx+b] with C2 the full 2-D convolution of the 3x3 weight with the blur kernel (6x6).
     # (as one small GEMM: C2[o,i,m,n] = Σ_{ky,kx} blur[m-ky][n-kx] · Ws[o,i,ky,kx])
-    shift = blur.new_zeros(6, 6, 3, 3)
-    for ky in range(3):
-        for kx in range(3):
-            shift[ky:ky + 4, kx:kx + 4, ky, kx] = blur
-    c2 = torch.einsum("mnkl,oikl->oimn", shift.to(x.dtype), ws)
+    c2 = _composed_up_weights(ws, blur, x.dtype)
     out = x.new_zeros(bs, cout, ho, wo)
     for a in (0, 1):
         for b in (0, 1):
@@ -120,9 +131,52 @@ def _region_sum(x, styles, labels, weight, mod_w, mod_b, mod_scale, mod_lr, demo
     return out
 
 
+def _tables(x, styles, weight, mod_w, mod_b, mod_scale, mod_lr, demodulate):
+    """(s [bs,nreg,cin], scaled weight [cout,cin,k,k], d [bs,nreg,cout] | None) of the one-pass form, under autograd."""
+    cin, k = x.shape[1], weight.shape[-1]
+    s = F.linear(styles, mod_w * mod_scale, mod_b * mod_lr)
+    ws = weight[0] * (1.0 / math.sqrt(cin * k * k))
+    d = torch.rsqrt(torch.einsum("bri,oi->bro", s * s, (ws * ws).sum((2, 3))) + 1e-8) if demodulate else None      # :280
+    return s, ws, d
+
+
+def _labels_at(labels, ho, wo):
+    if labels.shape[-2:] != (ho, wo):                                                # nearest resize of the region map (:391)
+        labels = F.interpolate(labels[:, None].float(), size=(ho, wo), mode="nearest")[:, 0]
+    return labels
+
+
 def styled_conv(x, styles, weight, mod_w, mod_b, noise_weight, act_bias, *, labels, noise, act: bool, upsample: bool, blur, demodulate: bool,
-                mod_scale: float, mod_lr: float):
-    """``StyledConv.forward`` (model.py:382-423): region sum + noise injection (:335) + FusedLeakyReLU (:421)."""
+                mod_scale: float, mod_lr: float, fwd_out=None):
+    """``StyledConv.forward`` (model.py:382-423): region sum + noise injection (:335) + FusedLeakyReLU (:421).
+
+    With ``fwd_out`` (the value the fused forward kernel produced) a masked layer on the device is not re-evaluated at all: only the small
+    (s, d, weight) tables are rebuilt under autograd and the layer's gradients come from ``ops.masked_styled_conv_grad`` (§8 f1)."""
+    if fwd_out is not None and labels is not None and x.is_cuda:
+        from . import ops
+        if ops.NATIVE_BWD:
+            s, ws, d = _tables(x, styles, weight, mod_w, mod_b, mod_scale, mod_lr, demodulate)
+            up = 2 if upsample else 1
+            lab8 = _labels_at(labels, up * x.shape[2], up * x.shape[3]).to(torch.uint8)
+            if upsample:
+                c2 = _composed_up_weights(ws, blur, x.dtype)
+                wg = torch.stack([c2[:, :, a::2, b::2].flip(2, 3) for a in (0, 1) for b in (0, 1)])
+            else:
+                wg = ws[None]
+            use_noise = noise is not None and noise_weight is not None
+            return ops.masked_styled_conv_grad(x, wg, s, d, noise_weight if use_noise else None, act_bias, lab8, noise if use_noise else None, act,
+                                               fwd_out)
+    if fwd_out is not None and labels is None and x.is_cuda:
+        from . import ops
+        if ops.NATIVE_BWD:
+            bs, cin, k = x.shape[0], x.shape[1], weight.shape[-1]
+            s = F.linear(styles[:, 0], mod_w * mod_scale, mod_b * mod_lr)
+            wm = (weight * (1.0 / math.sqrt(cin * k * k))) * s.view(bs, 1, cin, 1, 1)                    # model.py:276-281
+            if demodulate:
+                wm = wm * torch.rsqrt(wm.pow(2).sum((2, 3, 4), keepdim=True) + 1e-8)
+            use_noise = noise is not None and noise_weight is not None
+            return ops.single_styled_conv_grad(x, wm, noise_weight if use_noise else None, act_bias, noise if use_noise else None, act,
+                                               blur if upsample else None, fwd_out)
     out = _region_sum(x, styles, labels, weight, mod_w, mod_b, mod_scale, mod_lr, demodulate, upsample, blur)
     if noise is not None and noise_weight is not None:
         out = out + noise_weight * noise

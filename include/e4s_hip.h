@@ -282,6 +282,36 @@ E4S_API int e4s_swap_head_mask(uint8_t* res, uint8_t* hole_mask, uint8_t* hole_m
 E4S_API int e4s_foreground_masks(float* content, float* border, float* full, const uint8_t* swapped, const uint8_t* hole_mask,
                                  int bs, int h, int w, int radius, void* stream);
 
+/* ---- f1: gradients of the one-pass region-modulated convolution (PTI tuning, training/video_swap_ft_coach.py:242-299) -----------
+ *     z[b,o,p] = sum_{i,k} W[o,i,k] * s[b,c(p),i] * x[b,i,p+k-pad],   y = d[b,c(p),o] * z        (model.py:389-398, 447-454)
+ *     out = leaky_relu(y + noise_weight*noise + act_bias, 0.2) * sqrt(2)                          (model.py:335, 421)
+ * The two GEMMs of the backward (U_g = W_g^T gz_g, dW_g = gz_g cols_g^T) are library fp32 GEMMs on the host side; these are the passes
+ * around them.  x [bs,cin,h,w], s [bs,nreg,cin], d [bs,nreg,cout] (NULL = no demodulation), ks 1 or 3 (pad ks/2, stride 1).
+ * up = 1: labels uint8 [bs,h,w], one group.  up = 2 (the up-sampling layers in their composed form): labels
+ * [bs,2h,2w] at the OUTPUT resolution, four groups g = 2a+b, one per output parity: output pixel (2qy+a, 2qx+b) is a 3x3 correlation
+ * of x around q with the composed weight W_g under c_g(q) = labels[2qy+a][2qx+b].  A label >= nreg is no region (zero, no gradient).
+ *   e4s_mconv_unfold : cols[G, bs, cin*ks*ks, h*w] = s[c_g(q),i] * x[i, q+k-pad]
+ *   e4s_mconv_scale  : from gy = dL/d(out) [bs,cout,up*h,up*w] and the forward output `out`:  g' = gy * act'(out);
+ *                      gz[G,bs,cout,h*w] = g' * d[c(p),o] (parity-planar);  per pixel chunk (nchunk = ceil(up*h*up*w / chunk_px), the
+ *                      caller adds the chunks up): q[nchunk,bs,nreg,cout] = per-region sums of g'*y (dL/dd = q / d),
+ *                      dbias[nchunk,bs,cout] = sum g',  dnw[nchunk,bs,cout] = sum g'*noise.  q, dbias, dnw, out, noise, act_bias optional;
+ *                      with act = 0 and no noise / bias, `out` is y itself.  noise [noise_bs, up*h*up*w], noise_bs 1 or bs.
+ *                      labels NULL = one region (every pixel is region 0): the single-region layers of the generator.
+ *   e4s_mconv_fold   : from U[G, bs, cin*ks*ks, h*w]:  dx[b,i,t] = sum_g sum_k s[c_g(t-k+pad),i] * U[g,b,(i,k),t-k+pad]  (may be NULL)
+ *                      ds_part[nchunk, bs, nreg, cin] = per pixel-chunk partial sums of sum_g sum_k U[g,b,(i,k),q] * x[i,q+k-pad] over
+ *                      each region's pixels (may be NULL), nchunk = ceil(h*w / chunk_px); dL/ds = ds_part.sum(0) */
+E4S_API int e4s_mconv_unfold(float* cols, const float* x, const float* s, const uint8_t* labels, int bs, int cin, int h, int w, int ks,
+                             int nreg, int up, void* stream);
+E4S_API int e4s_mconv_scale(float* gz, float* q, float* dbias, float* dnw, const float* gy, const float* out, const float* d,
+                            const uint8_t* labels, const float* noise, int noise_bs, const float* noise_weight, const float* act_bias,
+                            int act, int bs, int cout, int h, int w, int nreg, int up, int chunk_px, void* stream);
+/* cols[bs, C*ks*ks, ho*wo] = x[bs, C, stride*qy + ky - pad, stride*qx + kx - pad] (0 outside): the unfolded operand of a plain convolution's
+ * weight gradient as a library GEMM — the single-region layers past remaining_layer_idx (conv: dW = g' cols(x)^T, stride 1 pad 1;
+ * transposed conv, model.py:296-306: dW = x cols(gT)^T with stride 2 pad 0). */
+E4S_API int e4s_unfold2d(float* cols, const float* x, int bs, int C, int hi, int wi, int ho, int wo, int ks, int stride, int pad, void* stream);
+E4S_API int e4s_mconv_fold(float* dx, float* ds_part, const float* U, const float* x, const float* s, const uint8_t* labels, int bs, int cin,
+                           int h, int w, int ks, int nreg, int up, int chunk_px, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

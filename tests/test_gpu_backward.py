@@ -159,3 +159,78 @@ def test_style_vector_optimisation_reduces_the_loss():
     assert losses[-1] < 0.9 * losses[0], losses
     for k, v in net.state_dict().items():
         assert torch.equal(v, before[k]), k          # the network did not move
+
+
+@pytest.mark.parametrize("ks,upsample,demod,shape", [(3, False, True, (2, 20, 24, 80, 72)), (3, True, True, (2, 12, 20, 18, 22)),
+                                                     (1, False, False, (2, 24, 3, 33, 40)), (3, False, True, (1, 8, 8, 4, 4)),
+                                                     (3, True, True, (1, 8, 16, 4, 4))])
+@pytest.mark.parametrize("masked", [True, False])
+def test_native_masked_conv_gradients_against_stock_pytorch_and_fp64(ks, upsample, demod, shape, masked):
+    """csrc/modconv_bwd.hip (unfold / scale / fold kernels + fp32 GEMMs) against (a) the same layer written with stock PyTorch ops on the
+    GPU and (b) the reference's own form — Σ_c modconv(x, style_c) ⊙ mask_c, then noise, bias, leaky-relu (model.py:389-423) — in fp64 on
+    the CPU: gradients w.r.t. the input, the conv weight, the styles, the modulation weights, the noise weight and the activation bias.
+    ``masked=False`` is a single-region layer (no label map: ``_SingleStyledConvGrad``).  Two native routes: the re-evaluating core (``_MaskedConvCore``, what ToRGB uses) and the one that differentiates from the saved
+    forward value without re-evaluating the layer (``_MaskedStyledConvGrad``, what StyledConv uses).  Ragged sizes, more pixels than one
+    fold chunk, and pixels that belong to no region (label 255)."""
+    import torch.nn.functional as F
+    from e4s2024_amd import ops, torch_ref
+    bs, cin, cout, h, w = shape
+    nreg, sdim = (5 if masked else 1), 16
+    g = torch.Generator().manual_seed(100 + ks + 2 * upsample + h)
+    x = torch.randn(bs, cin, h, w, generator=g)
+    weight = torch.randn(1, cout, cin, ks, ks, generator=g)
+    styles = torch.randn(bs, nreg, sdim, generator=g)
+    mod_w, mod_b = torch.randn(cin, sdim, generator=g), torch.ones(cin)
+    nw, act_bias = torch.tensor([0.7]), torch.randn(cout, generator=g)
+    ho, wo = (2 * h, 2 * w) if upsample else (h, w)
+    noise = torch.randn(1, 1, ho, wo, generator=g)
+    lab = torch.from_numpy(seeded.blocky_labels(7 + h, bs, nreg, max(ho, wo), cells=4))[:, :ho, :wo].contiguous().to(torch.uint8)
+    lab[:, 0, :3] = 255                                   # no region
+    if not masked:
+        lab = None
+    gout = torch.randn(bs, cout, ho, wo, generator=g)
+    blur = torch.tensor([1., 3., 3., 1.])
+    blur = (blur[:, None] * blur[None, :]) / blur.sum() ** 2 * 4
+    mod_scale = 1.0 / np.sqrt(sdim)
+    names = ("dx", "dweight", "dstyles", "dmod_w", "dnoise_weight", "dact_bias")
+
+    def run(route, dev, dtype, fwd_out=None):
+        leaves = [t.to(dev, dtype).requires_grad_(True) for t in (x, weight, styles, mod_w, nw, act_bias)]
+        old = ops.NATIVE_BWD
+        ops.NATIVE_BWD = route != "stock"
+        try:
+            out = torch_ref.styled_conv(leaves[0], leaves[2], leaves[1], leaves[3], mod_b.to(dev, dtype), leaves[4], leaves[5], labels=None if lab is None else lab.to(dev),
+                                        noise=noise.to(dev, dtype), act=True, upsample=upsample, blur=blur.to(dev, dtype) if upsample else None,
+                                        demodulate=demod, mod_scale=mod_scale, mod_lr=1.0, fwd_out=fwd_out)
+            grads = torch.autograd.grad(out, leaves, gout.to(dev, dtype))
+        finally:
+            ops.NATIVE_BWD = old
+        return out.detach(), [t.cpu().double() for t in grads]
+
+    def reference_fp64():                                  # the reference's twelve-pass form with its own per-region ModulatedConv2d
+        leaves = [t.double().requires_grad_(True) for t in (x, weight, styles, mod_w, nw, act_bias)]
+        xx, ww, st, mw, nwl, bl = leaves
+        out = 0
+        for c in range(nreg):
+            s = F.linear(st[:, c], mw * mod_scale, mod_b.double())
+            y = torch_ref._modulated(xx, s, ww, demod, upsample, blur.double() if upsample else None)
+            out = out + (y * (lab == c)[:, None].double() if masked else y)
+        out = F.leaky_relu(out + nwl * noise.double() + bl.view(1, -1, 1, 1), 0.2) * np.sqrt(2.0)
+        return out.detach(), list(torch.autograd.grad(out, leaves, gout.double()))
+
+    out_stock, stock = run("stock", DEV, torch.float32)
+    out_core, core = run("core", DEV, torch.float32)
+    out_saved, saved = run("saved", DEV, torch.float32, fwd_out=out_stock)
+    out_ref, ref = reference_fp64()
+    assert torch.equal(out_saved, out_stock)                # the saved-forward route returns the value it was given
+    oscale = out_ref.abs().max().item()
+    assert (out_core.cpu().double() - out_ref).abs().max().item() / oscale <= 2e-5
+    if masked:      # no region: only noise + bias pass through the activation
+        passthrough = F.leaky_relu(act_bias.view(-1, 1) + 0.7 * noise[0, 0, 0, :3].view(1, -1), 0.2) * 2 ** 0.5
+        assert (out_core[:, :, 0, :3].cpu() - passthrough[None]).abs().max().item() <= 1e-6
+    for name, a, b, c, r in zip(names, core, saved, stock, ref):
+        scale = max(1e-6, r.abs().max().item())
+        assert (a - r).abs().max().item() / scale <= 3e-5, f"{name}: re-evaluating native core vs fp64 reference form"
+        assert (b - r).abs().max().item() / scale <= 3e-5, f"{name}: saved-forward native route vs fp64 reference form"
+        assert (c - r).abs().max().item() / scale <= 3e-5, f"{name}: stock PyTorch vs fp64 reference form"
+    assert core[0].abs().max().item() > 0 and saved[4].abs().max().item() > 0

@@ -1,0 +1,3 @@
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_backward.py -m gpu -q -x --tb=short 2>&1 | grep -v Warning | tail -12
+timeout 600 python tools/time_pti.py --steps 4 2>&1 | tail -30
