@@ -2,15 +2,22 @@
 
 Mirrors one inner iteration of ``VideoSwapPTICoach.train_e4s`` (training/video_swap_ft_coach.py:253-299) for the part that lives on the
 hot path: ``cal_style_codes`` -> ``gen_img`` -> pixel loss -> ``backward`` -> optimiser step, with the style vectors and region map of a
-frame as fixed inputs.  The forward runs on the fused HIP kernels; the backward currently goes through the stock-PyTorch forms of
-``torch_ref.py``.  The perceptual / identity / parsing losses of ``calc_loss`` (:176-223) are separate networks outside the path
-(LPIPS-alex, ArcFace, a UNet parser) and plug in through ``extra_loss``.
+frame as fixed inputs.  The forward runs on the fused HIP kernels; the backward of the synthesis layers differentiates from their
+outputs with the gradient kernels of ``csrc/modconv_bwd.hip`` + library GEMMs (``ops._MaskedStyledConvGrad`` /
+``ops._SingleStyledConvGrad``), only the small per-layer style tables go through autograd (``torch_ref.py``).  The perceptual /
+identity / parsing losses of ``calc_loss`` (:176-223) are separate networks outside the path (LPIPS-alex, ArcFace, a UNet parser) and
+plug in through ``extra_loss``.
+
+Several GPUs: one process per GPU, each on its own frame; the one exchange step is the gradient average before the
+optimiser step (``sync_gradients``: a few large flat all-reduces over RCCL, not one per tensor).  That is a batch-of-N Adam step, not
+the reference's N sequential batch-1 steps, so result parity with the reference is not claimed for the multi-GPU mode.
 """
 from __future__ import annotations
 
 from typing import Callable, Optional
 
 import torch
+import torch.distributed as dist
 import torch.nn.functional as F
 
 
@@ -27,6 +34,45 @@ def _loss(net, style_vectors, mask, target, foreground_mask, l2_lambda, extra_lo
     if extra_loss is not None:
         loss = loss + extra_loss(recon, target)
     return loss, recon
+
+
+def sync_gradients(params, group=None, bucket_bytes: int = 256 << 20) -> int:
+    """Average ``p.grad`` over the ranks of ``group`` in place: gradients are packed into flat buckets of about ``bucket_bytes``
+    (xGMI rings are per-link bound, so few large all-reduces: SURVEY §8e), one ``all_reduce`` each, launched back to back and waited
+    for together.  A parameter without a gradient on this rank contributes zeros (every rank must issue the same collectives).
+    Returns the number of all-reduces issued; a no-op (0) outside a process group or at world size 1."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0
+    world = dist.get_world_size(group)
+    if world == 1:
+        return 0
+    params = [p for p in params if p.requires_grad]
+    buckets, cur, cur_bytes = [], [], 0
+    for p in params:
+        nbytes = p.numel() * p.element_size()
+        if cur and (cur_bytes + nbytes > bucket_bytes or cur[0].dtype != p.dtype):
+            buckets.append(cur)
+            cur, cur_bytes = [], 0
+        cur.append(p)
+        cur_bytes += nbytes
+    if cur:
+        buckets.append(cur)
+    pending = []
+    for bucket in buckets:
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
+        pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True), flat, bucket))
+    for work, flat, bucket in pending:
+        work.wait()
+        flat.div_(world)
+        off = 0
+        for p in bucket:
+            n = p.numel()
+            if p.grad is None:
+                p.grad = flat[off:off + n].view_as(p).clone()
+            else:
+                p.grad.copy_(flat[off:off + n].view_as(p))
+            off += n
+    return len(buckets)
 
 
 class GraphedPTIStep:
@@ -78,13 +124,15 @@ class GraphedPTIStep:
 
 def pti_step(net, optimizer: torch.optim.Optimizer, style_vectors: torch.Tensor, mask: torch.Tensor, target: torch.Tensor,
              foreground_mask: Optional[torch.Tensor] = None, l2_lambda: float = 1.0,
-             extra_loss: Optional[Callable[[torch.Tensor, torch.Tensor], torch.Tensor]] = None):
+             extra_loss: Optional[Callable[[torch.Tensor, torch.Tensor], torch.Tensor]] = None, group=None):
     """One optimiser step.  ``style_vectors [bs, 12, 1280]``, ``mask`` one-hot ``[bs, 12, 512, 512]`` (or uint8 labels),
     ``target [bs, 3, 1024, 1024]`` in [-1, 1]; ``foreground_mask [bs, 1, 1024, 1024]`` restricts the loss as at :283-288.
+    Inside a ``torch.distributed`` process group every rank passes its own frame and the gradients are averaged before the update.
     Returns ``(loss value, reconstruction)``."""
     loss, recon = _loss(net, style_vectors, mask, target, foreground_mask, l2_lambda, extra_loss, True)   # the coach calls gen_img with fresh noise
     optimizer.zero_grad()
     loss.backward()
+    sync_gradients([p for g in optimizer.param_groups for p in g["params"]], group)
     optimizer.step()
     return loss.detach(), recon.detach()
 

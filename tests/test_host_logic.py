@@ -232,6 +232,51 @@ def test_run_clip_world2_gloo(tmp_path, n_frames, port):
     assert f"RANK0_OK {n_frames}" in outs[0]
 
 
+_SYNC_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[3])
+from e4s2024_amd import pti
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[4], RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.manual_seed(0)
+net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+unused = torch.nn.Parameter(torch.ones(4))                       # no gradient on any rank: stays zero, same collectives everywhere
+only0 = torch.nn.Parameter(torch.ones(2))                        # gradient on rank 0 only
+params = list(net.parameters()) + [unused, only0]
+xs, ys = torch.randn(world, 4, 6), torch.randn(world, 4, 3)
+opt = torch.optim.SGD(params, lr=0.1)
+loss = torch.nn.functional.mse_loss(net(xs[rank]), ys[rank]) + (only0.sum() * 3 if rank == 0 else 0)
+opt.zero_grad(); loss.backward()
+n = pti.sync_gradients(params, bucket_bytes=64)                  # tiny buckets: several all-reduces in flight
+assert n >= 3, n
+ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+ref.load_state_dict(net.state_dict())
+sum(torch.nn.functional.mse_loss(ref(xs[r]), ys[r]) for r in range(world)).div(world).backward()
+for a, b in zip(net.parameters(), ref.parameters()):
+    assert torch.allclose(a.grad, b.grad, atol=1e-6), (a.grad - b.grad).abs().max()
+assert unused.grad is not None and unused.grad.abs().max() == 0
+assert torch.allclose(only0.grad, torch.full((2,), 3.0 / world))
+assert pti.sync_gradients(params, bucket_bytes=1 << 30) == 1
+print("SYNC_OK", rank)
+dist.destroy_process_group()
+'''
+
+
+def test_pti_gradient_average_world2_gloo(tmp_path):
+    """SURVEY §8e-3: the one exchange step of multi-GPU PTI — bucketed flat all-reduce of the gradients — gives every rank the gradient of
+    the rank-averaged loss, also for parameters that got no gradient on some (or all) ranks."""
+    script = tmp_path / "sync_worker.py"
+    script.write_text(_SYNC_WORKER)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", ROOT, "29617"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "SYNC_OK 0" in outs[0] and "SYNC_OK 1" in outs[1]
+    from e4s2024_amd import pti
+    assert pti.sync_gradients([torch.nn.Parameter(torch.ones(2))]) == 0      # no process group: nothing to do
+
+
 def test_run_clip_single_process_equals_sharded_result():
     from e4s2024_amd.runner import FrameShardRunner
     r = FrameShardRunner()

@@ -6,11 +6,16 @@ import sqlite3
 import sys
 
 
-def main(path, skip_first=0):
+def main(path, last_ms=None):
+    """``last_ms``: only the dispatches that started in the last ``last_ms`` milliseconds of the trace (e.g. the steady-state replays of a
+    script whose warm-up ran MIOpen's solver search)."""
     con = sqlite3.connect(path)
     cur = con.cursor()
     rows = cur.execute("select name, start, end, grid_x, grid_y, grid_z, workgroup_x, vgpr_count, accum_vgpr_count, lds_size "
                        "from kernels order by start").fetchall()
+    if last_ms is not None and rows:
+        t0 = rows[-1][2] - float(last_ms) * 1e6
+        rows = [r for r in rows if r[1] >= t0]
     agg = {}
     for name, s, e, gx, gy, gz, wx, vg, ag, lds in rows:
         a = agg.setdefault(name, [0, 0, 10**18, 0, vg, ag, lds])
@@ -25,4 +30,4 @@ def main(path, skip_first=0):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], *(sys.argv[2:3]))
