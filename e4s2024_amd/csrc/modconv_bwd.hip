@@ -41,7 +41,7 @@ __global__ __launch_bounds__(NT) void mconv_unfold_kernel(float* __restrict__ co
         }
     const int lw = up * w;
     for (int g = 0; g < up * up; ++g) {
-        const int c = lab[((size_t)b * up * h + up * py + g / up) * lw + up * px + g % up];
+        const int c = lab ? lab[((size_t)b * up * h + up * py + g / up) * lw + up * px + g % up] : 0;
         const float sv = c < nreg ? s[((size_t)b * nreg + c) * cin + i] : 0.f;
         float* cp = cols + (((size_t)g * bs + b) * cin + i) * KK * P + p;
 #pragma unroll
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(NT) void mconv_fold_kernel(float* __restrict__ dx, 
     const int P = h * w, lw = up * w;
     if (threadIdx.x <= E4S_MAX_REGIONS) stab[threadIdx.x] = threadIdx.x < nreg ? s[((size_t)b * nreg + threadIdx.x) * cin + i] : 0.f;
     __syncthreads();
-    const uint8_t* lp = lab + (size_t)b * up * h * lw;
+    const uint8_t* lp = lab ? lab + (size_t)b * up * h * lw : nullptr;      // no label map: every pixel is region 0
     const float* xp = x + ((size_t)b * cin + i) * P;
     float acc[E4S_MAX_REGIONS];
 #pragma unroll
@@ -159,12 +159,12 @@ __global__ __launch_bounds__(NT) void mconv_fold_kernel(float* __restrict__ dx, 
                     // dx: this pixel as the INPUT of tap k, i.e. of output position (py - ky + pad, px - kx + pad)
                     const int oy = py - ky + PAD, ox = px - kx + PAD;
                     if (dx && oy >= 0 && oy < h && ox >= 0 && ox < w) {
-                        const int c = lp[(up * oy + ga) * lw + up * ox + gb];
+                        const int c = lp ? lp[(up * oy + ga) * lw + up * ox + gb] : 0;
                         gsum += stab[c < nreg ? c : E4S_MAX_REGIONS] * ug[(size_t)k * P + oy * w + ox];
                     }
                 }
             if (ds_part) {
-                const int c = lp[(up * py + ga) * lw + up * px + gb];
+                const int c = lp ? lp[(up * py + ga) * lw + up * px + gb] : 0;
 #pragma unroll
                 for (int r = 0; r < E4S_MAX_REGIONS; ++r) acc[r] += c == r ? t : 0.f;
             }
@@ -208,6 +208,85 @@ __global__ __launch_bounds__(NT) void unfold2d_kernel(float* __restrict__ cols, 
         }
 }
 
+// ---- gradient of a layer's style tables (model.py:276-281 in the one-pass form), three launches instead of ~25 small library ops:
+//     s = styles · (mod_w·ms)ᵀ + mod_b·lr        ws = c · weight        d = rsqrt(s² · wsq + 1e-8),   wsq[i,o] = Σ_k ws[o,i,k]²
+// given gs = dL/ds, gd = dL/dd, gws = dL/dws (each optional):
+//     t = -½ · gd · d³                      gs' = gs + 2 s ⊙ (t · wsqᵀ)             gwsq = tᵀ · s²
+//     g_weight = c · (gws + 2 ws ⊙ gwsq)    g_styles = ms · gs' · mod_w             g_mod_w = ms · gs'ᵀ · styles        g_mod_b = lr · Σ_B gs'
+// B = bs*nreg rows.  Tables are small (B <= 96 rows, <= 512 channels): one thread per output element, loops over the short dimension.
+__global__ __launch_bounds__(NT) void tables_bwd_s_kernel(float* __restrict__ gs_tot, float* __restrict__ t_out, const float* __restrict__ gs,
+                                                          const float* __restrict__ gd, const float* __restrict__ s, const float* __restrict__ d,
+                                                          const float* __restrict__ wsq, int cin, int cout) {
+    extern __shared__ float tl[];                  // t[b, :]
+    const int b = blockIdx.y;
+    for (int o = threadIdx.x; o < cout; o += NT) {
+        const float dv = d[(size_t)b * cout + o];
+        const float tv = -0.5f * gd[(size_t)b * cout + o] * dv * dv * dv;
+        tl[o] = tv;
+        if (blockIdx.x == 0) t_out[(size_t)b * cout + o] = tv;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= cin) return;
+    float acc = 0.f;
+    for (int o = 0; o < cout; ++o) acc += tl[o] * wsq[(size_t)i * cout + o];      // wsq is [cin, cout], as e4s_modconv_prep_weights writes it
+    const size_t e = (size_t)b * cin + i;
+    gs_tot[e] = (gs ? gs[e] : 0.f) + 2.f * s[e] * acc;
+}
+
+__global__ __launch_bounds__(NT) void tables_bwd_w_kernel(float* __restrict__ g_weight, const float* __restrict__ gws, const float* __restrict__ t,
+                                                          const float* __restrict__ s, const float* __restrict__ weight, float c, int B, int cin,
+                                                          int cout, int kk) {
+    const int e = blockIdx.x * NT + threadIdx.x;
+    if (e >= cout * cin) return;
+    const int o = e / cin, i = e - o * cin;
+    float gwsq = 0.f;
+    if (t)
+        for (int b = 0; b < B; ++b) {
+            const float sv = s[(size_t)b * cin + i];
+            gwsq += t[(size_t)b * cout + o] * sv * sv;
+        }
+    for (int k = 0; k < kk; ++k) {
+        const size_t a = (size_t)e * kk + k;
+        g_weight[a] = c * ((gws ? gws[a] : 0.f) + 2.f * c * weight[a] * gwsq);
+    }
+}
+
+__global__ __launch_bounds__(NT) void tables_bwd_mod_kernel(float* __restrict__ g_styles, float* __restrict__ g_mod_w, float* __restrict__ g_mod_b,
+                                                            const float* __restrict__ gs_tot, const float* __restrict__ styles,
+                                                            const float* __restrict__ mod_w, float ms, float lr, int B, int sd, int cin) {
+    // 64 outputs (j) per workgroup, the reduction split over its four waves (a serial 512-long loop per thread is latency-bound: 150 us)
+    __shared__ float part[4][64];
+    __shared__ float pb[4];
+    const int jj = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + jj;
+    const bool rows = (int)blockIdx.y < B;         // g_styles[b, j] = ms * Σ_i gs'[b,i] * mod_w[i,j]
+    const int b = blockIdx.y, i = blockIdx.y - B;  // else g_mod_w[i, j] = ms * Σ_b gs'[b,i] * styles[b,j];  g_mod_b[i] = lr * Σ_b gs'[b,i]
+    float acc = 0.f, accb = 0.f;
+    if (j < sd) {
+        if (rows) {
+            const int n = (cin + 3) / 4, i0 = sl * n, i1 = min(cin, i0 + n);
+#pragma unroll 8
+            for (int q = i0; q < i1; ++q) acc += gs_tot[(size_t)b * cin + q] * mod_w[(size_t)q * sd + j];
+        } else {
+            for (int q = sl; q < B; q += 4) {
+                const float g = gs_tot[(size_t)q * cin + i];
+                acc += g * styles[(size_t)q * sd + j];
+                accb += g;
+            }
+        }
+    }
+    part[sl][jj] = acc;
+    if (jj == 0) pb[sl] = accb;                    // the same for every lane of the wave (does not depend on j)
+    __syncthreads();
+    if (sl == 0 && j < sd) {
+        const float v = ms * (part[0][jj] + part[1][jj] + part[2][jj] + part[3][jj]);
+        if (rows) g_styles[(size_t)b * sd + j] = v;
+        else g_mod_w[(size_t)i * sd + j] = v;
+    }
+    if (!rows && blockIdx.x == 0 && threadIdx.x == 0) g_mod_b[i] = lr * (pb[0] + pb[1] + pb[2] + pb[3]);
+}
+
 int bad_shape(int bs, int c, int h, int w, int ks, int nreg, int up) {
     return !(bs >= 0 && bs <= 65535 && c >= 1 && c <= 65535 && h >= 1 && w >= 1 && (int64_t)h * w * up * up < ((int64_t)1 << 24) &&
              (ks == 1 || ks == 3) && nreg >= 1 && nreg <= E4S_MAX_REGIONS && (up == 1 || up == 2));
@@ -229,7 +308,7 @@ extern "C" int e4s_unfold2d(float* cols, const float* x, int bs, int C, int hi, 
 
 extern "C" int e4s_mconv_unfold(float* cols, const float* x, const float* s, const uint8_t* labels, int bs, int cin, int h, int w, int ks, int nreg,
                                 int up, void* stream) {
-    E4S_REQUIRE(cols && x && s && labels, "mconv_unfold: null tensor");
+    E4S_REQUIRE(cols && x && s, "mconv_unfold: null tensor");
     E4S_REQUIRE(!bad_shape(bs, cin, h, w, ks, nreg, up), "mconv_unfold: bad size (3x3 / 1x1, nreg 1..%d, up 1 / 2)", E4S_MAX_REGIONS);
     if (bs == 0) return 0;
     const dim3 grid(cdiv(h * w, NT), cin, bs);
@@ -255,7 +334,7 @@ extern "C" int e4s_mconv_scale(float* gz, float* q, float* dbias, float* dnw, co
 
 extern "C" int e4s_mconv_fold(float* dx, float* ds_part, const float* U, const float* x, const float* s, const uint8_t* labels, int bs, int cin, int h,
                               int w, int ks, int nreg, int up, int chunk_px, void* stream) {
-    E4S_REQUIRE((dx || ds_part) && U && s && labels, "mconv_fold: null tensor");
+    E4S_REQUIRE((dx || ds_part) && U && s, "mconv_fold: null tensor");
     E4S_REQUIRE(!ds_part || x, "mconv_fold: the style gradient needs x");
     E4S_REQUIRE(chunk_px >= NT && chunk_px % NT == 0, "mconv_fold: chunk_px must be a multiple of %d", NT);
     E4S_REQUIRE(!bad_shape(bs, cin, h, w, ks, nreg, up), "mconv_fold: bad size (3x3 / 1x1, nreg 1..%d, up 1 / 2)", E4S_MAX_REGIONS);
@@ -266,4 +345,29 @@ extern "C" int e4s_mconv_fold(float* dx, float* ds_part, const float* U, const f
     else
         hipLaunchKernelGGL(mconv_fold_kernel<1>, grid, dim3(NT), 0, (hipStream_t)stream, dx, ds_part, U, x, s, labels, cin, h, w, nreg, up, chunk_px);
     return check_launch("mconv_fold");
+}
+
+extern "C" int e4s_style_tables_bwd(float* g_styles, float* g_mod_w, float* g_mod_b, float* g_weight, float* scratch, const float* gs, const float* gd,
+                                    const float* gws, const float* styles, const float* mod_w, const float* s, const float* d, const float* weight,
+                                    const float* wsq, float weight_scale, float mod_scale, float mod_lr, int rows, int sdim, int cin, int cout, int kk,
+                                    void* stream) {
+    E4S_REQUIRE(scratch && styles && mod_w && s && weight, "style_tables_bwd: null tensor");
+    E4S_REQUIRE((gd == nullptr) || (d && wsq), "style_tables_bwd: the demodulation gradient needs d and wsq");
+    E4S_REQUIRE(rows >= 1 && sdim >= 1 && cin >= 1 && rows + cin <= 65535 && cout >= 1 && cout <= 8192 && kk >= 1,
+                "style_tables_bwd: bad size");
+    hipStream_t st = (hipStream_t)stream;
+    float* t = scratch;                            // [rows, cout]
+    float* gs_tot = scratch + (size_t)rows * cout; // [rows, cin]
+    const float* gsp = gs;
+    if (gd) {
+        hipLaunchKernelGGL(tables_bwd_s_kernel, dim3(cdiv(cin, NT), rows), dim3(NT), sizeof(float) * cout, st, gs_tot, t, gs, gd, s, d, wsq, cin, cout);
+        gsp = gs_tot;
+    }
+    if (g_weight && (gd || gws))
+        hipLaunchKernelGGL(tables_bwd_w_kernel, dim3(cdiv(cout * cin, NT)), dim3(NT), 0, st, g_weight, gws, gd ? t : nullptr, s, weight, weight_scale, rows,
+                           cin, cout, kk);
+    if (gsp && g_styles && g_mod_w && g_mod_b)
+        hipLaunchKernelGGL(tables_bwd_mod_kernel, dim3(cdiv(sdim, 64), rows + cin), dim3(NT), 0, st, g_styles, g_mod_w, g_mod_b, gsp, styles, mod_w,
+                           mod_scale, mod_lr, rows, sdim, cin);
+    return check_launch("style_tables_bwd");
 }

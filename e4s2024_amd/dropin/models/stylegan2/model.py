@@ -173,15 +173,16 @@ class ModulatedConv2d(nn.Module):
             return ops._attach("ModulatedConv2d", out, input, styles, self.weight, self.modulation.weight, self.modulation.bias, noise_weight,
                                act_bias, ref=self._torch_ref(labels, noise, act))
         wt, s, d = self.tables(styles, masked=labels is not None)
+        saved = (s, d, self._weights(labels is not None)[1]) if labels is not None else None
         out = ops.region_modconv3x3(input, wt, s, d, labels, noise, noise_weight, act_bias, act, self.out_channel, self.upsample, rgb=rgb,
                                     want_out=want_out)
         if rgb is not None:
             return tuple(None if o is None else ops._attach("ModulatedConv2d", o, input, styles, self.weight, self.modulation.weight,
                                                             self.modulation.bias, noise_weight, act_bias) for o in out)
         return ops._attach("ModulatedConv2d", out, input, styles, self.weight, self.modulation.weight, self.modulation.bias, noise_weight,
-                           act_bias, ref=self._torch_ref(labels, noise, act))
+                           act_bias, ref=self._torch_ref(labels, noise, act, saved))
 
-    def _torch_ref(self, labels, noise, act):
+    def _torch_ref(self, labels, noise, act, tables=None):
         """The differentiable PyTorch form of ``forward_regions`` for the backward pass (torch_ref.styled_conv)."""
         blur = self.blur.kernel if self.upsample else None
         mod = self.modulation
@@ -189,7 +190,7 @@ class ModulatedConv2d(nn.Module):
         def ref(x, styles, weight, mod_w, mod_b, noise_weight, act_bias, fwd_out=None):
             return torch_ref.styled_conv(x, styles, weight, mod_w, mod_b, noise_weight, act_bias, labels=labels, noise=noise, act=act,
                                          upsample=self.upsample, blur=blur, demodulate=self.demodulate, mod_scale=mod.scale, mod_lr=mod.lr_mul,
-                                         fwd_out=fwd_out)
+                                         fwd_out=fwd_out, tables=tables)
         ref.takes_fwd_out = True      # the backward differentiates from the kernel's own output: the layer is not re-evaluated
         return ref
 
@@ -298,9 +299,10 @@ class ToRGB(nn.Module):
         if skip is not None and (tuple(up_kernel.shape) != (4, 4) or self.upsample.factor != 2):
             raise NotImplementedError("ToRGB backward is written for the 4x4, factor-2 skip upsample")
 
-        def ref(x, st, sk, w, mw, mb, bias):
+        def ref(x, st, sk, w, mw, mb, bias, fwd_out=None):
             return torch_ref.to_rgb(x, st if self.mask_op else st[:, None, :], sk, w, mw, mb, bias, labels=labels, up_kernel=up_kernel,
-                                    mod_scale=mod.scale, mod_lr=mod.lr_mul)
+                                    mod_scale=mod.scale, mod_lr=mod.lr_mul, fwd_out=fwd_out, tables=(s, None, None))
+        ref.takes_fwd_out = True
         return ops._attach("ToRGB", out, input, style, skip, self.conv.weight, self.conv.modulation.weight, self.conv.modulation.bias, self.bias,
                            ref=ref)
 

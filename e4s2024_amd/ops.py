@@ -926,6 +926,89 @@ def masked_styled_conv_grad(x, wg, s, d, noise_weight, act_bias, lab, noise, act
     return _MaskedStyledConvGrad.apply(x, wg, s, d, noise_weight, act_bias, lab, noise, act, out)
 
 
+class _StyleTablesSaved(torch.autograd.Function):
+    """A layer's style tables ``(s, ws, d)`` when ``s`` and ``d`` are already known (the forward kernels computed them for the fused layer):
+    only ``ws = weight / sqrt(cin k²)`` is evaluated, and the gradient w.r.t. styles, conv weight, modulation weight and bias is three
+    launches of ``e4s_style_tables_bwd`` instead of ~25 small library ops per layer (a PTI step does this for 26 layers)."""
+
+    @staticmethod
+    def forward(ctx, styles, weight, mod_w, mod_b, s, d, wsq, mod_scale, mod_lr):
+        cout, cin, k = weight.shape[1], weight.shape[2], weight.shape[-1]
+        c = 1.0 / math.sqrt(cin * k * k)
+        styles_c, s = _c(styles, "styles"), _c(s, "s")
+        if s.shape != (styles.shape[0], styles.shape[1], cin) or (d is not None and (wsq is None or d.shape != s.shape[:2] + (cout,))):
+            raise ValueError(f"style tables: s {tuple(s.shape)} / d do not fit styles {tuple(styles.shape)} and weight {tuple(weight.shape)}")
+        ctx.save_for_backward(styles_c, _c(weight, "weight"), _c(mod_w, "modulation.weight"), s, d, wsq)
+        ctx.consts = (c, float(mod_scale), float(mod_lr))
+        ws = weight[0] * c
+        if d is None:
+            empty = s.new_empty(0)
+            ctx.mark_non_differentiable(empty)
+            return s.view_as(s), ws, empty
+        return s.view_as(s), ws, d.view_as(d)
+
+    @staticmethod
+    def backward(ctx, gs, gws, gd):
+        styles, weight, mod_w, s, d, wsq = ctx.saved_tensors
+        c, ms, lr = ctx.consts
+        cout, cin, k = weight.shape[1], weight.shape[2], weight.shape[-1]
+        rows, sdim = styles.shape[0] * styles.shape[1], styles.shape[2]
+        if d is None:
+            gd = None
+        have_s = gs is not None or gd is not None
+        g_styles = torch.empty_like(styles) if have_s else None
+        g_mod_w = torch.empty_like(mod_w) if have_s else None
+        g_mod_b = torch.empty((cin,), dtype=torch.float32, device=styles.device) if have_s else None
+        g_weight = torch.empty_like(weight) if (gws is not None or gd is not None) else None
+        scratch = torch.empty((rows * (cout + cin),), dtype=torch.float32, device=styles.device)
+        lib().call("e4s_style_tables_bwd", _p(g_styles), _p(g_mod_w), _p(g_mod_b), _p(g_weight), _p(scratch),
+                   _p(None if gs is None else gs.contiguous()), _p(None if gd is None else gd.contiguous()),
+                   _p(None if gws is None else gws.contiguous()), _p(styles), _p(mod_w), _p(s), _p(d), _p(weight), _p(wsq), c, ms, lr, rows, sdim,
+                   cin, cout, k * k, _stream())
+        return g_styles, g_weight, g_mod_w, g_mod_b, None, None, None, None, None
+
+
+def style_tables_saved(styles, weight, mod_w, mod_b, s, d, wsq, mod_scale, mod_lr):
+    s_out, ws, d_out = _StyleTablesSaved.apply(styles, weight, mod_w, mod_b, s, d, wsq, mod_scale, mod_lr)
+    return s_out, ws, (d_out if d is not None else None)
+
+
+class _ToRGBGrad(torch.autograd.Function):
+    """``ToRGB.forward`` (model.py:439-479) with a known forward value: ``out = Σ_c [c(p)=c] · W · (s_c ⊙ x) + bias + upsample(skip)``
+    (1x1, no demodulation; ``lab`` None = one region).  Gradients of x, the scaled weight ``w [3,cin,1,1]``, ``s [bs,nreg,cin]``, the
+    bias and the skip image from the kernels of ``csrc/modconv_bwd.hip`` and the FIR kernel — the layer is not re-evaluated."""
+
+    @staticmethod
+    def forward(ctx, x, w, s, bias, skip, lab, up_kernel, out):
+        x, wg, s = _c(x, "x"), _c(w, "w")[None], _c(s, "s")
+        if lab is not None:
+            lab = _labels_u8(lab, "labels")
+            _check_mconv(x, wg, s, None, lab, 1)
+        elif s.shape[1] != 1 or wg.shape[2] != x.shape[1] or s.shape[2] != x.shape[1]:
+            raise ValueError("ToRGB without a label map takes one style per sample")
+        ctx.save_for_backward(x, wg, s, lab, up_kernel)
+        ctx.bias_shape = None if bias is None else tuple(bias.shape)
+        ctx.skip_shape = None if skip is None else tuple(skip.shape)
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, wg, s, lab, up_kernel = ctx.saved_tensors
+        need_x, need_w, need_s, need_b, need_skip = ctx.needs_input_grad[:5]
+        g = grad.contiguous()
+        gz, _, dbias, _ = _mconv_scale(g, None, None, lab, s.shape[1], 1, want_sums=True)
+        dx, ds, dw = _mconv_input_grads(gz, wg, x, s, lab, 1, need_x, need_s, need_w)
+        g_b = dbias.sum(0).view(ctx.bias_shape) if (need_b and ctx.bias_shape is not None) else None
+        g_skip = None
+        if need_skip and ctx.skip_shape is not None:      # transpose of upfirdn2d(skip, k, up=2, pad=(2,1)) (op/upfirdn2d.py:100-105)
+            g_skip = upfirdn2d_raw(g, torch.flip(up_kernel, (0, 1)), (1, 1), (2, 2), (1, 1, 1, 1)).view(ctx.skip_shape)
+        return dx, None if dw is None else dw[0], ds, g_b, g_skip, None, None, None
+
+
+def torgb_grad(x, w, s, bias, skip, lab, up_kernel, out):
+    return _ToRGBGrad.apply(x, w, s, bias, skip, lab, up_kernel, out)
+
+
 class _SingleStyledConvGrad(torch.autograd.Function):
     """A single-region ``StyledConv`` (the layers past ``remaining_layer_idx``) whose forward value ``out`` is already known: gradients
     without re-evaluating the layer.  ``wmod [bs,cout,cin,k,k]`` is the modulated (and demodulated) weight, built under autograd by the

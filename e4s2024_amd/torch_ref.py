@@ -43,8 +43,17 @@ def equal_linear(x, weight, bias, scale: float, lr_mul: float, activation: bool)
 
 def local_mlps(x, w0: Sequence[torch.Tensor], b0, w2, b2, scale0: float, scale2: float, lr0: float, lr2: float, slope: float, addend=None):
     """The per-region ``LocalMLP`` stack of ``Net3.cal_style_codes`` (networks.py:23-49, 236-244): ``x [bs, n, dim]`` -> ``[bs, n, out]``."""
+    n = len(w0)
+    if n > 1 and all(w.shape == w0[0].shape for w in w0) and all(w.shape == w2[0].shape for w in w2):
+        # same-shaped groups: two batched GEMMs instead of 2n small ones (the backward of a PTI step is bound by launch count)
+        xg = x.transpose(0, 1)                                                               # [n, bs, dim]
+        h = F.leaky_relu(torch.baddbmm((torch.stack(tuple(b0)) * lr0)[:, None, :], xg, (torch.stack(tuple(w0)) * scale0).transpose(1, 2)), slope)
+        bias2 = torch.stack(tuple(b2)) * lr2
+        if addend is not None:
+            bias2 = bias2 + addend
+        return torch.baddbmm(bias2[:, None, :], h, (torch.stack(tuple(w2)) * scale2).transpose(1, 2)).transpose(0, 1)
     outs = []
-    for g in range(len(w0)):
+    for g in range(n):
         h = F.leaky_relu(F.linear(x[:, g], w0[g] * scale0, b0[g] * lr0), slope)
         o = F.linear(h, w2[g] * scale2, b2[g] * lr2)
         outs.append(o if addend is None else o + addend)
@@ -66,13 +75,37 @@ def _modulated(x, s, weight, demodulate: bool, upsample: bool, blur: Optional[to
     return y.view(bs, cout, h, w)
 
 
+_SHIFT_CACHE = {}
+
+
+def _blur_shift(blur, dtype):
+    """shift[m,n,ky,kx] = blur[m-ky][n-kx] (6x6x3x3) and its parity-gathered form T[g=2a+b,dy,dx,ky,kx] = shift[4-2dy+a, 4-2dx+b, ky, kx];
+    constants of the layer's blur kernel, built once per (buffer, dtype)."""
+    key = (blur.data_ptr(), blur._version, blur.device, dtype)
+    hit = _SHIFT_CACHE.get(key)
+    if hit is None:
+        shift = torch.zeros(6, 6, 3, 3, dtype=torch.float64)
+        b = blur.detach().double().cpu()
+        for ky in range(3):
+            for kx in range(3):
+                shift[ky:ky + 4, kx:kx + 4, ky, kx] = b
+        par = torch.stack([shift[a::2, b_::2].flip(0, 1) for a in (0, 1) for b_ in (0, 1)])            # [4, 3(dy), 3(dx), 3, 3]
+        hit = (shift.to(blur.device, dtype), par.to(blur.device, dtype))
+        if len(_SHIFT_CACHE) > 64:
+            _SHIFT_CACHE.clear()
+        _SHIFT_CACHE[key] = hit
+    return hit
+
+
 def _composed_up_weights(ws, blur, dtype):
     """C2[o,i,m,n] = Σ_{ky,kx} blur[m-ky][n-kx] · Ws[o,i,ky,kx]: the full 2-D convolution of the 3x3 weight with the 4x4 blur (6x6)."""
-    shift = blur.new_zeros(6, 6, 3, 3)
-    for ky in range(3):
-        for kx in range(3):
-            shift[ky:ky + 4, kx:kx + 4, ky, kx] = blur
-    return torch.einsum("mnkl,oikl->oimn", shift.to(dtype), ws)
+    return torch.einsum("mnkl,oikl->oimn", _blur_shift(blur, dtype)[0], ws)
+
+
+def _parity_weights(ws, blur, dtype):
+    """The composed 3x3 weight of each output parity g = 2a+b of an up-sampling layer, ``[4, cout, cin, 3, 3]``:
+    ``W_g[dy,dx] = C2[4-2dy+a][4-2dx+b]`` (= ``C2[:, :, a::2, b::2].flip(2, 3)``), as one contraction with a cached constant."""
+    return torch.einsum("gyxkl,oikl->goiyx", _blur_shift(blur, dtype)[1], ws)
 
 
 def _region_sum(x, styles, labels, weight, mod_w, mod_b, mod_scale, mod_lr, demodulate, upsample, blur):
@@ -91,14 +124,14 @@ def _region_sum(x, styles, labels, weight, mod_w, mod_b, mod_scale, mod_lr, demo
     if x.is_cuda:
         from . import ops
         if ops.NATIVE_BWD:                                                        # §8 f1: HIP gradient kernels + two library GEMMs
-            lab8 = lab.to(torch.uint8)
+            lab8 = _labels_at(labels, ho, wo, as_u8=True)
             if not upsample:
                 return ops.masked_conv_core(x, ws, s, d, lab8)
-            c2 = _composed_up_weights(ws, blur, x.dtype)
+            wg = _parity_weights(ws, blur, x.dtype)
             out = x.new_zeros(bs, cout, ho, wo)
             for a in (0, 1):
                 for b in (0, 1):
-                    out[:, :, a::2, b::2] = ops.masked_conv_core(x, c2[:, :, a::2, b::2].flip(2, 3), s, d, lab8[:, a::2, b::2])
+                    out[:, :, a::2, b::2] = ops.masked_conv_core(x, wg[2 * a + b], s, d, lab8[:, a::2, b::2])
             return out
     lab = lab.long()
     valid = (lab < nreg)
@@ -131,8 +164,8 @@ def _region_sum(x, styles, labels, weight, mod_w, mod_b, mod_scale, mod_lr, demo
     return out
 
 
-def _tables(x, styles, weight, mod_w, mod_b, mod_scale, mod_lr, demodulate):
-    """(s [bs,nreg,cin], scaled weight [cout,cin,k,k], d [bs,nreg,cout] | None) of the one-pass form, under autograd."""
+def _tables_autograd(x, styles, weight, mod_w, mod_b, mod_scale, mod_lr, demodulate):
+    """(s [bs,nreg,cin], scaled weight [cout,cin,k,k], d [bs,nreg,cout] | None) of the one-pass form, op by op under autograd."""
     cin, k = x.shape[1], weight.shape[-1]
     s = F.linear(styles, mod_w * mod_scale, mod_b * mod_lr)
     ws = weight[0] * (1.0 / math.sqrt(cin * k * k))
@@ -140,14 +173,92 @@ def _tables(x, styles, weight, mod_w, mod_b, mod_scale, mod_lr, demodulate):
     return s, ws, d
 
 
-def _labels_at(labels, ho, wo):
-    if labels.shape[-2:] != (ho, wo):                                                # nearest resize of the region map (:391)
-        labels = F.interpolate(labels[:, None].float(), size=(ho, wo), mode="nearest")[:, 0]
-    return labels
+class _StyleTables(torch.autograd.Function):
+    """``_tables_autograd`` with its gradient written out (half the launches of the op-by-op graph; a PTI step evaluates it for 26 layers):
+
+        s = styles · (mod_w·scale)ᵀ + mod_b·lr        ws = weight / sqrt(cin k²)        d = rsqrt(s² · wsqᵀ + 1e-8),  wsq = Σ_k ws²
+    """
+
+    @staticmethod
+    def forward(ctx, styles, weight, mod_w, mod_b, mod_scale, mod_lr, demodulate):
+        cin, k = weight.shape[2], weight.shape[-1]
+        c = 1.0 / math.sqrt(cin * k * k)
+        s = F.linear(styles, mod_w * mod_scale, mod_b * mod_lr)
+        ws = weight[0] * c
+        wsq = d = None
+        if demodulate:
+            wsq = (ws * ws).sum((2, 3))
+            d = torch.rsqrt(torch.matmul(s * s, wsq.t()) + 1e-8)
+        ctx.save_for_backward(styles, mod_w, s, ws, wsq, d)
+        ctx.consts = (c, mod_scale, mod_lr)
+        if d is None:
+            ctx.mark_non_differentiable(empty := s.new_empty(0))
+            return s, ws, empty
+        return s, ws, d
+
+    @staticmethod
+    def backward(ctx, gs, gws, gd):
+        styles, mod_w, s, ws, wsq, d = ctx.saved_tensors
+        c, scale, lr = ctx.consts
+        if d is not None and gd is not None:
+            t = gd * d * d * d * (-0.5)                                               # dL/d(s²·wsqᵀ)
+            back = (torch.matmul(t, wsq) * s) * 2.0
+            gs = back if gs is None else gs + back
+            gwsq = torch.matmul(t.reshape(-1, t.shape[-1]).t(), (s * s).reshape(-1, s.shape[-1]))      # [cout, cin]
+            back_w = ws * gwsq[:, :, None, None] * 2.0
+            gws = back_w if gws is None else gws + back_w
+        g_weight = None if gws is None else (gws * c)[None]
+        g_styles = g_mod_w = g_mod_b = None
+        if gs is not None:
+            g2 = gs.reshape(-1, gs.shape[-1])
+            g_styles = (torch.matmul(g2, mod_w) * scale).view_as(styles)
+            g_mod_w = torch.matmul(g2.t(), styles.reshape(-1, styles.shape[-1])) * scale
+            g_mod_b = g2.sum(0) * lr
+        return g_styles, g_weight, g_mod_w, g_mod_b, None, None, None
+
+
+def _tables(x, styles, weight, mod_w, mod_b, mod_scale, mod_lr, demodulate, saved=None):
+    """(s [bs,nreg,cin], scaled weight [cout,cin,k,k], d [bs,nreg,cout] | None) of the one-pass form.  ``saved = (s, d, wsq)``: the
+    tables the forward kernels already computed for this layer (device only) — then nothing is re-evaluated and the gradient is
+    ``e4s_style_tables_bwd``."""
+    if saved is not None and x.is_cuda:
+        from . import ops
+        if ops.NATIVE_BWD:
+            return ops.style_tables_saved(styles, weight, mod_w, mod_b, saved[0], saved[1] if demodulate else None, saved[2] if demodulate else None,
+                                          mod_scale, mod_lr)
+    s, ws, d = _StyleTables.apply(styles, weight, mod_w, mod_b, mod_scale, mod_lr, bool(demodulate))
+    return s, ws, (d if demodulate else None)
+
+
+def _labels_at(labels, ho, wo, as_u8: bool = False):
+    """Nearest resize of the region map (:391).  The resized maps are kept on the tensor object: every layer of a pass shares the same
+    ``labels`` tensor, and several layers share a resolution."""
+    if labels.shape[-2:] == (ho, wo) and not (as_u8 and labels.dtype != torch.uint8):
+        return labels
+    cache = getattr(labels, "_e4s_resized", None)
+    if cache is None:
+        cache = {}
+        try:
+            labels._e4s_resized = cache
+        except AttributeError:
+            pass
+    # an entry made while a hipGraph is being captured belongs to that graph (and one made before must not be baked into it)
+    key = (ho, wo, as_u8, labels._version, labels.is_cuda and torch.cuda.is_current_stream_capturing())
+    if len(cache) > 32:
+        cache.clear()
+    out = cache.get(key)
+    if out is None:
+        out = labels
+        if labels.shape[-2:] != (ho, wo):
+            out = F.interpolate(labels[:, None].float(), size=(ho, wo), mode="nearest")[:, 0]
+        if as_u8:
+            out = out.to(torch.uint8)
+        cache[key] = out
+    return out
 
 
 def styled_conv(x, styles, weight, mod_w, mod_b, noise_weight, act_bias, *, labels, noise, act: bool, upsample: bool, blur, demodulate: bool,
-                mod_scale: float, mod_lr: float, fwd_out=None):
+                mod_scale: float, mod_lr: float, fwd_out=None, tables=None):
     """``StyledConv.forward`` (model.py:382-423): region sum + noise injection (:335) + FusedLeakyReLU (:421).
 
     With ``fwd_out`` (the value the fused forward kernel produced) a masked layer on the device is not re-evaluated at all: only the small
@@ -155,14 +266,10 @@ def styled_conv(x, styles, weight, mod_w, mod_b, noise_weight, act_bias, *, labe
     if fwd_out is not None and labels is not None and x.is_cuda:
         from . import ops
         if ops.NATIVE_BWD:
-            s, ws, d = _tables(x, styles, weight, mod_w, mod_b, mod_scale, mod_lr, demodulate)
+            s, ws, d = _tables(x, styles, weight, mod_w, mod_b, mod_scale, mod_lr, demodulate, saved=tables)
             up = 2 if upsample else 1
-            lab8 = _labels_at(labels, up * x.shape[2], up * x.shape[3]).to(torch.uint8)
-            if upsample:
-                c2 = _composed_up_weights(ws, blur, x.dtype)
-                wg = torch.stack([c2[:, :, a::2, b::2].flip(2, 3) for a in (0, 1) for b in (0, 1)])
-            else:
-                wg = ws[None]
+            lab8 = _labels_at(labels, up * x.shape[2], up * x.shape[3], as_u8=True)
+            wg = _parity_weights(ws, blur, x.dtype) if upsample else ws[None]
             use_noise = noise is not None and noise_weight is not None
             return ops.masked_styled_conv_grad(x, wg, s, d, noise_weight if use_noise else None, act_bias, lab8, noise if use_noise else None, act,
                                                fwd_out)
@@ -187,8 +294,15 @@ def styled_conv(x, styles, weight, mod_w, mod_b, noise_weight, act_bias, *, labe
     return out
 
 
-def to_rgb(x, styles, skip, weight, mod_w, mod_b, bias, *, labels, up_kernel, mod_scale: float, mod_lr: float):
-    """``ToRGB.forward`` (model.py:439-479): 1x1 modulated conv without demodulation, + bias, + upsampled skip (Upsample :34-53)."""
+def to_rgb(x, styles, skip, weight, mod_w, mod_b, bias, *, labels, up_kernel, mod_scale: float, mod_lr: float, fwd_out=None, tables=None):
+    """``ToRGB.forward`` (model.py:439-479): 1x1 modulated conv without demodulation, + bias, + upsampled skip (Upsample :34-53).
+    With ``fwd_out`` (the fused kernel's value) on the device: gradients from ``ops.torgb_grad`` without re-evaluating the layer."""
+    if fwd_out is not None and x.is_cuda:
+        from . import ops
+        if ops.NATIVE_BWD and (skip is None or (tuple(up_kernel.shape) == (4, 4) and skip.shape[-1] * 2 == x.shape[-1])):
+            s, ws, _ = _tables(x, styles, weight, mod_w, mod_b, mod_scale, mod_lr, False, saved=tables)
+            lab8 = None if labels is None else _labels_at(labels, x.shape[2], x.shape[3], as_u8=True)
+            return ops.torgb_grad(x, ws, s, bias, skip, lab8, up_kernel, fwd_out)
     out = _region_sum(x, styles, labels, weight, mod_w, mod_b, mod_scale, mod_lr, False, False, None)
     out = out + bias
     if skip is not None:

@@ -296,10 +296,19 @@ E4S_API int e4s_foreground_masks(float* content, float* border, float* full, con
  *                      caller adds the chunks up): q[nchunk,bs,nreg,cout] = per-region sums of g'*y (dL/dd = q / d),
  *                      dbias[nchunk,bs,cout] = sum g',  dnw[nchunk,bs,cout] = sum g'*noise.  q, dbias, dnw, out, noise, act_bias optional;
  *                      with act = 0 and no noise / bias, `out` is y itself.  noise [noise_bs, up*h*up*w], noise_bs 1 or bs.
- *                      labels NULL = one region (every pixel is region 0): the single-region layers of the generator.
+ *   labels NULL (all three) = one region, every pixel is region 0: the single-region layers of the generator (nreg = 1).
  *   e4s_mconv_fold   : from U[G, bs, cin*ks*ks, h*w]:  dx[b,i,t] = sum_g sum_k s[c_g(t-k+pad),i] * U[g,b,(i,k),t-k+pad]  (may be NULL)
  *                      ds_part[nchunk, bs, nreg, cin] = per pixel-chunk partial sums of sum_g sum_k U[g,b,(i,k),q] * x[i,q+k-pad] over
  *                      each region's pixels (may be NULL), nchunk = ceil(h*w / chunk_px); dL/ds = ds_part.sum(0) */
+/* Gradient of a layer's style tables (EqualLinear modulation + demodulation, model.py:150-161, 276-281, in the one-pass form):
+ *     s = styles (mod_w*mod_scale)^T + mod_b*mod_lr,   ws = weight_scale*weight,   d = rsqrt(s^2 wsq + 1e-8),  wsq[i,o] = sum_k ws[o,i,k]^2 ([cin,cout], as e4s_modconv_prep_weights writes it)
+ * gs [rows,cin], gd [rows,cout], gws [cout,cin,kk] = dL/ds, dL/dd, dL/dws (each may be NULL; gd needs d and wsq), rows = bs*nreg.
+ * Outputs: g_styles [rows,sdim], g_mod_w [cin,sdim], g_mod_b [cin] (written when gs or gd is given), g_weight [cout,cin,kk] w.r.t. the
+ * unscaled weight (written when gws or gd is given).  scratch: rows*(cout+cin) floats. */
+E4S_API int e4s_style_tables_bwd(float* g_styles, float* g_mod_w, float* g_mod_b, float* g_weight, float* scratch, const float* gs,
+                                 const float* gd, const float* gws, const float* styles, const float* mod_w, const float* s, const float* d,
+                                 const float* weight, const float* wsq, float weight_scale, float mod_scale, float mod_lr, int rows, int sdim,
+                                 int cin, int cout, int kk, void* stream);
 E4S_API int e4s_mconv_unfold(float* cols, const float* x, const float* s, const uint8_t* labels, int bs, int cin, int h, int w, int ks,
                              int nreg, int up, void* stream);
 E4S_API int e4s_mconv_scale(float* gz, float* q, float* dbias, float* dnw, const float* gy, const float* out, const float* d,

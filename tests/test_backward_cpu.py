@@ -77,3 +77,42 @@ def test_local_mlps_and_equal_linear():
         assert (got[:, g] - O.equal_linear(h, w2[g], b2[g])).abs().max().item() <= 1e-5
     y = torch_ref.equal_linear(x[:, 0], w0[0], b0[0], 0.01 / np.sqrt(10), 0.01, True)
     assert (y - O.equal_linear(x[:, 0], w0[0], b0[0], lr_mul=0.01, activation=True)).abs().max().item() <= 1e-5
+
+
+def test_hand_written_table_gradient_parity_weights_and_batched_mlps_equal_the_op_by_op_forms():
+    """The launch-count optimisations of the PTI backward are algebra, not approximations: in fp64 they equal the plain forms —
+    ``_StyleTables`` vs autograd through ``_tables_autograd``; the one-contraction parity weights vs slicing + flipping the 6x6 composed
+    kernel; the two batched GEMMs of the per-region MLPs vs the per-region loop."""
+    import torch.nn.functional as F
+    from e4s2024_amd import torch_ref as R
+    torch.manual_seed(0)
+    f64 = dict(dtype=torch.float64)
+    for demod in (True, False):
+        x = torch.randn(2, 6, 4, 4, **f64)
+        leaves = [torch.randn(2, 3, 8, **f64).requires_grad_(True), torch.randn(1, 5, 6, 3, 3, **f64).requires_grad_(True),
+                  torch.randn(6, 8, **f64).requires_grad_(True), torch.randn(6, **f64).requires_grad_(True)]
+
+        def run(fn):
+            st, w, mw, mb = leaves
+            s, ws, d = fn(x, st, w, mw, mb, 0.3, 0.7, demod)
+            loss = (s * torch.arange(s.numel(), **f64).view_as(s)).sum() + (ws ** 2).sum() + ((d ** 3).sum() if d is not None else 0)
+            return [s, ws, d], torch.autograd.grad(loss, leaves)
+        (o1, g1), (o2, g2) = run(R._tables), run(R._tables_autograd)
+        assert all((a is None and b is None) or torch.allclose(a, b, rtol=1e-12) for a, b in zip(o1, o2))
+        assert all(torch.allclose(a, b, rtol=1e-10, atol=1e-12) for a, b in zip(g1, g2))
+    blur = torch.tensor([1., 3., 3., 1.], **f64)
+    blur = blur[:, None] * blur[None, :] / blur.sum() ** 2 * 4
+    ws = torch.randn(5, 6, 3, 3, **f64)
+    c2 = R._composed_up_weights(ws, blur, torch.float64)
+    wg = R._parity_weights(ws, blur, torch.float64)
+    for a in (0, 1):
+        for b in (0, 1):
+            assert torch.allclose(wg[2 * a + b], c2[:, :, a::2, b::2].flip(2, 3), rtol=1e-12)
+    n, bs, dim, hid, out = 4, 3, 7, 9, 5
+    w0, b0 = [torch.randn(hid, dim, **f64) for _ in range(n)], [torch.randn(hid, **f64) for _ in range(n)]
+    w2, b2 = [torch.randn(out, hid, **f64) for _ in range(n)], [torch.randn(out, **f64) for _ in range(n)]
+    xx, addend = torch.randn(bs, n, dim, **f64), torch.randn(out, **f64)
+    got = R.local_mlps(xx, w0, b0, w2, b2, 0.5, 0.25, 1.5, 0.75, 0.01, addend)
+    exp = torch.stack([F.linear(F.leaky_relu(F.linear(xx[:, g], w0[g] * 0.5, b0[g] * 1.5), 0.01), w2[g] * 0.25, b2[g] * 0.75) + addend
+                       for g in range(n)], dim=1)
+    assert got.shape == exp.shape and torch.allclose(got, exp, rtol=1e-12)

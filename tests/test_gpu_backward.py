@@ -194,14 +194,14 @@ def test_native_masked_conv_gradients_against_stock_pytorch_and_fp64(ks, upsampl
     mod_scale = 1.0 / np.sqrt(sdim)
     names = ("dx", "dweight", "dstyles", "dmod_w", "dnoise_weight", "dact_bias")
 
-    def run(route, dev, dtype, fwd_out=None):
+    def run(route, dev, dtype, fwd_out=None, tables=None):
         leaves = [t.to(dev, dtype).requires_grad_(True) for t in (x, weight, styles, mod_w, nw, act_bias)]
         old = ops.NATIVE_BWD
         ops.NATIVE_BWD = route != "stock"
         try:
             out = torch_ref.styled_conv(leaves[0], leaves[2], leaves[1], leaves[3], mod_b.to(dev, dtype), leaves[4], leaves[5], labels=None if lab is None else lab.to(dev),
                                         noise=noise.to(dev, dtype), act=True, upsample=upsample, blur=blur.to(dev, dtype) if upsample else None,
-                                        demodulate=demod, mod_scale=mod_scale, mod_lr=1.0, fwd_out=fwd_out)
+                                        demodulate=demod, mod_scale=mod_scale, mod_lr=1.0, fwd_out=fwd_out, tables=tables)
             grads = torch.autograd.grad(out, leaves, gout.to(dev, dtype))
         finally:
             ops.NATIVE_BWD = old
@@ -221,6 +221,10 @@ def test_native_masked_conv_gradients_against_stock_pytorch_and_fp64(ks, upsampl
     out_stock, stock = run("stock", DEV, torch.float32)
     out_core, core = run("core", DEV, torch.float32)
     out_saved, saved = run("saved", DEV, torch.float32, fwd_out=out_stock)
+    # the same route with the style tables the forward kernels compute (e4s_style_demod) handed over: gradient = e4s_style_tables_bwd
+    wsq = (weight[0] / np.sqrt(cin * ks * ks)).pow(2).sum((2, 3)).t().to(DEV).contiguous()          # [cin, cout], the layout of e4s_modconv_prep_weights
+    s_hip, d_hip = ops.style_demod(styles.to(DEV), mod_w.to(DEV), mod_b.to(DEV), wsq if demod else None, cout)
+    _, saved_tables = run("saved", DEV, torch.float32, fwd_out=out_stock, tables=(s_hip, d_hip, wsq))
     out_ref, ref = reference_fp64()
     assert torch.equal(out_saved, out_stock)                # the saved-forward route returns the value it was given
     oscale = out_ref.abs().max().item()
@@ -228,9 +232,72 @@ def test_native_masked_conv_gradients_against_stock_pytorch_and_fp64(ks, upsampl
     if masked:      # no region: only noise + bias pass through the activation
         passthrough = F.leaky_relu(act_bias.view(-1, 1) + 0.7 * noise[0, 0, 0, :3].view(1, -1), 0.2) * 2 ** 0.5
         assert (out_core[:, :, 0, :3].cpu() - passthrough[None]).abs().max().item() <= 1e-6
+    for name, a, r in zip(names, saved_tables, ref):
+        assert (a - r).abs().max().item() / max(1e-6, r.abs().max().item()) <= 3e-5, f"{name}: saved forward + saved tables vs fp64 reference form"
     for name, a, b, c, r in zip(names, core, saved, stock, ref):
         scale = max(1e-6, r.abs().max().item())
         assert (a - r).abs().max().item() / scale <= 3e-5, f"{name}: re-evaluating native core vs fp64 reference form"
         assert (b - r).abs().max().item() / scale <= 3e-5, f"{name}: saved-forward native route vs fp64 reference form"
         assert (c - r).abs().max().item() / scale <= 3e-5, f"{name}: stock PyTorch vs fp64 reference form"
     assert core[0].abs().max().item() > 0 and saved[4].abs().max().item() > 0
+
+
+@pytest.mark.parametrize("masked", [True, False])
+@pytest.mark.parametrize("with_skip", [True, False])
+def test_native_torgb_gradients_against_stock_pytorch_and_fp64(masked, with_skip):
+    """``ops._ToRGBGrad`` (gradients of ToRGB from the kernels of csrc/modconv_bwd.hip + the FIR kernel, no re-evaluation) against the
+    stock-PyTorch form on the GPU and the reference's per-region form in fp64 (model.py:439-479): x, conv weight, styles, modulation
+    weight, bias and the skip image."""
+    import torch.nn.functional as F
+    from e4s2024_amd import ops, torch_ref
+    bs, cin, h, w, sdim = 2, 24, 36, 28, 16
+    nreg = 5 if masked else 1
+    g = torch.Generator().manual_seed(300 + masked + 2 * with_skip)
+    x = torch.randn(bs, cin, h, w, generator=g)
+    weight = torch.randn(1, 3, cin, 1, 1, generator=g)
+    styles = torch.randn(bs, nreg, sdim, generator=g)
+    mod_w, mod_b = torch.randn(cin, sdim, generator=g), torch.ones(cin)
+    bias = torch.randn(1, 3, 1, 1, generator=g)
+    skip = torch.randn(bs, 3, h // 2, w // 2, generator=g) if with_skip else None
+    lab = torch.from_numpy(seeded.blocky_labels(9, bs, nreg, max(h, w), cells=4))[:, :h, :w].contiguous().to(torch.uint8) if masked else None
+    if masked:
+        lab[:, 1, 2:5] = 255
+    gout = torch.randn(bs, 3, h, w, generator=g)
+    k1 = torch.tensor([1., 3., 3., 1.])
+    up_kernel = (k1[:, None] * k1[None, :]) / k1.sum() ** 2 * 4
+    mod_scale = 1.0 / np.sqrt(sdim)
+
+    def run(route, dev, dtype, fwd_out=None):
+        leaves = [t.to(dev, dtype).requires_grad_(True) for t in (x, weight, styles, mod_w, bias) + ((skip,) if with_skip else ())]
+        old = ops.NATIVE_BWD
+        ops.NATIVE_BWD = route != "stock"
+        try:
+            out = torch_ref.to_rgb(leaves[0], leaves[2], leaves[5] if with_skip else None, leaves[1], leaves[3], mod_b.to(dev, dtype), leaves[4],
+                                   labels=None if lab is None else lab.to(dev), up_kernel=up_kernel.to(dev, dtype), mod_scale=mod_scale, mod_lr=1.0,
+                                   fwd_out=fwd_out)
+            grads = torch.autograd.grad(out, leaves, gout.to(dev, dtype))
+        finally:
+            ops.NATIVE_BWD = old
+        return out.detach(), [t.cpu().double() for t in grads]
+
+    def reference_fp64():
+        leaves = [t.double().requires_grad_(True) for t in (x, weight, styles, mod_w, bias) + ((skip,) if with_skip else ())]
+        out = 0
+        for c in range(nreg):
+            s = F.linear(leaves[2][:, c], leaves[3] * mod_scale, mod_b.double())
+            y = torch_ref._modulated(leaves[0], s, leaves[1], False, False, None)
+            out = out + (y * (lab == c)[:, None].double() if masked else y)
+        out = out + leaves[4]
+        if with_skip:
+            out = out + torch_ref.fir_resample(leaves[5], up_kernel.double(), up=2, pad=(2, 1))
+        return out.detach(), list(torch.autograd.grad(out, leaves, gout.double()))
+
+    out_stock, stock = run("stock", DEV, torch.float32)
+    out_saved, saved = run("saved", DEV, torch.float32, fwd_out=out_stock)
+    out_ref, ref = reference_fp64()
+    assert torch.equal(out_saved, out_stock)
+    assert (out_stock.cpu().double() - out_ref).abs().max().item() / out_ref.abs().max().item() <= 2e-5
+    for name, a, b, r in zip(("dx", "dweight", "dstyles", "dmod_w", "dbias", "dskip"), saved, stock, ref):
+        scale = max(1e-6, r.abs().max().item())
+        assert (a - r).abs().max().item() / scale <= 3e-5, f"{name}: native ToRGB gradient vs fp64 reference form"
+        assert (b - r).abs().max().item() / scale <= 3e-5, f"{name}: stock PyTorch vs fp64 reference form"

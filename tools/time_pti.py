@@ -43,6 +43,6 @@ torch.cuda.synchronize(); tg = time.time()
 for i in range(args.steps):
     gl, _ = g(vec, lab, target)
 torch.cuda.synchronize()
-print(f"PTI step as one hipGraph: {(time.time() - tg) / args.steps:.3f} s/iter, loss now {gl.item():.4f}")
+print(f"PTI step as one hipGraph: {(time.time() - tg) / args.steps * 1e3:.2f} ms/iter, loss now {gl.item():.4f}")
 print(f"PTI step (fused HIP forward + PyTorch backward): {(time.time() - t0) / args.steps:.3f} s/iter, loss {losses[0]:.4f} -> {losses[-1]:.4f}, "
       f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
