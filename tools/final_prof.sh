@@ -4,7 +4,7 @@ export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out; cd $R
 timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -3 > gpurun_out/final_gpu_tests.txt; cat gpurun_out/final_gpu_tests.txt
 timeout 900 python bench.py 2> gpurun_out/final_bench.err | grep '^{' > gpurun_out/final_bench.json; cut -c1-400 gpurun_out/final_bench.json
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench -o bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-full-swap > $R/gpurun_out/prof_bench.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench -o bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-full-swap --no-pti > $R/gpurun_out/prof_bench.log 2>&1
 grep '^{' $R/gpurun_out/prof_bench.log > $R/gpurun_out/final_bench_under_rocprof.json
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_swap -o swap -- python3 $R/tools/time_swap.py 8 6 > $R/gpurun_out/prof_swap.log 2>&1
 cd $R
@@ -12,6 +12,12 @@ python tools/rocpd_summary.py gpurun_out/prof_bench/bench_results.db | cut -c1-2
 python tools/rocpd_summary.py gpurun_out/prof_swap/swap_results.db | cut -c1-260 > gpurun_out/final_swap_kernel_stats.txt
 tail -7 gpurun_out/prof_swap.log > gpurun_out/final_swap_timing.txt
 rm -rf gpurun_out/prof_bench gpurun_out/prof_swap
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_pti -o pti -- python3 $R/tools/time_pti.py --steps 4 > $R/gpurun_out/prof_pti.log 2>&1
+cd $R
+python tools/rocpd_summary.py gpurun_out/prof_pti/pti_results.db 60 | cut -c1-260 > gpurun_out/final_pti_kernel_stats.txt   # steady state: the last 60 ms = graph replays
+grep "PTI step" gpurun_out/prof_pti.log > gpurun_out/final_pti_timing.txt
+rm -rf gpurun_out/prof_pti
 bash tools/pmc_pass.sh "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" pmc_sq
 cd $R; python tools/rocpd_pmc.py gpurun_out/pmc_sq/pmc_results.db region_modconv > gpurun_out/final_pmc_sq.txt; python tools/rocpd_pmc.py gpurun_out/pmc_sq/pmc_results.db up_fused >> gpurun_out/final_pmc_sq.txt; rm -rf gpurun_out/pmc_sq
 bash tools/pmc_pass.sh "FETCH_SIZE" pmc_fetch
