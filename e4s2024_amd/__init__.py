@@ -78,6 +78,12 @@ def install(force: bool = False) -> str:
     return DROPIN_DIR
 
 
+def invalidate_weight_caches(module) -> int:
+    """See ``ops.invalidate_weight_caches``: forget the prepared weight copies under ``module`` after raw ``p.data`` writes."""
+    from . import ops
+    return ops.invalidate_weight_caches(module)
+
+
 def uninstall() -> None:
     global _finder
     if _finder is not None and _finder in sys.meta_path:

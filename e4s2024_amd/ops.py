@@ -286,6 +286,20 @@ def _volatile(t: torch.Tensor) -> bool:
     return torch.is_grad_enabled() and t.requires_grad
 
 
+def invalidate_weight_caches(module: torch.nn.Module) -> int:
+    """Drop every re-laid-out weight copy held by the drop-in modules under ``module`` (they are rebuilt by the next forward).  Needed only
+    after writing parameters behind autograd's back between two ``no_grad`` forwards — ``p.data.copy_(...)``, an EMA update — which
+    leaves no trace the caches could key on; ``load_state_dict``, ordinary in-place ops and any training forward are tracked."""
+    n = 0
+    for m in module.modules():
+        for v in vars(m).values():
+            for c in (v if isinstance(v, (list, tuple)) else (v,)):
+                if isinstance(c, (PreparedWeights, PreparedConv)):
+                    c.key = None
+                    n += 1
+    return n
+
+
 class PreparedWeights:
     """K-major, scale-folded copy of a ModulatedConv2d weight (+ blur-composed parity kernels for up layers, + the
     squared-sum table for demodulation), as fp32 (``wt``) or as split-bf16 slabs (``wt = (whi, wlo)``).  Rebuilt when the

@@ -301,3 +301,46 @@ def test_native_torgb_gradients_against_stock_pytorch_and_fp64(masked, with_skip
         scale = max(1e-6, r.abs().max().item())
         assert (a - r).abs().max().item() / scale <= 3e-5, f"{name}: native ToRGB gradient vs fp64 reference form"
         assert (b - r).abs().max().item() / scale <= 3e-5, f"{name}: stock PyTorch vs fp64 reference form"
+
+
+@pytest.mark.parametrize("update", ["fused_adam", "data_write"])
+def test_weights_updated_behind_the_version_counter_are_seen_by_the_next_forward(sg2, manifest, update):
+    """``torch.optim.Adam(fused=True)`` and ``p.data`` writes change a parameter without bumping its version counter (measured on this
+    build: tools/probes/version_probe.py).  The re-laid-out weight copies of the kernels must not survive such an update: after a training
+    forward + update, a ``no_grad`` forward equals the forward of a freshly built generator holding the updated weights.  Raw writes
+    with no training forward in between are covered by ``e4s2024_amd.invalidate_weight_caches``."""
+    size, rli, ncls, bs = 64, 5, 5, 1
+    lab = seeded.blocky_labels(22, bs, ncls, 64, cells=8)
+    n_latent = int(np.log2(size)) * 2 - 2
+    codes = seeded.seeded_codes(23, bs, ncls, n_latent, seeded.seeded_latent_avg(2, n_latent)).to(DEV)
+    sd = seeded.seeded_state_dict(template_from_manifest(manifest["generator_64_rli5"]), 21, "net3")
+    mask = seeded.labels_to_onehot(lab, ncls).to(DEV)
+
+    def build(state):
+        g = sg2.Generator(size, 512, 8, split_layer_idx=5, remaining_layer_idx=rli)
+        g.load_state_dict(state)
+        return g.to(DEV)
+
+    gen = build({k[2:]: v for k, v in sd.items()}).train()
+    with torch.no_grad():
+        before = gen([codes], None, mask, input_is_latent=True, randomize_noise=False)[0].clone()     # fills every weight cache
+    params = [p for p in gen.parameters() if p.requires_grad]
+    versions = [p._version for p in params]
+    if update == "fused_adam":
+        opt = torch.optim.Adam(params, lr=5e-2, fused=True)
+        img = gen([codes], None, mask, input_is_latent=True, randomize_noise=False)[0]
+        opt.zero_grad()
+        img.square().mean().backward()
+        opt.step()
+    else:
+        import e4s2024_amd
+        with torch.no_grad():
+            for p in params:
+                p.data.mul_(1.05)
+        assert e4s2024_amd.invalidate_weight_caches(gen) >= 10      # raw writes between two no_grad forwards leave no trace: the caller says so
+    assert [p._version for p in params] == versions, "this build now bumps versions here: the test no longer exercises the hazard"
+    with torch.no_grad():
+        after = gen([codes], None, mask, input_is_latent=True, randomize_noise=False)[0]
+        fresh = build(gen.state_dict())([codes], None, mask, input_is_latent=True, randomize_noise=False)[0]
+    assert (after - before).abs().max().item() > 1e-3            # the update did change the image
+    assert torch.equal(after, fresh)
