@@ -208,6 +208,104 @@ __global__ __launch_bounds__(NT) void unfold2d_kernel(float* __restrict__ cols, 
         }
 }
 
+// The 3x3 fold with four pixels of a row per thread (w % 4 == 0): 18 aligned 16-byte loads of U + 6 dword loads per group and four pixels
+// instead of 72 dword loads — the scalar kernel above is bound by the number of vector-memory instructions, not by bytes.
+__global__ __launch_bounds__(NT) void mconv_fold4_kernel(float* __restrict__ dx, float* __restrict__ ds_part, const float* __restrict__ U,
+                                                         const float* __restrict__ x, const float* __restrict__ s, const uint8_t* __restrict__ lab,
+                                                         int cin, int h, int w, int nreg, int up, int chunk_px) {
+    __shared__ float stab[E4S_MAX_REGIONS + 1];
+    __shared__ float red[NT / 64][E4S_MAX_REGIONS];
+    const int bs = gridDim.z;
+    const int b = blockIdx.z, i = blockIdx.y, chunk = blockIdx.x;
+    const int P = h * w, lw = up * w;
+    if (threadIdx.x <= E4S_MAX_REGIONS) stab[threadIdx.x] = threadIdx.x < nreg ? s[((size_t)b * nreg + threadIdx.x) * cin + i] : 0.f;
+    __syncthreads();
+    const uint8_t* lp = lab ? lab + (size_t)b * up * h * lw : nullptr;
+    const float* xp = x + ((size_t)b * cin + i) * P;
+    float acc[E4S_MAX_REGIONS];
+#pragma unroll
+    for (int c = 0; c < E4S_MAX_REGIONS; ++c) acc[c] = 0.f;
+    const int p_end = min(P, (chunk + 1) * chunk_px);
+    for (int p = chunk * chunk_px + 4 * threadIdx.x; p < p_end; p += 4 * NT) {
+        const int py = p / w, px = p - py * w;
+        // x around the four pixels: rows py-1..py+1, columns px-1..px+4
+        float xr[3][6];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int yy = py + r - 1;
+            const bool in = ds_part && yy >= 0 && yy < h;
+            const float4 v = in ? *reinterpret_cast<const float4*>(xp + yy * w + px) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xr[r][0] = (in && px >= 1) ? xp[yy * w + px - 1] : 0.f;
+            xr[r][1] = v.x; xr[r][2] = v.y; xr[r][3] = v.z; xr[r][4] = v.w;
+            xr[r][5] = (in && px + 4 < w) ? xp[yy * w + px + 4] : 0.f;
+        }
+        float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < up * up; ++g) {
+            const int ga = g / up, gb = g % up;
+            const float* ug = U + (((size_t)g * bs + b) * cin + i) * 9 * P;
+            // region and modulation of the 3 x 6 output positions around the four pixels (0 outside the image / no region)
+            int lr[6];
+            float sv[3][6];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const int yy = py + r - 1, xx = px + c - 1;
+                    int lc = E4S_MAX_REGIONS;
+                    if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+                        lc = lp ? lp[(up * yy + ga) * lw + up * xx + gb] : 0;
+                        if (lc >= nreg) lc = E4S_MAX_REGIONS;
+                    }
+                    sv[r][c] = stab[lc];
+                    if (r == 1) lr[c] = lc;
+                }
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float* uk = ug + (size_t)(ky * 3 + kx) * P;
+                    if (ds_part) {                       // these four pixels as OUTPUT positions of tap (ky, kx)
+                        const float4 v = *reinterpret_cast<const float4*>(uk + p);
+                        t[0] += v.x * xr[ky][kx]; t[1] += v.y * xr[ky][kx + 1]; t[2] += v.z * xr[ky][kx + 2]; t[3] += v.w * xr[ky][kx + 3];
+                    }
+                    if (dx) {                            // as INPUT positions: output position = (py - ky + 1, px + j - kx + 1)
+                        const int oy = py - ky + 1, rr = 2 - ky, off = 1 - kx;
+                        if (oy >= 0 && oy < h) {
+                            const float4 v = *reinterpret_cast<const float4*>(uk + oy * w + px);
+                            float u0, u1, u2, u3;
+                            if (off == 0) { u0 = v.x; u1 = v.y; u2 = v.z; u3 = v.w; }
+                            else if (off == 1) { u0 = v.y; u1 = v.z; u2 = v.w; u3 = px + 4 < w ? uk[oy * w + px + 4] : 0.f; }
+                            else { u0 = px >= 1 ? uk[oy * w + px - 1] : 0.f; u1 = v.x; u2 = v.y; u3 = v.z; }
+                            gsum[0] += sv[rr][off + 1] * u0; gsum[1] += sv[rr][off + 2] * u1;
+                            gsum[2] += sv[rr][off + 3] * u2; gsum[3] += sv[rr][off + 4] * u3;
+                        }
+                    }
+                }
+            if (ds_part) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < E4S_MAX_REGIONS; ++r) acc[r] += lr[j + 1] == r ? t[j] : 0.f;
+            }
+        }
+        if (dx) *reinterpret_cast<float4*>(dx + ((size_t)b * cin + i) * P + p) = make_float4(gsum[0], gsum[1], gsum[2], gsum[3]);
+    }
+    if (!ds_part) return;
+#pragma unroll
+    for (int r = 0; r < E4S_MAX_REGIONS; ++r) {
+        const float v = wave_sum(acc[r]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][r] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < nreg) {
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NT / 64; ++wv) v += red[wv][threadIdx.x];
+        ds_part[(((size_t)chunk * bs + b) * nreg + threadIdx.x) * cin + i] = v;
+    }
+}
+
 // ---- gradient of a layer's style tables (model.py:276-281 in the one-pass form), three launches instead of ~25 small library ops:
 //     s = styles · (mod_w·ms)ᵀ + mod_b·lr        ws = c · weight        d = rsqrt(s² · wsq + 1e-8),   wsq[i,o] = Σ_k ws[o,i,k]²
 // given gs = dL/ds, gd = dL/dd, gws = dL/dws (each optional):
@@ -340,7 +438,10 @@ extern "C" int e4s_mconv_fold(float* dx, float* ds_part, const float* U, const f
     E4S_REQUIRE(!bad_shape(bs, cin, h, w, ks, nreg, up), "mconv_fold: bad size (3x3 / 1x1, nreg 1..%d, up 1 / 2)", E4S_MAX_REGIONS);
     if (bs == 0) return 0;
     const dim3 grid(cdiv(h * w, chunk_px), cin, bs);
-    if (ks == 3)
+    const bool vec4 = ks == 3 && w % 4 == 0 && chunk_px % (4 * NT) == 0 && ((((uintptr_t)U | (uintptr_t)x | (uintptr_t)dx) & 15) == 0);
+    if (vec4)
+        hipLaunchKernelGGL(mconv_fold4_kernel, grid, dim3(NT), 0, (hipStream_t)stream, dx, ds_part, U, x, s, labels, cin, h, w, nreg, up, chunk_px);
+    else if (ks == 3)
         hipLaunchKernelGGL(mconv_fold_kernel<3>, grid, dim3(NT), 0, (hipStream_t)stream, dx, ds_part, U, x, s, labels, cin, h, w, nreg, up, chunk_px);
     else
         hipLaunchKernelGGL(mconv_fold_kernel<1>, grid, dim3(NT), 0, (hipStream_t)stream, dx, ds_part, U, x, s, labels, cin, h, w, nreg, up, chunk_px);
