@@ -122,6 +122,7 @@ struct SbParams {
     int noise_bstride;
     int act;
     int bs, cin, cout, h, w, nreg, up;
+    int x_nhwc, out_nhwc;    // channels-last activations [bs,h,w,c] (cin / cout multiples of 16 / 4): 16-byte loads and stores
     int tiles_x, tiles_y;
     int ksplit, chunks_per;  // split-K: block ks handles chunks [ks*chunks_per, (ks+1)*chunks_per)
     float* partial;
@@ -150,6 +151,8 @@ struct SbCfg {
     static constexpr int WPT = (W4 + NT - 1) / NT;          // uint4 per thread
     static constexpr int SS_FLOATS = E4S_MAX_REGIONS * CKS;
     static constexpr int LDS_BYTES = XS_FLOATS * 4 + W4 * 16 + SS_FLOATS * 4;
+    static constexpr int LDS_BYTES_UNI = XS_FLOATS * 4 + W4 * 16;   // single-region kernels keep no per-region style table: 32 co x 256 px
+                                                                    // is then 40 192 B, four workgroups per CU instead of three
     static_assert(WC * WP == 4 || WC * WP == 8, "256- or 512-thread workgroups");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS per CU");
     static_assert((E4S_MAX_REGIONS + 4) * TN * 4 + 64 <= W4 * 16, "demod + bias + ToRGB tables overlay the weight stage");
@@ -164,8 +167,9 @@ struct SbCfg {
 // an (h+1) x (w+1) grid of positions (a,b); tap (ky,kx) of the 3x3 kernel contributes W[ky][kx] * x[a-(ky>>1)][b-(kx>>1)] to the
 // pre-blur pixel z[2a+(ky&1)][2b+(kx&1)], so the 9 taps feed four accumulator sets (one per output parity) and the raw sums
 // are written to z [bs,cout,2h+1,2w+1]; e4s_blur_epilogue then applies blur, demodulation, noise, bias and activation.
-template <int CB, int PB, int WC, int WP, int LOG_TW, int MINW, bool UNI, bool TCONV, bool RGB = false>
+template <int CB, int PB, int WC, int WP, int LOG_TW, int MINW, bool UNI, bool TCONV, bool RGB = false, bool XN = false>
 __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(const SbParams p) {
+    // XN = the input activation is channels-last (compile-time: the two staging paths must not share a register allocation)
     static_assert(!TCONV || UNI, "the transposed-conv split is only built for single-region layers");
     constexpr int NACC = TCONV ? 4 : 1;
     using C = SbCfg<CB, PB, WC, WP, LOG_TW>;
@@ -240,6 +244,18 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
     auto& acc = accs[0];
 
     // register stage of the NEXT chunk
+    constexpr int EPT4 = XN ? (C::PATCH * 4 + C::NT - 1) / C::NT : 1;   // channels-last items per thread
+    float4 xq[EPT4];
+    int goffs4[EPT4];
+    bool ginb4[EPT4];
+#pragma unroll
+    for (int j = 0; j < EPT4; ++j) {
+        const int e = (tid + j * C::NT) >> 2;
+        const int py = e / C::PW, px = e - py * C::PW;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        ginb4[j] = (e < C::PATCH) && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+        goffs4[j] = ginb4[j] ? gy * p.w + gx : 0;
+    }
     float xr[CKS][C::EPT];
     unsigned wr[C::WPT][4];   // scalar components: a uint4 array here ends up in scratch
     float sr = 0.f;
@@ -254,11 +270,19 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
     auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
         const int ci0 = chunk * CKS;
         const int cmax = p.cin - 1 - ci0;
+        if constexpr (XN) {   // channels-last: item = (patch pixel, 16-byte quarter of its 64-byte chunk); consecutive lanes read consecutive bytes
 #pragma unroll
-        for (int c = 0; c < CKS; ++c) {
-            const float* xc = xb + (size_t)(ci0 + (c < cmax ? c : cmax)) * hw;
+            for (int j = 0; j < EPT4; ++j) {
+                const int it = tid + j * C::NT;
+                xq[j] = *reinterpret_cast<const float4*>(xb + (size_t)goffs4[j] * p.cin + ci0 + 4 * (it & 3));
+            }
+        } else {
 #pragma unroll
-            for (int j = 0; j < C::EPT; ++j) xr[c][j] = xc[goffs[j]];
+            for (int c = 0; c < CKS; ++c) {
+                const float* xc = xb + (size_t)(ci0 + (c < cmax ? c : cmax)) * hw;
+#pragma unroll
+                for (int j = 0; j < C::EPT; ++j) xr[c][j] = xc[goffs[j]];
+            }
         }
         const size_t wbase = ((size_t)par * nchunk + chunk) * 18 * p.cout;  // uint4 units: [tap][half][cout]
 #pragma unroll
@@ -278,7 +302,27 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
         }
     };
     auto store_chunk = [&](int chunk) __attribute__((always_inline)) {
-        if constexpr (UNI) {
+        if constexpr (XN) {
+#pragma unroll
+            for (int j = 0; j < EPT4; ++j) {
+                const int it = tid + j * C::NT;
+                const int e = it >> 2, q = it & 3;
+                if (e < C::PATCH) {
+                    float4 v = ginb4[j] ? xq[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (UNI) {
+                        const float4 sc = *reinterpret_cast<const float4*>(sb + chunk * CKS + 4 * q);   // cin % 16 == 0 on this path
+                        unsigned h0, h1, l0, l1;
+                        split2(v.x * sc.x, v.y * sc.y, h0, l0);
+                        split2(v.z * sc.z, v.w * sc.w, h1, l1);
+                        const int slot = (e * 2 + ((q >> 1) ^ ((e >> 3) & 1))) * 2 + (q & 1);             // 8-byte piece of the swizzled 16-byte half
+                        reinterpret_cast<uint2*>(xh4)[slot] = make_uint2(h0, h1);
+                        reinterpret_cast<uint2*>(xl4)[slot] = make_uint2(l0, l1);
+                    } else {
+                        xf4[e * 4 + (q ^ ((e >> 2) & 3))] = v;
+                    }
+                }
+            }
+        } else if constexpr (UNI) {
             // s of the single region for the 16 channels of this chunk (wave-uniform loads)
             float sc[CKS];
 #pragma unroll
@@ -507,19 +551,28 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
 #pragma unroll
         for (int i = 0; i < CB; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = (wc * CB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                const int co = co0 + n;
-                if (co < p.cout && pix_ok) {
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float v4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * r4 + e;
+                    const int n = (wc * CB + i) * 32 + e + 8 * r4 + 4 * khalf;
+                    const int co = co0 + n;
                     float v = acc[i][q][r] * drow[n] * dz + nz + bt[n];
                     if (p.act) v = (v > 0.f ? v : v * 0.2f) * 1.41421356237309515f;
-                    if (!RGB || p.out) p.out[((size_t)b * p.cout + co) * ho * wo + opix] = v;   // out == NULL: only the fused RGB is wanted
-                    if constexpr (RGB) {
-                        rgb0 += v * wsr[n * 3 + 0];
-                        rgb1 += v * wsr[n * 3 + 1];
-                        rgb2 += v * wsr[n * 3 + 2];
+                    v4[e] = v;
+                    if (co < p.cout && pix_ok) {
+                        if ((!RGB || p.out) && !p.out_nhwc) p.out[((size_t)b * p.cout + co) * ho * wo + opix] = v;   // out == NULL: only the fused RGB is wanted
+                        if constexpr (RGB) {
+                            rgb0 += v * wsr[n * 3 + 0];
+                            rgb1 += v * wsr[n * 3 + 1];
+                            rgb2 += v * wsr[n * 3 + 2];
+                        }
                     }
                 }
+                const int co4 = co0 + (wc * CB + i) * 32 + 8 * r4 + 4 * khalf;      // four consecutive output channels of this pixel
+                if (p.out_nhwc && (!RGB || p.out) && pix_ok && co4 < p.cout)
+                    *reinterpret_cast<float4*>(p.out + ((size_t)b * ho * wo + opix) * p.cout + co4) = make_float4(v4[0], v4[1], v4[2], v4[3]);
             }
         }
         if constexpr (RGB) {  // WC == 1: this wave holds every output channel of its pixels, split over the two half-waves
@@ -602,6 +655,7 @@ static int launch_sb(SbParams& p, hipStream_t st, float* workspace, int64_t work
     // tuning knob (A/B in one process): E4S_SB_MINWAVES=1 lets the register allocator use > 256 registers (1 wave/SIMD)
     static const int minw = [] { const char* e = getenv("E4S_SB_MINWAVES"); return e ? atoi(e) : 2; }();
     static const int uni_ok = [] { const char* e = getenv("E4S_SB_UNI"); return e ? atoi(e) : 1; }();
+    static const int uni_lds = [] { const char* e = getenv("E4S_SB_UNI_LDS_FULL"); return (e && atoi(e)) ? C::LDS_BYTES : C::LDS_BYTES_UNI; }();
     if (p.rgb_out) {
         if constexpr (WC == 1) {
             constexpr int MW = C::NT / 256 >= 2 ? 2 : 2;
@@ -610,8 +664,12 @@ static int launch_sb(SbParams& p, hipStream_t st, float* workspace, int64_t work
                                                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
                 if (attr2 != hipSuccess) return fail((int)attr2, "region_modconv3x3_sb: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr2));
             }
-            if (!p.labels && p.nreg == 1)
-                hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, MW, true, false, true>), grid, dim3(C::NT), C::LDS_BYTES, st, p);
+            if (!p.labels && p.nreg == 1 && p.x_nhwc)
+                hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, MW, true, false, true, true>), grid, dim3(C::NT), uni_lds, st, p);
+            else if (p.x_nhwc)
+                return fail(E4S_ERR_ARG, "region_modconv3x3_sb: channels-last input is built for the single-region layers only");
+            else if (!p.labels && p.nreg == 1)
+                hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, MW, true, false, true>), grid, dim3(C::NT), uni_lds, st, p);
             else
                 hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, MW, false, false, true>), grid, dim3(C::NT), C::LDS_BYTES, st, p);
             return check_launch("region_modconv3x3_sb");
@@ -620,12 +678,16 @@ static int launch_sb(SbParams& p, hipStream_t st, float* workspace, int64_t work
     constexpr bool BIG = C::LDS_BYTES > 64 * 1024;   // one workgroup per CU
     constexpr int BIGW = C::NT / 256;                // waves per SIMD that workgroup provides
     if constexpr (BIG) {
+        if (p.x_nhwc) return fail(E4S_ERR_ARG, "region_modconv3x3_sb: channels-last input is built for the single-region layers only");
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, BIGW, false, false>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (attr != hipSuccess) return fail((int)attr, "region_modconv3x3_sb: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
         hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, BIGW, false, false>), grid, dim3(C::NT), C::LDS_BYTES, st, p);
+    } else if (p.x_nhwc) {
+        if (p.labels || p.nreg != 1) return fail(E4S_ERR_ARG, "region_modconv3x3_sb: channels-last input is built for the single-region layers only");
+        hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, 2, true, false, false, true>), grid, dim3(C::NT), uni_lds, st, p);
     } else if (!p.labels && p.nreg == 1 && uni_ok)
-        hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, 2, true, false>), grid, dim3(C::NT), C::LDS_BYTES, st, p);
+        hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, 2, true, false>), grid, dim3(C::NT), uni_lds, st, p);
     else if (minw >= 2)
         hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, 2, false, false>), grid, dim3(C::NT), C::LDS_BYTES, st, p);
     else
@@ -642,6 +704,8 @@ extern "C" int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16
                                         const float* act_bias, int act, int bs, int cin, int cout, int h, int w, int nreg, int up,
                                         float* workspace, int64_t workspace_floats, float* rgb_out, const float* rgb_wt, const float* rgb_s,
                                         const float* rgb_bias, const float* rgb_skip, const float* rgb_up_kernel, void* stream) {
+    const int layout = up & (E4S_X_NHWC | E4S_OUT_NHWC);
+    up &= 1;
     E4S_REQUIRE((out || rgb_out) && x && whi && wlo && s, "region_modconv3x3_sb: null tensor");
     E4S_REQUIRE(!rgb_out || (rgb_wt && rgb_s && rgb_bias && (!rgb_skip || rgb_up_kernel) && w >= 32 && !up), "region_modconv3x3_sb: incomplete fused-ToRGB arguments");
     E4S_REQUIRE(bs >= 0 && cin >= 1 && cout >= 1 && h >= 1 && w >= 1, "region_modconv3x3_sb: bad size");
@@ -655,15 +719,21 @@ extern "C" int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16
     SbParams p;
     p.out = out; p.x = x; p.whi = reinterpret_cast<const uint4*>(whi); p.wlo = reinterpret_cast<const uint4*>(wlo); p.s = s; p.d = d;
     p.labels = labels; p.noise = noise; p.noise_weight = noise_weight; p.act_bias = act_bias; p.lh = lh; p.lw = lw; p.act = act;
-    p.bs = bs; p.cin = cin; p.cout = cout; p.h = h; p.w = w; p.nreg = nreg; p.up = up ? 1 : 0;
+    p.bs = bs; p.cin = cin; p.cout = cout; p.h = h; p.w = w; p.nreg = nreg;
+    p.x_nhwc = (layout & E4S_X_NHWC) ? 1 : 0;
+    p.out_nhwc = (layout & E4S_OUT_NHWC) ? 1 : 0;
+    p.up = up;
+    E4S_REQUIRE(!p.x_nhwc || (cin % 16 == 0 && ((uintptr_t)x & 15) == 0), "region_modconv3x3_sb: channels-last input needs cin %% 16 == 0 and a 16-byte aligned tensor");
+    E4S_REQUIRE(!p.out_nhwc || (out && cout % 4 == 0 && ((uintptr_t)out & 15) == 0 && w >= 32),
+                "region_modconv3x3_sb: channels-last output needs cout %% 4 == 0, a 16-byte aligned tensor and w >= 32 (no split-K)");
     const int ho = up ? 2 * h : h, wo = up ? 2 * w : w;
     p.lscale_y = labels ? (float)lh / (float)ho : 1.f;
     p.lscale_x = labels ? (float)lw / (float)wo : 1.f;
     p.noise_bstride = (noise && noise_bs > 1) ? ho * wo : 0;
     p.rgb_out = rgb_out; p.rgb_wt = rgb_wt; p.rgb_s = rgb_s; p.rgb_bias = rgb_bias; p.rgb_skip = rgb_skip; p.rgb_upk = rgb_up_kernel;
     hipStream_t st = (hipStream_t)stream;
-    float* ws = workspace;
-    const int64_t wf = workspace_floats;
+    float* ws = p.out_nhwc ? nullptr : workspace;     // the split-K partial sums are laid out channels-first
+    const int64_t wf = p.out_nhwc ? 0 : workspace_floats;
     if (w >= 32) {
         static const int wide = [] { const char* e = getenv("E4S_SB_WIDE"); return e ? atoi(e) : 1; }();
         if (wide && labels && cout >= 128) return launch_sb<4, 1, 1, 8, 5>(p, st, ws, wf);   // 512 threads: 128 co x 256 px; on masked layers

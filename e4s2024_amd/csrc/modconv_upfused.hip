@@ -34,6 +34,7 @@ struct UpFusedParams {
     int bs, cin, cout, h, w;
     int tiles_x, tiles_y;
 };
+// channels-last activations ([bs,h,w,c]) are compile-time variants: XN = input, ON = output (E4S_X_NHWC / E4S_OUT_NHWC in `act`)
 
 constexpr int UF_T = 16;                    // positions per tile side
 constexpr int UF_STEP = UF_T - 2;           // 14 new positions per tile
@@ -43,6 +44,7 @@ constexpr int UF_PATCH = UF_PW * UF_PW;     // 289
 constexpr int UF_NT = 512;                  // 8 waves: wave v owns position rows 2v, 2v+1
 constexpr int UF_ZS = 34;                   // row stride of the pre-blur tile in LDS (32 + 2: float2-aligned, spreads banks)
 constexpr int UF_ZCO = 8;                   // output channels blurred per LDS pass
+constexpr int UF_ZCS_NHWC = 32 * UF_ZS + 8; // channel stride of the pre-blur tile for channels-last output: +8 floats so that 8 channels x 8 columns hit 64 banks
 
 E4S_PROF_DECL(g_prof_up)
 
@@ -52,15 +54,16 @@ struct UfCfg {
     static constexpr int W4 = 2 * 9 * 2 * TN;                 // uint4 per chunk: [hi/lo][tap][half][TN]
     static constexpr int WPT = (W4 + UF_NT - 1) / UF_NT;
     static constexpr int MAIN_BYTES = W4 * 16 + UF_PATCH * 64;   // weights + x hi/lo planes
-    static constexpr int ZT_BYTES = UF_ZCO * 32 * UF_ZS * 4;
+    static constexpr int ZT_BYTES = UF_ZCO * UF_ZCS_NHWC * 4;
     static constexpr int BODY = MAIN_BYTES > ZT_BYTES ? MAIN_BYTES : ZT_BYTES;
     static constexpr int EP_FLOATS = 2 * TN + UF_OUT * UF_OUT;   // epilogue operands fetched at kernel start: d, bias, noise_weight * noise tile
     static constexpr int LDS_BYTES = BODY + EP_FLOATS * 4;
 };
 
-template <int CB, int MINW>
+template <int CB, int MINW, bool XN = false, bool ON = false>
 __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedParams p) {
     using C = UfCfg<CB>;
+    constexpr int UF_ZCS = ON ? UF_ZCS_NHWC : 32 * UF_ZS;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint4* wsm = reinterpret_cast<uint4*>(lds_raw);                       // [2][9][2][TN]
     uint4* xh4 = reinterpret_cast<uint4*>(lds_raw + C::W4 * 16);          // [PATCH][2] uint4 = 16 bf16 (hi), halves swizzled
@@ -101,13 +104,32 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
             for (int r = 0; r < 16; ++r) accs[a][i][r] = 0.f;
 
     float xr[CKS];
+    // channels-last input: item = (patch pixel, 16-byte quarter of its 64-byte chunk), consecutive lanes read consecutive bytes
+    constexpr int EPT4 = XN ? (UF_PATCH * 4 + UF_NT - 1) / UF_NT : 1;
+    float4 xq[EPT4];
+    int goff4[EPT4];
+    bool inb4[EPT4];
+#pragma unroll
+    for (int j = 0; j < EPT4; ++j) {
+        const int e = (tid + j * UF_NT) >> 2;
+        const int ey = e / UF_PW, ex = e - ey * UF_PW;
+        const int gy = p0y - 1 + ey, gx = p0x - 1 + ex;
+        inb4[j] = e < UF_PATCH && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+        goff4[j] = inb4[j] ? gy * p.w + gx : 0;
+    }
     unsigned wr[C::WPT][4];   // scalar components (a uint4 array would be placed in scratch)
     const ptrdiff_t wdelta = p.wlo - p.whi;
     auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
         const int ci0 = chunk * CKS;
         const int cmax = p.cin - 1 - ci0;
+        if constexpr (XN) {
 #pragma unroll
-        for (int c = 0; c < CKS; ++c) xr[c] = xb[(size_t)(ci0 + (c < cmax ? c : cmax)) * hw + sgoff];
+            for (int j = 0; j < EPT4; ++j)
+                xq[j] = *reinterpret_cast<const float4*>(xb + (size_t)goff4[j] * p.cin + ci0 + 4 * ((tid + j * UF_NT) & 3));
+        } else {
+#pragma unroll
+            for (int c = 0; c < CKS; ++c) xr[c] = xb[(size_t)(ci0 + (c < cmax ? c : cmax)) * hw + sgoff];
+        }
         const size_t wbase = (size_t)chunk * 18 * p.cout;   // uint4 units: [tap][half][cout]
 #pragma unroll
         for (int v = 0; v < C::WPT; ++v) {
@@ -122,7 +144,23 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
         }
     };
     auto store_chunk = [&](int chunk) __attribute__((always_inline)) {
-        if (tid < UF_PATCH) {
+        if constexpr (XN) {
+#pragma unroll
+            for (int j = 0; j < EPT4; ++j) {
+                const int it = tid + j * UF_NT;
+                const int e = it >> 2, q = it & 3;
+                if (e < UF_PATCH) {
+                    const float4 v = inb4[j] ? xq[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 sc = *reinterpret_cast<const float4*>(sb + chunk * CKS + 4 * q);   // cin % 16 == 0 on this path
+                    unsigned h0, h1, l0, l1;
+                    split2(v.x * sc.x, v.y * sc.y, h0, l0);
+                    split2(v.z * sc.z, v.w * sc.w, h1, l1);
+                    const int slot = (e * 2 + ((q >> 1) ^ ((e >> 3) & 1))) * 2 + (q & 1);
+                    reinterpret_cast<uint2*>(xh4)[slot] = make_uint2(h0, h1);
+                    reinterpret_cast<uint2*>(xl4)[slot] = make_uint2(l0, l1);
+                }
+            }
+        } else if (tid < UF_PATCH) {
             unsigned hi[8], lo[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -210,15 +248,17 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
 #pragma unroll
     for (int t = 0; t < 16; ++t) kf[t] = p.blur[15 - t];
     constexpr int NITEM = UF_ZCO * 2 * UF_OUT;       // 448
-    const int it_co = tid / (2 * UF_OUT);
-    const int it_rem = tid - it_co * 2 * UF_OUT;
+    // channels-first output: consecutive lanes = consecutive pixels of one channel; channels-last: consecutive lanes = the 8 channels of a pixel
+    const int it_co = ON ? (tid & 7) : tid / (2 * UF_OUT);
+    const int it_rem = ON ? (tid >> 3) : tid - it_co * 2 * UF_OUT;
     const int it_rg = it_rem / UF_OUT, it_x = it_rem - it_rg * UF_OUT;
     const int oy0 = tyt * UF_OUT + it_rg * UF_STEP, ox = txt * UF_OUT + it_x;
     const bool it_ok = tid < NITEM && ox < wo && oy0 < ho;
     const int nrow = it_ok ? (ho - oy0 < UF_STEP ? ho - oy0 : UF_STEP) : 0;   // valid output rows of this item
     float* ob = p.out + (size_t)b * p.cout * ho * wo;
     const unsigned pix0 = (unsigned)(oy0 * wo + ox);
-    const float* zc = zt + (it_co * 32 + it_rg * UF_STEP + 1) * UF_ZS + it_x + 1;   // z row (local) of output row r, tap t: r + 1 + t
+    const float* zc = ON ? zt + it_co * UF_ZCS + (it_rg * UF_STEP + 1) * UF_ZS + it_x + 1
+                         : zt + (it_co * 32 + it_rg * UF_STEP + 1) * UF_ZS + it_x + 1;   // z row (local) of output row r, tap t: r + 1 + t
     float nz[UF_STEP];
 #pragma unroll
     for (int r = 0; r < UF_STEP; ++r) nz[r] = (tid < NITEM) ? ep_n[(it_rg * UF_STEP + r) * UF_OUT + it_x] : 0.f;
@@ -233,7 +273,7 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
                 const int col = 4 * khalf + rr;   // channel (within the group of 8) held by register 4g+rr of this half-wave
 #pragma unroll
                 for (int ci = 0; ci < 2; ++ci)
-                    *reinterpret_cast<float2*>(&zt[(col * 32 + 2 * pty + ci) * UF_ZS + 2 * ptx]) =
+                    *reinterpret_cast<float2*>(&zt[ON ? col * UF_ZCS + (2 * pty + ci) * UF_ZS + 2 * ptx : (col * 32 + 2 * pty + ci) * UF_ZS + 2 * ptx]) =
                         make_float2(accs[2 * ci][i][4 * g + rr], accs[2 * ci + 1][i][4 * g + rr]);
             }
             __syncthreads();
@@ -258,13 +298,14 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
                 }
                 const float dd = ep_d[i * 32 + 8 * g + it_co], bi = ep_b[i * 32 + 8 * g + it_co];
                 const float neg = p.act ? 0.2f : 1.f, gain = p.act ? 1.41421356237309515f : 1.f;
-                const unsigned o0 = (unsigned)co * (unsigned)(ho * wo) + pix0;
+                const unsigned o0 = ON ? pix0 * (unsigned)p.cout + (unsigned)co : (unsigned)co * (unsigned)(ho * wo) + pix0;
 #pragma unroll
                 for (int r = 0; r < UF_STEP; ++r) {
                     if (r < nrow) {
                         float v = __builtin_fmaf(a[r], dd, bi) + nz[r];
                         v = fmaxf(v, v * neg) * gain;     // leaky relu 0.2 (max picks v for v >= 0, 0.2 v otherwise)
-                        ob[o0 + (unsigned)(r * wo)] = v;
+                        if constexpr (ON) ob[o0 + (unsigned)(r * wo * p.cout)] = v;
+                        else ob[o0 + (unsigned)(r * wo)] = v;
                     }
                 }
             }
@@ -276,16 +317,16 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
     E4S_PROF_MARK(g_prof_up, 5);
 }
 
-template <int CB, int MINW>
+template <int CB, int MINW, bool XN = false, bool ON = false>
 int launch_up_fused(UpFusedParams& p, hipStream_t st) {
     using C = UfCfg<CB>;
     dim3 grid(p.tiles_x * p.tiles_y, cdiv(p.cout, C::TN), p.bs);
     if (C::LDS_BYTES > 64 * 1024) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&up_fused_sb_kernel<CB, MINW>),
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&up_fused_sb_kernel<CB, MINW, XN, ON>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (attr != hipSuccess) return fail((int)attr, "modconv_up_fused_sb: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
     }
-    hipLaunchKernelGGL((up_fused_sb_kernel<CB, MINW>), grid, dim3(UF_NT), C::LDS_BYTES, st, p);
+    hipLaunchKernelGGL((up_fused_sb_kernel<CB, MINW, XN, ON>), grid, dim3(UF_NT), C::LDS_BYTES, st, p);
     return check_launch("modconv_up_fused_sb");
 }
 
@@ -311,6 +352,10 @@ extern "C" int e4s_modconv_up_fused_sb(float* out, const float* x, const uint16_
     E4S_REQUIRE((int64_t)cout * 4 * h * w < ((int64_t)1 << 31) && (int64_t)cin * h * w < ((int64_t)1 << 31), "modconv_up_fused_sb: one sample must stay below 2^31 elements");
     E4S_REQUIRE((((uintptr_t)whi | (uintptr_t)wlo) & 15) == 0, "modconv_up_fused_sb: weight slabs must be 16-byte aligned");
     E4S_REQUIRE(!noise || (noise_weight && (noise_bs == 1 || noise_bs == bs)), "modconv_up_fused_sb: noise needs its weight and batch 1 or bs");
+    const bool x_nhwc = (act & E4S_X_NHWC) != 0, out_nhwc = (act & E4S_OUT_NHWC) != 0;
+    act &= 1;
+    E4S_REQUIRE(!x_nhwc || (cin % 16 == 0 && ((uintptr_t)x & 15) == 0), "modconv_up_fused_sb: channels-last input needs cin %% 16 == 0 and a 16-byte aligned tensor");
+    E4S_REQUIRE(!out_nhwc || cout % 8 == 0, "modconv_up_fused_sb: channels-last output needs cout %% 8 == 0");
     if (bs == 0) return 0;
     UpFusedParams p;
     p.out = out; p.x = x; p.whi = reinterpret_cast<const uint4*>(whi); p.wlo = reinterpret_cast<const uint4*>(wlo); p.s = s; p.d = d;
@@ -322,5 +367,8 @@ extern "C" int e4s_modconv_up_fused_sb(float* out, const float* x, const uint16_
     hipStream_t st = (hipStream_t)stream;
     static const int cb2 = [] { const char* e = getenv("E4S_UPFUSED_CB2"); return e ? atoi(e) : 0; }();
     if (cb2 && cout > 32) return launch_up_fused<2, 2>(p, st);   // 64 co per workgroup: x staged once, 1 workgroup per CU
+    if (x_nhwc && out_nhwc) return launch_up_fused<1, 4, true, true>(p, st);
+    if (x_nhwc) return launch_up_fused<1, 4, true, false>(p, st);
+    if (out_nhwc) return launch_up_fused<1, 4, false, true>(p, st);
     return launch_up_fused<1, 4>(p, st);                          // 32 co per workgroup, 2 workgroups per CU
 }

@@ -165,17 +165,29 @@ class ModulatedConv2d(nn.Module):
         s, d = self._tables(styles, wsq)
         return wt, s, d
 
-    def forward_regions(self, input, styles, labels, noise=None, noise_weight=None, act_bias=None, act=False, rgb=None, want_out=True):
+    def accepts_nhwc(self, masked):
+        """Can this layer read a channels-last activation?  (the single-region layers on the split-bf16 kernels; engine-internal)"""
+        if masked or self.kernel_size != 3 or ops.MODCONV_MODE != "sb" or self.in_channel % 16 or self.out_channel % 8:
+            return False
+        return (ops.UP_FUSED and self._two_stage(False)) if self.upsample else True
+
+    def forward_regions(self, input, styles, labels, noise=None, noise_weight=None, act_bias=None, act=False, rgb=None, want_out=True,
+                        x_nhwc=False, out_nhwc=False):
         if self._two_stage(labels is not None):
             # single-region up layer: transposed conv at 1x its MACs into a pre-blur buffer, then blur + epilogue
             wt, s, d = self.tables(styles, masked=False)
-            out = ops.modconv_up_single(input, wt, s, d, self.blur.kernel, noise, noise_weight, act_bias, act, self.out_channel)
+            out = ops.modconv_up_single(input, wt, s, d, self.blur.kernel, noise, noise_weight, act_bias, act, self.out_channel,
+                                        x_nhwc=x_nhwc, out_nhwc=out_nhwc)
+            if x_nhwc or out_nhwc:
+                return out          # inference only (Generator.forward takes this route under no_grad)
             return ops._attach("ModulatedConv2d", out, input, styles, self.weight, self.modulation.weight, self.modulation.bias, noise_weight,
                                act_bias, ref=self._torch_ref(labels, noise, act))
         wt, s, d = self.tables(styles, masked=labels is not None)
         saved = (s, d, self._weights(labels is not None)[1]) if labels is not None else None
         out = ops.region_modconv3x3(input, wt, s, d, labels, noise, noise_weight, act_bias, act, self.out_channel, self.upsample, rgb=rgb,
-                                    want_out=want_out)
+                                    want_out=want_out, x_nhwc=x_nhwc, out_nhwc=out_nhwc)
+        if x_nhwc or out_nhwc:
+            return out              # inference only (Generator.forward takes this route under no_grad)
         if rgb is not None:
             return tuple(None if o is None else ops._attach("ModulatedConv2d", o, input, styles, self.weight, self.modulation.weight,
                                                             self.modulation.bias, noise_weight, act_bias) for o in out)
@@ -243,10 +255,14 @@ class StyledConv(nn.Module):
         self.activate = FusedLeakyReLU(out_channel)
         self.mask_op = mask_op
 
-    def forward(self, input, style, mask, noise=None, _fused_rgb=None, _want_out=True):
+    def forward(self, input, style, mask, noise=None, _fused_rgb=None, _want_out=True, _x_nhwc=False, _out_nhwc=False):
         """``_fused_rgb=(to_rgb, rgb_style [bs,512], skip)`` (engine-internal, used by ``Generator.forward``) also evaluates that
-        single-region ToRGB in this layer's epilogue and returns ``(out, rgb)``."""
-        bs, _, H, W = input.shape
+        single-region ToRGB in this layer's epilogue and returns ``(out, rgb)``.  ``_x_nhwc`` / ``_out_nhwc`` (engine-internal): the
+        activation comes in / goes out channels-last, ``[bs, H, W, C]``."""
+        if _x_nhwc:
+            bs, H, W, _ = input.shape
+        else:
+            bs, _, H, W = input.shape
         H_out, W_out = (H * 2, W * 2) if self.conv.upsample else (H, W)
         if noise is None:  # reference :331-333
             noise = input.new_empty(bs, 1, H_out, W_out).normal_()
@@ -266,7 +282,7 @@ class StyledConv(nn.Module):
             r_wt, r_s, _ = to_rgb.conv.tables(rgb_style[:, None, :])
             rgb = (r_wt, r_s, to_rgb.bias, skip, to_rgb.upsample.kernel if skip is not None else None)
         return self.conv.forward_regions(input, styles, labels, noise, self.noise.weight, self.activate.bias, act=True, rgb=rgb,
-                                         want_out=_want_out or rgb is None)
+                                         want_out=_want_out or rgb is None, x_nhwc=_x_nhwc, out_nhwc=_out_nhwc)
 
 
 class ToRGB(nn.Module):
@@ -427,27 +443,51 @@ class Generator(nn.Module):
         skip = self.to_rgb1(out, latent[:, :, 1], mask)
 
         intermediate_feats = None
+        # Channels-last chain (inference): from the last layer before the single-region stages on, activations stay [bs, H, W, C] between the
+        # fused kernels — a tile's halo is then shared by all channels of a pixel instead of costing three cache lines per channel row
+        # (measured: 1.8 -> 5 TB/s on the staging read pattern, tools/probes/tile_read_probe.hip).  Nothing outside these kernels sees it.
+        chain = ops.NHWC_CHAIN and not torch.is_grad_enabled() and out.is_cuda and latent.ndim == 4 and ops.FUSE_RGB
+        nhwc = False                           # layout of `out` right now
+
+        def up_takes_nhwc(jj):                 # may the up-conv of stage jj read channels-last?
+            if not chain or jj >= len(self.to_rgbs) or 2 * jj + 1 < rli or not ops.nhwc_link("u", jj):
+                return False
+            cu = self.convs[2 * jj]
+            return (not cu.mask_op) and cu.conv.accepts_nhwc(False)
+
         for j, to_rgb in enumerate(self.to_rgbs):
             i = 2 * j + 1                      # W+ index shared by to_rgbs[j-1] and this resolution's up-conv
             per_region = i < rli               # reference :670 — below it every layer receives one code per region
             code = (lambda k: latent[:, :, k]) if per_region else (lambda k: latent[:, 0, k])
-            out = self.convs[2 * j](out, code(i), mask, noise=noise[1 + 2 * j])
+            conv2 = self.convs[2 * j + 1]
+            # this stage's second conv can take channels-last input iff it is a single-region layer whose ToRGB rides in its epilogue
+            c2_fused = ((not per_region or (rli != 17 and i + 2 == rli)) and not to_rgb.mask_op and tuple(to_rgb.upsample.kernel.shape) == (4, 4)
+                        and ops.can_fuse_rgb(conv2.conv.out_channel, out.shape[2 if nhwc else -1] * 2, False, conv2.mask_op))
+            c2_nhwc_in = chain and c2_fused and not conv2.mask_op and conv2.conv.accepts_nhwc(False) and ops.nhwc_link("c", j)
+            if nhwc or c2_nhwc_in:
+                out = self.convs[2 * j](out, code(i), mask, noise=noise[1 + 2 * j], _x_nhwc=nhwc, _out_nhwc=c2_nhwc_in)
+                nhwc = c2_nhwc_in
+            else:
+                out = self.convs[2 * j](out, code(i), mask, noise=noise[1 + 2 * j])
             if per_region and i + 2 == self.split_layer_idx:   # reference :673-678
                 if use_structure_code:
                     out = structure_feats
                 intermediate_feats = out
             single = (not per_region) or (rli != 17 and i + 2 == rli)   # reference :681-688
-            conv2 = self.convs[2 * j + 1]
             # (inference only: the fused pair has no backward form — under autograd the two layers run separately)
             needs_grad = torch.is_grad_enabled() and (out.requires_grad or latent.requires_grad or any(p.requires_grad for p in conv2.parameters())
                                                       or any(p.requires_grad for p in to_rgb.parameters()))
             if (single and not needs_grad and not to_rgb.mask_op and out.is_cuda and tuple(to_rgb.upsample.kernel.shape) == (4, 4)
-                    and ops.can_fuse_rgb(conv2.conv.out_channel, out.shape[-1], False, conv2.mask_op)):
+                    and ops.can_fuse_rgb(conv2.conv.out_channel, out.shape[2 if nhwc else -1], False, conv2.mask_op)):
                 # the single-region ToRGB rides in the conv's epilogue: the activation is not read back for the 1x1 conv
                 # (the last layer's own activation is consumed by nothing but this ToRGB: it is not written)
+                last = j + 1 == len(self.to_rgbs)
+                nhwc_out = (not last) and up_takes_nhwc(j + 1) and conv2.conv.out_channel % 4 == 0
                 out, skip = conv2(out, code(i + 1), mask, noise=noise[2 + 2 * j], _fused_rgb=(to_rgb, latent[:, 0, i + 2], skip),
-                                  _want_out=j + 1 < len(self.to_rgbs))
+                                  _want_out=not last, _x_nhwc=nhwc, _out_nhwc=nhwc_out)
+                nhwc = nhwc_out
             else:
+                assert not nhwc, "channels-last activation reached a layer that cannot read it"
                 out = conv2(out, code(i + 1), mask, noise=noise[2 + 2 * j])
                 skip = to_rgb(out, latent[:, 0, i + 2] if single else latent[:, :, i + 2], mask, skip)
 

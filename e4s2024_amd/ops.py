@@ -343,11 +343,17 @@ UP_FUSED = os.environ.get("E4S_UP_FUSED", "1") != "0"     # single-region up lay
 UP_TWO_STAGE = os.environ.get("E4S_UP_TWO_STAGE", "1") != "0"
 
 
-def modconv_up_single(x, wt, s, d, blur, noise, noise_weight, act_bias, act: bool, cout: int) -> torch.Tensor:
-    """Single-region up layer: transposed conv (1x MACs) into a pre-blur buffer, then blur + demod + noise + bias + act."""
+def modconv_up_single(x, wt, s, d, blur, noise, noise_weight, act_bias, act: bool, cout: int, x_nhwc: bool = False, out_nhwc: bool = False) -> torch.Tensor:
+    """Single-region up layer: transposed conv (1x MACs) into a pre-blur buffer, then blur + demod + noise + bias + act.
+    ``x_nhwc`` / ``out_nhwc``: channels-last activations ``[bs, h, w, c]`` (fused kernel only)."""
     x = _c(x, "input")
-    bs, cin, h, w = x.shape
-    out = torch.empty((bs, cout, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    if x_nhwc:
+        bs, h, w, cin = x.shape
+    else:
+        bs, cin, h, w = x.shape
+    if (x_nhwc or out_nhwc) and not (UP_FUSED and cin % 16 == 0 and cout % 8 == 0):
+        raise ValueError("channels-last activations need the fused up kernel, cin % 16 == 0 and cout % 8 == 0")
+    out = torch.empty((bs, 2 * h, 2 * w, cout) if out_nhwc else (bs, cout, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
     nz = nbs = None
     if noise is not None:
         nz = _c(noise, "noise")
@@ -357,7 +363,8 @@ def modconv_up_single(x, wt, s, d, blur, noise, noise_weight, act_bias, act: boo
     if UP_FUSED:
         ev = _timed("modconv_up_fused_sb")
         lib().call("e4s_modconv_up_fused_sb", _p(out), _p(x), _p(wt[0]), _p(wt[1]), _p(s), _p(d), _p(_c(blur, "blur kernel")), _p(nz), nbs or 0,
-                   _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, _stream())
+                   _p(noise_weight) if nz is not None else None, _p(act_bias), (1 if act else 0) | (2 if x_nhwc else 0) | (4 if out_nhwc else 0),
+                   bs, cin, cout, h, w, _stream())
         if ev is not None:
             ev.record()
         return out
@@ -449,6 +456,16 @@ def _workspace(device, floats: int) -> torch.Tensor:
 
 # Fusing the single-region ToRGB into the preceding conv's epilogue is correct but measured neutral on MI355X (the longer epilogue
 # costs what the separate HBM-bound ToRGB launch costs), so it is off by default.
+# Channels-last activations between the single-region layers of Generator.forward.  Off by default: measured in the pipeline (bench.py,
+# batch 4) the 1024x1024 / 512x512 convs gain 0.06 / 0.04 ms from reading channels-last, and the fused up-sampling kernel loses 0.08 ms
+# writing it (32-byte pieces of a pixel's line per blur pass) — 897 vs 900-904 faces/s for every combination of links.
+NHWC_CHAIN = os.environ.get("E4S_NHWC_CHAIN", "0") != "0"
+# which hand-overs may be channels-last: "u<J>" = into the up-conv of stage J (res 2^(J+3)), "c<J>" = into that stage's second conv; "all"
+NHWC_LINKS = os.environ.get("E4S_NHWC_LINKS", "all")
+
+
+def nhwc_link(kind: str, stage: int) -> bool:
+    return NHWC_CHAIN and (NHWC_LINKS == "all" or f"{kind}{stage}" in NHWC_LINKS.split(","))
 FUSE_RGB = os.environ.get("E4S_FUSE_RGB", "1") != "0"
 
 
@@ -458,17 +475,24 @@ def can_fuse_rgb(cout: int, w: int, up: bool, masked: bool) -> bool:
     return FUSE_RGB and MODCONV_MODE == "sb" and not up and w >= 32 and (cout <= 64 or (masked and wide and cout == 128))
 
 
-def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: bool, cout: int, up: bool, rgb=None, want_out: bool = True):
+def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: bool, cout: int, up: bool, rgb=None, want_out: bool = True,
+                      x_nhwc: bool = False, out_nhwc: bool = False):
     """``rgb = (wt_rgb [cout,3], s_rgb [bs,1,cout], bias [1,3,1,1], skip or None, up_kernel)`` fuses the following single-region
     ToRGB; the call then returns ``(out, rgb_image)``.  ``want_out=False`` (with ``rgb``) skips writing the layer's own activation
-    and returns ``(None, rgb_image)``."""
+    and returns ``(None, rgb_image)``.  ``x_nhwc`` / ``out_nhwc``: the activation is channels-last, ``[bs, h, w, c]`` (split-bf16 kernel,
+    width >= 32; the 256x256-and-up layers chain in this layout inside ``Generator.forward``)."""
     x = _c(x, "input")
-    bs, cin, h, w = x.shape
+    if x_nhwc:
+        bs, h, w, cin = x.shape
+    else:
+        bs, cin, h, w = x.shape
     nreg = s.shape[1]
     ho, wo = (2 * h, 2 * w) if up else (h, w)
     if not want_out and rgb is None:
         raise ValueError("want_out=False only makes sense together with a fused ToRGB")
-    out = torch.empty((bs, cout, ho, wo), dtype=torch.float32, device=x.device) if want_out else None
+    if (x_nhwc or out_nhwc) and not (isinstance(wt, tuple) and w >= 32 and cin % 16 == 0 and cout % 4 == 0):
+        raise ValueError("channels-last activations need the split-bf16 kernel, width >= 32, cin % 16 == 0 and cout % 4 == 0")
+    out = torch.empty((bs, ho, wo, cout) if out_nhwc else (bs, cout, ho, wo), dtype=torch.float32, device=x.device) if want_out else None
     lh = lw = 0
     if labels is not None:
         lh, lw = labels.shape[1:]
@@ -500,8 +524,8 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
         rgb_args = (None,) * 6
     if sb:
         lib().call("e4s_region_modconv3x3_sb", _p(out), _p(x), _p(wt[0]), _p(wt[1]), _p(s), _p(d), _p(labels), lh, lw, _p(nz), nbs or 0,
-                   _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, 1 if up else 0,
-                   _p(ws), wsn, *rgb_args, _stream())
+                   _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg,
+                   (1 if up else 0) | (2 if x_nhwc else 0) | (4 if out_nhwc else 0), _p(ws), wsn, *rgb_args, _stream())
     else:
         lib().call("e4s_region_modconv3x3", _p(out), _p(x), _p(wt), _p(s), _p(d), _p(labels), lh, lw, _p(nz), nbs or 0,
                    _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, 1 if up else 0,

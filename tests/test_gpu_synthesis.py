@@ -189,6 +189,28 @@ def test_fused_torgb_epilogue_matches_separate_launch(gpu_net3):
     assert (a - b).abs().max().item() <= 2e-5
 
 
+@pytest.mark.parametrize("links", ["all", "c7", "u6,c6"])
+def test_channels_last_chain_gives_the_same_image(gpu_net3, links):
+    """``E4S_NHWC_CHAIN=1``: the single-region layers hand their activations over channels-last (kernel variants of csrc/modconv_sb.hip and
+    csrc/modconv_upfused.hip).  Same image as the channels-first default up to the rounding of the split products, for the whole chain and
+    for partial chains (every mix of layouts at the kernel boundaries)."""
+    if _ops.MODCONV_MODE != "sb":
+        pytest.skip("split-bf16 kernels only")
+    codes, mask = _config2_inputs(2)
+    codes, mask = codes.to(DEV), mask.to(DEV)
+    old = (_ops.NHWC_CHAIN, _ops.NHWC_LINKS)
+    try:
+        with torch.no_grad():
+            _ops.NHWC_CHAIN = False
+            a, _, _ = gpu_net3.gen_img(None, codes, mask, randomize_noise=False)
+            _ops.NHWC_CHAIN, _ops.NHWC_LINKS = True, links
+            b, _, _ = gpu_net3.gen_img(None, codes, mask, randomize_noise=False)
+    finally:
+        _ops.NHWC_CHAIN, _ops.NHWC_LINKS = old
+    assert a.shape == b.shape and (a - b).abs().max().item() <= 1e-4
+    assert not torch.equal(a, b) or links != "all"      # the chain really took another route (products round differently)
+
+
 @pytest.mark.parametrize("shape", [(2, 20, 40, 9, 13), (1, 16, 24, 8, 8), (3, 48, 33, 30, 17), (1, 64, 32, 64, 64)])
 def test_up_fused_matches_two_stage_and_oracle(sg2, shape):
     """Single-region up layer: the one-launch kernel (pre-blur tile kept in LDS) against the tconv + blur-epilogue pair and the
