@@ -10,7 +10,7 @@ rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_swap -o swap -- python3 $
 cd $R
 python tools/rocpd_summary.py gpurun_out/prof_bench/bench_results.db | cut -c1-260 > gpurun_out/final_bench_kernel_stats.txt
 python tools/rocpd_summary.py gpurun_out/prof_swap/swap_results.db | cut -c1-260 > gpurun_out/final_swap_kernel_stats.txt
-tail -7 gpurun_out/prof_swap.log > gpurun_out/final_swap_timing.txt
+grep -E "ms / batch|ms per face" gpurun_out/prof_swap.log > gpurun_out/final_swap_timing.txt
 rm -rf gpurun_out/prof_bench gpurun_out/prof_swap
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_pti -o pti -- python3 $R/tools/time_pti.py --steps 4 > $R/gpurun_out/prof_pti.log 2>&1
