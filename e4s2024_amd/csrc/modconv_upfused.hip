@@ -259,9 +259,9 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
     const unsigned pix0 = (unsigned)(oy0 * wo + ox);
     const float* zc = ON ? zt + it_co * UF_ZCS + (it_rg * UF_STEP + 1) * UF_ZS + it_x + 1
                          : zt + (it_co * 32 + it_rg * UF_STEP + 1) * UF_ZS + it_x + 1;   // z row (local) of output row r, tap t: r + 1 + t
-    float nz[UF_STEP];
-#pragma unroll
-    for (int r = 0; r < UF_STEP; ++r) nz[r] = (tid < NITEM) ? ep_n[(it_rg * UF_STEP + r) * UF_OUT + it_x] : 0.f;
+    // (the noise of this item's 14 outputs is read from LDS where it is used: 14 registers less across the whole epilogue — the kernel
+    //  sits at the 128-register limit of two workgroups per CU and used to spill 80 bytes per lane here)
+    const float* nzp = ep_n + (tid < NITEM ? it_rg * UF_STEP * UF_OUT + it_x : 0);
 
     E4S_PROF_MARK(g_prof_up, 3);
 #pragma unroll
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
 #pragma unroll
                 for (int r = 0; r < UF_STEP; ++r) {
                     if (r < nrow) {
-                        float v = __builtin_fmaf(a[r], dd, bi) + nz[r];
+                        float v = __builtin_fmaf(a[r], dd, bi) + nzp[r * UF_OUT];
                         v = fmaxf(v, v * neg) * gain;     // leaky relu 0.2 (max picks v for v >= 0, 0.2 v otherwise)
                         if constexpr (ON) ob[o0 + (unsigned)(r * wo * p.cout)] = v;
                         else ob[o0 + (unsigned)(r * wo)] = v;
