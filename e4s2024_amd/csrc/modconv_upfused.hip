@@ -33,6 +33,7 @@ struct UpFusedParams {
     int act;
     int bs, cin, cout, h, w;
     int tiles_x, tiles_y;
+    int exp;                 // tuning experiments of the -DE4S_PHASE_PROF build (E4S_UF_EXP): 1 = no output stores, 2 = no blur, 4 = no z-tile writes
 };
 // channels-last activations ([bs,h,w,c]) are compile-time variants: XN = input, ON = output (E4S_X_NHWC / E4S_OUT_NHWC in `act`)
 
@@ -278,34 +279,48 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
             }
             __syncthreads();
             const int co = co0 + i * 32 + 8 * g + it_co;
+#ifdef E4S_PHASE_PROF
+            if (p.exp & 2) { __syncthreads(); continue; }
+#endif
             if (nrow > 0 && co < p.cout) {
-                float a[UF_STEP];
-#pragma unroll
-                for (int r = 0; r < UF_STEP; ++r) a[r] = 0.f;
-#pragma unroll
-                for (int zr = 0; zr < UF_STEP + 3; ++zr) {
-                    const float z0 = zc[zr * UF_ZS], z1 = zc[zr * UF_ZS + 1], z2 = zc[zr * UF_ZS + 2], z3 = zc[zr * UF_ZS + 3];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int r = zr - t;
-                        if (r >= 0 && r < UF_STEP) {
-                            a[r] = __builtin_fmaf(z0, kf[t * 4], a[r]);
-                            a[r] = __builtin_fmaf(z1, kf[t * 4 + 1], a[r]);
-                            a[r] = __builtin_fmaf(z2, kf[t * 4 + 2], a[r]);
-                            a[r] = __builtin_fmaf(z3, kf[t * 4 + 3], a[r]);
-                        }
-                    }
-                }
                 const float dd = ep_d[i * 32 + 8 * g + it_co], bi = ep_b[i * 32 + 8 * g + it_co];
                 const float neg = p.act ? 0.2f : 1.f, gain = p.act ? 1.41421356237309515f : 1.f;
                 const unsigned o0 = ON ? pix0 * (unsigned)p.cout + (unsigned)co : (unsigned)co * (unsigned)(ho * wo) + pix0;
+                // the 14 rows in two halves of 7: seven accumulators instead of fourteen (three z rows are read twice) — with fourteen the
+                // kernel spilled into scratch inside this loop, and a scratch access costs a global-memory round trip
+                constexpr int HR = UF_STEP / 2;
 #pragma unroll
-                for (int r = 0; r < UF_STEP; ++r) {
-                    if (r < nrow) {
-                        float v = __builtin_fmaf(a[r], dd, bi) + nzp[r * UF_OUT];
-                        v = fmaxf(v, v * neg) * gain;     // leaky relu 0.2 (max picks v for v >= 0, 0.2 v otherwise)
-                        if constexpr (ON) ob[o0 + (unsigned)(r * wo * p.cout)] = v;
-                        else ob[o0 + (unsigned)(r * wo)] = v;
+                for (int hf = 0; hf < 2; ++hf) {
+                    float a[HR];
+#pragma unroll
+                    for (int r = 0; r < HR; ++r) a[r] = 0.f;
+#pragma unroll
+                    for (int zr = 0; zr < HR + 3; ++zr) {
+                        const float* zp = zc + (hf * HR + zr) * UF_ZS;
+                        const float z0 = zp[0], z1 = zp[1], z2 = zp[2], z3 = zp[3];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int r = zr - t;
+                            if (r >= 0 && r < HR) {
+                                a[r] = __builtin_fmaf(z0, kf[t * 4], a[r]);
+                                a[r] = __builtin_fmaf(z1, kf[t * 4 + 1], a[r]);
+                                a[r] = __builtin_fmaf(z2, kf[t * 4 + 2], a[r]);
+                                a[r] = __builtin_fmaf(z3, kf[t * 4 + 3], a[r]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < HR; ++r) {
+                        const int ro = hf * HR + r;
+                        if (ro < nrow) {
+                            float v = __builtin_fmaf(a[r], dd, bi) + nzp[ro * UF_OUT];
+                            v = fmaxf(v, v * neg) * gain;     // leaky relu 0.2 (max picks v for v >= 0, 0.2 v otherwise)
+#ifdef E4S_PHASE_PROF
+                            if ((p.exp & 1) && v != 12345.678f) continue;
+#endif
+                            if constexpr (ON) ob[o0 + (unsigned)(ro * wo * p.cout)] = v;
+                            else ob[o0 + (unsigned)(ro * wo)] = v;
+                        }
                     }
                 }
             }
@@ -364,6 +379,7 @@ extern "C" int e4s_modconv_up_fused_sb(float* out, const float* x, const uint16_
     p.act = act; p.bs = bs; p.cin = cin; p.cout = cout; p.h = h; p.w = w;
     p.tiles_x = cdiv(2 * w, UF_OUT);
     p.tiles_y = cdiv(2 * h, UF_OUT);
+    { const char* e = getenv("E4S_UF_EXP"); p.exp = e ? atoi(e) : 0; }
     hipStream_t st = (hipStream_t)stream;
     static const int cb2 = [] { const char* e = getenv("E4S_UPFUSED_CB2"); return e ? atoi(e) : 0; }();
     if (cb2 && cout > 32) return launch_up_fused<2, 2>(p, st);   // 64 co per workgroup: x staged once, 1 workgroup per CU
