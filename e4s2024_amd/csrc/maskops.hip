@@ -137,7 +137,91 @@ __global__ __launch_bounds__(256) void foreground_masks_kernel(float* __restrict
     }
 }
 
+// ---- multi-band blend (swap_face_fine/multi_band_blending.py:5-74): the two pyramid steps of cv2.pyrDown / cv2.pyrUp on float planes.
+// pyrDown: 5x5 kernel [1 4 6 4 1]^2 / 256 at the even pixels, BORDER_REFLECT_101; round_u8 = the 8-bit variant's (sum + 128) >> 8.
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * (n - 1) - i : i;
+}
+
+__global__ __launch_bounds__(256) void pyr_down_kernel(float* __restrict__ out, const float* __restrict__ in, int h, int w, int oh, int ow, int round_u8) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= oh * ow) return;
+    const int oy = i / ow, ox = i - oy * ow;
+    const float* ip = in + (size_t)blockIdx.y * h * w;
+    const float k[5] = {1.f, 4.f, 6.f, 4.f, 1.f};
+    int xs[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) xs[t] = reflect101(2 * ox + t - 2, w);
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const float* row = ip + (size_t)reflect101(2 * oy + u - 2, h) * w;
+        float r = 0.f;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) r += k[t] * row[xs[t]];
+        acc += k[u] * r;
+    }
+    out[(size_t)blockIdx.y * oh * ow + i] = round_u8 ? fminf(fmaxf(floorf((acc + 128.f) * (1.f / 256.f)), 0.f), 255.f) : acc * (1.f / 256.f);
+}
+
+// pyrUp weights of destination index D over source indices (i-1, i, i+1), i = D >> 1, in eighths: even D: (1, 6, 1) with s[-1] = s[1];
+// odd D: (0, 4, 4); the last source pixel: even (1, 7, 0), odd (0, 8, 0); a one-pixel source: (0, 8, 0).
+__device__ __forceinline__ void pyr_up_taps(int D, int n, int idx[3], float wgt[3]) {
+    const int i = D >> 1;
+    idx[0] = i > 0 ? i - 1 : (n > 1 ? 1 : 0);
+    idx[1] = i;
+    idx[2] = i + 1 < n ? i + 1 : i;
+    if (n == 1) { wgt[0] = 0.f; wgt[1] = 8.f; wgt[2] = 0.f; return; }
+    const bool last = i == n - 1;
+    if (D & 1) { wgt[0] = 0.f; wgt[1] = last ? 8.f : 4.f; wgt[2] = last ? 0.f : 4.f; }
+    else { wgt[0] = 1.f; wgt[1] = last ? 7.f : 6.f; wgt[2] = last ? 0.f : 1.f; }
+}
+
+// out = up(in), or minuend - up(in) (Laplacian level), or up(in) + addend (reconstruction)
+__global__ __launch_bounds__(256) void pyr_up_kernel(float* __restrict__ out, const float* __restrict__ in, const float* __restrict__ minuend,
+                                                     const float* __restrict__ addend, int h, int w) {
+    const int ow = 2 * w, oh = 2 * h;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= oh * ow) return;
+    const int Y = i / ow, X = i - Y * ow;
+    int yi[3], xi[3];
+    float yw[3], xw[3];
+    pyr_up_taps(Y, h, yi, yw);
+    pyr_up_taps(X, w, xi, xw);
+    const float* ip = in + (size_t)blockIdx.y * h * w;
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const float* row = ip + (size_t)yi[u] * w;
+        acc += yw[u] * (xw[0] * row[xi[0]] + xw[1] * row[xi[1]] + xw[2] * row[xi[2]]);
+    }
+    acc *= (1.f / 64.f);
+    const size_t o = (size_t)blockIdx.y * oh * ow + i;
+    if (minuend) acc = minuend[o] - acc;
+    if (addend) acc += addend[o];
+    out[o] = acc;
+}
+
 }  // namespace
+
+extern "C" int e4s_pyr_down(float* out, const float* in, int planes, int h, int w, int round_u8, void* stream) {
+    E4S_REQUIRE(out && in, "pyr_down: null tensor");
+    E4S_REQUIRE(planes >= 0 && planes <= 65535 && h >= 1 && w >= 1 && (int64_t)h * w < ((int64_t)1 << 30), "pyr_down: bad size");
+    if (planes == 0) return 0;
+    const int oh = (h + 1) / 2, ow = (w + 1) / 2;
+    hipLaunchKernelGGL(pyr_down_kernel, dim3(cdiv(oh * ow, 256), planes), dim3(256), 0, (hipStream_t)stream, out, in, h, w, oh, ow, round_u8);
+    return check_launch("pyr_down");
+}
+
+extern "C" int e4s_pyr_up(float* out, const float* in, const float* minuend, const float* addend, int planes, int h, int w, void* stream) {
+    E4S_REQUIRE(out && in, "pyr_up: null tensor");
+    E4S_REQUIRE(planes >= 0 && planes <= 65535 && h >= 1 && w >= 1 && (int64_t)h * w < ((int64_t)1 << 28), "pyr_up: bad size");
+    if (planes == 0) return 0;
+    hipLaunchKernelGGL(pyr_up_kernel, dim3(cdiv(4 * h * w, 256), planes), dim3(256), 0, (hipStream_t)stream, out, in, minuend, addend, h, w);
+    return check_launch("pyr_up");
+}
 
 extern "C" int e4s_swap_head_mask(uint8_t* res, uint8_t* hole_mask, uint8_t* hole_map, int32_t* lines, const uint8_t* source, const uint8_t* target,
                                   int32_t* scratch, int bs, int h, int w, void* stream) {

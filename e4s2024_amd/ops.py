@@ -1137,6 +1137,58 @@ def single_styled_conv_grad(x, wmod, noise_weight, act_bias, noise, act, blur, o
     return _SingleStyledConvGrad.apply(x, wmod, noise_weight, act_bias, noise, act, blur, out)
 
 
+# ------------------------------------------------------------------------------------ f3: multi-band blend
+def pyr_down(x: torch.Tensor, round_u8: bool = False) -> torch.Tensor:
+    """``cv2.pyrDown`` on ``[..., H, W]`` float planes (``round_u8``: the 8-bit variant's rounding, for a pyramid of a uint8 image)."""
+    x = _c(x, "image")
+    h, w = x.shape[-2:]
+    out = torch.empty(x.shape[:-2] + ((h + 1) // 2, (w + 1) // 2), dtype=torch.float32, device=x.device)
+    lib().call("e4s_pyr_down", _p(out), _p(x), x.numel() // (h * w), h, w, int(round_u8), _stream())
+    return out
+
+
+def pyr_up(x: torch.Tensor, minuend: Optional[torch.Tensor] = None, addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``cv2.pyrUp`` on ``[..., H, W]`` float planes -> ``[..., 2H, 2W]``; ``minuend - up(x)`` or ``up(x) + addend`` when given."""
+    x = _c(x, "image")
+    h, w = x.shape[-2:]
+    out = torch.empty(x.shape[:-2] + (2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    for name, t in (("minuend", minuend), ("addend", addend)):
+        if t is not None and (tuple(t.shape) != tuple(out.shape) or not t.is_contiguous() or t.dtype != torch.float32):
+            raise ValueError(f"pyr_up: {name} must be a contiguous float32 tensor of the output shape {tuple(out.shape)}")
+    lib().call("e4s_pyr_up", _p(out), _p(x), _p(minuend), _p(addend), x.numel() // (h * w), h, w, _stream())
+    return out
+
+
+def laplacian_blend(a_u8: torch.Tensor, b: torch.Tensor, mask: torch.Tensor, num_levels: int = 10) -> torch.Tensor:
+    """``Laplacian_Pyramid_Blending_with_mask(A, B, m, num_levels)`` (swap_face_fine/multi_band_blending.py:5-48) on the device, with the
+    types of its call site: ``a_u8`` uint8 ``[bs, 3, H, W]`` (its Gaussian pyramid is rounded to 8 bits per level like cv2's), ``b`` float
+    ``[bs, 3, H, W]`` in [0, 255], ``mask`` float ``[bs, 1 or 3, H, W]``.  Returns the float blend ``[bs, 3, H, W]``."""
+    if a_u8.dtype != torch.uint8 or a_u8.dim() != 4 or b.shape != a_u8.shape:
+        raise ValueError("laplacian_blend: A is uint8 [bs, 3, H, W] and B a float tensor of the same shape")
+    h, w = a_u8.shape[-2:]
+    if (h >> num_levels) < 1 or (w >> num_levels) < 1 or h % (1 << (num_levels - 1)) or w % (1 << (num_levels - 1)):
+        raise ValueError(f"laplacian_blend: {h}x{w} cannot carry {num_levels} pyramid levels (the reference runs 1024x1024 with 10)")
+    ga, gb = a_u8.float().contiguous(), _c(b, "B")
+    gm = _c(mask.expand(-1, 3, -1, -1) if mask.shape[1] == 1 else mask, "mask")
+    gpa, gpb, gpm = [ga], [gb], [gm]
+    for _ in range(num_levels - 1):              # (the reference's last pyrDown, level num_levels, is never used)
+        ga, gb, gm = pyr_down(ga, True), pyr_down(gb), pyr_down(gm)
+        gpa.append(ga); gpb.append(gb); gpm.append(gm)
+    out = torch.lerp(gpb[-1], gpa[-1], gpm[-1])                                    # la*gm + lb*(1-gm) at the coarsest level
+    for i in range(num_levels - 1, 0, -1):
+        la, lb = pyr_up(gpa[i], minuend=gpa[i - 1]), pyr_up(gpb[i], minuend=gpb[i - 1])
+        out = pyr_up(out, addend=torch.lerp(lb, la, gpm[i - 1]))
+    return out
+
+
+def blending(full_img_u8: torch.Tensor, ori_img: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """``blending(full_img, ori_img, mask)`` (multi_band_blending.py:51-74) for 1024 x 1024 frames (its resizes are then identities):
+    uint8 ``[bs, 3, H, W]`` = the clipped, truncated ten-level blend."""
+    if tuple(full_img_u8.shape[-2:]) != (1024, 1024):
+        raise NotImplementedError("blending: the reference resizes to 1024x1024 first; pass 1024x1024 frames")
+    return laplacian_blend(full_img_u8, ori_img, mask, 10).clamp_(0, 255).to(torch.uint8)
+
+
 # ------------------------------------------------------------------------------------ a7
 def grouped_linear(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Optional[Sequence[Optional[torch.Tensor]]], *, scale: float,
                    bias_mul: float = 1.0, act: int = 0, slope: float = 0.2, addend: Optional[torch.Tensor] = None,

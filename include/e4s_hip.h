@@ -284,6 +284,14 @@ E4S_API int e4s_tensor2im_u8(uint8_t* out, const float* img, int bs, int h, int 
  *   content (may be NULL), border, full : float32 [bs, 1, h, w] in {0, 1};  hole_mask may be NULL. */
 E4S_API int e4s_swap_head_mask(uint8_t* res, uint8_t* hole_mask, uint8_t* hole_map, int32_t* lines, const uint8_t* source,
                                const uint8_t* target, int32_t* scratch, int bs, int h, int w, void* stream);
+/* The two pyramid steps of the multi-band blend (swap_face_fine/multi_band_blending.py:5-48; cv2.pyrDown / cv2.pyrUp, OpenCV
+ * modules/imgproc/src/pyramids.cpp) on float planes [planes, h, w]:
+ *   e4s_pyr_down : out [planes, (h+1)/2, (w+1)/2] = 5x5 kernel [1 4 6 4 1]^2 / 256 at the even pixels, BORDER_REFLECT_101;
+ *                  round_u8 != 0 = the 8-bit variant's rounding, floor((sum + 128) / 256) (the reference's pyramid of the uint8 frame)
+ *   e4s_pyr_up   : out [planes, 2h, 2w] = up(in), or minuend - up(in) (a Laplacian level), or up(in) + addend (reconstruction);
+ *                  up = zero insertion convolved with 4x the same kernel (OpenCV's border rule for the last source pixel) */
+E4S_API int e4s_pyr_down(float* out, const float* in, int planes, int h, int w, int round_u8, void* stream);
+E4S_API int e4s_pyr_up(float* out, const float* in, const float* minuend, const float* addend, int planes, int h, int w, void* stream);
 E4S_API int e4s_foreground_masks(float* content, float* border, float* full, const uint8_t* swapped, const uint8_t* hole_mask,
                                  int bs, int h, int w, int radius, void* stream);
 

@@ -537,3 +537,88 @@ def foreground_mask(swapped: np.ndarray, hole: np.ndarray) -> np.ndarray:
     """face_swap_video_pipeline.py:456-461: everything except background / ear-ring / ear / hair / neck, plus the hole."""
     fg = ~np.isin(swapped, (0, 11, 7, 4, 8))
     return np.logical_or(fg, hole).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------ f3: multi-band (Laplacian pyramid) blend
+# swap_face_fine/multi_band_blending.py:5-74, called per frame at face_swap_video_pipeline.py:473.  PARITY UNPINNED: the arithmetic is
+# OpenCV's (cv2.pyrDown / cv2.pyrUp / cv2.add; opencv-python 4.7.0.72 in requirements.txt), which is neither under /root/reference nor
+# installed in this image, and the reference holds no fixture for it.  What follows restates OpenCV's published algorithm
+# (modules/imgproc/src/pyramids.cpp: 5x5 kernel [1 4 6 4 1]^2 / 256, BORDER_REFLECT_101, 8-bit results rounded as (sum + 128) >> 8;
+# pyrUp = zero-insertion convolved with 4x that kernel, evaluated as [1 6 1]/8 at even and [4 4]/8 at odd destinations, with the last
+# source pixel treated as (s[n-2] + 7 s[n-1]) / 8 and s[n-1]) and anchors on the reference's own call site for types and level bookkeeping.
+_PYR_K = np.array([1.0, 4.0, 6.0, 4.0, 1.0])
+
+
+def _reflect101(idx: np.ndarray, n: int) -> np.ndarray:
+    if n == 1:
+        return np.zeros_like(idx)
+    idx = np.abs(idx)
+    return np.where(idx >= n, 2 * (n - 1) - idx, idx)
+
+
+def _pyr_down_axis(a: np.ndarray, axis: int) -> np.ndarray:
+    n = a.shape[axis]
+    out_n = (n + 1) // 2
+    centers = 2 * np.arange(out_n)
+    acc = 0
+    for t, k in zip(range(-2, 3), _PYR_K):
+        acc = acc + k * np.take(a, _reflect101(centers + t, n), axis=axis)
+    return acc
+
+
+def pyr_down(img: np.ndarray) -> np.ndarray:
+    """cv2.pyrDown of an [H, W, C] image.  uint8 in -> uint8 out, rounded (sum + 128) >> 8; float in -> same float type, sum / 256."""
+    a = img.astype(np.float64)
+    s = _pyr_down_axis(_pyr_down_axis(a, 1), 0)
+    if img.dtype == np.uint8:
+        return np.clip(np.floor((s + 128.0) / 256.0), 0, 255).astype(np.uint8)
+    return (s / 256.0).astype(img.dtype)
+
+
+def _pyr_up_axis(a: np.ndarray, axis: int) -> np.ndarray:
+    n = a.shape[axis]
+    a = np.moveaxis(a, axis, 0)
+    out = np.empty((2 * n,) + a.shape[1:], dtype=np.float64)
+    if n == 1:
+        out[0] = out[1] = 8.0 * a[0]
+    else:
+        prev = np.concatenate([a[1:2], a[:-1]])            # s[i-1], reflected at the first pixel
+        nxt = np.concatenate([a[1:], a[-1:]])              # s[i+1]; the last pixel has its own rule below
+        out[0::2] = prev + 6.0 * a + nxt
+        out[1::2] = 4.0 * (a + nxt)
+        out[2 * n - 2] = a[n - 2] + 7.0 * a[n - 1]
+        out[2 * n - 1] = 8.0 * a[n - 1]
+    return np.moveaxis(out, 0, axis)
+
+
+def pyr_up(img: np.ndarray) -> np.ndarray:
+    """cv2.pyrUp of an [H, W, C] float image to [2H, 2W, C]."""
+    s = _pyr_up_axis(_pyr_up_axis(img.astype(np.float64), 1), 0) / 64.0
+    return s.astype(img.dtype if img.dtype != np.uint8 else np.float64)
+
+
+def laplacian_blend(a_u8: np.ndarray, b: np.ndarray, m: np.ndarray, num_levels: int = 10) -> np.ndarray:
+    """``Laplacian_Pyramid_Blending_with_mask(A, B, m, num_levels)`` (multi_band_blending.py:5-48) with the types of its one caller
+    (``blending`` :51-74, at 1024 x 1024): A uint8 (its Gaussian pyramid is rounded to 8 bits at every level), B float64, m float32."""
+    ga, gb, gm = a_u8.copy(), b.copy(), m.copy()
+    gpa, gpb, gpm = [ga], [gb], [gm]
+    for _ in range(num_levels):
+        ga, gb, gm = pyr_down(ga), pyr_down(gb), pyr_down(gm)
+        gpa.append(ga.astype(np.float32)); gpb.append(gb.astype(np.float32)); gpm.append(gm.astype(np.float32))
+    lpa, lpb, gmr = [gpa[num_levels - 1]], [gpb[num_levels - 1]], [gpm[num_levels - 1]]
+    for i in range(num_levels - 1, 0, -1):
+        lpa.append(gpa[i - 1].astype(np.float32) - pyr_up(gpa[i]))
+        lpb.append(gpb[i - 1].astype(np.float32) - pyr_up(gpb[i]))
+        gmr.append(gpm[i - 1])
+    ls = [la * g + lb * (1.0 - g) for la, lb, g in zip(lpa, lpb, gmr)]
+    out = ls[0]
+    for i in range(1, num_levels):
+        out = pyr_up(out) + ls[i]
+    return out
+
+
+def blending(full_img_u8: np.ndarray, ori_img: np.ndarray, mask: np.ndarray) -> np.ndarray:
+    """``blending`` (multi_band_blending.py:51-74) for 1024 x 1024 inputs (its two cv2.resize calls are then identities): uint8 [H,W,3]."""
+    assert full_img_u8.shape[:2] == (1024, 1024) and ori_img.shape[:2] == (1024, 1024), "restated for the 1024 x 1024 call site"
+    img = laplacian_blend(full_img_u8, ori_img.astype(np.float64), mask.astype(np.float32), 10)
+    return np.clip(img, 0, 255).astype(np.uint8)

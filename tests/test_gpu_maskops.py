@@ -70,3 +70,66 @@ def test_swap_head_mask_argument_errors():
     e = torch.zeros(0, 8, 8, dtype=torch.uint8, device=DEV)
     res, hole, hole_map, lines = ops.swap_head_mask(e, e)       # empty batch
     assert res.shape == (0, 8, 8) and lines.shape == (0, 2)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 64, 48), (1, 1, 7, 5), (1, 2, 1, 9), (3, 1, 2, 2)])
+def test_pyramid_steps_against_the_oracle(shape):
+    """e4s_pyr_down / e4s_pyr_up against the numpy restatement of cv2.pyrDown / cv2.pyrUp (oracle; unpinned: no cv2 in this image):
+    float and 8-bit rounding, odd sizes, one-pixel rows, and the fused Laplacian / reconstruction forms."""
+    from e4s2024_amd import ops
+    rs = np.random.RandomState(5)
+    x8 = rs.randint(0, 256, shape).astype(np.uint8)
+    xf = rs.rand(*shape).astype(np.float32) * 255
+    hwc = lambda a: np.moveaxis(a.reshape((-1,) + a.shape[-2:]), 0, -1)          # planes -> [H, W, planes]
+    back = lambda a, like: np.moveaxis(a, -1, 0).reshape(like.shape[:-2] + a.shape[:2])
+    d8 = ops.pyr_down(torch.from_numpy(x8).float().to(DEV), round_u8=True).cpu().numpy()
+    assert np.array_equal(d8, back(O.pyr_down(hwc(x8)), x8).astype(np.float32))
+    df = ops.pyr_down(torch.from_numpy(xf).to(DEV)).cpu().numpy()
+    assert np.abs(df - back(O.pyr_down(hwc(xf)), xf)).max() <= 1e-4
+    up = ops.pyr_up(torch.from_numpy(xf).to(DEV)).cpu().numpy()
+    ref = back(O.pyr_up(hwc(xf)), xf)
+    assert up.shape == ref.shape and np.abs(up - ref).max() <= 1e-4
+    other = rs.rand(*up.shape).astype(np.float32)
+    t = torch.from_numpy(other).to(DEV)
+    assert np.abs(ops.pyr_up(torch.from_numpy(xf).to(DEV), minuend=t).cpu().numpy() - (other - ref)).max() <= 1e-4
+    assert np.abs(ops.pyr_up(torch.from_numpy(xf).to(DEV), addend=t).cpu().numpy() - (ref + other)).max() <= 1e-4
+
+
+def test_multi_band_blend_1024_against_the_oracle():
+    """``blending`` (multi_band_blending.py:51-74) at its call-site size: the ten-level blend of a uint8 frame A and a float frame B under a
+    soft border mask, against the oracle's float64 restatement — equal up to one grey level where fp32 vs fp64 lands on the other side of
+    the final truncation; mask 1 returns A exactly, mask 0 returns trunc(B)."""
+    from e4s2024_amd import ops
+    rs = np.random.RandomState(11)
+    a = rs.randint(0, 256, (1024, 1024, 3)).astype(np.uint8)
+    b = (rs.rand(1024, 1024, 3) * 255).astype(np.float64)
+    yy, xx = np.mgrid[0:1024, 0:1024]
+    m = np.clip(1.5 - np.hypot(yy - 500, xx - 540) / 200.0, 0, 1).astype(np.float32)[..., None].repeat(3, -1)
+    ref = O.blending(a, b, m)
+    chw = lambda t: torch.from_numpy(np.ascontiguousarray(np.moveaxis(t, -1, 0)))[None].to(DEV)
+    out = ops.blending(chw(a), chw(b).float(), chw(m)).cpu().numpy()[0]
+    diff = np.abs(out.astype(np.int32) - np.moveaxis(ref, -1, 0).astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() <= 2e-3, (diff.max(), (diff > 0).mean())
+    ones, zeros = torch.ones(1, 1, 1024, 1024, device=DEV), torch.zeros(1, 1, 1024, 1024, device=DEV)
+    assert torch.equal(ops.blending(chw(a), chw(b).float(), ones), chw(a))
+    tb = ops.blending(chw(a), chw(b).float(), zeros).cpu().numpy()[0].astype(np.int32)
+    assert np.abs(tb - np.moveaxis(np.floor(b), -1, 0)).max() <= 1
+
+
+def test_paste_back_chain_against_the_oracle():
+    """pipeline.paste_back = reference :464-473 — masks resized bilinearly (align_corners=False), alpha paste, ten-level multi-band blend —
+    against the same chain on the CPU (torch interpolate + the oracle's blend)."""
+    import torch.nn.functional as F
+    from e4s2024_amd import pipeline
+    rs = np.random.RandomState(21)
+    sw = rs.randint(0, 256, (1, 1024, 1024, 3)).astype(np.uint8)
+    tg = rs.randint(0, 256, (1, 1024, 1024, 3)).astype(np.uint8)
+    lab = T(seeded.blocky_labels(5, 1, 12, 512, 16))
+    content, border, _ = ops.foreground_masks(lab.to(DEV), None, 5)
+    out = pipeline.paste_back(T(sw).to(DEV), T(tg).to(DEV), content, border).cpu().numpy()[0]
+    cm = F.interpolate(content.cpu(), (1024, 1024), mode="bilinear", align_corners=False)[0, 0, :, :, None].numpy()
+    bm = F.interpolate(border.cpu(), (1024, 1024), mode="bilinear", align_corners=False)[0, 0, :, :, None].numpy().repeat(3, -1)
+    pasted = sw[0] * cm + tg[0] * (1 - cm)
+    ref = O.blending(tg[0], pasted, bm)
+    diff = np.abs(out.astype(np.int32) - ref.astype(np.int32))
+    assert out.shape == ref.shape and diff.max() <= 1 and (diff > 0).mean() <= 2e-3, (diff.max(), (diff > 0).mean())

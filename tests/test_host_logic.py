@@ -308,3 +308,25 @@ def test_handoff_files_roundtrip(tmp_path):
     q = (((clip.target.clamp(-1, 1) + 1) / 2 * 255).to(torch.uint8).float() / 255 - 0.5) / 0.5
     assert torch.allclose(back.target, q, atol=1e-6)
     assert torch.load(tmp_path / "styleVec" / "D_style_vec_0005.pt").shape == (1, 12, 1280)
+
+
+def test_multi_band_blend_oracle_properties():
+    """The oracle's restatement of cv2.pyrDown / pyrUp / the Laplacian blend (unpinned: cv2 is not in this image) at least has the
+    properties the algorithm guarantees: constants survive both pyramid steps, the 8-bit step rounds like (sum + 128) >> 8, mask = 1
+    returns A exactly, mask = 0 returns B, and sizes follow (n + 1) // 2 and 2 n."""
+    from oracle import e4s_oracle as O
+    rs = np.random.RandomState(3)
+    c = np.full((9, 6, 2), 7.0)
+    assert np.allclose(O.pyr_down(c), 7.0) and O.pyr_down(c).shape == (5, 3, 2)
+    assert np.allclose(O.pyr_up(c), 7.0) and O.pyr_up(c).shape == (18, 12, 2)
+    assert (O.pyr_down(np.full((8, 8, 1), 200, np.uint8)) == 200).all()
+    a = rs.randint(0, 256, (8, 8, 1)).astype(np.uint8)
+    d = O.pyr_down(a)
+    k = np.array([1, 4, 6, 4, 1])
+    pad = np.pad(a[..., 0].astype(np.int64), 2, mode="reflect")
+    exp = np.array([[(np.outer(k, k) * pad[2 * y:2 * y + 5, 2 * x:2 * x + 5]).sum() + 128 >> 8 for x in range(4)] for y in range(4)])
+    assert np.array_equal(d[..., 0], exp)
+    A = rs.randint(0, 256, (64, 64, 3)).astype(np.uint8)
+    B = rs.rand(64, 64, 3) * 255
+    assert np.array_equal(np.clip(O.laplacian_blend(A, B, np.ones((64, 64, 3), np.float32), 6), 0, 255).astype(np.uint8), A)
+    assert np.abs(O.laplacian_blend(A, B, np.zeros((64, 64, 3), np.float32), 6) - B).max() <= 1e-3
