@@ -204,7 +204,45 @@ __global__ __launch_bounds__(256) void pyr_up_kernel(float* __restrict__ out, co
     out[o] = acc;
 }
 
+// One level of the blend in one pass:  out = up(prev) + [ (a_hi - up(a_lo)) * m + (b_hi - up(b_lo)) * (1 - m) ]
+// = the Laplacian levels of A and B, their mask-weighted mix (la*gm + lb*(1-gm)) and the reconstruction step (multi_band_blending.py:27-46).
+__global__ __launch_bounds__(256) void pyr_blend_level_kernel(float* __restrict__ out, const float* __restrict__ prev, const float* __restrict__ a_hi,
+                                                              const float* __restrict__ a_lo, const float* __restrict__ b_hi,
+                                                              const float* __restrict__ b_lo, const float* __restrict__ m_hi, int h, int w) {
+    const int ow = 2 * w, oh = 2 * h;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= oh * ow) return;
+    const int Y = i / ow, X = i - Y * ow;
+    int yi[3], xi[3];
+    float yw[3], xw[3];
+    pyr_up_taps(Y, h, yi, yw);
+    pyr_up_taps(X, w, xi, xw);
+    const size_t lo = (size_t)blockIdx.y * h * w;
+    float up_p = 0.f, up_a = 0.f, up_b = 0.f;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const size_t r = lo + (size_t)yi[u] * w;
+        up_p += yw[u] * (xw[0] * prev[r + xi[0]] + xw[1] * prev[r + xi[1]] + xw[2] * prev[r + xi[2]]);
+        up_a += yw[u] * (xw[0] * a_lo[r + xi[0]] + xw[1] * a_lo[r + xi[1]] + xw[2] * a_lo[r + xi[2]]);
+        up_b += yw[u] * (xw[0] * b_lo[r + xi[0]] + xw[1] * b_lo[r + xi[1]] + xw[2] * b_lo[r + xi[2]]);
+    }
+    const size_t o = (size_t)blockIdx.y * oh * ow + i;
+    const float la = a_hi[o] - up_a * (1.f / 64.f), lb = b_hi[o] - up_b * (1.f / 64.f);
+    const float mv = m_hi[o];
+    out[o] = up_p * (1.f / 64.f) + (la * mv + lb * (1.f - mv));      // the reference's form: exact at mask 0 and 1
+}
+
 }  // namespace
+
+extern "C" int e4s_pyr_blend_level(float* out, const float* prev, const float* a_hi, const float* a_lo, const float* b_hi, const float* b_lo,
+                                   const float* m_hi, int planes, int h, int w, void* stream) {
+    E4S_REQUIRE(out && prev && a_hi && a_lo && b_hi && b_lo && m_hi, "pyr_blend_level: null tensor");
+    E4S_REQUIRE(planes >= 0 && planes <= 65535 && h >= 1 && w >= 1 && (int64_t)h * w < ((int64_t)1 << 28), "pyr_blend_level: bad size");
+    if (planes == 0) return 0;
+    hipLaunchKernelGGL(pyr_blend_level_kernel, dim3(cdiv(4 * h * w, 256), planes), dim3(256), 0, (hipStream_t)stream, out, prev, a_hi, a_lo, b_hi, b_lo,
+                       m_hi, h, w);
+    return check_launch("pyr_blend_level");
+}
 
 extern "C" int e4s_pyr_down(float* out, const float* in, int planes, int h, int w, int round_u8, void* stream) {
     E4S_REQUIRE(out && in, "pyr_down: null tensor");

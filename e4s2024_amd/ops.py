@@ -1176,8 +1176,12 @@ def laplacian_blend(a_u8: torch.Tensor, b: torch.Tensor, mask: torch.Tensor, num
         gpa.append(ga); gpb.append(gb); gpm.append(gm)
     out = torch.lerp(gpb[-1], gpa[-1], gpm[-1])                                    # la*gm + lb*(1-gm) at the coarsest level
     for i in range(num_levels - 1, 0, -1):
-        la, lb = pyr_up(gpa[i], minuend=gpa[i - 1]), pyr_up(gpb[i], minuend=gpb[i - 1])
-        out = pyr_up(out, addend=torch.lerp(lb, la, gpm[i - 1]))
+        # Laplacian levels of A and B, their masked mix and the reconstruction step in one pass (10 -> 4 plane sets of traffic per level)
+        hi, lo = gpa[i - 1], gpa[i]
+        nxt = torch.empty_like(hi)
+        lib().call("e4s_pyr_blend_level", _p(nxt), _p(out), _p(hi), _p(lo), _p(gpb[i - 1]), _p(gpb[i]), _p(gpm[i - 1]),
+                   lo.numel() // (lo.shape[-2] * lo.shape[-1]), lo.shape[-2], lo.shape[-1], _stream())
+        out = nxt
     return out
 
 

@@ -292,6 +292,10 @@ E4S_API int e4s_swap_head_mask(uint8_t* res, uint8_t* hole_mask, uint8_t* hole_m
  *                  up = zero insertion convolved with 4x the same kernel (OpenCV's border rule for the last source pixel) */
 E4S_API int e4s_pyr_down(float* out, const float* in, int planes, int h, int w, int round_u8, void* stream);
 E4S_API int e4s_pyr_up(float* out, const float* in, const float* minuend, const float* addend, int planes, int h, int w, void* stream);
+/* One level of the blend (multi_band_blending.py:27-46) in one pass over [planes, 2h, 2w]: with la = a_hi - up(a_lo), lb = b_hi - up(b_lo),
+ * out = up(prev) + la*m_hi + lb*(1 - m_hi);  *_lo and prev are [planes, h, w], *_hi [planes, 2h, 2w]. */
+E4S_API int e4s_pyr_blend_level(float* out, const float* prev, const float* a_hi, const float* a_lo, const float* b_hi, const float* b_lo,
+                                const float* m_hi, int planes, int h, int w, void* stream);
 E4S_API int e4s_foreground_masks(float* content, float* border, float* full, const uint8_t* swapped, const uint8_t* hole_mask,
                                  int bs, int h, int w, int radius, void* stream);
 
