@@ -32,6 +32,7 @@ _PROTOS = {
     "e4s_swap_head_mask": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
     "e4s_foreground_masks": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_pyr_down": [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr],
+    "e4s_resample_u8": [c_ptr] * 5 + [c_int] * 7 + [c_ptr],
     "e4s_pyr_blend_level": [c_ptr] * 7 + [c_int, c_int, c_int, c_ptr],
     "e4s_pyr_up": [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
     "e4s_mconv_unfold": [c_ptr] * 4 + [c_int] * 7 + [c_ptr],

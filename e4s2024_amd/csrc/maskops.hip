@@ -232,7 +232,43 @@ __global__ __launch_bounds__(256) void pyr_blend_level_kernel(float* __restrict_
     out[o] = up_p * (1.f / 64.f) + (la * mv + lb * (1.f - mv));      // the reference's form: exact at mask 0 and 1
 }
 
+// One pass of Pillow's 8-bit resampler (src/libImaging/Resample.c: ImagingResampleHorizontal_8bpc / Vertical_8bpc) over a uint8
+// [bs, H, W, C] image: out = clip8((2^21 + sum_j k[o][j] * in[xmin[o] + j]) >> 22) along `axis` (1 = width, 0 = height), integer arithmetic.
+__global__ __launch_bounds__(256) void resample_u8_kernel(uint8_t* __restrict__ out, const uint8_t* __restrict__ in, const int* __restrict__ xmin,
+                                                          const int* __restrict__ cnt, const int* __restrict__ kk, int ksize, int h, int w, int c,
+                                                          int out_size, int axis) {
+    const int oh = axis == 0 ? out_size : h, ow = axis == 1 ? out_size : w;
+    const int64_t n = (int64_t)oh * ow * c;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int ch = (int)(i % c);
+    const int x = (int)((i / c) % ow), y = (int)(i / ((int64_t)c * ow));
+    const int o = axis == 1 ? x : y;
+    const int lo = xmin[o], m = cnt[o];
+    const int* k = kk + (size_t)o * ksize;
+    const uint8_t* ip = in + (size_t)blockIdx.y * h * w * c;
+    const size_t step = axis == 1 ? (size_t)c : (size_t)w * c;
+    const uint8_t* src = axis == 1 ? ip + ((size_t)y * w + lo) * c + ch : ip + ((size_t)lo * w + x) * c + ch;
+    int acc = 1 << 21;
+    for (int j = 0; j < m; ++j) acc += k[j] * (int)src[j * step];
+    acc >>= 22;
+    out[(size_t)blockIdx.y * n + i] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+}
+
 }  // namespace
+
+extern "C" int e4s_resample_u8(uint8_t* out, const uint8_t* in, const int32_t* xmin, const int32_t* count, const int32_t* coeffs, int ksize, int bs,
+                               int h, int w, int c, int out_size, int axis, void* stream) {
+    E4S_REQUIRE(out && in && xmin && count && coeffs, "resample_u8: null tensor");
+    E4S_REQUIRE(bs >= 0 && bs <= 65535 && h >= 1 && w >= 1 && c >= 1 && c <= 4 && out_size >= 1 && ksize >= 1 && (axis == 0 || axis == 1),
+                "resample_u8: bad size");
+    if (bs == 0) return 0;
+    const int64_t n = (int64_t)(axis == 0 ? out_size : h) * (axis == 1 ? out_size : w) * c;
+    E4S_REQUIRE(n < ((int64_t)1 << 31), "resample_u8: output too large");
+    hipLaunchKernelGGL(resample_u8_kernel, dim3((unsigned)cdiv64(n, 256), bs), dim3(256), 0, (hipStream_t)stream, out, in, xmin, count, coeffs, ksize, h, w,
+                       c, out_size, axis);
+    return check_launch("resample_u8");
+}
 
 extern "C" int e4s_pyr_blend_level(float* out, const float* prev, const float* a_hi, const float* a_lo, const float* b_hi, const float* b_lo,
                                    const float* m_hi, int planes, int h, int w, void* stream) {

@@ -1137,6 +1137,62 @@ def single_styled_conv_grad(x, wmod, noise_weight, act_bias, noise, act, blur, o
     return _SingleStyledConvGrad.apply(x, wmod, noise_weight, act_bias, noise, act, blur, out)
 
 
+# ------------------------------------------------------------------------------------ f3: Pillow's resize on the device
+_pil_tables = {}
+
+
+def _pil_bicubic_tables(in_size: int, out_size: int, device):
+    """Pillow's ``precompute_coeffs`` + ``normalize_coeffs_8bpc`` for the BICUBIC filter (src/libImaging/Resample.c): per output index the
+    first input index, the tap count and the taps in 22-bit fixed point.  Computed once per (in, out, device) in float64 like the library."""
+    key = (in_size, out_size, str(device))
+    hit = _pil_tables.get(key)
+    if hit is None:
+        scale = in_size / out_size
+        fscale = max(scale, 1.0)
+        support = 2.0 * fscale
+        ksize = int(math.ceil(support)) * 2 + 1
+        xmin, cnt, kk = [], [], []
+        ss = 1.0 / fscale
+        for xx in range(out_size):
+            center = (xx + 0.5) * scale
+            lo = max(int(center - support + 0.5), 0)
+            hi = min(int(center + support + 0.5), in_size)
+            ws = []
+            for x in range(hi - lo):
+                t = abs((x + lo - center + 0.5) * ss)
+                ws.append(((1.5 * t - 2.5) * t * t + 1.0) if t < 1.0 else ((((t - 5.0) * t + 8.0) * t - 4.0) * -0.5 if t < 2.0 else 0.0))
+            tot = sum(ws)
+            if tot != 0.0:
+                ws = [v / tot for v in ws]
+            row = [int(-0.5 + v * (1 << 22)) if v < 0 else int(0.5 + v * (1 << 22)) for v in ws]
+            xmin.append(lo); cnt.append(hi - lo); kk.append(row + [0] * (ksize - len(row)))
+        hit = (torch.tensor(xmin, dtype=torch.int32, device=device), torch.tensor(cnt, dtype=torch.int32, device=device),
+               torch.tensor(kk, dtype=torch.int32, device=device), ksize)
+        if len(_pil_tables) > 32:
+            _pil_tables.clear()
+        _pil_tables[key] = hit
+    return hit
+
+
+def pil_resize(img_u8: torch.Tensor, size) -> torch.Tensor:
+    """``PIL.Image.resize(size)`` (size = (width, height); Pillow's default BICUBIC with its 8-bit fixed-point arithmetic) of uint8
+    ``[bs, H, W, C]`` frames on the device, bit for bit: a horizontal then a vertical pass, each rounded to 8 bits
+    (face_swap_video_pipeline.py:447 softens the swapped face with ``.resize((512, 512)).resize((1024, 1024))``)."""
+    if img_u8.dtype != torch.uint8 or img_u8.dim() != 4 or not img_u8.is_cuda:
+        raise ValueError("pil_resize: uint8 [bs, H, W, C] CUDA frames")
+    wd, ht = int(size[0]), int(size[1])
+    out = img_u8.contiguous()
+    for axis, target in ((1, wd), (0, ht)):
+        bs, h, w, c = out.shape
+        if target == (w if axis == 1 else h):
+            continue
+        xmin, cnt, kk, ksize = _pil_bicubic_tables(w if axis == 1 else h, target, out.device)
+        nxt = torch.empty((bs, h, target, c) if axis == 1 else (bs, target, w, c), dtype=torch.uint8, device=out.device)
+        lib().call("e4s_resample_u8", _p(nxt), _p(out), _p(xmin), _p(cnt), _p(kk), ksize, bs, h, w, c, target, axis, _stream())
+        out = nxt
+    return out
+
+
 # ------------------------------------------------------------------------------------ f3: multi-band blend
 def pyr_down(x: torch.Tensor, round_u8: bool = False) -> torch.Tensor:
     """``cv2.pyrDown`` on ``[..., H, W]`` float planes (``round_u8``: the 8-bit variant's rounding, for a pyramid of a uint8 image)."""

@@ -127,20 +127,22 @@ def swap_batch(net, parser, driven: torch.Tensor, target: torch.Tensor, comp_ind
 
 
 @torch.no_grad()
-def paste_back(swapped_u8: torch.Tensor, target_u8: torch.Tensor, content: torch.Tensor, border: torch.Tensor) -> torch.Tensor:
-    """The reference's "past back" of a swapped face into its target crop (face_swap_video_pipeline.py:464-473), on the device:
+def paste_back(swapped_u8: torch.Tensor, target_u8: torch.Tensor, content: torch.Tensor, border: torch.Tensor, soften: bool = True) -> torch.Tensor:
+    """The reference's "past back" of a swapped face into its target crop (face_swap_video_pipeline.py:447, 464-473), on the device:
 
+        swapped -> PIL resize to 512 x 512 and back to 1024 x 1024 (default BICUBIC; ``soften``, :447), bit-exact with Pillow
         content, border -> bilinear to the frame size (align_corners=False)
         pasted = swapped * content + T * (1 - content)
         out    = blending(T, pasted, mask=border)             (swap_face_fine/multi_band_blending.py:51-74, ten pyramid levels)
 
     ``swapped_u8`` / ``target_u8``: uint8 ``[bs, 1024, 1024, 3]`` (what ``swap_batch`` returns / the aligned target crop); ``content`` /
     ``border``: float ``[bs, 1, h, w]`` from ``swap_batch(..., mask_surgery=True)``.  Returns uint8 ``[bs, 1024, 1024, 3]``.
-    (The reference round-trips the swapped face through a 512 x 512 PIL resize first, :447 — a bilinear-with-antialias filter that is
-    not restated here; pass the frame already treated that way if that softening is wanted.)"""
+    """
     if swapped_u8.dtype != torch.uint8 or target_u8.dtype != torch.uint8 or swapped_u8.shape != target_u8.shape or swapped_u8.shape[-1] != 3:
         raise ValueError("paste_back: swapped and target frames are uint8 [bs, H, W, 3] of the same shape")
     bs, h, w, _ = swapped_u8.shape
+    if soften:
+        swapped_u8 = ops.pil_resize(ops.pil_resize(swapped_u8, (512, 512)), (w, h))
     t = target_u8.permute(0, 3, 1, 2).contiguous()
     sw = swapped_u8.permute(0, 3, 1, 2).float()
     cm = ops.bilinear_resize(content.float().contiguous(), (h, w), align_corners=False)

@@ -284,6 +284,12 @@ E4S_API int e4s_tensor2im_u8(uint8_t* out, const float* img, int bs, int h, int 
  *   content (may be NULL), border, full : float32 [bs, 1, h, w] in {0, 1};  hole_mask may be NULL. */
 E4S_API int e4s_swap_head_mask(uint8_t* res, uint8_t* hole_mask, uint8_t* hole_map, int32_t* lines, const uint8_t* source,
                                const uint8_t* target, int32_t* scratch, int bs, int h, int w, void* stream);
+/* One pass of Pillow's 8-bit image resampler (PIL.Image.resize, src/libImaging/Resample.c) — the reference softens every swapped face with
+ * `.resize((512, 512)).resize((1024, 1024))` (face_swap_video_pipeline.py:447, default filter BICUBIC) — on uint8 [bs, h, w, c] images:
+ * along axis 1 (width) or 0 (height), out[o] = clip8((2^21 + sum_{j < count[o]} coeffs[o*ksize + j] * in[xmin[o] + j]) >> 22).
+ * The tables are Pillow's precompute_coeffs + normalize_coeffs_8bpc (22-bit fixed point), computed by the host (ops.pil_resize). */
+E4S_API int e4s_resample_u8(uint8_t* out, const uint8_t* in, const int32_t* xmin, const int32_t* count, const int32_t* coeffs, int ksize,
+                            int bs, int h, int w, int c, int out_size, int axis, void* stream);
 /* The two pyramid steps of the multi-band blend (swap_face_fine/multi_band_blending.py:5-48; cv2.pyrDown / cv2.pyrUp, OpenCV
  * modules/imgproc/src/pyramids.cpp) on float planes [planes, h, w]:
  *   e4s_pyr_down : out [planes, (h+1)/2, (w+1)/2] = 5x5 kernel [1 4 6 4 1]^2 / 256 at the even pixels, BORDER_REFLECT_101;

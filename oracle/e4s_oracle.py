@@ -622,3 +622,65 @@ def blending(full_img_u8: np.ndarray, ori_img: np.ndarray, mask: np.ndarray) -> 
     assert full_img_u8.shape[:2] == (1024, 1024) and ori_img.shape[:2] == (1024, 1024), "restated for the 1024 x 1024 call site"
     img = laplacian_blend(full_img_u8, ori_img.astype(np.float64), mask.astype(np.float32), 10)
     return np.clip(img, 0, 255).astype(np.uint8)
+
+
+# ------------------------------------------------------------------------------------ f3: PIL's default resize of the swapped face
+# face_swap_video_pipeline.py:447 — ``swapped_face_image.resize((512, 512)).resize((1024, 1024))`` — is Pillow's ``Image.resize`` with
+# its default filter for RGB images, BICUBIC (Pillow==10.1.0 in requirements.txt:134; src/libImaging/Resample.c, unchanged in the
+# Pillow 12 of this image).  Restated in integers exactly as the library computes it; PINNED: tests/test_oracle_golden.py compares it
+# with PIL itself on ragged sizes, up- and down-scaling.
+_PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def _pil_bicubic(x: np.ndarray) -> np.ndarray:
+    a = -0.5
+    x = np.abs(x)
+    return np.where(x < 1.0, ((a + 2.0) * x - (a + 3.0)) * x * x + 1.0, np.where(x < 2.0, (((x - 5.0) * x + 8.0) * x - 4.0) * a, 0.0))
+
+
+def pil_resample_coeffs(in_size: int, out_size: int):
+    """``precompute_coeffs`` + ``normalize_coeffs_8bpc`` (Resample.c) for the bicubic filter over the whole axis:
+    ``(xmin [out], count [out], k int32 [out, ksize])``."""
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    xmin = np.zeros(out_size, np.int32)
+    cnt = np.zeros(out_size, np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        lo = max(int(center - support + 0.5), 0)
+        hi = min(int(center + support + 0.5), in_size)
+        n = hi - lo
+        w = _pil_bicubic((np.arange(n) + lo - center + 0.5) * ss)
+        tot = w.sum()
+        if tot != 0.0:
+            w = w / tot
+        scaled = w * float(1 << _PIL_PRECISION_BITS)
+        kk[xx, :n] = np.where(w < 0, np.trunc(-0.5 + scaled), np.trunc(0.5 + scaled)).astype(np.int64)
+        xmin[xx], cnt[xx] = lo, n
+    return xmin, cnt, kk
+
+
+def _pil_resample_axis(img: np.ndarray, out_size: int, axis: int) -> np.ndarray:
+    xmin, cnt, kk = pil_resample_coeffs(img.shape[axis], out_size)
+    a = np.moveaxis(img, axis, 0).astype(np.int64)
+    out = np.empty((out_size,) + a.shape[1:], np.uint8)
+    for xx in range(out_size):
+        acc = np.tensordot(kk[xx, :cnt[xx]].astype(np.int64), a[xmin[xx]:xmin[xx] + cnt[xx]], axes=(0, 0)) + (1 << (_PIL_PRECISION_BITS - 1))
+        out[xx] = np.clip(acc >> _PIL_PRECISION_BITS, 0, 255)
+    return np.moveaxis(out, 0, axis)
+
+
+def pil_resize_bicubic(img_u8: np.ndarray, size) -> np.ndarray:
+    """``PIL.Image.fromarray(img).resize(size)`` (size = (width, height), default BICUBIC) of a uint8 ``[H, W, C]`` image: a horizontal then
+    a vertical pass, each rounded to 8 bits (ImagingResample)."""
+    wd, ht = size
+    out = img_u8
+    if wd != img_u8.shape[1]:
+        out = _pil_resample_axis(out, wd, 1)
+    if ht != img_u8.shape[0]:
+        out = _pil_resample_axis(out, ht, 0)
+    return out

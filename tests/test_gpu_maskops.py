@@ -117,7 +117,7 @@ def test_multi_band_blend_1024_against_the_oracle():
 
 
 def test_paste_back_chain_against_the_oracle():
-    """pipeline.paste_back = reference :464-473 — masks resized bilinearly (align_corners=False), alpha paste, ten-level multi-band blend —
+    """pipeline.paste_back = reference :447, :464-473 — the swapped face softened through Pillow's 512 x 512 round trip, masks resized bilinearly (align_corners=False), alpha paste, ten-level multi-band blend —
     against the same chain on the CPU (torch interpolate + the oracle's blend)."""
     import torch.nn.functional as F
     from e4s2024_amd import pipeline
@@ -127,9 +127,25 @@ def test_paste_back_chain_against_the_oracle():
     lab = T(seeded.blocky_labels(5, 1, 12, 512, 16))
     content, border, _ = ops.foreground_masks(lab.to(DEV), None, 5)
     out = pipeline.paste_back(T(sw).to(DEV), T(tg).to(DEV), content, border).cpu().numpy()[0]
+    PIL = pytest.importorskip("PIL.Image")
+    sw = np.array(PIL.fromarray(sw[0]).resize((512, 512)).resize((1024, 1024)))[None]          # :447, Pillow itself
     cm = F.interpolate(content.cpu(), (1024, 1024), mode="bilinear", align_corners=False)[0, 0, :, :, None].numpy()
     bm = F.interpolate(border.cpu(), (1024, 1024), mode="bilinear", align_corners=False)[0, 0, :, :, None].numpy().repeat(3, -1)
     pasted = sw[0] * cm + tg[0] * (1 - cm)
     ref = O.blending(tg[0], pasted, bm)
     diff = np.abs(out.astype(np.int32) - ref.astype(np.int32))
     assert out.shape == ref.shape and diff.max() <= 1 and (diff > 0).mean() <= 2e-3, (diff.max(), (diff > 0).mean())
+
+
+def test_pil_resize_on_the_device_equals_pillow_bit_for_bit():
+    """ops.pil_resize (e4s_resample_u8) against Pillow itself: the reference's softening round trip 1024 -> 512 -> 1024 of the swapped face
+    (face_swap_video_pipeline.py:447) and ragged up / down sizes, batch 2."""
+    PIL = pytest.importorskip("PIL.Image")
+    rs = np.random.RandomState(4)
+    a = rs.randint(0, 256, (2, 1024, 1024, 3)).astype(np.uint8)
+    out = ops.pil_resize(ops.pil_resize(T(a).to(DEV), (512, 512)), (1024, 1024)).cpu().numpy()
+    for b in range(2):
+        assert np.array_equal(out[b], np.array(PIL.fromarray(a[b]).resize((512, 512)).resize((1024, 1024))))
+    for (h, w), (ow, oh) in [((37, 53), (20, 31)), ((50, 41), (123, 77)), ((9, 7), (3, 2)), ((64, 48), (64, 24))]:
+        x = rs.randint(0, 256, (1, h, w, 3)).astype(np.uint8)
+        assert np.array_equal(ops.pil_resize(T(x).to(DEV), (ow, oh)).cpu().numpy()[0], np.array(PIL.fromarray(x[0]).resize((ow, oh))))

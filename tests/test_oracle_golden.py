@@ -175,3 +175,22 @@ def test_g12_mask_surgery():
     for r in (0, 1, 3, 7):
         _, border, full = O.create_masks_expansion(m, r)
         assert (border == g[f"morph.r{r}.border"]).all() and (full == g[f"morph.r{r}.full"]).all(), r
+
+
+def test_pil_bicubic_resize_restatement_equals_pillow():
+    """Row f3, face_swap_video_pipeline.py:447: the oracle's integer restatement of ``PIL.Image.resize`` (default BICUBIC, Resample.c) equals
+    Pillow itself bit for bit — down, up, ragged, tiny — and the product's coefficient tables (ops._pil_bicubic_tables, sequential sums as
+    in the C code) equal the oracle's."""
+    PIL = pytest.importorskip("PIL.Image")
+    import torch
+    from e4s2024_amd import ops
+    rs = np.random.RandomState(0)
+    for (h, w), (ow, oh) in [((37, 53), (20, 31)), ((64, 64), (32, 32)), ((32, 32), (64, 64)), ((50, 41), (123, 77)), ((9, 7), (3, 2)),
+                             ((128, 96), (128, 48)), ((5, 5), (5, 5))]:
+        a = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        ref = np.array(PIL.fromarray(a).resize((ow, oh)))
+        assert np.array_equal(O.pil_resize_bicubic(a, (ow, oh)), ref), ((h, w), (ow, oh))
+    for n_in, n_out in [(1024, 512), (512, 1024), (53, 20), (41, 123)]:
+        xmin, cnt, kk = O.pil_resample_coeffs(n_in, n_out)
+        t_xmin, t_cnt, t_kk, ksize = ops._pil_bicubic_tables(n_in, n_out, torch.device("cpu"))
+        assert ksize == kk.shape[1] and np.array_equal(t_xmin.numpy(), xmin) and np.array_equal(t_cnt.numpy(), cnt) and np.array_equal(t_kk.numpy(), kk)
