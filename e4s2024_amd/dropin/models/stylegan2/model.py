@@ -408,8 +408,12 @@ class Generator(nn.Module):
     def get_latent(self, input):
         return self.style(input)
 
-    def forward(self, styles, structure_feats, mask, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
-                input_is_latent=False, noise=None, randomize_noise=True, use_structure_code=False):
+    def forward(self, *args, **kwargs):
+        with ops.one_forward():        # parameters do not change inside one pass: a trained layer's weights are re-laid out once per pass
+            return self._forward(*args, **kwargs)
+
+    def _forward(self, styles, structure_feats, mask, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
+                 input_is_latent=False, noise=None, randomize_noise=True, use_structure_code=False):
         if not input_is_latent:
             styles = [self.style(s) for s in styles]
 

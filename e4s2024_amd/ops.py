@@ -286,6 +286,23 @@ def _volatile(t: torch.Tensor) -> bool:
     return torch.is_grad_enabled() and t.requires_grad
 
 
+_forward_stamp = None      # identity of the Generator.forward in progress (None outside one)
+
+
+class one_forward:
+    """``with ops.one_forward():`` around one forward pass during which the parameters do not change: a trained layer's weights are then
+    prepared once in that pass even if several call sites ask for them (tables plan, layer, backward hand-over), instead of once per ask."""
+
+    def __enter__(self):
+        global _forward_stamp
+        self.prev, _forward_stamp = _forward_stamp, object()
+        return self
+
+    def __exit__(self, *exc):
+        global _forward_stamp
+        _forward_stamp = self.prev
+
+
 def invalidate_weight_caches(module: torch.nn.Module) -> int:
     """Drop every re-laid-out weight copy held by the drop-in modules under ``module`` (they are rebuilt by the next forward).  Needed only
     after writing parameters behind autograd's back between two ``no_grad`` forwards — ``p.data.copy_(...)``, an EMA update — which
@@ -305,10 +322,10 @@ class PreparedWeights:
     squared-sum table for demodulation), as fp32 (``wt``) or as split-bf16 slabs (``wt = (whi, wlo)``).  Rebuilt when the
     parameter (or blur buffer) changes version or storage, or the arithmetic mode changes."""
 
-    __slots__ = ("key", "wt", "wsq")
+    __slots__ = ("key", "wt", "wsq", "stamp")
 
     def __init__(self):
-        self.key, self.wt, self.wsq = None, None, None
+        self.key, self.wt, self.wsq, self.stamp = None, None, None, None
 
     def get(self, weight: torch.Tensor, blur: Optional[torch.Tensor], up: bool, demodulate: bool, tconv: bool = False):
         """``tconv``: slabs of the bare 3x3 weight of an up layer (for the transposed-conv + blur-epilogue pair)."""
@@ -317,6 +334,8 @@ class PreparedWeights:
             up, blur = False, None
         key = (weight.data_ptr(), weight._version, weight.device, None if blur is None else (blur.data_ptr(), blur._version), up, demodulate, sb)
         if _volatile(weight):
+            if _forward_stamp is not None and self.stamp is _forward_stamp and self.wt is not None and self.key == ("volatile",) + key:
+                return self.wt, self.wsq          # prepared earlier in this very forward pass
             self.key = None
         if key != self.key:
             w = _c(weight.detach(), "weight")
@@ -335,7 +354,9 @@ class PreparedWeights:
             else:
                 wt = torch.empty((npar, cin, k * k, cout), dtype=torch.float32, device=w.device)
                 lib().call("e4s_modconv_prep_weights", _p(wt), _p(wsq), _p(w), _p(bk), cout, cin, k, 1 if up else 0, _stream())
-            self.key, self.wt, self.wsq = (None if _volatile(weight) else key), wt, wsq
+            vol = _volatile(weight)
+            self.key, self.wt, self.wsq = ((("volatile",) + key) if (vol and _forward_stamp is not None) else (None if vol else key)), wt, wsq
+            self.stamp = _forward_stamp if vol else None
         return self.wt, self.wsq
 
 
