@@ -869,6 +869,11 @@ def _mconv_scale(gy, out, d, lab, nreg: int, up: int = 1, want_q: bool = False, 
     return (gz,) + tuple(None if t is None else (t.sum(0) if nchunk > 1 else t[0]) for t in (q, dbias, dnw))
 
 
+def _sum_dim(t, dim: int):
+    """``t.sum(dim)`` without a launch when that dimension has one element (batch 1 is the PTI case)."""
+    return t.select(dim, 0) if t.shape[dim] == 1 else t.sum(dim)
+
+
 def _gemm_nt(a, b):
     """``a [..., M, K] @ b [..., N, K]ᵀ``.  A long reduction (K = all the pixels of a layer) with a small M x N goes to the library as a
     batch of K-chunks — a single GEMM would use a handful of workgroups (measured: 1.13 -> 0.36 ms for 32 x 1M x 288)."""
@@ -907,7 +912,7 @@ def _mconv_input_grads(gz, wg, x, s, lab, up: int, need_x: bool, need_s: bool, n
             ds = part.sum(0) if nchunk > 1 else part[0]
     if need_w:
         cols = _mconv_unfold(x, s, lab, ks, up)
-        dw = _gemm_nt(gz, cols).sum(1).view_as(wg)
+        dw = _sum_dim(_gemm_nt(gz, cols), 1).view_as(wg)
     return dx, ds, dw
 
 
@@ -989,7 +994,7 @@ class _MaskedStyledConvGrad(torch.autograd.Function):
                                          act=ctx.act, want_sums=True)
         dx, ds, dw = _mconv_input_grads(gz, wg, x, s, lab, ctx.up, need_x, need_s, need_w)
         g_nw = dnw.sum().view_as(nw) if (need_nw and dnw is not None) else None
-        g_b = dbias.sum(0).view_as(bias) if (need_b and bias is not None) else None
+        g_b = _sum_dim(dbias, 0).view_as(bias) if (need_b and bias is not None) else None
         return dx, dw, ds, None if q is None else q / d, g_nw, g_b, None, None, None, None
 
 
@@ -1069,7 +1074,7 @@ class _ToRGBGrad(torch.autograd.Function):
         g = grad.contiguous()
         gz, _, dbias, _ = _mconv_scale(g, None, None, lab, s.shape[1], 1, want_sums=True)
         dx, ds, dw = _mconv_input_grads(gz, wg, x, s, lab, 1, need_x, need_s, need_w)
-        g_b = dbias.sum(0).view(ctx.bias_shape) if (need_b and ctx.bias_shape is not None) else None
+        g_b = _sum_dim(dbias, 0).view(ctx.bias_shape) if (need_b and ctx.bias_shape is not None) else None
         g_skip = None
         if need_skip and ctx.skip_shape is not None:      # transpose of upfirdn2d(skip, k, up=2, pad=(2,1)) (op/upfirdn2d.py:100-105)
             g_skip = upfirdn2d_raw(g, torch.flip(up_kernel, (0, 1)), (1, 1), (2, 2), (1, 1, 1, 1)).view(ctx.skip_shape)
@@ -1150,7 +1155,7 @@ class _SingleStyledConvGrad(torch.autograd.Function):
             dx = dxm if want_dx else dx
             dw = dwm if want_dw else dw
         g_nw = dnw.sum().view_as(nw) if (need_nw and dnw is not None) else None
-        g_b = dbias.sum(0).view_as(bias) if (need_b and bias is not None) else None
+        g_b = _sum_dim(dbias, 0).view_as(bias) if (need_b and bias is not None) else None
         return None if dx is None else dx.view_as(x), dw, g_nw, g_b, None, None, None, None
 
 
