@@ -443,8 +443,10 @@ class Generator(nn.Module):
         if latent.ndim == 4 and latent.is_cuda:
             ops.style_demod_plan(self._table_jobs(latent))     # every layer's modulation / demodulation table in two launches
         out = self.input(latent)
-        out = self.conv1(out, latent[:, :, 0], mask, noise=noise[0])
-        skip = self.to_rgb1(out, latent[:, :, 1], mask)
+        # one view per W+ index: under autograd the 18 views are one unbind (its backward one stack), not 26 zero-filled slice gradients
+        lat = latent.unbind(2) if latent.ndim == 4 else None
+        out = self.conv1(out, lat[0] if lat is not None else latent[:, :, 0], mask, noise=noise[0])
+        skip = self.to_rgb1(out, lat[1] if lat is not None else latent[:, :, 1], mask)
 
         intermediate_feats = None
         # Channels-last chain (inference): from the last layer before the single-region stages on, activations stay [bs, H, W, C] between the
@@ -462,7 +464,10 @@ class Generator(nn.Module):
         for j, to_rgb in enumerate(self.to_rgbs):
             i = 2 * j + 1                      # W+ index shared by to_rgbs[j-1] and this resolution's up-conv
             per_region = i < rli               # reference :670 — below it every layer receives one code per region
-            code = (lambda k: latent[:, :, k]) if per_region else (lambda k: latent[:, 0, k])
+            if lat is not None:
+                code = (lambda k: lat[k]) if per_region else (lambda k: lat[k][:, 0])
+            else:
+                code = (lambda k: latent[:, :, k]) if per_region else (lambda k: latent[:, 0, k])
             conv2 = self.convs[2 * j + 1]
             # this stage's second conv can take channels-last input iff it is a single-region layer whose ToRGB rides in its epilogue
             c2_fused = ((not per_region or (rli != 17 and i + 2 == rli)) and not to_rgb.mask_op and tuple(to_rgb.upsample.kernel.shape) == (4, 4)
@@ -487,13 +492,16 @@ class Generator(nn.Module):
                 # (the last layer's own activation is consumed by nothing but this ToRGB: it is not written)
                 last = j + 1 == len(self.to_rgbs)
                 nhwc_out = (not last) and up_takes_nhwc(j + 1) and conv2.conv.out_channel % 4 == 0
-                out, skip = conv2(out, code(i + 1), mask, noise=noise[2 + 2 * j], _fused_rgb=(to_rgb, latent[:, 0, i + 2], skip),
+                out, skip = conv2(out, code(i + 1), mask, noise=noise[2 + 2 * j], _fused_rgb=(to_rgb, lat[i + 2][:, 0] if lat is not None else latent[:, 0, i + 2], skip),
                                   _want_out=not last, _x_nhwc=nhwc, _out_nhwc=nhwc_out)
                 nhwc = nhwc_out
             else:
                 assert not nhwc, "channels-last activation reached a layer that cannot read it"
                 out = conv2(out, code(i + 1), mask, noise=noise[2 + 2 * j])
-                skip = to_rgb(out, latent[:, 0, i + 2] if single else latent[:, :, i + 2], mask, skip)
+                if lat is not None:
+                    skip = to_rgb(out, lat[i + 2][:, 0] if single else lat[i + 2], mask, skip)
+                else:
+                    skip = to_rgb(out, latent[:, 0, i + 2] if single else latent[:, :, i + 2], mask, skip)
 
         ops._table_plan.clear()
         image = skip
