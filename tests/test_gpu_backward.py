@@ -344,3 +344,26 @@ def test_weights_updated_behind_the_version_counter_are_seen_by_the_next_forward
         fresh = build(gen.state_dict())([codes], None, mask, input_is_latent=True, randomize_noise=False)[0]
     assert (after - before).abs().max().item() > 1e-3            # the update did change the image
     assert torch.equal(after, fresh)
+
+
+def test_trained_weights_are_prepared_once_per_forward_and_never_reused_across_forwards(sg2):
+    """``ops.one_forward``: inside one pass several call sites share one re-laid-out copy of a trained weight; the next pass (the weights may
+    have been written behind the version counter in between) builds a new one; outside a pass nothing is shared."""
+    from e4s2024_amd import ops
+    conv = sg2.ModulatedConv2d(32, 32, 3, 512).to(DEV)
+    assert conv.weight.requires_grad
+    with ops.one_forward():
+        a = conv._weights(True)
+        b = conv._weights(True)
+        assert a[0][0] is b[0][0] and a[1] is b[1]
+    with torch.no_grad():
+        conv.weight.data.mul_(2.0)                      # no version bump
+    with ops.one_forward():
+        c = conv._weights(True)
+    assert c[0][0] is not a[0][0]
+    assert torch.allclose(c[1], a[1] * 4.0, rtol=1e-5)  # wsq of the doubled weight
+    d, e = conv._weights(True), conv._weights(True)     # outside a pass: rebuilt on every ask
+    assert d[0][0] is not e[0][0]
+    with torch.no_grad():                               # inference: ordinary version-keyed caching
+        f, g = conv._weights(True), conv._weights(True)
+    assert f[0][0] is g[0][0]
