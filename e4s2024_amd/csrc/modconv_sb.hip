@@ -140,8 +140,14 @@ struct SbCfg {
     static constexpr int TN = WC * CB * 32;
     static constexpr int NPB = WP * PB;
     static constexpr int TW = 1 << LOG_TW;
-    static constexpr int RPB = 32 >> LOG_TW;
-    static constexpr int TH = NPB * RPB;
+    static constexpr int RPB = 32 >> LOG_TW;                // tile rows per 32-pixel MFMA block (tiles up to 32 wide)
+    static constexpr int BPR = TW > 32 ? TW / 32 : 1;       // 32-pixel blocks per tile row (64-wide tiles: a row segment of 66 pixels costs
+                                                            // 3 cache lines per channel for 264 B instead of 3 for 136 B)
+    static constexpr int TH = TW > 32 ? NPB / BPR : NPB * RPB;
+    static_assert(TW <= 32 || NPB % BPR == 0, "whole rows only");
+    // tile coordinates of lane l5 (0..31) of pixel block pbk
+    __host__ __device__ static constexpr int blk_y(int pbk, int l5) { return TW > 32 ? pbk / BPR : pbk * RPB + (l5 >> LOG_TW); }
+    __host__ __device__ static constexpr int blk_x(int pbk, int l5) { return TW > 32 ? (pbk % BPR) * 32 + l5 : (l5 & (TW - 1)); }
     static constexpr int PW = TW + 2, PH = TH + 2;
     static constexpr int PATCH = PH * PW;
     static constexpr int NT = 64 * WC * WP;                 // threads per workgroup (256 or 512)
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
         const int pbk = wp * PB + q;
-        const int ty = pbk * C::RPB + (l5 >> LOG_TW), tx = l5 & (C::TW - 1);
+        const int ty = C::blk_y(pbk, l5), tx = C::blk_x(pbk, l5);
         xoff[q] = ty * C::PW + tx;
         const int y = y0 + ty, x = x0 + tx;
         int c = 0;
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
 #pragma unroll
         for (int q = 0; q < PB; ++q) {
             const int pbk = wp * PB + q;
-            const int a = y0 + pbk * C::RPB + (l5 >> LOG_TW), bb = x0 + (l5 & (C::TW - 1));
+            const int a = y0 + C::blk_y(pbk, l5), bb = x0 + C::blk_x(pbk, l5);
 #pragma unroll
             for (int cl = 0; cl < 4; ++cl) {
                 const int zy = 2 * a + (cl >> 1), zx = 2 * bb + (cl & 1);
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
 #pragma unroll
         for (int q = 0; q < PB; ++q) {
             const int pbk = wp * PB + q;
-            const int y = y0 + pbk * C::RPB + (l5 >> LOG_TW), x = x0 + (l5 & (C::TW - 1));
+            const int y = y0 + C::blk_y(pbk, l5), x = x0 + C::blk_x(pbk, l5);
             if (y >= p.h || x >= p.w) continue;
             const size_t opix = (size_t)(p.up ? 2 * y + pa : y) * wo + (p.up ? 2 * x + pb_ : x);
 #pragma unroll
@@ -502,7 +508,7 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
         const int pbk = wp * PB + q;
-        const int y = y0 + pbk * C::RPB + (l5 >> LOG_TW), x = x0 + (l5 & (C::TW - 1));
+        const int y = y0 + C::blk_y(pbk, l5), x = x0 + C::blk_x(pbk, l5);
         const int oy = p.up ? 2 * y + pa : y, ox = p.up ? 2 * x + pb_ : x;
         nzq[q] = (p.noise && y < p.h && x < p.w) ? nw * p.noise[(size_t)b * p.noise_bstride + (size_t)oy * wo + ox] : 0.f;
     }
@@ -511,7 +517,7 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
 #pragma unroll
         for (int q = 0; q < PB; ++q) {
             const int pbk = wp * PB + q;
-            const int oy = y0 + pbk * C::RPB + (l5 >> LOG_TW), ox = x0 + (l5 & (C::TW - 1));   // fused ToRGB runs on same-resolution layers only
+            const int oy = y0 + C::blk_y(pbk, l5), ox = x0 + C::blk_x(pbk, l5);   // fused ToRGB runs on same-resolution layers only
             const bool ok = oy < p.h && ox < p.w;
             const int hs = ho >> 1, wsk = wo >> 1;
 #pragma unroll
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
         const int pbk = wp * PB + q;
-        const int y = y0 + pbk * C::RPB + (l5 >> LOG_TW), x = x0 + (l5 & (C::TW - 1));
+        const int y = y0 + C::blk_y(pbk, l5), x = x0 + C::blk_x(pbk, l5);
         const bool pix_ok = y < p.h && x < p.w;
         const int oy = p.up ? 2 * y + pa : y, ox = p.up ? 2 * x + pb_ : x;
         const size_t opix = (size_t)oy * wo + ox;
@@ -736,6 +742,15 @@ extern "C" int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16
     const int64_t wf = p.out_nhwc ? 0 : workspace_floats;
     if (w >= 32) {
         static const int wide = [] { const char* e = getenv("E4S_SB_WIDE"); return e ? atoi(e) : 1; }();
+        // 64 x 4 instead of 32 x 8 pixel tiles (bit 0: single-region layers, bit 1: masked layers): a 66-pixel patch row costs three cache
+        // lines per channel like a 34-pixel one.  Tile-read probe: 1.8 -> 2.5-2.9 TB/s; in the pipeline (inputs partly cache-resident)
+        // the 1024x1024 / 512x512 layers gain 3.5 % / 2.5 %, the masked layers nothing measurable: on for the single-region layers.
+        static const int tw64 = [] { const char* e = getenv("E4S_SB_TW64"); return e ? atoi(e) : 1; }();
+        if (w >= 64 && !labels && (tw64 & 1)) {
+            if (cout > 32) return launch_sb<2, 2, 1, 4, 6>(p, st, ws, wf);   // 64 co x (64 x 4) px
+            return launch_sb<1, 2, 1, 4, 6>(p, st, ws, wf);                  // 32 co x (64 x 4) px
+        }
+        if (w >= 64 && wide && labels && cout >= 128 && (tw64 & 2)) return launch_sb<4, 1, 1, 8, 6>(p, st, ws, wf);
         if (wide && labels && cout >= 128) return launch_sb<4, 1, 1, 8, 5>(p, st, ws, wf);   // 512 threads: 128 co x 256 px; on masked layers
                                                                                               // the on-the-fly split of B feeds 12 MFMAs, not 6
         if (cout > 32) return launch_sb<2, 2, 1, 4, 5>(p, st, ws, wf);   // 64 co x 256 px

@@ -7,6 +7,25 @@
 
 constexpr int TW = 32, TH = 8, PW = TW + 2, PH = TH + 2, PATCH = PW * PH, NT = 256, CKS = 16;
 
+// channels-first with other tile shapes of the same 256 pixels (wider rows waste less of each 128-byte line on the halo)
+template <int W_, int H_>
+__global__ __launch_bounds__(NT) void read_nchw_shape(float* out, const float* x, int C, int H, int W) {
+    constexpr int pw = W_ + 2, ph = H_ + 2;
+    const int tx = blockIdx.x % (W / W_), ty = blockIdx.x / (W / W_), b = blockIdx.y;
+    const float* xb = x + (size_t)b * C * H * W;
+    float acc = 0.f;
+    for (int c0 = 0; c0 < C; c0 += CKS) {
+        for (int e = threadIdx.x; e < pw * ph; e += NT) {
+            const int py = e / pw, px = e - py * pw;
+            int gy = ty * H_ - 1 + py, gx = tx * W_ - 1 + px;
+            gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy); gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+#pragma unroll
+            for (int c = 0; c < CKS; ++c) acc += xb[(size_t)(c0 + c) * H * W + gy * W + gx];
+        }
+    }
+    out[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NT + threadIdx.x] = acc;
+}
+
 // channels-first: thread <-> patch pixel, 16 dword loads per pixel and chunk (one per channel plane)
 // xcd != 0: workgroups are dealt round-robin to the 8 XCDs (each with its own L2); renumber so that every XCD walks one contiguous band of tiles
 __device__ __forceinline__ int tile_of(int id, int ntile, int xcd) {
@@ -78,6 +97,20 @@ int main() {
                 printf("%s%3d ch @ %4d^2 bs %d, %s, %d channels per load phase: %.3f ms = %.2f TB/s of algorithmic bytes (%.0f MB)\n", xcd ? "XCD-banded " : "linear     ", C, H, bs,
                        layout ? "channels-last " : "channels-first", CKS * depth, best, n * 4 / (best * 1e-3) / 1e12, n * 4 / 1e6);
             }
+        for (int shape = 0; shape < 3; ++shape) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 5; ++rep) {
+                hipEventRecord(e0, 0);
+                if (shape == 0) hipLaunchKernelGGL((read_nchw_shape<64, 4>), dim3((H / 4) * (W / 64), bs), dim3(NT), 0, 0, out, x, C, H, W);
+                if (shape == 1) hipLaunchKernelGGL((read_nchw_shape<128, 2>), dim3((H / 2) * (W / 128), bs), dim3(NT), 0, 0, out, x, C, H, W);
+                if (shape == 2) hipLaunchKernelGGL((read_nchw_shape<16, 16>), dim3((H / 16) * (W / 16), bs), dim3(NT), 0, 0, out, x, C, H, W);
+                hipEventRecord(e1, 0); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                best = ms < best ? ms : best;
+            }
+            printf("%3d ch @ %4d^2 bs %d, channels-first, tile %s: %.3f ms = %.2f TB/s of algorithmic bytes\n", C, H, bs,
+                   shape == 0 ? "64 x 4" : (shape == 1 ? "128 x 2" : "16 x 16"), best, n * 4 / (best * 1e-3) / 1e12);
+        }
         hipFree(x); hipFree(out);
     }
     return 0;
