@@ -408,9 +408,11 @@ class Generator(nn.Module):
     def get_latent(self, input):
         return self.style(input)
 
-    def forward(self, *args, **kwargs):
+    def forward(self, styles, structure_feats, mask, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
+                input_is_latent=False, noise=None, randomize_noise=True, use_structure_code=False):
         with ops.one_forward():        # parameters do not change inside one pass: a trained layer's weights are re-laid out once per pass
-            return self._forward(*args, **kwargs)
+            return self._forward(styles, structure_feats, mask, return_latents, inject_index, truncation, truncation_latent, input_is_latent,
+                                 noise, randomize_noise, use_structure_code)
 
     def _forward(self, styles, structure_feats, mask, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
                  input_is_latent=False, noise=None, randomize_noise=True, use_structure_code=False):
