@@ -122,7 +122,8 @@ struct SbParams {
     int noise_bstride;
     int act;
     int bs, cin, cout, h, w, nreg, up;
-    int x_nhwc, out_nhwc;    // channels-last activations [bs,h,w,c] (cin / cout multiples of 16 / 4): 16-byte loads and stores
+    int x_nhwc, out_nhwc;    // channel-blocked activations [bs, c/8, h, w, 8] (cin % 16 == 0 / cout % 8 == 0): a pixel's 8 channels are 32
+                             // contiguous bytes and consecutive pixels follow — 16-byte loads / stores that fill whole cache lines on both sides
     int tiles_x, tiles_y;
     int ksplit, chunks_per;  // split-K: block ks handles chunks [ks*chunks_per, (ks+1)*chunks_per)
     float* partial;
@@ -276,11 +277,12 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
     auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
         const int ci0 = chunk * CKS;
         const int cmax = p.cin - 1 - ci0;
-        if constexpr (XN) {   // channels-last: item = (patch pixel, 16-byte quarter of its 64-byte chunk); consecutive lanes read consecutive bytes
+        if constexpr (XN) {   // channel-blocked input: item = (patch pixel, 16-byte quarter of the chunk's 16 channels)
 #pragma unroll
             for (int j = 0; j < EPT4; ++j) {
                 const int it = tid + j * C::NT;
-                xq[j] = *reinterpret_cast<const float4*>(xb + (size_t)goffs4[j] * p.cin + ci0 + 4 * (it & 3));
+                // [bs][cin/8][h][w][8]: quarter q of the chunk = channels ci0 + 4q .. +3 -> block (ci0/8 + q/2), offset 4*(q&1) inside the pixel's 32 bytes
+                xq[j] = *reinterpret_cast<const float4*>(xb + ((size_t)(ci0 / 8 + ((it & 3) >> 1)) * hw + goffs4[j]) * 8 + 4 * (it & 3 & 1));
             }
         } else {
 #pragma unroll
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
                 }
                 const int co4 = co0 + (wc * CB + i) * 32 + 8 * r4 + 4 * khalf;      // four consecutive output channels of this pixel
                 if (p.out_nhwc && (!RGB || p.out) && pix_ok && co4 < p.cout)
-                    *reinterpret_cast<float4*>(p.out + ((size_t)b * ho * wo + opix) * p.cout + co4) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+                    *reinterpret_cast<float4*>(p.out + (((size_t)b * (p.cout / 8) + co4 / 8) * ho * wo + opix) * 8 + (co4 & 7)) = make_float4(v4[0], v4[1], v4[2], v4[3]);
             }
         }
         if constexpr (RGB) {  // WC == 1: this wave holds every output channel of its pixels, split over the two half-waves
@@ -730,8 +732,8 @@ extern "C" int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16
     p.out_nhwc = (layout & E4S_OUT_NHWC) ? 1 : 0;
     p.up = up;
     E4S_REQUIRE(!p.x_nhwc || (cin % 16 == 0 && ((uintptr_t)x & 15) == 0), "region_modconv3x3_sb: channels-last input needs cin %% 16 == 0 and a 16-byte aligned tensor");
-    E4S_REQUIRE(!p.out_nhwc || (out && cout % 4 == 0 && ((uintptr_t)out & 15) == 0 && w >= 32),
-                "region_modconv3x3_sb: channels-last output needs cout %% 4 == 0, a 16-byte aligned tensor and w >= 32 (no split-K)");
+    E4S_REQUIRE(!p.out_nhwc || (out && cout % 8 == 0 && ((uintptr_t)out & 15) == 0 && w >= 32),
+                "region_modconv3x3_sb: channel-blocked output needs cout %% 8 == 0, a 16-byte aligned tensor and w >= 32 (no split-K)");
     const int ho = up ? 2 * h : h, wo = up ? 2 * w : w;
     p.lscale_y = labels ? (float)lh / (float)ho : 1.f;
     p.lscale_x = labels ? (float)lw / (float)wo : 1.f;

@@ -35,7 +35,7 @@ struct UpFusedParams {
     int tiles_x, tiles_y;
     int exp;                 // tuning experiments of the -DE4S_PHASE_PROF build (E4S_UF_EXP): 1 = no output stores, 2 = no blur, 4 = no z-tile writes
 };
-// channels-last activations ([bs,h,w,c]) are compile-time variants: XN = input, ON = output (E4S_X_NHWC / E4S_OUT_NHWC in `act`)
+// channel-blocked activations ([bs, c/8, h, w, 8]) are compile-time variants: XN = input, ON = output (E4S_X_NHWC / E4S_OUT_NHWC in `act`)
 
 constexpr int UF_T = 16;                    // positions per tile side
 constexpr int UF_STEP = UF_T - 2;           // 14 new positions per tile
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
         if constexpr (XN) {
 #pragma unroll
             for (int j = 0; j < EPT4; ++j)
-                xq[j] = *reinterpret_cast<const float4*>(xb + (size_t)goff4[j] * p.cin + ci0 + 4 * ((tid + j * UF_NT) & 3));
+                xq[j] = *reinterpret_cast<const float4*>(xb + ((size_t)(ci0 / 8 + (((tid + j * UF_NT) & 3) >> 1)) * hw + goff4[j]) * 8 + 4 * ((tid + j * UF_NT) & 1));
         } else {
 #pragma unroll
             for (int c = 0; c < CKS; ++c) xr[c] = xb[(size_t)(ci0 + (c < cmax ? c : cmax)) * hw + sgoff];
@@ -285,7 +285,8 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
             if (nrow > 0 && co < p.cout) {
                 const float dd = ep_d[i * 32 + 8 * g + it_co], bi = ep_b[i * 32 + 8 * g + it_co];
                 const float neg = p.act ? 0.2f : 1.f, gain = p.act ? 1.41421356237309515f : 1.f;
-                const unsigned o0 = ON ? pix0 * (unsigned)p.cout + (unsigned)co : (unsigned)co * (unsigned)(ho * wo) + pix0;
+                // channel-blocked output [cout/8][ho][wo][8]: the 8 channels of this pass are one block, lanes (channel, x) write contiguous bytes
+                const unsigned o0 = ON ? ((unsigned)(co >> 3) * (unsigned)(ho * wo) + pix0) * 8u + (unsigned)(co & 7) : (unsigned)co * (unsigned)(ho * wo) + pix0;
                 // the 14 rows in two halves of 7: seven accumulators instead of fourteen (three z rows are read twice) — with fourteen the
                 // kernel spilled into scratch inside this loop, and a scratch access costs a global-memory round trip
                 constexpr int HR = UF_STEP / 2;
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
 #ifdef E4S_PHASE_PROF
                             if ((p.exp & 1) && v != 12345.678f) continue;
 #endif
-                            if constexpr (ON) ob[o0 + (unsigned)(ro * wo * p.cout)] = v;
+                            if constexpr (ON) ob[o0 + (unsigned)(ro * wo * 8)] = v;
                             else ob[o0 + (unsigned)(ro * wo)] = v;
                         }
                     }

@@ -260,7 +260,7 @@ class StyledConv(nn.Module):
         single-region ToRGB in this layer's epilogue and returns ``(out, rgb)``.  ``_x_nhwc`` / ``_out_nhwc`` (engine-internal): the
         activation comes in / goes out channels-last, ``[bs, H, W, C]``."""
         if _x_nhwc:
-            bs, H, W, _ = input.shape
+            bs, _, H, W, _ = input.shape          # channel-blocked [bs, C/8, H, W, 8]
         else:
             bs, _, H, W = input.shape
         H_out, W_out = (H * 2, W * 2) if self.conv.upsample else (H, W)
@@ -473,7 +473,7 @@ class Generator(nn.Module):
             conv2 = self.convs[2 * j + 1]
             # this stage's second conv can take channels-last input iff it is a single-region layer whose ToRGB rides in its epilogue
             c2_fused = ((not per_region or (rli != 17 and i + 2 == rli)) and not to_rgb.mask_op and tuple(to_rgb.upsample.kernel.shape) == (4, 4)
-                        and ops.can_fuse_rgb(conv2.conv.out_channel, out.shape[2 if nhwc else -1] * 2, False, conv2.mask_op))
+                        and ops.can_fuse_rgb(conv2.conv.out_channel, out.shape[3 if nhwc else -1] * 2, False, conv2.mask_op))
             c2_nhwc_in = chain and c2_fused and not conv2.mask_op and conv2.conv.accepts_nhwc(False) and ops.nhwc_link("c", j)
             if nhwc or c2_nhwc_in:
                 out = self.convs[2 * j](out, code(i), mask, noise=noise[1 + 2 * j], _x_nhwc=nhwc, _out_nhwc=c2_nhwc_in)
@@ -489,11 +489,11 @@ class Generator(nn.Module):
             needs_grad = torch.is_grad_enabled() and (out.requires_grad or latent.requires_grad or any(p.requires_grad for p in conv2.parameters())
                                                       or any(p.requires_grad for p in to_rgb.parameters()))
             if (single and not needs_grad and not to_rgb.mask_op and out.is_cuda and tuple(to_rgb.upsample.kernel.shape) == (4, 4)
-                    and ops.can_fuse_rgb(conv2.conv.out_channel, out.shape[2 if nhwc else -1], False, conv2.mask_op)):
+                    and ops.can_fuse_rgb(conv2.conv.out_channel, out.shape[3 if nhwc else -1], False, conv2.mask_op)):
                 # the single-region ToRGB rides in the conv's epilogue: the activation is not read back for the 1x1 conv
                 # (the last layer's own activation is consumed by nothing but this ToRGB: it is not written)
                 last = j + 1 == len(self.to_rgbs)
-                nhwc_out = (not last) and up_takes_nhwc(j + 1) and conv2.conv.out_channel % 4 == 0
+                nhwc_out = (not last) and up_takes_nhwc(j + 1) and conv2.conv.out_channel % 8 == 0
                 out, skip = conv2(out, code(i + 1), mask, noise=noise[2 + 2 * j], _fused_rgb=(to_rgb, lat[i + 2][:, 0] if lat is not None else latent[:, 0, i + 2], skip),
                                   _want_out=not last, _x_nhwc=nhwc, _out_nhwc=nhwc_out)
                 nhwc = nhwc_out

@@ -366,15 +366,16 @@ UP_TWO_STAGE = os.environ.get("E4S_UP_TWO_STAGE", "1") != "0"
 
 def modconv_up_single(x, wt, s, d, blur, noise, noise_weight, act_bias, act: bool, cout: int, x_nhwc: bool = False, out_nhwc: bool = False) -> torch.Tensor:
     """Single-region up layer: transposed conv (1x MACs) into a pre-blur buffer, then blur + demod + noise + bias + act.
-    ``x_nhwc`` / ``out_nhwc``: channels-last activations ``[bs, h, w, c]`` (fused kernel only)."""
+    ``x_nhwc`` / ``out_nhwc``: channel-blocked activations ``[bs, c/8, h, w, 8]`` (fused kernel only)."""
     x = _c(x, "input")
     if x_nhwc:
-        bs, h, w, cin = x.shape
+        bs, cb, h, w, _ = x.shape          # channel-blocked [bs, cin/8, h, w, 8]
+        cin = cb * 8
     else:
         bs, cin, h, w = x.shape
     if (x_nhwc or out_nhwc) and not (UP_FUSED and cin % 16 == 0 and cout % 8 == 0):
-        raise ValueError("channels-last activations need the fused up kernel, cin % 16 == 0 and cout % 8 == 0")
-    out = torch.empty((bs, 2 * h, 2 * w, cout) if out_nhwc else (bs, cout, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+        raise ValueError("channel-blocked activations need the fused up kernel, cin % 16 == 0 and cout % 8 == 0")
+    out = torch.empty((bs, cout // 8, 2 * h, 2 * w, 8) if out_nhwc else (bs, cout, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
     nz = nbs = None
     if noise is not None:
         nz = _c(noise, "noise")
@@ -477,16 +478,20 @@ def _workspace(device, floats: int) -> torch.Tensor:
 
 # Fusing the single-region ToRGB into the preceding conv's epilogue is correct but measured neutral on MI355X (the longer epilogue
 # costs what the separate HBM-bound ToRGB launch costs), so it is off by default.
-# Channels-last activations between the single-region layers of Generator.forward.  Off by default: measured in the pipeline (bench.py,
-# batch 4) the 1024x1024 / 512x512 convs gain 0.06 / 0.04 ms from reading channels-last, and the fused up-sampling kernel loses 0.08 ms
-# writing it (32-byte pieces of a pixel's line per blur pass) — 897 vs 900-904 faces/s for every combination of links.
-NHWC_CHAIN = os.environ.get("E4S_NHWC_CHAIN", "0") != "0"
-# which hand-overs may be channels-last: "u<J>" = into the up-conv of stage J (res 2^(J+3)), "c<J>" = into that stage's second conv; "all"
-NHWC_LINKS = os.environ.get("E4S_NHWC_LINKS", "all")
+# Channel-blocked activations ([bs, C/8, H, W, 8]) between the single-region layers of Generator.forward (inference).  A pixel's 8 channels
+# are 32 contiguous bytes and consecutive pixels follow: the fused up-sampling kernel's blur passes (8 channels each) and the conv epilogues
+# write contiguous lines, and the following conv reads a patch row of 34 pixels as ~9 fully used cache lines per 8 channels instead of 3 partly
+# used ones per channel (tile-read probe: 1.8 -> 5 TB/s).  Measured in the pipeline (bench.py, batch 4), hand-overs into the second conv of
+# the 512x512 and 1024x1024 stages ("c" links): 958 -> 990 faces/s (fused up-sampling 0.705 -> 0.672 ms, 1024x1024 conv 0.515 -> 0.470,
+# 512x512 conv 0.361 -> 0.324).  Hand-overs INTO the up-sampling kernel ("u" links) are off: its channel-blocked staging variant spills.
+NHWC_CHAIN = os.environ.get("E4S_NHWC_CHAIN", "1") != "0"
+# which hand-overs are channel-blocked: "c" = into the second conv of every single-region stage (default), "all", or an explicit list of
+# "u<J>" (into the up-conv of stage J, resolution 2^(J+3)) / "c<J>" (into that stage's second conv)
+NHWC_LINKS = os.environ.get("E4S_NHWC_LINKS", "c")
 
 
 def nhwc_link(kind: str, stage: int) -> bool:
-    return NHWC_CHAIN and (NHWC_LINKS == "all" or f"{kind}{stage}" in NHWC_LINKS.split(","))
+    return NHWC_CHAIN and (NHWC_LINKS == "all" or NHWC_LINKS == kind or f"{kind}{stage}" in NHWC_LINKS.split(","))
 FUSE_RGB = os.environ.get("E4S_FUSE_RGB", "1") != "0"
 
 
@@ -500,20 +505,21 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
                       x_nhwc: bool = False, out_nhwc: bool = False):
     """``rgb = (wt_rgb [cout,3], s_rgb [bs,1,cout], bias [1,3,1,1], skip or None, up_kernel)`` fuses the following single-region
     ToRGB; the call then returns ``(out, rgb_image)``.  ``want_out=False`` (with ``rgb``) skips writing the layer's own activation
-    and returns ``(None, rgb_image)``.  ``x_nhwc`` / ``out_nhwc``: the activation is channels-last, ``[bs, h, w, c]`` (split-bf16 kernel,
-    width >= 32; the 256x256-and-up layers chain in this layout inside ``Generator.forward``)."""
+    and returns ``(None, rgb_image)``.  ``x_nhwc`` / ``out_nhwc``: the activation is channel-blocked, ``[bs, c/8, h, w, 8]`` (split-bf16
+    kernel, width >= 32; the 256x256-and-up layers can chain in this layout inside ``Generator.forward``)."""
     x = _c(x, "input")
     if x_nhwc:
-        bs, h, w, cin = x.shape
+        bs, cb, h, w, _ = x.shape          # channel-blocked [bs, cin/8, h, w, 8]
+        cin = cb * 8
     else:
         bs, cin, h, w = x.shape
     nreg = s.shape[1]
     ho, wo = (2 * h, 2 * w) if up else (h, w)
     if not want_out and rgb is None:
         raise ValueError("want_out=False only makes sense together with a fused ToRGB")
-    if (x_nhwc or out_nhwc) and not (isinstance(wt, tuple) and w >= 32 and cin % 16 == 0 and cout % 4 == 0):
-        raise ValueError("channels-last activations need the split-bf16 kernel, width >= 32, cin % 16 == 0 and cout % 4 == 0")
-    out = torch.empty((bs, ho, wo, cout) if out_nhwc else (bs, cout, ho, wo), dtype=torch.float32, device=x.device) if want_out else None
+    if (x_nhwc or out_nhwc) and not (isinstance(wt, tuple) and w >= 32 and cin % 16 == 0 and cout % 8 == 0):
+        raise ValueError("channel-blocked activations need the split-bf16 kernel, width >= 32, cin % 16 == 0 and cout % 8 == 0")
+    out = torch.empty((bs, cout // 8, ho, wo, 8) if out_nhwc else (bs, cout, ho, wo), dtype=torch.float32, device=x.device) if want_out else None
     lh = lw = 0
     if labels is not None:
         lh, lw = labels.shape[1:]

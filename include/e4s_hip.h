@@ -118,9 +118,10 @@ E4S_API int e4s_region_modconv3x3(float* out, const float* x, const float* wt, c
  * channel chunk*16 + half*8 + e (zero beyond cin).  k = 3 only.  All other arguments as e4s_modconv_prep_weights / e4s_region_modconv3x3. */
 E4S_API int e4s_modconv_prep_weights_sb(uint16_t* whi, uint16_t* wlo, float* wsq, const float* weight, const float* blur,
                                         int cout, int cin, int up, void* stream);
-/* Layout flags OR-ed into the `up` argument of e4s_region_modconv3x3_sb: activations channels-last, [bs,h,w,c] instead of [bs,c,h,w]
- * (the layers from 256x256 up are bound by the NUMBER of vector-memory instructions; channels-last makes a pixel's 16 input channels
- * four 16-byte loads and a lane's four consecutive output channels one 16-byte store).  cin % 16 == 0 / cout % 4 == 0, w >= 32. */
+/* Layout flags OR-ed into the `up` argument of e4s_region_modconv3x3_sb (and the `act` argument of e4s_modconv_up_fused_sb): the activation
+ * is channel-blocked, [bs, c/8, h, w, 8] instead of [bs, c, h, w] — a pixel's 8 channels are 32 contiguous bytes and consecutive pixels
+ * follow, so a tile's halo columns share their cache lines with all 8 channels and both producer and consumer move contiguous bytes.
+ * cin % 16 == 0 / cout % 8 == 0, w >= 32, single-region layers (input) / any layer (output). */
 #define E4S_X_NHWC 2
 #define E4S_OUT_NHWC 4
 E4S_API int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16_t* whi, const uint16_t* wlo, const float* s, const float* d,

@@ -172,7 +172,9 @@ def test_g8_cal_style_codes(gpu_net3):
 
 
 def test_fused_torgb_epilogue_matches_separate_launch(gpu_net3):
-    """The optional fusion of the single-region ToRGBs (256/512/1024) into the conv epilogue gives the same image."""
+    """The optional fusion of the single-region ToRGBs (256/512/1024) into the conv epilogue — and with it the channel-blocked hand-overs
+    of the 512x512 / 1024x1024 stages, which are only taken together with the fused ToRGBs — gives the same image up to the rounding of the
+    split products (both variants are 6e-5 from the oracle; the parity bar is 1e-3)."""
     if _ops.MODCONV_MODE != "sb":
         pytest.skip("fused ToRGB exists on the split-bf16 kernel only")
     codes, mask = _config2_inputs(2)
@@ -186,14 +188,14 @@ def test_fused_torgb_epilogue_matches_separate_launch(gpu_net3):
             b, _, _ = gpu_net3.gen_img(None, codes, mask, randomize_noise=False)
     finally:
         _ops.FUSE_RGB = old
-    assert (a - b).abs().max().item() <= 2e-5
+    assert (a - b).abs().max().item() <= 1e-4
 
 
-@pytest.mark.parametrize("links", ["all", "c7", "u6,c6"])
+@pytest.mark.parametrize("links", ["all", "c", "c7", "u6,c6"])
 def test_channels_last_chain_gives_the_same_image(gpu_net3, links):
-    """``E4S_NHWC_CHAIN=1``: the single-region layers hand their activations over channels-last (kernel variants of csrc/modconv_sb.hip and
-    csrc/modconv_upfused.hip).  Same image as the channels-first default up to the rounding of the split products, for the whole chain and
-    for partial chains (every mix of layouts at the kernel boundaries)."""
+    """The single-region layers hand their activations over channel-blocked, [bs, C/8, H, W, 8] (kernel variants of csrc/modconv_sb.hip and
+    csrc/modconv_upfused.hip; default: the "c" links).  Same image as with channels-first hand-overs up to the rounding of the split
+    products, for the whole chain and for partial chains (every mix of layouts at the kernel boundaries)."""
     if _ops.MODCONV_MODE != "sb":
         pytest.skip("split-bf16 kernels only")
     codes, mask = _config2_inputs(2)
