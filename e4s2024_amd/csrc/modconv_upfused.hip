@@ -105,28 +105,19 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
             for (int r = 0; r < 16; ++r) accs[a][i][r] = 0.f;
 
     float xr[CKS];
-    // channels-last input: item = (patch pixel, 16-byte quarter of its 64-byte chunk), consecutive lanes read consecutive bytes
-    constexpr int EPT4 = XN ? (UF_PATCH * 4 + UF_NT - 1) / UF_NT : 1;
-    float4 xq[EPT4];
-    int goff4[EPT4];
-    bool inb4[EPT4];
-#pragma unroll
-    for (int j = 0; j < EPT4; ++j) {
-        const int e = (tid + j * UF_NT) >> 2;
-        const int ey = e / UF_PW, ex = e - ey * UF_PW;
-        const int gy = p0y - 1 + ey, gx = p0x - 1 + ex;
-        inb4[j] = e < UF_PATCH && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
-        goff4[j] = inb4[j] ? gy * p.w + gx : 0;
-    }
     unsigned wr[C::WPT][4];   // scalar components (a uint4 array would be placed in scratch)
     const ptrdiff_t wdelta = p.wlo - p.whi;
     auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
         const int ci0 = chunk * CKS;
         const int cmax = p.cin - 1 - ci0;
-        if constexpr (XN) {
+        if constexpr (XN) {   // channel-blocked input [cin/8][h][w][8]: this thread's patch pixel, the chunk's two 8-channel blocks, 4 x 16 bytes
 #pragma unroll
-            for (int j = 0; j < EPT4; ++j)
-                xq[j] = *reinterpret_cast<const float4*>(xb + ((size_t)(ci0 / 8 + (((tid + j * UF_NT) & 3) >> 1)) * hw + goff4[j]) * 8 + 4 * ((tid + j * UF_NT) & 1));
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const float4 v = *reinterpret_cast<const float4*>(xb + ((size_t)(ci0 / 8 + blk) * hw + sgoff) * 8 + 4 * hf);
+                    xr[8 * blk + 4 * hf] = v.x; xr[8 * blk + 4 * hf + 1] = v.y; xr[8 * blk + 4 * hf + 2] = v.z; xr[8 * blk + 4 * hf + 3] = v.w;
+                }
         } else {
 #pragma unroll
             for (int c = 0; c < CKS; ++c) xr[c] = xb[(size_t)(ci0 + (c < cmax ? c : cmax)) * hw + sgoff];
@@ -145,23 +136,7 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
         }
     };
     auto store_chunk = [&](int chunk) __attribute__((always_inline)) {
-        if constexpr (XN) {
-#pragma unroll
-            for (int j = 0; j < EPT4; ++j) {
-                const int it = tid + j * UF_NT;
-                const int e = it >> 2, q = it & 3;
-                if (e < UF_PATCH) {
-                    const float4 v = inb4[j] ? xq[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    const float4 sc = *reinterpret_cast<const float4*>(sb + chunk * CKS + 4 * q);   // cin % 16 == 0 on this path
-                    unsigned h0, h1, l0, l1;
-                    split2(v.x * sc.x, v.y * sc.y, h0, l0);
-                    split2(v.z * sc.z, v.w * sc.w, h1, l1);
-                    const int slot = (e * 2 + ((q >> 1) ^ ((e >> 3) & 1))) * 2 + (q & 1);
-                    reinterpret_cast<uint2*>(xh4)[slot] = make_uint2(h0, h1);
-                    reinterpret_cast<uint2*>(xl4)[slot] = make_uint2(l0, l1);
-                }
-            }
-        } else if (tid < UF_PATCH) {
+        if (tid < UF_PATCH) {
             unsigned hi[8], lo[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {

@@ -483,15 +483,17 @@ def _workspace(device, floats: int) -> torch.Tensor:
 # write contiguous lines, and the following conv reads a patch row of 34 pixels as ~9 fully used cache lines per 8 channels instead of 3 partly
 # used ones per channel (tile-read probe: 1.8 -> 5 TB/s).  Measured in the pipeline (bench.py, batch 4), hand-overs into the second conv of
 # the 512x512 and 1024x1024 stages ("c" links): 958 -> 990 faces/s (fused up-sampling 0.705 -> 0.672 ms, 1024x1024 conv 0.515 -> 0.470,
-# 512x512 conv 0.361 -> 0.324).  Hand-overs INTO the up-sampling kernel ("u" links) are off: its channel-blocked staging variant spills.
+# 512x512 conv 0.361 -> 0.324); with the hand-overs into the up-sampling kernels as well ("u" links; the kernel reads its patch pixel's two
+# 8-channel blocks with four 16-byte loads) another +1.3 % (fused up-sampling 0.707 -> 0.640 ms).
 NHWC_CHAIN = os.environ.get("E4S_NHWC_CHAIN", "1") != "0"
-# which hand-overs are channel-blocked: "c" = into the second conv of every single-region stage (default), "all", or an explicit list of
-# "u<J>" (into the up-conv of stage J, resolution 2^(J+3)) / "c<J>" (into that stage's second conv)
-NHWC_LINKS = os.environ.get("E4S_NHWC_LINKS", "c")
+# which hand-overs are channel-blocked: "all" (default), or a list of "c" / "u" (every hand-over into a second conv / into an up-conv),
+# "u<J>" (into the up-conv of stage J, resolution 2^(J+3)) and "c<J>" (into that stage's second conv)
+NHWC_LINKS = os.environ.get("E4S_NHWC_LINKS", "all")
 
 
 def nhwc_link(kind: str, stage: int) -> bool:
-    return NHWC_CHAIN and (NHWC_LINKS == "all" or NHWC_LINKS == kind or f"{kind}{stage}" in NHWC_LINKS.split(","))
+    items = NHWC_LINKS.split(",")
+    return NHWC_CHAIN and (NHWC_LINKS == "all" or kind in items or f"{kind}{stage}" in items)
 FUSE_RGB = os.environ.get("E4S_FUSE_RGB", "1") != "0"
 
 
