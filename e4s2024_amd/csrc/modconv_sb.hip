@@ -251,18 +251,6 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
     auto& acc = accs[0];
 
     // register stage of the NEXT chunk
-    constexpr int EPT4 = XN ? (C::PATCH * 4 + C::NT - 1) / C::NT : 1;   // channels-last items per thread
-    float4 xq[EPT4];
-    int goffs4[EPT4];
-    bool ginb4[EPT4];
-#pragma unroll
-    for (int j = 0; j < EPT4; ++j) {
-        const int e = (tid + j * C::NT) >> 2;
-        const int py = e / C::PW, px = e - py * C::PW;
-        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-        ginb4[j] = (e < C::PATCH) && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
-        goffs4[j] = ginb4[j] ? gy * p.w + gx : 0;
-    }
     float xr[CKS][C::EPT];
     unsigned wr[C::WPT][4];   // scalar components: a uint4 array here ends up in scratch
     float sr = 0.f;
@@ -277,13 +265,14 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
     auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
         const int ci0 = chunk * CKS;
         const int cmax = p.cin - 1 - ci0;
-        if constexpr (XN) {   // channel-blocked input: item = (patch pixel, 16-byte quarter of the chunk's 16 channels)
+        if constexpr (XN) {   // channel-blocked input [cin/8][h][w][8]: each patch pixel's two 8-channel blocks, four 16-byte loads per pixel
 #pragma unroll
-            for (int j = 0; j < EPT4; ++j) {
-                const int it = tid + j * C::NT;
-                // [bs][cin/8][h][w][8]: quarter q of the chunk = channels ci0 + 4q .. +3 -> block (ci0/8 + q/2), offset 4*(q&1) inside the pixel's 32 bytes
-                xq[j] = *reinterpret_cast<const float4*>(xb + ((size_t)(ci0 / 8 + ((it & 3) >> 1)) * hw + goffs4[j]) * 8 + 4 * (it & 3 & 1));
-            }
+            for (int j = 0; j < C::EPT; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(xb + ((size_t)(ci0 / 8 + (q >> 1)) * hw + goffs[j]) * 8 + 4 * (q & 1));
+                    xr[4 * q][j] = v.x; xr[4 * q + 1][j] = v.y; xr[4 * q + 2][j] = v.z; xr[4 * q + 3][j] = v.w;
+                }
         } else {
 #pragma unroll
             for (int c = 0; c < CKS; ++c) {
@@ -310,27 +299,7 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
         }
     };
     auto store_chunk = [&](int chunk) __attribute__((always_inline)) {
-        if constexpr (XN) {
-#pragma unroll
-            for (int j = 0; j < EPT4; ++j) {
-                const int it = tid + j * C::NT;
-                const int e = it >> 2, q = it & 3;
-                if (e < C::PATCH) {
-                    float4 v = ginb4[j] ? xq[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    if constexpr (UNI) {
-                        const float4 sc = *reinterpret_cast<const float4*>(sb + chunk * CKS + 4 * q);   // cin % 16 == 0 on this path
-                        unsigned h0, h1, l0, l1;
-                        split2(v.x * sc.x, v.y * sc.y, h0, l0);
-                        split2(v.z * sc.z, v.w * sc.w, h1, l1);
-                        const int slot = (e * 2 + ((q >> 1) ^ ((e >> 3) & 1))) * 2 + (q & 1);             // 8-byte piece of the swizzled 16-byte half
-                        reinterpret_cast<uint2*>(xh4)[slot] = make_uint2(h0, h1);
-                        reinterpret_cast<uint2*>(xl4)[slot] = make_uint2(l0, l1);
-                    } else {
-                        xf4[e * 4 + (q ^ ((e >> 2) & 3))] = v;
-                    }
-                }
-            }
-        } else if constexpr (UNI) {
+        if constexpr (UNI) {
             // s of the single region for the 16 channels of this chunk (wave-uniform loads)
             float sc[CKS];
 #pragma unroll
