@@ -505,7 +505,7 @@ class Generator(nn.Module):
                 else:
                     skip = to_rgb(out, latent[:, 0, i + 2] if single else latent[:, :, i + 2], mask, skip)
 
-        ops._table_plan.clear()
+        ops.table_plan_clear()
         image = skip
         if return_latents:
             return image, latent, intermediate_feats

@@ -89,13 +89,18 @@ class FaceParser(nn.Module):
         self.seg.eval()
 
     # ---- tensor entry points -------------------------------------------------------------------------------------
-    def preprocess_tensor(self, img01):
-        """``[bs, 3, S, S]`` in [0, 1] with S >= 512 -> normalised ``[bs, 3, 512, 512]`` (reference :154-156)."""
-        f = img01.shape[-1] // 512
+    def preprocess_tensor(self, img01, downsample=True):
+        """``[bs, 3, S, S]`` in [0, 1] -> normalised ``[bs, 3, S / f, S / f]``.  As in the reference (:152-156) every image that is at
+        least 512 wide goes through ``self.downsample``, whose factor ``f = self.size // 512`` is fixed by the constructor and NOT derived
+        from the image: the default ``size=1024`` parser maps 1024 -> 512 (the only case on the swap path), 512 -> 256, 2048 -> 1024.
+        ``downsample=False`` is the reference's other branch (:157-160, images narrower than 512 after their PIL resize to 512): clamp
+        and normalise only."""
+        f = self.downsample.factor if downsample else 1
         if f == 1:
             return ops.bicubic_down_normalize(img01, None, 1, self._mean, self._std)     # clamp + normalise only
-        ds = self.downsample if f == self.downsample.factor else BicubicDownSample(factor=f)
-        return ops.bicubic_down_normalize(img01, ds.taps.to(img01.device), f, self._mean, self._std)
+        if img01.shape[-1] % f or img01.shape[-2] % f:
+            raise ValueError(f"image size {tuple(img01.shape[-2:])} is not a multiple of the parser's down-sampling factor {f}")
+        return ops.bicubic_down_normalize(img01, self.downsample.taps.to(img01.device), f, self._mean, self._std)
 
     def parse_batch(self, img01, seg12=True):
         """``[bs, 3, S, S]`` in [0, 1] -> uint8 labels ``[bs, 512, 512]`` (12-class when ``seg12``)."""
@@ -107,7 +112,7 @@ class FaceParser(nn.Module):
         if img.size[0] >= 512:
             return self.preprocess_tensor(_pil_to_tensor01(img, self.device))
         im = img.resize((512, 512), Image.BILINEAR)                                    # reference :157-159
-        return self.preprocess_tensor(_pil_to_tensor01(im, self.device))
+        return self.preprocess_tensor(_pil_to_tensor01(im, self.device), downsample=False)
 
     def forward(self, img):
         """PIL image -> LongTensor ``[512, 512]`` of 19-class labels (reference :162-176)."""

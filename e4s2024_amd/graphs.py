@@ -28,15 +28,18 @@ class GraphedCall:
         self._strict = ops.STRICT_MASK
         ops.STRICT_MASK = False                       # the one-hot check reads a flag back to the host
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side), torch.no_grad():
-                for _ in range(warmup):                # builds the weight caches / split-K workspace outside the capture
+            # warm-up AND capture run on this object's own stream: the per-stream host state of ops (region-map cache, split-K workspace)
+            # is then created eagerly, before the capture, and the graph bakes in pointers that outlive its private pool
+            self.stream = torch.cuda.Stream()
+            ops.prepare_stream_context(self.stream)
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream), torch.no_grad():
+                for _ in range(warmup):                # builds the weight caches outside the capture
                     self.fn(*self.static_in)
-            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.current_stream().wait_stream(self.stream)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph), torch.no_grad():
+            with torch.cuda.graph(self.graph, stream=self.stream), torch.no_grad():
                 self.static_out = self.fn(*self.static_in)
         finally:
             ops.STRICT_MASK = self._strict

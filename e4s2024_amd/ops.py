@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes
 import math
 import os
+import threading
 import weakref
 from typing import Optional, Sequence, Tuple
 
@@ -228,18 +229,55 @@ def upfirdn2d(input: torch.Tensor, kernel: torch.Tensor, up: int = 1, down: int 
     return _UpFirDn2d.apply(input, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))
 
 
+# ------------------------------------------------------------------------- per-stream host state
+class _StreamCtx:
+    """Host-side state of the wrappers, one instance per (device, HIP stream): the region-map cache, the style-table plan of the forward
+    pass in progress, its identity stamp and the split-K workspace.  The C ABI itself is stateless; with this, the Python layer is too as
+    far as concurrent users are concerned — two host threads each driving their own stream share nothing here (the supported concurrency
+    model: ONE host thread per stream; the prepared weight copies, which ARE shared, publish themselves atomically and are ordered across
+    streams by an event, see ``_Prepared``)."""
+
+    __slots__ = ("label_cache", "table_plan", "forward_stamp", "workspace")
+
+    def __init__(self):
+        self.label_cache, self.table_plan, self.forward_stamp, self.workspace = {}, {}, None, None
+
+
+_ctxs = {}
+_ctx_lock = threading.Lock()
+
+
+def _ctx(stream=None) -> _StreamCtx:
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    key = (stream.device.index, stream.cuda_stream)
+    c = _ctxs.get(key)
+    if c is None:
+        with _ctx_lock:
+            c = _ctxs.setdefault(key, _StreamCtx())
+    return c
+
+
+def prepare_stream_context(stream) -> None:
+    """Create ``stream``'s context and its split-K workspace NOW (eagerly, outside any capture), so that a hipGraph captured on that stream
+    later bakes in a pointer that outlives the graph's private memory pool."""
+    with torch.cuda.stream(stream):
+        _workspace(stream.device, 1)
+
+
 # ------------------------------------------------------------------------------ region map
-_label_cache = {}
 STRICT_MASK = os.environ.get("E4S_STRICT_MASK", "1") != "0"
 
 
 def mask_to_labels(mask: torch.Tensor, strict: Optional[bool] = None) -> torch.Tensor:
     """One-hot ``[bs, ncls, H, W]`` float mask (``labelMap2OneHot``, utils/torch_utils.py:207-213) → uint8 ``[bs, H, W]``
-    region map.  The result is cached per mask *object* (all 26 layers of one ``Generator.forward`` share it).
+    region map.  The result is cached per mask *object* and stream (all 26 layers of one ``Generator.forward`` share it).
     ``strict`` (default on; ``E4S_STRICT_MASK=0`` disables) checks on the device that the mask really is one-hot and
     raises otherwise — the one-pass kernels are only equivalent to the reference's masked sum for one-hot masks."""
     if mask.dtype == torch.uint8 and mask.dim() == 3:
         return _req(mask, "labels", torch.uint8).contiguous()
+    _req(mask, "mask")
+    _label_cache = _ctx().label_cache
     key = id(mask)
     ent = _label_cache.get(key)
     if ent is not None and ent[0]() is mask and ent[1] == mask._version:
@@ -286,46 +324,108 @@ def _volatile(t: torch.Tensor) -> bool:
     return torch.is_grad_enabled() and t.requires_grad
 
 
-_forward_stamp = None      # identity of the Generator.forward in progress (None outside one)
-
-
 class one_forward:
     """``with ops.one_forward():`` around one forward pass during which the parameters do not change: a trained layer's weights are then
-    prepared once in that pass even if several call sites ask for them (tables plan, layer, backward hand-over), instead of once per ask."""
+    prepared once in that pass even if several call sites ask for them (tables plan, layer, backward hand-over), instead of once per ask.
+    The stamp identifying the pass lives in the current stream's context."""
 
     def __enter__(self):
-        global _forward_stamp
-        self.prev, _forward_stamp = _forward_stamp, object()
+        self.ctx = _ctx()
+        self.prev, self.ctx.forward_stamp = self.ctx.forward_stamp, object()
         return self
 
     def __exit__(self, *exc):
-        global _forward_stamp
-        _forward_stamp = self.prev
+        self.ctx.forward_stamp = self.prev
 
 
 def invalidate_weight_caches(module: torch.nn.Module) -> int:
     """Drop every re-laid-out weight copy held by the drop-in modules under ``module`` (they are rebuilt by the next forward).  Needed only
-    after writing parameters behind autograd's back between two ``no_grad`` forwards — ``p.data.copy_(...)``, an EMA update — which
-    leaves no trace the caches could key on; ``load_state_dict``, ordinary in-place ops and any training forward are tracked."""
+    after writing parameters behind autograd's back between two ``no_grad`` forwards — ``p.data.copy_(...)``, an EMA update, a replay of a
+    captured optimiser step (``pti.GraphedPTIStep`` does it itself) — which leaves no trace the caches could key on; ``load_state_dict``,
+    ordinary in-place ops and any training forward are tracked."""
     n = 0
     for m in module.modules():
         for v in vars(m).values():
             for c in (v if isinstance(v, (list, tuple)) else (v,)):
-                if isinstance(c, (PreparedWeights, PreparedConv)):
+                if isinstance(c, _Prepared):
                     c.key = None
                     n += 1
     return n
 
 
-class PreparedWeights:
+class _Prepared:
+    """Base of the prepared-weight caches.  The cached copy is ONE tuple ``(key, payload, stream id, event, streams that may read it)``
+    stored with a single attribute assignment, so a reader on another host thread sees either the old or the new copy, never a mix.
+    Streams: the copy is built by kernels on the stream that first asks for it; a hit from a different stream (``pipeline.swap_batch`` runs
+    the driven and the target chain on two streams over the same encoder / parser weights) first makes that stream wait for the build's
+    event and marks the tensors as in use there (they belong to the building stream's allocator pool)."""
+
+    __slots__ = ("_state",)
+    _EMPTY = (None, None, None, None, frozenset())
+
+    def __init__(self):
+        self._state = self._EMPTY
+
+    @property
+    def key(self):
+        return self._state[0]
+
+    @key.setter
+    def key(self, value):
+        if value is not None:
+            raise ValueError("a prepared-weight key can only be reset to None")
+        self._state = self._EMPTY
+
+    def _lookup(self, key):
+        """Payload of the cached copy if it was built for ``key`` (ordered after its build on the current stream), else None."""
+        st = self._state
+        if key is None or st[0] != key:
+            return None
+        cur = torch.cuda.current_stream()
+        sid = cur.cuda_stream
+        if sid != st[2] and sid not in st[4] and st[3] is not None and not torch.cuda.is_current_stream_capturing():
+            cur.wait_event(st[3])
+            for t in self._tensors(st[1]):
+                t.record_stream(cur)
+            self._state = st[:4] + (st[4] | {sid},)
+        return st[1]
+
+    def _publish(self, key, payload):
+        cur = torch.cuda.current_stream()
+        ev = None
+        if not torch.cuda.is_current_stream_capturing():
+            ev = torch.cuda.Event()
+            ev.record(cur)
+        self._state = (key, payload, cur.cuda_stream, ev, frozenset())
+        return payload
+
+    def __reduce__(self):                 # copy / deepcopy / pickle of a module: the copy starts with an empty cache (no tensors, no events)
+        return (self.__class__, ())
+
+    @staticmethod
+    def _tensors(payload):
+        out = []
+        for v in payload:
+            for t in (v if isinstance(v, (tuple, list)) else (v,)):
+                if isinstance(t, torch.Tensor):
+                    out.append(t)
+        return out
+
+
+class PreparedWeights(_Prepared):
     """K-major, scale-folded copy of a ModulatedConv2d weight (+ blur-composed parity kernels for up layers, + the
     squared-sum table for demodulation), as fp32 (``wt``) or as split-bf16 slabs (``wt = (whi, wlo)``).  Rebuilt when the
     parameter (or blur buffer) changes version or storage, or the arithmetic mode changes."""
 
-    __slots__ = ("key", "wt", "wsq", "stamp")
+    __slots__ = ()
 
-    def __init__(self):
-        self.key, self.wt, self.wsq, self.stamp = None, None, None, None
+    @property
+    def wt(self):
+        return None if self._state[1] is None else self._state[1][0]
+
+    @property
+    def wsq(self):
+        return None if self._state[1] is None else self._state[1][1]
 
     def get(self, weight: torch.Tensor, blur: Optional[torch.Tensor], up: bool, demodulate: bool, tconv: bool = False):
         """``tconv``: slabs of the bare 3x3 weight of an up layer (for the transposed-conv + blur-epilogue pair)."""
@@ -333,31 +433,32 @@ class PreparedWeights:
         if tconv:
             up, blur = False, None
         key = (weight.data_ptr(), weight._version, weight.device, None if blur is None else (blur.data_ptr(), blur._version), up, demodulate, sb)
-        if _volatile(weight):
-            if _forward_stamp is not None and self.stamp is _forward_stamp and self.wt is not None and self.key == ("volatile",) + key:
-                return self.wt, self.wsq          # prepared earlier in this very forward pass
-            self.key = None
-        if key != self.key:
-            w = _c(weight.detach(), "weight")
-            _, cout, cin, k, _ = w.shape
-            npar = 4 if up else 1
-            wsq = torch.empty((cin, cout), dtype=torch.float32, device=w.device) if demodulate else None
-            bk = _c(blur, "blur kernel") if up else None
-            if up and tuple(bk.shape) != (4, 4):
-                raise NotImplementedError(f"up-conv blur kernel must be 4x4, got {tuple(bk.shape)}")
-            if sb:
-                shape = (npar, (cin + 15) // 16, 9, 2, cout, 8)
-                whi = torch.empty(shape, dtype=torch.int16, device=w.device)
-                wlo = torch.empty(shape, dtype=torch.int16, device=w.device)
-                lib().call("e4s_modconv_prep_weights_sb", _p(whi), _p(wlo), _p(wsq), _p(w), _p(bk), cout, cin, 1 if up else 0, _stream())
-                wt = (whi, wlo)
-            else:
-                wt = torch.empty((npar, cin, k * k, cout), dtype=torch.float32, device=w.device)
-                lib().call("e4s_modconv_prep_weights", _p(wt), _p(wsq), _p(w), _p(bk), cout, cin, k, 1 if up else 0, _stream())
-            vol = _volatile(weight)
-            self.key, self.wt, self.wsq = ((("volatile",) + key) if (vol and _forward_stamp is not None) else (None if vol else key)), wt, wsq
-            self.stamp = _forward_stamp if vol else None
-        return self.wt, self.wsq
+        vol = _volatile(weight)
+        if vol:
+            # a parameter under training: valid for the forward pass in progress only (its stamp is part of the key), never across passes
+            stamp = _ctx().forward_stamp
+            key = None if stamp is None else ("volatile", id(stamp)) + key
+        hit = self._lookup(key)
+        if hit is not None and (not vol or hit[2] is stamp):
+            return hit[0], hit[1]
+        w = _c(weight.detach(), "weight")
+        _, cout, cin, k, _ = w.shape
+        npar = 4 if up else 1
+        wsq = torch.empty((cin, cout), dtype=torch.float32, device=w.device) if demodulate else None
+        bk = _c(blur, "blur kernel") if up else None
+        if up and tuple(bk.shape) != (4, 4):
+            raise NotImplementedError(f"up-conv blur kernel must be 4x4, got {tuple(bk.shape)}")
+        if sb:
+            shape = (npar, (cin + 15) // 16, 9, 2, cout, 8)
+            whi = torch.empty(shape, dtype=torch.int16, device=w.device)
+            wlo = torch.empty(shape, dtype=torch.int16, device=w.device)
+            lib().call("e4s_modconv_prep_weights_sb", _p(whi), _p(wlo), _p(wsq), _p(w), _p(bk), cout, cin, 1 if up else 0, _stream())
+            wt = (whi, wlo)
+        else:
+            wt = torch.empty((npar, cin, k * k, cout), dtype=torch.float32, device=w.device)
+            lib().call("e4s_modconv_prep_weights", _p(wt), _p(wsq), _p(w), _p(bk), cout, cin, k, 1 if up else 0, _stream())
+        self._publish(key, (wt, wsq, stamp if vol else None))      # (holding the stamp object keeps its id unique while this copy lives)
+        return wt, wsq
 
 
 UP_FUSED = os.environ.get("E4S_UP_FUSED", "1") != "0"     # single-region up layers: one launch (blur in LDS) instead of tconv + blur epilogue
@@ -400,13 +501,15 @@ def modconv_up_single(x, wt, s, d, blur, noise, noise_weight, act_bias, act: boo
     return out
 
 
-_table_plan = {}     # id(ModulatedConv2d) -> (styles data_ptr/shape/stride key, s, d); filled by style_demod_plan for one forward
+# the style-table plan of the forward pass in progress lives in the stream context (``_StreamCtx.table_plan``):
+# id(ModulatedConv2d) -> (styles data_ptr/shape/stride key, s, d); filled by style_demod_plan for one forward
 
 
 def style_demod_plan(jobs):
     """jobs: list of (key, styles [bs,nreg,sdim], mod_weight, mod_bias, wsq or None, cout).  Computes every layer's (s, d) in two
     launches and remembers them under ``key`` for the ``style_demod`` calls of the same forward pass."""
     from ._lib import StyleJob
+    _table_plan = _ctx().table_plan
     _table_plan.clear()
     if not jobs:
         return
@@ -441,8 +544,12 @@ def style_demod_plan(jobs):
     del keep
 
 
+def table_plan_clear() -> None:
+    _ctx().table_plan.clear()
+
+
 def style_demod_planned(key, styles):
-    ent = _table_plan.get(key)
+    ent = _ctx().table_plan.get(key)
     if ent is not None and ent[0] == (styles.data_ptr(), tuple(styles.shape), styles.stride(), styles._version):
         return ent[1], ent[2]
     return None
@@ -464,15 +571,19 @@ def style_demod(styles: torch.Tensor, mod_weight: torch.Tensor, mod_bias: torch.
     return s, d
 
 
-_workspaces = {}
 SPLITK_MAX_OUT_FLOATS = 1 << 21   # only feature maps up to 8 MB of output (<= 32x32 at 512 ch, bs 4) are candidates for split-K
 
 
 def _workspace(device, floats: int) -> torch.Tensor:
-    ws = _workspaces.get(device)
-    if ws is None or ws.numel() < floats:
-        ws = torch.empty(floats, dtype=torch.float32, device=device)
-        _workspaces[device] = ws
+    """Split-K partial sums of the stream's launches.  Allocated ONCE per stream at its maximum (16 slices x SPLITK_MAX_OUT_FLOATS
+    floats = 128 MB) and never replaced: a hipGraph captured earlier keeps the pointer baked in, so growing the buffer on demand would
+    leave such a graph writing into freed memory; per stream because launches on two streams run concurrently."""
+    c = _ctx()
+    ws = c.workspace
+    if ws is None or ws.device != torch.device(device):
+        ws = c.workspace = torch.empty(16 * SPLITK_MAX_OUT_FLOATS, dtype=torch.float32, device=device)
+    if ws.numel() < floats:
+        raise RuntimeError(f"split-K workspace request of {floats} floats exceeds its fixed size {ws.numel()}")
     return ws
 
 
@@ -586,17 +697,28 @@ def region_torgb(x, wt, s, labels, bias, skip, up_kernel) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- a8 / a9 (conv.hip, norm.hip, parser.hip)
-class PreparedConv:
+class PreparedConv(_Prepared):
     """K-major copy of a plain conv weight ``[cout, cin, k, k]`` (optionally with an eval-mode BatchNorm2d folded in),
-    rebuilt when a parameter or BN buffer changes version or storage."""
+    rebuilt when a parameter or BN buffer changes version or storage.  ``get`` returns the prepared copy as an immutable record
+    ``(wt, bias, shape)`` (attributes), which is what ``conv2d`` takes."""
 
-    __slots__ = ("key", "wt", "bias", "shape", "exact")
+    __slots__ = ("exact",)
+
+    class Copy(tuple):
+        __slots__ = ()
+        wt = property(lambda self: self[0])
+        bias = property(lambda self: self[1])
+        shape = property(lambda self: self[2])
 
     def __init__(self, exact=False):
         """``exact=True`` pins this convolution to the exact-fp32 MFMA kernel whatever ``CONV_MODE`` says (the face parser:
         its argmax must match the reference pixel for pixel, and split-bf16's ~2e-5 relative logit error flips near-ties);
         ``exact="sb3"`` asks for the three-way bf16 split (fp32-class error) where a split kernel exists, fp32 elsewhere."""
-        self.key, self.wt, self.bias, self.shape, self.exact = None, None, None, None, exact
+        super().__init__()
+        self.exact = exact
+
+    def __reduce__(self):
+        return (self.__class__, (self.exact,))
 
     def use_sb(self, cin: int, kh: int, kw: int) -> int:
         """Number of bf16 terms per operand: 2 (``wt = (whi, wlo)``) or 3 (``(w0, w1, w2)``) for 3x3 / 1x1 kernels with at least 16
@@ -612,36 +734,37 @@ class PreparedConv:
         key = tuple((t.data_ptr(), t._version) for t in ts) + (weight.device, CONV_MODE)
         if any(_volatile(t) for t in ts):
             key = None
-        if key is None or key != self.key:
-            w = _c(weight.detach(), "weight")
-            cout, cin, kh, kw = w.shape
-            sb = self.use_sb(cin, kh, kw)
-            if sb:
-                shape = ((cin + 15) // 16, kh * kw, 2, cout, 8)
-                wt = tuple(torch.empty(shape, dtype=torch.int16, device=w.device) for _ in range(sb))
-            else:
-                wt = torch.empty((cin, kh * kw, cout), dtype=torch.float32, device=w.device)
-            bias = torch.empty((cout,), dtype=torch.float32, device=w.device) if (bn is not None or conv_bias is not None) else None
-            if bn is not None:
-                if bn.training:
-                    raise RuntimeError("BatchNorm2d must be in eval mode to be folded into the convolution (the parser runs in eval mode)")
-                g, be, mu, var, eps = _c(bn.weight.detach(), "bn.weight"), _c(bn.bias.detach(), "bn.bias"), _c(bn.running_mean, "bn.running_mean"), \
-                    _c(bn.running_var, "bn.running_var"), float(bn.eps)
-            else:
-                g = be = mu = var = None
-                eps = 0.0
-            cb = _c(conv_bias.detach(), "conv bias") if conv_bias is not None else None
-            if sb == 3:
-                lib().call("e4s_conv_prep_weights_sb3", _p(wt[0]), _p(wt[1]), _p(wt[2]), _p(bias), _p(w), _p(g), _p(be), _p(mu), _p(var), eps, _p(cb),
-                           cout, cin, kh, kw, _stream())
-            elif sb:
-                lib().call("e4s_conv_prep_weights_sb", _p(wt[0]), _p(wt[1]), _p(bias), _p(w), _p(g), _p(be), _p(mu), _p(var), eps, _p(cb), cout,
-                           cin, kh, kw, _stream())
-            else:
-                lib().call("e4s_conv_prep_weights", _p(wt), _p(bias), _p(w), _p(g), _p(be), _p(mu), _p(var), eps, _p(cb), cout, cin, kh, kw,
-                           _stream())
-            self.key, self.wt, self.bias, self.shape = key, wt, bias, (cout, cin, kh, kw)
-        return self
+        hit = self._lookup(key)
+        if hit is not None:
+            return hit
+        w = _c(weight.detach(), "weight")
+        cout, cin, kh, kw = w.shape
+        sb = self.use_sb(cin, kh, kw)
+        if sb:
+            shape = ((cin + 15) // 16, kh * kw, 2, cout, 8)
+            wt = tuple(torch.empty(shape, dtype=torch.int16, device=w.device) for _ in range(sb))
+        else:
+            wt = torch.empty((cin, kh * kw, cout), dtype=torch.float32, device=w.device)
+        bias = torch.empty((cout,), dtype=torch.float32, device=w.device) if (bn is not None or conv_bias is not None) else None
+        if bn is not None:
+            if bn.training:
+                raise RuntimeError("BatchNorm2d must be in eval mode to be folded into the convolution (the parser runs in eval mode)")
+            g, be, mu, var, eps = _c(bn.weight.detach(), "bn.weight"), _c(bn.bias.detach(), "bn.bias"), _c(bn.running_mean, "bn.running_mean"), \
+                _c(bn.running_var, "bn.running_var"), float(bn.eps)
+        else:
+            g = be = mu = var = None
+            eps = 0.0
+        cb = _c(conv_bias.detach(), "conv bias") if conv_bias is not None else None
+        if sb == 3:
+            lib().call("e4s_conv_prep_weights_sb3", _p(wt[0]), _p(wt[1]), _p(wt[2]), _p(bias), _p(w), _p(g), _p(be), _p(mu), _p(var), eps, _p(cb),
+                       cout, cin, kh, kw, _stream())
+        elif sb:
+            lib().call("e4s_conv_prep_weights_sb", _p(wt[0]), _p(wt[1]), _p(bias), _p(w), _p(g), _p(be), _p(mu), _p(var), eps, _p(cb), cout,
+                       cin, kh, kw, _stream())
+        else:
+            lib().call("e4s_conv_prep_weights", _p(wt), _p(bias), _p(w), _p(g), _p(be), _p(mu), _p(var), eps, _p(cb), cout, cin, kh, kw,
+                       _stream())
+        return self._publish(key, PreparedConv.Copy((wt, bias, (cout, cin, kh, kw))))
 
 
 def conv2d(x: torch.Tensor, prepared: PreparedConv, stride: int = 1, pad: int = 0, *, x1: Optional[torch.Tensor] = None, in_norm=None,

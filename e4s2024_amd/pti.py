@@ -20,6 +20,8 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from . import ops
+
 
 def trainable_parameters(net):
     """``configure_optimizer`` (video_swap_ft_coach.py:171-177): every parameter the constructor left ``requires_grad=True``."""
@@ -39,14 +41,22 @@ def _loss(net, style_vectors, mask, target, foreground_mask, l2_lambda, extra_lo
 def sync_gradients(params, group=None, bucket_bytes: int = 256 << 20) -> int:
     """Average ``p.grad`` over the ranks of ``group`` in place: gradients are packed into flat buckets of about ``bucket_bytes``
     (xGMI rings are per-link bound, so few large all-reduces: SURVEY §8e), one ``all_reduce`` each, launched back to back and waited
-    for together.  A parameter without a gradient on this rank contributes zeros (every rank must issue the same collectives).
-    Returns the number of all-reduces issued; a no-op (0) outside a process group or at world size 1."""
+    for together.  Which parameters take part is agreed on first — one small MAX all-reduce of a has-gradient flag per parameter: a
+    parameter that NO rank has a gradient for (the optimiser's list follows the reference and includes the whole encoder, which the PTI
+    loss never reaches) is skipped exactly as a single-GPU step skips it — no zero gradient, no Adam state, no xGMI traffic; one that only
+    some ranks have a gradient for contributes zeros from the others (every rank must issue the same collectives).
+    Returns the number of gradient all-reduces issued; a no-op (0) outside a process group or at world size 1."""
     if not (dist.is_available() and dist.is_initialized()):
         return 0
     world = dist.get_world_size(group)
     if world == 1:
         return 0
     params = [p for p in params if p.requires_grad]
+    if not params:
+        return 0
+    flags = torch.tensor([0 if p.grad is None else 1 for p in params], dtype=torch.int32, device=params[0].device)
+    dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
+    params = [p for p, f in zip(params, flags.tolist()) if f]
     buckets, cur, cur_bytes = [], [], 0
     for p in params:
         nbytes = p.numel() * p.element_size()
@@ -89,25 +99,28 @@ class GraphedPTIStep:
                  randomize_noise: bool = True, warmup: int = 3):
         if mask.dtype != torch.uint8:
             raise TypeError("GraphedPTIStep needs the uint8 region map (ops.mask_to_labels(onehot)), not a float mask")
+        self.net = net
         self.static = [style_vectors.clone(), mask.clone(), target.clone()] + ([foreground_mask.clone()] if foreground_mask is not None else [])
         fg = self.static[3] if foreground_mask is not None else None
         args = (net, self.static[0], self.static[1], self.static[2], fg, l2_lambda, extra_loss, randomize_noise)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        self.stream = torch.cuda.Stream()                 # warm-up and capture on one stream of our own (see graphs.GraphedCall)
+        ops.prepare_stream_context(self.stream)
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
             for _ in range(warmup):
                 optimizer.zero_grad(set_to_none=True)
                 loss, _ = _loss(*args)
                 loss.backward()
                 optimizer.step()
-        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=self.stream):
             self.loss, self.recon = _loss(*args)
             self.loss.backward()
             optimizer.step()
+        ops.invalidate_weight_caches(net)
 
     def __call__(self, style_vectors, mask, target, foreground_mask=None):
         """Copies the frame into the static buffers and replays the step; returns the (static) loss and reconstruction tensors."""
@@ -120,6 +133,10 @@ class GraphedPTIStep:
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         self.graph.replay()
+        # The replay has just moved the parameters (fused Adam inside the graph) without running any Python forward and without bumping a
+        # tensor version: a re-laid-out copy cached by an earlier no_grad forward (a preview between steps) would otherwise still match
+        # its key and render with the old weights.  Forgetting the copies costs a few attribute writes; the next eval rebuilds them.
+        ops.invalidate_weight_caches(self.net)
         return self.loss, self.recon
 
 

@@ -9,7 +9,8 @@ independent units, so they shard with no data-path dependency.  One process per 
   rank 0 to every rank once per clip;
 * gather     — finished frames travel to rank 0 as **uint8 HWC** (``tensor2im`` semantics, 3 MB per 1024² frame instead of
   12.6 MB fp32); with 8 GPUs that is ~1 GB/s into rank 0 over 7 dedicated links (≈153 GB/s each), i.e. negligible, so a
-  plain ``gather`` is used (shards are padded to the largest shard, at most one frame of padding per rank).
+  plain ``gather`` is used — per batch and asynchronously in ``run_clip_streamed`` (frames leave while the next batch is computed; what
+  the clip benchmark times), or once at the end in ``run_clip`` (shards padded to the largest shard, at most one frame per rank).
 
 Weights are replicated (each rank loads the same checkpoint / seed); there is no collective inside a frame.
 """
@@ -92,6 +93,68 @@ class FrameShardRunner:
             dist.barrier(group=self.group)
 
     # ---- the clip loop -------------------------------------------------------------------------------------------
+    def run_clip_streamed(self, n_frames: int, shared, frame_inputs: Callable[[int, int], object],
+                          synth_fn: Callable[[object, object], torch.Tensor], batch: int = 4, dst: int = 0,
+                          out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """Like ``run_clip`` but the finished frames travel to rank ``dst`` batch by batch while the next batch is being computed, instead
+        of in one padded gather at the end (face_swap_video_pipeline.py:404-486 writes each frame out as soon as it is done).
+
+        Round ``k`` = every rank's ``k``-th batch of its own block.  All ranks issue the same sequence of ``gather`` calls (one per round,
+        ``async_op``: the collective runs on the backend's own stream); a rank whose block has no ``k``-th batch, or a short last one,
+        sends padding.  Rank ``dst`` scatters each round's buffers into ``out [n_frames, H, W, 3]`` (allocated on first use; pass a
+        preallocated one to keep the allocation out of a timed region) after the round's gather has completed — at the latest when the
+        next but one round is issued, so at most two rounds of frames are in flight."""
+        start, stop = shard_range(n_frames, self.rank, self.world)
+        blocks = [shard_range(n_frames, r, self.world) for r in range(self.world)]
+        rounds = max(-(-(e - s) // batch) for s, e in blocks) if n_frames > 0 else 0
+        pending = []          # (work, send buffer, receive buffers, round)
+
+        def finish(item):
+            nonlocal out
+            work, send, bufs, k = item
+            if work is not None:
+                work.wait()
+            if self.rank != dst:
+                return
+            for r, (s, e) in enumerate(blocks):
+                lo = s + k * batch
+                hi = min(lo + batch, e)
+                if hi > lo:
+                    src = bufs[r] if bufs is not None else send
+                    if out is None:
+                        out = torch.empty((n_frames,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+                    out[lo:hi].copy_(src[: hi - lo])
+
+        shape = None
+        for k in range(rounds):
+            lo = start + k * batch
+            hi = min(lo + batch, stop)
+            frames = None
+            if hi > lo:
+                frames = synth_fn(shared, frame_inputs(lo, hi))
+                if frames.dtype != torch.uint8 or frames.shape[0] != hi - lo:
+                    raise ValueError("synth_fn must return uint8 frames [n, H, W, 3] for the requested block")
+                shape = tuple(frames.shape[1:])
+            elif shape is None:     # this rank has no frames at all: learn the frame shape from a probe, send padding
+                shape = tuple(synth_fn(shared, frame_inputs(0, min(1, n_frames))).shape[1:])
+            if frames is not None and frames.shape[0] == batch:
+                send = frames.contiguous()
+            else:
+                send = torch.zeros((batch,) + shape, dtype=torch.uint8, device=self.device)
+                if frames is not None:
+                    send[: frames.shape[0]] = frames
+            if self.distributed and self.world > 1:
+                bufs = [torch.empty_like(send) for _ in range(self.world)] if self.rank == dst else None
+                work = dist.gather(send, bufs, dst=dst, group=self.group, async_op=True)
+            else:
+                bufs, work = None, None
+            pending.append((work, send, bufs, k))
+            if len(pending) > 2:
+                finish(pending.pop(0))
+        while pending:
+            finish(pending.pop(0))
+        return out if self.rank == dst else None
+
     def run_clip(self, n_frames: int, shared: torch.Tensor, frame_inputs: Callable[[int, int], object],
                  synth_fn: Callable[[torch.Tensor, object], torch.Tensor], batch: int = 4, dst: int = 0) -> Optional[torch.Tensor]:
         """Synthesise frames ``[0, n_frames)``: this rank takes its block, walks it in batches of ``batch`` calling

@@ -511,6 +511,35 @@ def swap_head_mask_hole_first(source: np.ndarray, target: np.ndarray):
     return res, hole, hole_map, nose_line, eye_line
 
 
+def swap_comp_style_vector(style_vectors1: Tensor, style_vectors2: Tensor, comp_indices: Sequence[int] = (),
+                           below_face_interpolation: bool = False) -> Tensor:
+    """``swap_comp_style_vector`` — swap_face_fine/swap_face_mask.py:336-367.  ``style_vectors1`` = the TARGET frame's per-region style
+    vectors ``[1, 12, D]``, ``style_vectors2`` = the driven (source) face's.  Assignment for assignment:
+
+        :346-349  the listed components come from the source
+        :355      ears (7) = mean of both, unconditionally (the ``if`` above it is commented out in the reference)
+        :358      ear-rings (11) always the target's
+        :361-362  neck (8) = mean of both when ``belowFace_interpolation``
+        :365-366  teeth (9) the target's when ``torch.sum(source[:, 9, :]) == 0`` (an empty region's vector is exactly zero:
+                  models/encoders/psp_encoders.py:368-370)
+
+    The reference is only ever called with batch 1 (face_swap_video_pipeline.py:429-436); for a batch the teeth rule (a sum over the whole
+    ``[:, 9, :]`` slice) is applied here per sample, i.e. a batch behaves as that many batch-1 calls."""
+    if style_vectors1.shape != style_vectors2.shape or style_vectors1.dim() != 3:
+        raise ValueError("style vectors must both be [bs, n_comp, D]")
+    out = style_vectors1.clone()
+    for c in comp_indices:
+        out[:, c, :] = style_vectors2[:, c, :]
+    out[:, 7, :] = (style_vectors1[:, 7, :] + style_vectors2[:, 7, :]) / 2
+    out[:, 11, :] = style_vectors1[:, 11, :]
+    if below_face_interpolation:
+        out[:, 8, :] = (style_vectors1[:, 8, :] + style_vectors2[:, 8, :]) / 2
+    for b in range(out.shape[0]):
+        if torch.sum(style_vectors2[b: b + 1, 9, :]) == 0:
+            out[b, 9, :] = style_vectors1[b, 9, :]
+    return out
+
+
 def _flat_morph(mask: np.ndarray, radius: int, op) -> np.ndarray:
     """Flat (2r+1)^2 dilation / erosion with the 'geodesic' border of utils/morphology.py:76-81, 150-155: pixels outside the image
     are ignored.  ``mask``: float ``[..., H, W]``."""

@@ -410,6 +410,55 @@ def g12():
     save("g12_mask_surgery", **out)
 
 
+def g13():
+    print("G13 style-vector mix: swap_comp_style_vector (swap_face_fine/swap_face_mask.py:336-367)")
+    import types
+    if not hasattr(np, "long"):
+        np.long = np.int64
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    import importlib
+    sfm = importlib.import_module("swap_face_fine.swap_face_mask")
+    default_idx = sorted(set(range(12)) - {0, 4, 11})        # face_swap_video_pipeline.py:436
+    D = 96
+    out = {}
+
+    def vec(key, bs=1):
+        return rnd(31, "g13." + key, (bs, 12, D))
+
+    cases = []
+    t, s = vec("default.t"), vec("default.s")
+    cases.append(("default", t, s, default_idx, False))
+    s2 = vec("no_teeth.s"); s2[:, 9, :] = 0
+    cases.append(("no_teeth", vec("no_teeth.t"), s2, default_idx, False))
+    s3 = vec("teeth_cancel.s"); s3[:, 9, :] = 0; s3[:, 9, 0] = 1.5; s3[:, 9, 5] = -1.5      # sums to exactly 0 without being empty
+    cases.append(("teeth_cancel", vec("teeth_cancel.t"), s3, default_idx, False))
+    cases.append(("below_face", vec("below.t"), vec("below.s"), default_idx, True))
+    s4 = vec("below_no_teeth.s"); s4[:, 9, :] = 0
+    cases.append(("below_no_teeth", vec("below_no_teeth.t"), s4, [1, 2, 3, 5, 6, 8, 9, 10], True))
+    cases.append(("no_indices", vec("none.t"), vec("none.s"), [], False))
+    cases.append(("all_indices", vec("all.t"), vec("all.s"), list(range(12)), False))
+    for name, t, s, idx, below in cases:
+        ref = sfm.swap_comp_style_vector(t.clone(), s.clone(), list(idx), belowFace_interpolation=below)
+        ora = O.swap_comp_style_vector(t, s, idx, below)
+        assert torch.equal(ref, ora), name
+        out.update({f"{name}.target": t, f"{name}.source": s, f"{name}.idx": np.array(idx, np.int64), f"{name}.below": np.array(int(below)),
+                    f"{name}.out": ref})
+        print(f"  {name:18s} idx={idx} below={below}: restatement == reference (bit-exact)")
+    # a batch = that many batch-1 calls of the reference (it is only ever called with one frame): sample 1 has no teeth, sample 2 a cancelling sum
+    tb, sb_ = vec("batch.t", 4), vec("batch.s", 4)
+    sb_[1, 9, :] = 0
+    sb_[2, 9, :] = 0; sb_[2, 9, 3] = 2.0; sb_[2, 9, 4] = -2.0
+    for below in (False, True):
+        ref = torch.cat([sfm.swap_comp_style_vector(tb[b: b + 1].clone(), sb_[b: b + 1].clone(), list(default_idx), belowFace_interpolation=below)
+                         for b in range(4)])
+        assert torch.equal(ref, O.swap_comp_style_vector(tb, sb_, default_idx, below))
+        out[f"batch.out_below{int(below)}"] = ref
+    out.update({"batch.target": tb, "batch.source": sb_, "batch.idx": np.array(default_idx, np.int64)})
+    out["names"] = np.array([c[0] for c in cases])
+    print("  batch of 4 (per-sample reference calls), below on/off: restatement == reference (bit-exact)")
+    save("g13_style_mix", **out)
+
+
 def g0(Net3, sg2):
     """state_dict manifests (key -> shape, dtype) of the reference modules: pure data."""
     import argparse as ap
@@ -460,6 +509,7 @@ def main():
     if want("g9"): g9_10()
     if want("g11"): g11()
     if want("g12"): g12()
+    if want("g13"): g13()
 
 
 if __name__ == "__main__":

@@ -4,7 +4,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import load_golden, install_dropin
+from conftest import load_golden, install_dropin, record_parity
 from e4s2024_amd import seeded
 from oracle import e4s_oracle as O
 
@@ -128,7 +128,7 @@ def test_g7_get_style_vectors_golden(gpu_net3):
         vec, struct = gpu_net3.get_style_vectors(img.to(DEV), mask.to(DEV))
     assert tuple(vec.shape) == (1, 12, 1280) and tuple(struct.shape) == (1, 512, 16, 16) and struct.abs().max().item() == 0
     d = maxdiff(vec, g["vectors"])
-    print(f"get_style_vectors: max-abs diff vs reference golden = {d:.3e} (|ref|max = {np.abs(g['vectors']).max():.3f})")
+    record_parity("g7.get_style_vectors_vs_reference_golden", d, 1e-3, f"|ref|max = {np.abs(g['vectors']).max():.3f}")
     assert d <= 1e-3
     assert vec[0, 9].abs().max().item() == 0 and vec[0, 11].abs().max().item() == 0
 

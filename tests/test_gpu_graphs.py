@@ -50,3 +50,46 @@ def test_graphed_full_swap_matches_eager(gpu_net3, parser):
     d2 = seeded.seeded_image(8, 1, 1024).to(DEV)
     ref2, _ = pipeline.swap_batch(gpu_net3, parser, d2, t)
     assert torch.equal(g(d2, t)[0], ref2)
+
+
+def test_two_threads_two_streams_match_the_serial_run(gpu_net3):
+    """Host-state hygiene: the Python layer keeps its state per HIP stream, so two host threads that each drive their own
+    stream through the same network — different codes, different masks, 4 x 4 .. 32 x 32 layers on split-K workspaces, style-table plans,
+    region-map caches all in flight at once — produce exactly the bits of the two calls run one after the other."""
+    import threading
+    from e4s2024_amd import seeded
+    la = seeded.seeded_latent_avg(2, 18)
+    jobs = []
+    for k in range(2):
+        codes = seeded.seeded_codes(61 + k, 2, 12, 18, la).to(DEV)
+        lab = torch.from_numpy(seeded.blocky_labels(71 + k, 2, 12, 512, 16 if k == 0 else 64)).to(DEV).to(torch.uint8)
+        jobs.append((codes, lab))
+    with torch.no_grad():
+        serial = [gpu_net3.gen_img(None, c, m, randomize_noise=False)[0].clone() for c, m in jobs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in jobs]
+    results = [[None] * 6 for _ in jobs]
+    errors = []
+    gate = threading.Barrier(len(jobs))
+
+    def work(i):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(streams[i]), torch.no_grad():
+                gate.wait()
+                for r in range(6):
+                    results[i][r] = gpu_net3.gen_img(None, jobs[i][0], jobs[i][1], randomize_noise=False)[0]
+            streams[i].synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    torch.cuda.synchronize()
+    for i in range(len(jobs)):
+        for r in range(6):
+            assert torch.equal(results[i][r], serial[i]), f"thread {i}, repetition {r}: differs from the serial run"

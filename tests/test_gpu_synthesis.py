@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, install_dropin, template_from_manifest
+from conftest import load_golden, install_dropin, template_from_manifest, record_parity
 from e4s2024_amd import seeded
 from oracle import e4s_oracle as O
 
@@ -94,7 +94,7 @@ def test_g5_small_generators(sg2, manifest, tag, man):
         img, none, feats = gen([codes.to(DEV)], None, seeded.labels_to_onehot(lab, ncls).to(DEV), input_is_latent=True, randomize_noise=False)
     assert none is None
     d = maxdiff(img, g[tag + ".image"])
-    print(f"Generator({size}) [{_ops.MODCONV_MODE}]: max-abs pixel diff vs reference golden = {d:.3e}")
+    record_parity(f"g5.generator{size}.pixels_vs_reference_golden[{_ops.MODCONV_MODE}]", d, 5e-4)
     assert d <= 5e-4
     f = feats.flatten().cpu()
     assert maxdiff(f[:: max(1, f.numel() // 4096)], g[tag + ".feats_sample"]) <= 5e-4
@@ -115,7 +115,7 @@ def test_g6_gen_img_1024_golden(gpu_net3):
     assert minus1 == -1 and tuple(img.shape) == (1, 3, 1024, 1024) and tuple(feats.shape) == (1, 512, 16, 16)
     ic = img.cpu()
     d = max(maxdiff(ic.flatten()[g["pix_idx"]], g["pix"]), maxdiff(ic[0, :, 480:544, 480:544], g["crop"]), maxdiff(ic[0, :, 777, :], g["row"]))
-    print(f"gen_img 1024 blocky [{_ops.MODCONV_MODE}]: max-abs pixel diff vs reference golden = {d:.3e}")
+    record_parity(f"g6.gen_img1024_blocky.pixels_vs_reference_golden[{_ops.MODCONV_MODE}]", d, PIXEL_TOL)
     assert d <= PIXEL_TOL
     assert maxdiff(feats.flatten().cpu()[::32], g["feats_sample"]) <= PIXEL_TOL
     assert abs(ic.double().mean().item() - g["stats"][0]) < 1e-4
@@ -129,7 +129,7 @@ def test_g6_gen_img_1024_iid_labels_golden(gpu_net3):
         img, _, _ = gpu_net3.gen_img(torch.zeros(1, 512, 32, 32, device=DEV), codes.to(DEV), mask.to(DEV), randomize_noise=False)
     ic = img.cpu()
     d = max(maxdiff(ic.flatten()[g["pix_idx"]], g["pix"]), maxdiff(ic[0, :, 448:576, 448:576], g["crop"]))
-    print(f"gen_img 1024 iid [{_ops.MODCONV_MODE}]: max-abs pixel diff vs reference golden = {d:.3e}")
+    record_parity(f"g6.gen_img1024_iid.pixels_vs_reference_golden[{_ops.MODCONV_MODE}]", d, PIXEL_TOL)
     assert d <= PIXEL_TOL
 
 

@@ -194,3 +194,24 @@ def test_pil_bicubic_resize_restatement_equals_pillow():
         xmin, cnt, kk = O.pil_resample_coeffs(n_in, n_out)
         t_xmin, t_cnt, t_kk, ksize = ops._pil_bicubic_tables(n_in, n_out, torch.device("cpu"))
         assert ksize == kk.shape[1] and np.array_equal(t_xmin.numpy(), xmin) and np.array_equal(t_cnt.numpy(), cnt) and np.array_equal(t_kk.numpy(), kk)
+
+
+G13_CASES = ("default", "no_teeth", "teeth_cancel", "below_face", "below_no_teeth", "no_indices", "all_indices")
+
+
+def test_g13_style_vector_mix():
+    """f2: ``swap_comp_style_vector`` (swap_face_fine/swap_face_mask.py:336-367) — the oracle restatement AND the product's batched,
+    sync-free ``pipeline.mix_style_vectors`` (pure tensor plumbing, runs on any device) reproduce the reference's own outputs bit for bit,
+    incl. a driven face without teeth, a teeth vector that merely sums to zero, neck interpolation on/off, and a batch = per-sample calls."""
+    from e4s2024_amd import pipeline
+    g = load_golden("g13_style_mix")
+    assert tuple(g["names"]) == G13_CASES
+    for name in G13_CASES:
+        t, s, idx, below = T(g[f"{name}.target"]), T(g[f"{name}.source"]), [int(i) for i in g[f"{name}.idx"]], bool(g[f"{name}.below"])
+        assert torch.equal(O.swap_comp_style_vector(t, s, idx, below), T(g[f"{name}.out"])), name
+        assert torch.equal(pipeline.mix_style_vectors(t, s, idx, below), T(g[f"{name}.out"])), name
+    t, s, idx = T(g["batch.target"]), T(g["batch.source"]), [int(i) for i in g["batch.idx"]]
+    assert idx == list(pipeline.DEFAULT_COMP_INDICES)
+    for below in (False, True):
+        assert torch.equal(O.swap_comp_style_vector(t, s, idx, below), T(g[f"batch.out_below{int(below)}"]))
+        assert torch.equal(pipeline.mix_style_vectors(t, s, idx, below), T(g[f"batch.out_below{int(below)}"]))
