@@ -2,16 +2,22 @@
 """Headline benchmark: 1024x1024 faces/sec of the region-aware StyleGAN2 synthesis (BASELINE.json configs[1]:
 ``Net3.gen_img`` from random W+ codes and random 12-class masks, batch 4 per GPU, randomize_noise=False).
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W        (N>1: one rank per GPU — launched by torch.distributed.run, or, when called
+                                                          plainly, bench.py starts that launcher itself as a child process)
 
-A step = one ``gen_img`` call on a batch of 4 faces whose codes / masks / weights are already resident in HBM.
+A step = one ``gen_img`` call on a batch of 4 faces whose codes / masks / weights are already resident in HBM; every step gets a fresh
+one-hot mask tensor object, so the per-frame mask -> region-map conversion runs inside the timed region (no cache hit).
 Frames are independent units: with N GPUs every rank synthesises its own batch (weak scaling, no data-path collective;
 RCCL is used for the start/stop barriers and the max-over-ranks reduction of the elapsed time only).
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline     — dominant kernel (the fp32-MFMA implicit-GEMM modulated conv): algorithmic FLOPs of its launches in a step
-                 / their HIP-event durations measured inside the timed region, against the 157.3 TFLOP/s fp32 matrix peak
+  roofline     — dominant kernel (the split-bf16 MFMA implicit-GEMM modulated conv): algorithmic FLOPs of its launches in a step
+                 / their HIP-event durations measured inside the timed region, against dense bf16 MFMA peak / 3 MFMAs per product
   cpu_baseline — the faithful 12-pass CPU oracle timed on one face on this host's cores (rank 0, N=1 only)
+  full_swap    — BASELINE configs[2] (N=1): p50 ms/frame at batch 8, its own roofline fraction and a parity check of one face of the
+                 timed batch against the CPU oracle chain
+  clip         — BASELINE configs[4]: a 256-frame clip, frames block-sharded over the ranks, broadcast of the clip's shared W+
+                 (latent_avg) and the streamed uint8 gather of the frames to rank 0 INSIDE the timed region (every N)
 """
 from __future__ import annotations
 
@@ -68,18 +74,42 @@ def conv3x3_flops_per_face(size=1024, want_executed=False):
     return out
 
 
+TRAFFIC_FILE = "profiles/r02_traffic.json"
+
+
 def _pmc_traffic(kernel_key):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE in separate runs, tools/final_prof.sh -> profiles/r01_traffic.json); None if no pass covers that kernel.
-    bench.py cannot collect counters itself — a --pmc run is a separate process around it."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    """(HBM bytes per launch of the dominant kernel, where that number comes from).  bench.py cannot collect PMC counters itself — a
+    rocprofv3 --pmc run is a separate process around this very command (tools/final_prof.sh: FETCH_SIZE and WRITE_SIZE in separate passes,
+    written to TRAFFIC_FILE) — so the figure is NOT live: it is reported only if the committed passes of THIS round cover the kernel that
+    dominates now, and tagged with its source; otherwise null."""
+    path = os.path.join(ROOT, TRAFFIC_FILE)
     try:
         with open(path) as f:
             t = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, f"none: {TRAFFIC_FILE} not present"
     ent = t.get(kernel_key)
-    return None if ent is None else ent.get("hbm_bytes_per_launch")
+    if ent is None:
+        return None, f"none: {TRAFFIC_FILE} has no pass for {kernel_key}"
+    return ent.get("hbm_bytes_per_launch"), f"committed rocprofv3 --pmc passes of this command ({TRAFFIC_FILE}; not measured in this run)"
+
+
+# BASELINE configs[2] unit of work (SURVEY §8d): 2 x BiSeNet (26.77) + 2 x encoder (229.34) + MLPs (0.10) + synthesis (148.52) GFLOP per face
+FULL_SWAP_GFLOP = {"parser": 2 * 26.77, "encoder": 2 * 229.34, "mlps": 0.10, "synthesis": 148.52}
+
+
+def _spawn_ranks(n):
+    """``python bench.py --gpus N`` outside a launcher: start ``torch.distributed.run`` with N ranks of this script as a CHILD process and
+    exit with its code.  Nothing in this process has touched the GPU yet (and nothing will)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -92,13 +122,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-swap", action="store_true", help="skip the secondary full-swap p50 measurement")
     ap.add_argument("--no-pti", action="store_true", help="skip the secondary PTI step measurement (BASELINE configs[3])")
+    ap.add_argument("--clip", type=int, default=256, help="frames of the clip-mode measurement (BASELINE configs[4]); 0 skips it")
+    ap.add_argument("--clip-batch", type=int, default=SWAP_BATCH)
+    ap.add_argument("--clip-unit", choices=["swap", "gen"], default="swap",
+                    help="per-frame work of the clip: the reference's per-frame swap (2 parses + 2 encodes + mask surgery + mix + synthesis) or synthesis only")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _spawn_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with python -m torch.distributed.run --nproc-per-node {args.gpus})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -132,8 +168,10 @@ def main():
     ops.STRICT_MASK = False                                       # the one-hot check costs a host sync; masks here are one-hot by construction
 
     def step():
+        # a fresh tensor OBJECT per step (a view: no copy, no extra kernel): ops.mask_to_labels caches per mask object, and a frame's
+        # one-hot mask -> uint8 region map conversion is per-frame work that belongs inside the timed region
         with torch.no_grad():
-            return net.gen_img(None, codes, mask, randomize_noise=False)[0]
+            return net.gen_img(None, codes, mask.view_as(mask), randomize_noise=False)[0]
 
     for _ in range(args.warmup):
         img = step()
@@ -157,9 +195,10 @@ def main():
         elapsed = float(t.item())
     assert torch.isfinite(img).all()
 
-    # ---- secondary metric of BASELINE.json: p50 ms/frame of the full swap (2 parses + 2 encodes + MLPs + synthesis), batch 8
-    full_swap = None
-    if rank == 0 and world == 1 and not args.no_full_swap:
+    # ---- the full-swap models (encoder, per-region MLPs, parser): seeded on every rank, used by the full-swap and clip measurements
+    parser = None
+    need_swap_models = (rank == 0 and world == 1 and not args.no_full_swap) or (args.clip > 0 and args.clip_unit == "swap")
+    if need_swap_models:
         from e4s2024_amd import pipeline
         from swap_face_fine.face_parsing.face_parsing_demo import FaceParser
         seeded.apply_seeded(net.encoder, 4, "net3", prefix="encoder.")
@@ -168,6 +207,10 @@ def main():
         parser = FaceParser(None, device=dev)
         seeded.apply_seeded(parser.seg, 7, "bisenet")
         parser.seg.eval()
+
+    # ---- secondary metric of BASELINE.json: p50 ms/frame of the full swap (2 parses + 2 encodes + MLPs + synthesis), batch 8
+    full_swap = None
+    if rank == 0 and world == 1 and not args.no_full_swap:
         drv = seeded.seeded_image(5, SWAP_BATCH, 1024).to(dev)
         tgt = seeded.seeded_image(6, SWAP_BATCH, 1024).to(dev)
         for _ in range(2):
@@ -176,16 +219,125 @@ def main():
         times = []
         for _ in range(13):                                   # 13 x 8 = 104 frames
             a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
-            a.record(); frames, _ = pipeline.swap_batch(net, parser, drv, tgt); b.record()
+            a.record(); frames, labs = pipeline.swap_batch(net, parser, drv, tgt); b.record()
             torch.cuda.synchronize()
             times.append(a.elapsed_time(b))
         times.sort()
         p50 = times[len(times) // 2]
+        # roofline of the unit: algorithmic GFLOP per face against the bf16 MFMA peak divided by the MFMAs each part spends per
+        # product (parser: three-way split = 6, everything else: two-way split = 3)
+        gf = FULL_SWAP_GFLOP
+        total_gf = sum(gf.values())
+        mfma_per_product = (gf["parser"] * 6 + (total_gf - gf["parser"]) * 3) / total_gf
+        fs_peak = BF16_MATRIX_PEAK_TFLOPS / mfma_per_product
+        fs_ach = total_gf * 1e9 * SWAP_BATCH / (p50 * 1e-3) / 1e12
         full_swap = {"p50_ms_per_frame": round(p50 / SWAP_BATCH, 3), "p50_ms_per_batch": round(p50, 3), "batch": SWAP_BATCH, "frames": 13 * SWAP_BATCH,
                      "swaps_per_s": round(SWAP_BATCH / p50 * 1e3, 1),
+                     "roofline": {"bound": "mfma", "achieved": round(fs_ach, 2), "peak": round(fs_peak, 1), "unit": "TFLOP/s", "frac": round(fs_ach / fs_peak, 4),
+                                  "algorithmic_gflop_per_face": round(total_gf, 2),
+                                  "peak_basis": f"dense bf16 MFMA 2500 TFLOP/s / {mfma_per_product:.3f} MFMAs per product (parser 6, encoder / MLPs / synthesis 3)"},
                      "unit_of_work": "2 x BiSeNet parse (three-way bf16 split, fp32-class) + 2 x get_style_vectors + style mix + cal_style_codes + gen_img + tensor2im, "
                                      "inputs resident in HBM (BASELINE configs[2])"}
-        del parser, drv, tgt, frames
+        if sd_cpu is not None:
+            # parity of the timed batch: one face of it through the CPU oracle chain (parse x2 -> style vectors x2 -> mix -> codes -> synthesis)
+            try:
+                from oracle import e4s_oracle as O
+                import numpy as np
+                torch.set_num_threads(min(16, os.cpu_count() or 1))
+                fb = 3
+                sd_all = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+                sd_bis = {k: v.detach().cpu() for k, v in parser.seg.state_dict().items()}
+                with torch.no_grad():
+                    lab_d_gpu = parser.parse_batch((drv[fb:fb + 1] + 1) / 2, seg12=True)[0].cpu().numpy()
+                    lab_t_gpu = labs[fb].cpu().numpy()
+                    flips = 0
+                    for img_, got in ((drv, lab_d_gpu), (tgt, lab_t_gpu)):
+                        logits = O.bisenet_forward(sd_bis, O.parser_preprocess((img_[fb:fb + 1].cpu() + 1) / 2))
+                        flips += int((O.remap_19_to_12(torch.argmax(logits, 1)[0].numpy().astype(np.uint8)) != got).sum())
+                    oh = lambda l: O.label_map_to_onehot(torch.from_numpy(l.astype(np.int64))[None, None], 12)   # noqa: E731
+                    v_d, _ = O.get_style_vectors(sd_all, drv[fb:fb + 1].cpu(), oh(lab_d_gpu))
+                    v_t, _ = O.get_style_vectors(sd_all, tgt[fb:fb + 1].cpu(), oh(lab_t_gpu))
+                    mixed = O.swap_comp_style_vector(v_t, v_d, pipeline.DEFAULT_COMP_INDICES, False)
+                    ref_img, _ = O.generator_forward(sd_all, O.cal_style_codes(sd_all, mixed, la, 13), oh(lab_t_gpu), None)
+                    img_f, _ = pipeline.swap_batch(net, parser, drv, tgt, to_uint8=False)
+                full_swap["parity"] = {"face": fb, "max_abs_pixel_diff_vs_oracle": float(f"{(img_f[fb].cpu() - ref_img[0]).abs().max().item():.3e}"),
+                                       "max_grey_level_diff_vs_oracle": int(np.abs(frames[fb].cpu().numpy().astype(np.int16)
+                                                                                   - O.tensor2im_array(ref_img[0]).astype(np.int16)).max()),
+                                       "parser_label_flips_vs_oracle": flips, "tol": 1e-3,
+                                       "how": "face 3 of the timed batch of 8 through oracle/e4s_oracle.py from the device's region maps"}
+                del img_f, ref_img
+            except Exception as e:      # noqa: BLE001 - a reported check must not cost the line
+                full_swap["parity"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        del drv, tgt, frames, labs
+
+    # ---- BASELINE configs[4]: a clip, frames block-sharded over the ranks (runner.FrameShardRunner); inside the timed region: the broadcast
+    # of the clip's shared W+ (latent_avg, what every frame's codes are offsets of) from rank 0, each rank's per-batch swaps, and the
+    # streamed uint8 gather of the finished frames to rank 0 (face_swap_video_pipeline.py:404-486 per frame)
+    clip_info = None
+    if args.clip > 0:
+        try:
+            from e4s2024_amd import runner as _runner
+            rn = _runner.FrameShardRunner(device=dev)
+            n_frames, cb = args.clip, args.clip_batch
+            POOL = 16
+            if args.clip_unit == "swap":
+                pool_d = seeded.seeded_image(50, POOL, 1024).to(dev)       # resident frame pools; frame i of the clip = pool[i % 16]
+                pool_t = seeded.seeded_image(60, POOL, 1024).to(dev)
+
+                def frame_inputs(lo, hi):
+                    idx = torch.arange(lo, hi, device=dev) % POOL
+                    return pool_d.index_select(0, idx), pool_t.index_select(0, idx)
+
+                def synth(shared, fi):
+                    net.latent_avg = shared
+                    return pipeline.swap_batch(net, parser, fi[0], fi[1], mask_surgery=True)[0]
+                unit = ("per frame: 2 x parse + 2 x get_style_vectors + swap_head_mask_hole_first + style mix + cal_style_codes + gen_img + tensor2im "
+                        "(pipeline.swap_batch(mask_surgery=True))")
+            else:
+                pool_c = seeded.seeded_codes(51, POOL, 12, 18, la).to(dev)
+                pool_l = torch.from_numpy(seeded.blocky_labels(52, POOL, 12, 512, 16)).to(dev).to(torch.uint8)
+
+                def frame_inputs(lo, hi):
+                    idx = torch.arange(lo, hi, device=dev) % POOL
+                    return pool_c.index_select(0, idx), pool_l.index_select(0, idx)
+
+                def synth(shared, fi):
+                    net.latent_avg = shared
+                    return _runner.gen_img_frames(net, fi[0], fi[1])
+                unit = "per frame: gen_img + tensor2im (runner.gen_img_frames)"
+            shared_src = la.to(dev) if rank == 0 else None
+            out_buf = torch.empty((n_frames, 1024, 1024, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
+            with torch.no_grad():
+                synth(la.to(dev), frame_inputs(0, cb))                    # warm-up batch (weight caches, allocator)
+            torch.cuda.synchronize()
+            rn.barrier()
+            torch.cuda.synchronize()
+            tc0 = time.perf_counter()
+            shared = rn.broadcast_shared(shared_src, (18, 512))
+            frames_all = rn.run_clip_streamed(n_frames, shared, frame_inputs, synth, batch=cb, out=out_buf)
+            torch.cuda.synchronize()
+            rn.barrier()
+            torch.cuda.synchronize()
+            clip_s = rn.max_over_ranks(time.perf_counter() - tc0)
+            ok = None
+            if rank == 0:
+                # the last batch of the LAST rank's block, recomputed here with the same batch composition, must equal what arrived
+                s_last, e_last = _runner.shard_range(n_frames, world - 1, world)
+                lo = s_last + ((e_last - s_last - 1) // cb) * cb
+                with torch.no_grad():
+                    again = synth(shared, frame_inputs(lo, e_last))
+                ok = bool(torch.equal(again, frames_all[lo:e_last]))
+            max_block = -(-n_frames // world)
+            clip_info = {"frames": n_frames, "batch": cb, "seconds": round(clip_s, 4), "frames_per_s": round(n_frames / clip_s, 1),
+                         "ms_per_frame": round(clip_s / n_frames * 1e3, 3), "scaling": "strong", "n_gpus": world, "unit_of_work": unit,
+                         "collectives_in_timed_region": f"broadcast latent_avg [18,512] from rank 0 + {-(-max_block // cb)} rounds of "
+                                                        f"async gather of uint8 frames ({cb} x 3 MB per rank per round) to rank 0",
+                         "gathered_frames_match_recomputation": ok}
+            del out_buf, frames_all
+        except Exception as e:      # noqa: BLE001 - secondary measurement
+            clip_info = {"error": f"{type(e).__name__}: {e}"[:300]}
+        net.latent_avg = la.to(dev)
+    del parser
 
     # ---- BASELINE configs[3]: one PTI optimiser step (cal_style_codes -> gen_img -> L2 -> backward -> Adam) at 1024x1024, batch 1,
     # the whole step replayed as one hipGraph.  Reported beside the headline, never part of `value`; a failure here must not cost the line.
@@ -241,7 +393,7 @@ def main():
             # is a third of the dense bf16 MFMA peak; exact mode is priced against the fp32 MFMA peak.
             peak = BF16_MATRIX_PEAK_TFLOPS / 3.0 if sb else FP32_MATRIX_PEAK_TFLOPS
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": _pmc_traffic(dom),
+                    "frac": round(ach / peak, 4), "traffic": _pmc_traffic(dom)[0], "traffic_source": _pmc_traffic(dom)[1],
                     "peak_basis": ("dense bf16 MFMA 2500 TFLOP/s / 3 MFMAs per fp32-accurate product (split-bf16)" if sb else "fp32 MFMA 157.3 TFLOP/s"),
                     "vs_fp32_mfma_peak": round(ach / FP32_MATRIX_PEAK_TFLOPS, 3),
                     "launches_per_step": calls // args.steps, "avg_launch_ms": round(avg_ms, 4),
@@ -279,11 +431,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16x3" if ops.MODCONV_MODE == "sb" else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: StyleGAN2 1024x1024 synthesis from random W+ (Net3.gen_img, randomize_noise=False), "
-                                   f"12-region {args.labels} masks, batch={bs}/GPU; arithmetic = "
+                                   f"12-region {args.labels} masks (a fresh one-hot mask tensor per step: the mask -> region-map conversion is timed), batch={bs}/GPU; arithmetic = "
                                    + ("split-bf16: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate (max-abs pixel error "
                                       "6e-5 vs the reference; plain bf16 would miss the 1e-3 bar)" if ops.MODCONV_MODE == "sb" else "exact fp32 MFMA"),
                        "batch_per_gpu": bs, "global_batch": bs * world, "resolution": 1024, "regions": 12, "parallelism": f"frames x{world}"},
-            "roofline": roof, "cpu_baseline": cpu, "full_swap": full_swap, "pti": pti_info,
+            "roofline": roof, "cpu_baseline": cpu, "full_swap": full_swap, "pti": pti_info, "clip": clip_info,
             "algorithmic_gflop_per_face": 148.52,
             "job_algorithmic_tflops_per_gpu": round(value * 148.52e9 / 1e12 / world, 2),
         }

@@ -374,7 +374,8 @@ def test_pti_step_gradients_1024_vs_oracle_autograd(net3_sd):
     training/video_swap_ft_coach.py:268-299) on the native gradient kernels, against autograd through the CPU oracle
     (cal_style_codes + the faithful twelve-pass generator_forward) for the style vectors and a sampled subset of the trainable
     parameters that covers every kind on the path: masked / single-region conv weights at every resolution class, up-sampling and
-    plain layers, modulation weights and biases, noise weights, activation biases, ToRGB (masked and single-region) and one per-region MLP."""
+    plain layers, modulation weights and biases, noise weights, activation biases, masked ToRGB and per-region MLPs (the single-region
+    layers past remaining_layer_idx are frozen by the reference's constructor: the gradient only passes through them)."""
     from conftest import default_opts, record_parity
     install_dropin()
     from models.networks import Net3
@@ -385,13 +386,15 @@ def test_pti_step_gradients_1024_vs_oracle_autograd(net3_sd):
     mask = seeded.labels_to_onehot(lab, 12)
     target = torch.tanh(T(seeded.seeded_array(5, "img", (1, 3, 1024, 1024), dist="normal")))
     subset = ["G.conv1.conv.weight", "G.conv1.conv.modulation.weight", "G.conv1.noise.weight", "G.conv1.activate.bias", "G.to_rgb1.conv.weight",
-              "G.convs.0.conv.weight", "G.convs.3.conv.modulation.bias", "G.convs.6.conv.weight", "G.convs.7.conv.weight", "G.convs.7.noise.weight",
-              "G.convs.8.conv.weight", "G.convs.8.conv.modulation.weight", "G.convs.9.activate.bias", "G.convs.10.conv.weight",
-              "G.convs.11.conv.weight", "G.convs.11.conv.modulation.weight", "G.convs.12.conv.weight", "G.convs.12.noise.weight",
-              "G.convs.13.conv.weight", "G.convs.13.activate.bias", "G.convs.14.conv.weight", "G.convs.14.conv.modulation.weight",
-              "G.convs.15.conv.weight", "G.convs.15.noise.weight", "G.convs.15.activate.bias",
-              "G.to_rgbs.2.conv.weight", "G.to_rgbs.4.conv.modulation.weight", "G.to_rgbs.5.conv.weight", "G.to_rgbs.6.bias", "G.to_rgbs.7.conv.weight",
-              "G.to_rgbs.7.conv.modulation.weight", "MLPs.6.mlp.0.weight", "MLPs.6.mlp.2.weight", "MLPs.6.mlp.2.bias", "MLPs.1.mlp.0.bias"]
+              "G.convs.0.conv.weight", "G.convs.3.conv.modulation.bias", "G.convs.5.conv.weight", "G.convs.6.conv.weight", "G.convs.7.conv.weight",
+              "G.convs.7.noise.weight", "G.convs.8.conv.weight", "G.convs.8.conv.modulation.weight", "G.convs.9.conv.weight", "G.convs.9.activate.bias",
+              "G.convs.10.conv.weight", "G.convs.10.noise.weight", "G.convs.11.conv.weight", "G.convs.11.conv.modulation.weight",
+              "G.convs.11.activate.bias", "G.to_rgbs.2.conv.weight", "G.to_rgbs.3.bias", "G.to_rgbs.4.conv.weight", "G.to_rgbs.4.conv.modulation.weight",
+              "MLPs.6.mlp.0.weight", "MLPs.6.mlp.2.weight", "MLPs.6.mlp.2.bias", "MLPs.1.mlp.0.bias"]
+    # the reference's Net3(train_G=True) freezes everything past remaining_layer_idx (the single-region layers convs[12..15], to_rgbs[5..7]:
+    # manifest "net3_1024_rli13_trainG_requires_grad_false"); the gradient still has to pass THROUGH them to reach every layer above
+    frozen = ["G.convs.12.conv.weight", "G.convs.13.conv.weight", "G.convs.14.conv.weight", "G.convs.15.conv.weight", "G.to_rgbs.5.conv.weight",
+              "G.to_rgbs.7.conv.weight"]
     assert all(k in net3_sd for k in subset)
 
     # ---- device: one PTI step's loss and backward on the drop-in Net3 (train_G=True), fixed noise buffers
@@ -406,6 +409,7 @@ def test_pti_step_gradients_1024_vs_oracle_autograd(net3_sd):
     loss.backward()
     torch.cuda.synchronize()
     named = dict(net.named_parameters())
+    assert all(not named[k].requires_grad and named[k].grad is None for k in frozen)
 
     # ---- oracle autograd on the host
     sd_o = {k: (v.clone().requires_grad_(True) if k in subset else v) for k, v in net3_sd.items()}
