@@ -26,9 +26,9 @@ _PROTOS = {
     "e4s_style_demod_batched": [c_ptr, c_int, c_int, c_int, c_ptr],
     "e4s_region_modconv3x3": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr, c_int] + [c_int] * 7 + [c_ptr, c_i64, c_ptr],
     "e4s_modconv_prep_weights_sb": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
-    "e4s_region_modconv3x3_sb": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr, c_int] + [c_int] * 7 + [c_ptr, c_i64] + [c_ptr] * 7,
+    "e4s_region_modconv3x3_sb": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr, c_int] + [c_int] * 7 + [c_ptr, c_i64] + [c_ptr] * 8,
     "e4s_modconv_tconv_sb": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr],
-    "e4s_modconv_up_fused_sb": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr],
+    "e4s_modconv_up_fused_sb": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr],
     "e4s_swap_head_mask": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
     "e4s_foreground_masks": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_pyr_down": [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr],
@@ -58,6 +58,9 @@ _PROTOS = {
     "e4s_bilinear_argmax": [c_ptr, c_ptr, c_ptr] + [c_int] * 6 + [c_ptr],
     "e4s_bicubic_down_normalize": [c_ptr] * 5 + [c_int] * 5 + [c_ptr],
     "e4s_tensor2im_u8": [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
+    "e4s_to_split_planes": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr],
+    "e4s_chain_conv3x3": [c_ptr, c_ptr],
+    "e4s_chain_upconv": [c_ptr, c_ptr, c_ptr],
     "e4s_grouped_linear": [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_int, c_f32] + [c_int] * 4 + [c_ptr],
 }
 
@@ -72,6 +75,13 @@ class StyleJob(ctypes.Structure):
     """Mirror of E4sStyleJob (include/e4s_hip.h)."""
     _fields_ = [("s", c_ptr), ("d", c_ptr), ("styles", c_ptr), ("stride_b", c_i64), ("stride_r", c_i64), ("mod_weight", c_ptr),
                 ("mod_bias", c_ptr), ("wsq", c_ptr), ("nreg", c_int), ("cin", c_int), ("cout", c_int), ("_pad", c_int)]
+
+
+class ChainLayer(ctypes.Structure):
+    """Mirror of E4sChainLayer (include/e4s_hip.h)."""
+    _fields_ = [(n, c_ptr) for n in ("x_sp", "whi", "wlo", "d", "noise", "noise_weight", "act_bias", "out_sp", "s_next", "rgb_out", "rgb_wt",
+                                      "rgb_s", "rgb_bias", "rgb_skip", "rgb_up_kernel")] + \
+               [(n, c_int) for n in ("noise_bs", "act", "bs", "cin", "cout", "h", "w", "_pad")]
 
 
 class _Lib:

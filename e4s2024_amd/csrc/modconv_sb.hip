@@ -134,6 +134,9 @@ struct SbParams {
     const float* rgb_bias;   // [3]
     const float* rgb_skip;   // [bs,3,ho/2,wo/2] or NULL
     const float* rgb_upk;    // [4,4]
+    // optional split-plane output (modconv_chain.hip): out = [hi|lo][bs][cout/8][ho][wo][8 x bf16] of act * s_next[b][co], for a single-region consumer
+    const float* s_next;     // [bs][cout]
+    int64_t plane_out;       // uint4 per plane
 };
 
 template <int CB, int PB, int WC, int WP, int LOG_TW>
@@ -162,7 +165,7 @@ struct SbCfg {
                                                                     // is then 40 192 B, four workgroups per CU instead of three
     static_assert(WC * WP == 4 || WC * WP == 8, "256- or 512-thread workgroups");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS per CU");
-    static_assert((E4S_MAX_REGIONS + 4) * TN * 4 + 64 <= W4 * 16, "demod + bias + ToRGB tables overlay the weight stage");
+    static_assert((E4S_MAX_REGIONS + 5) * TN * 4 + 64 <= W4 * 16, "demod + bias + ToRGB + next-modulation tables overlay the weight stage");
 };
 
 // UNI = every output pixel of the launch has the same region (unmasked layers): x*s is then a property of the INPUT pixel, so it is
@@ -174,8 +177,9 @@ struct SbCfg {
 // an (h+1) x (w+1) grid of positions (a,b); tap (ky,kx) of the 3x3 kernel contributes W[ky][kx] * x[a-(ky>>1)][b-(kx>>1)] to the
 // pre-blur pixel z[2a+(ky&1)][2b+(kx&1)], so the 9 taps feed four accumulator sets (one per output parity) and the raw sums
 // are written to z [bs,cout,2h+1,2w+1]; e4s_blur_epilogue then applies blur, demodulation, noise, bias and activation.
-template <int CB, int PB, int WC, int WP, int LOG_TW, int MINW, bool UNI, bool TCONV, bool RGB = false, bool XN = false>
+template <int CB, int PB, int WC, int WP, int LOG_TW, int MINW, bool UNI, bool TCONV, bool RGB = false, bool XN = false, bool OSP = false>
 __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(const SbParams p) {
+    // OSP = the activation leaves as split planes for the single-region chain (multiplied by the consumer's modulation, split into bf16 hi / lo)
     // XN = the input activation is channels-last (compile-time: the two staging paths must not share a register allocation)
     static_assert(!TCONV || UNI, "the transposed-conv split is only built for single-region layers");
     constexpr int NACC = TCONV ? 4 : 1;
@@ -463,6 +467,11 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
     for (int v = tid; v < C::TN; v += C::NT) bt[v] = (p.act_bias && co0 + v < p.cout) ? p.act_bias[co0 + v] : 0.f;
     float* wsr = bt + C::TN;                     // [TN][3]: ToRGB weight x its (single-region) modulation
     float* kfr = wsr + 3 * C::TN;                // [16] flipped skip-upsample taps
+    float* snt = kfr + 16;                       // [TN] next layer's modulation (OSP)
+    if constexpr (OSP) {
+        for (int v = tid; v < C::TN; v += C::NT) snt[v] = (co0 + v < p.cout) ? p.s_next[(size_t)b * p.cout + co0 + v] : 0.f;
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid < 4) reinterpret_cast<unsigned*>(p.out)[(size_t)p.plane_out * 8 + tid] = 0u;   // zero tail
+    }
     if constexpr (RGB) {
         for (int v = tid; v < 3 * C::TN; v += C::NT) {
             const int n = v / 3;
@@ -539,7 +548,7 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
                     if (p.act) v = (v > 0.f ? v : v * 0.2f) * 1.41421356237309515f;
                     v4[e] = v;
                     if (co < p.cout && pix_ok) {
-                        if ((!RGB || p.out) && !p.out_nhwc) p.out[((size_t)b * p.cout + co) * ho * wo + opix] = v;   // out == NULL: only the fused RGB is wanted
+                        if ((!RGB || p.out) && !p.out_nhwc && !OSP) p.out[((size_t)b * p.cout + co) * ho * wo + opix] = v;   // out == NULL: only the fused RGB is wanted
                         if constexpr (RGB) {
                             rgb0 += v * wsr[n * 3 + 0];
                             rgb1 += v * wsr[n * 3 + 1];
@@ -548,7 +557,18 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
                     }
                 }
                 const int co4 = co0 + (wc * CB + i) * 32 + 8 * r4 + 4 * khalf;      // four consecutive output channels of this pixel
-                if (p.out_nhwc && (!RGB || p.out) && pix_ok && co4 < p.cout)
+                if constexpr (OSP) {
+                    if (pix_ok && co4 < p.cout) {
+                        const int n4 = co4 - co0;
+                        unsigned h0, l0, h1, l1;
+                        split2(__fmul_rn(v4[0], snt[n4]), __fmul_rn(v4[1], snt[n4 + 1]), h0, l0);
+                        split2(__fmul_rn(v4[2], snt[n4 + 2]), __fmul_rn(v4[3], snt[n4 + 3]), h1, l1);
+                        uint2* osp = reinterpret_cast<uint2*>(p.out);
+                        const size_t o8 = (((size_t)b * (p.cout >> 3) + (co4 >> 3)) * ho * wo + opix) * 2 + khalf;   // this half-wave's 8 of the block's 16 bytes
+                        osp[o8] = make_uint2(h0, h1);
+                        osp[(size_t)p.plane_out * 2 + o8] = make_uint2(l0, l1);
+                    }
+                } else if (p.out_nhwc && (!RGB || p.out) && pix_ok && co4 < p.cout)
                     *reinterpret_cast<float4*>(p.out + (((size_t)b * (p.cout / 8) + co4 / 8) * ho * wo + opix) * 8 + (co4 & 7)) = make_float4(v4[0], v4[1], v4[2], v4[3]);
             }
         }
@@ -641,6 +661,16 @@ static int launch_sb(SbParams& p, hipStream_t st, float* workspace, int64_t work
                                                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
                 if (attr2 != hipSuccess) return fail((int)attr2, "region_modconv3x3_sb: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr2));
             }
+            if (p.s_next) {   // masked layer handing over to the single-region chain as split planes
+                if (!p.labels || p.x_nhwc || !p.out) return fail(E4S_ERR_ARG, "region_modconv3x3_sb: split-plane output is built for the masked fused-ToRGB layer");
+                if (C::LDS_BYTES > 64 * 1024) {
+                    static const hipError_t attr3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, MW, false, false, true, false, true>),
+                                                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+                    if (attr3 != hipSuccess) return fail((int)attr3, "region_modconv3x3_sb: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr3));
+                }
+                hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, MW, false, false, true, false, true>), grid, dim3(C::NT), C::LDS_BYTES, st, p);
+                return check_launch("region_modconv3x3_sb");
+            }
             if (!p.labels && p.nreg == 1 && p.x_nhwc)
                 hipLaunchKernelGGL((region_modconv_sb_kernel<CB, PB, WC, WP, LOG_TW, MW, true, false, true, true>), grid, dim3(C::NT), uni_lds, st, p);
             else if (p.x_nhwc)
@@ -680,9 +710,11 @@ extern "C" int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16
                                         const uint8_t* labels, int lh, int lw, const float* noise, int noise_bs, const float* noise_weight,
                                         const float* act_bias, int act, int bs, int cin, int cout, int h, int w, int nreg, int up,
                                         float* workspace, int64_t workspace_floats, float* rgb_out, const float* rgb_wt, const float* rgb_s,
-                                        const float* rgb_bias, const float* rgb_skip, const float* rgb_up_kernel, void* stream) {
-    const int layout = up & (E4S_X_NHWC | E4S_OUT_NHWC);
+                                        const float* rgb_bias, const float* rgb_skip, const float* rgb_up_kernel, const float* s_next, void* stream) {
+    const int layout = up & (E4S_X_NHWC | E4S_OUT_NHWC | E4S_OUT_SP);
     up &= 1;
+    E4S_REQUIRE(!(layout & E4S_OUT_SP) || (s_next && rgb_out && out && cout % 8 == 0 && !(layout & E4S_OUT_NHWC) && ((uintptr_t)out & 15) == 0),
+                "region_modconv3x3_sb: split-plane output needs s_next, the fused ToRGB, cout %% 8 == 0 and a 16-byte aligned tensor");
     E4S_REQUIRE((out || rgb_out) && x && whi && wlo && s, "region_modconv3x3_sb: null tensor");
     E4S_REQUIRE(!rgb_out || (rgb_wt && rgb_s && rgb_bias && (!rgb_skip || rgb_up_kernel) && w >= 32 && !up), "region_modconv3x3_sb: incomplete fused-ToRGB arguments");
     E4S_REQUIRE(bs >= 0 && cin >= 1 && cout >= 1 && h >= 1 && w >= 1, "region_modconv3x3_sb: bad size");
@@ -708,6 +740,8 @@ extern "C" int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16
     p.lscale_x = labels ? (float)lw / (float)wo : 1.f;
     p.noise_bstride = (noise && noise_bs > 1) ? ho * wo : 0;
     p.rgb_out = rgb_out; p.rgb_wt = rgb_wt; p.rgb_s = rgb_s; p.rgb_bias = rgb_bias; p.rgb_skip = rgb_skip; p.rgb_upk = rgb_up_kernel;
+    p.s_next = (layout & E4S_OUT_SP) ? s_next : nullptr;
+    p.plane_out = (int64_t)bs * (cout / 8) * ho * wo;
     hipStream_t st = (hipStream_t)stream;
     float* ws = p.out_nhwc ? nullptr : workspace;     // the split-K partial sums are laid out channels-first
     const int64_t wf = p.out_nhwc ? 0 : workspace_floats;

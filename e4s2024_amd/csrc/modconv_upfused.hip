@@ -33,9 +33,13 @@ struct UpFusedParams {
     int act;
     int bs, cin, cout, h, w;
     int tiles_x, tiles_y;
+    const float* s_next;     // [bs][cout] (OSP): modulation of the NEXT layer, applied before the bf16 split of the output
+    int64_t plane_in, plane_out;   // uint4 per split plane (XSP / OSP)
     int exp;                 // tuning experiments of the -DE4S_PHASE_PROF build (E4S_UF_EXP): 1 = no output stores, 2 = no blur, 4 = no z-tile writes
 };
-// channel-blocked activations ([bs, c/8, h, w, 8]) are compile-time variants: XN = input, ON = output (E4S_X_NHWC / E4S_OUT_NHWC in `act`)
+// channel-blocked activations ([bs, c/8, h, w, 8]) are compile-time variants: XN = input, ON = output (E4S_X_NHWC / E4S_OUT_NHWC in `act`);
+// XSP / OSP = split planes (modconv_chain.hip: [hi|lo][bs][c/8][h][w][8 x bf16], pre-modulated and pre-split by the producer): an XSP input
+// is copied into LDS as it is (no multiply, no split), an OSP output is multiplied by the next layer's modulation and split before it is written
 
 constexpr int UF_T = 16;                    // positions per tile side
 constexpr int UF_STEP = UF_T - 2;           // 14 new positions per tile
@@ -57,13 +61,14 @@ struct UfCfg {
     static constexpr int MAIN_BYTES = W4 * 16 + UF_PATCH * 64;   // weights + x hi/lo planes
     static constexpr int ZT_BYTES = UF_ZCO * UF_ZCS_NHWC * 4;
     static constexpr int BODY = MAIN_BYTES > ZT_BYTES ? MAIN_BYTES : ZT_BYTES;
-    static constexpr int EP_FLOATS = 2 * TN + UF_OUT * UF_OUT;   // epilogue operands fetched at kernel start: d, bias, noise_weight * noise tile
+    static constexpr int EP_FLOATS = 3 * TN + UF_OUT * UF_OUT;   // epilogue operands fetched at kernel start: d, bias, s_next, noise_weight * noise tile
     static constexpr int LDS_BYTES = BODY + EP_FLOATS * 4;
 };
 
-template <int CB, int MINW, bool XN = false, bool ON = false>
+template <int CB, int MINW, bool XN = false, bool ON = false, bool XSP = false, bool OSP = false>
 __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedParams p) {
     using C = UfCfg<CB>;
+    static_assert(!(XSP && XN) && !(OSP && !ON), "split-plane input excludes the fp32 blocked one; split-plane output uses the blocked item mapping");
     constexpr int UF_ZCS = ON ? UF_ZCS_NHWC : 32 * UF_ZS;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint4* wsm = reinterpret_cast<uint4*>(lds_raw);                       // [2][9][2][TN]
@@ -71,7 +76,8 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
     uint4* xl4 = xh4 + 2 * UF_PATCH;                                      // lo plane
     float* ep_d = reinterpret_cast<float*>(lds_raw + C::BODY);            // [TN] demodulation
     float* ep_b = ep_d + C::TN;                                           // [TN] activation bias
-    float* ep_n = ep_b + C::TN;                                           // [28][28] noise_weight * noise of this tile's outputs
+    float* ep_s = ep_b + C::TN;                                           // [TN] next layer's modulation (OSP)
+    float* ep_n = ep_s + C::TN;                                           // [28][28] noise_weight * noise of this tile's outputs
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -104,13 +110,21 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
 #pragma unroll
             for (int r = 0; r < 16; ++r) accs[a][i][r] = 0.f;
 
-    float xr[CKS];
+    float xr[CKS];            // (XSP: the 16 registers hold the chunk's four 16-byte fragments hi/half0, hi/half1, lo/half0, lo/half1 as bits)
     unsigned wr[C::WPT][4];   // scalar components (a uint4 array would be placed in scratch)
     const ptrdiff_t wdelta = p.wlo - p.whi;
     auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
         const int ci0 = chunk * CKS;
         const int cmax = p.cin - 1 - ci0;
-        if constexpr (XN) {   // channel-blocked input [cin/8][h][w][8]: this thread's patch pixel, the chunk's two 8-channel blocks, 4 x 16 bytes
+        if constexpr (XSP) {  // split planes: the chunk's fragments of this thread's patch pixel, 4 x 16 bytes, kept as bits
+            const uint4* xq = reinterpret_cast<const uint4*>(p.x);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const uint4 v = xq[(size_t)(f >> 1) * p.plane_in + ((size_t)(b * (p.cin >> 3) + (ci0 >> 3) + (f & 1)) * hw + sgoff)];
+                xr[4 * f] = __builtin_bit_cast(float, v.x); xr[4 * f + 1] = __builtin_bit_cast(float, v.y);
+                xr[4 * f + 2] = __builtin_bit_cast(float, v.z); xr[4 * f + 3] = __builtin_bit_cast(float, v.w);
+            }
+        } else if constexpr (XN) {   // channel-blocked input [cin/8][h][w][8]: this thread's patch pixel, the chunk's two 8-channel blocks, 4 x 16 bytes
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
@@ -138,11 +152,19 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
     auto store_chunk = [&](int chunk) __attribute__((always_inline)) {
         if (tid < UF_PATCH) {
             unsigned hi[8], lo[8];
+            if constexpr (XSP) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int c0 = chunk * CKS + 2 * c;
-                const float s0 = c0 < p.cin ? sb[c0] : 0.f, s1 = c0 + 1 < p.cin ? sb[c0 + 1] : 0.f;   // wave-uniform
-                split2(s_in ? xr[2 * c] * s0 : 0.f, s_in ? xr[2 * c + 1] * s1 : 0.f, hi[c], lo[c]);
+                for (int c = 0; c < 8; ++c) {
+                    hi[c] = s_in ? __builtin_bit_cast(unsigned, xr[c]) : 0u;
+                    lo[c] = s_in ? __builtin_bit_cast(unsigned, xr[8 + c]) : 0u;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int c0 = chunk * CKS + 2 * c;
+                    const float s0 = c0 < p.cin ? sb[c0] : 0.f, s1 = c0 + 1 < p.cin ? sb[c0 + 1] : 0.f;   // wave-uniform
+                    split2(s_in ? xr[2 * c] * s0 : 0.f, s_in ? xr[2 * c + 1] * s1 : 0.f, hi[c], lo[c]);
+                }
             }
             const int sw = (tid >> 3) & 1;
             xh4[tid * 2 + (0 ^ sw)] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
@@ -161,11 +183,13 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
     // has no global loads at all (they used to cost ~10 us per workgroup there, and a load behind a store drains the store first).
     const int ho = 2 * p.h, wo = 2 * p.w;
     float ep_r[4] = {1.f, 0.f, 0.f, 0.f};
+    float ep_sn = 0.f;
     {
         const int co = co0 + tid;
         if (tid < C::TN && co < p.cout) {
             if (p.d) ep_r[0] = p.d[(size_t)b * p.cout + co];
             if (p.act_bias) ep_r[1] = p.act_bias[co];
+            if constexpr (OSP) ep_sn = p.s_next[(size_t)b * p.cout + co];
         }
         if (p.noise) {
             const float nw0 = p.noise_weight[0];
@@ -182,7 +206,7 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
         __syncthreads();
         store_chunk(chunk);
         if (chunk == 0) {
-            if (tid < C::TN) { ep_d[tid] = ep_r[0]; ep_b[tid] = ep_r[1]; }
+            if (tid < C::TN) { ep_d[tid] = ep_r[0]; ep_b[tid] = ep_r[1]; if constexpr (OSP) ep_s[tid] = ep_sn; }
 #pragma unroll
             for (int k = 0; k < 2; ++k)
                 if (tid + k * UF_NT < UF_OUT * UF_OUT) ep_n[tid + k * UF_NT] = ep_r[2 + k];
@@ -232,6 +256,9 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
     const bool it_ok = tid < NITEM && ox < wo && oy0 < ho;
     const int nrow = it_ok ? (ho - oy0 < UF_STEP ? ho - oy0 : UF_STEP) : 0;   // valid output rows of this item
     float* ob = p.out + (size_t)b * p.cout * ho * wo;
+    if constexpr (OSP) {   // the zero element behind the output planes (padding source of the consumers' LDS-DMA)
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid < 4) reinterpret_cast<unsigned*>(p.out)[(size_t)p.plane_out * 8 + tid] = 0u;
+    }
     const unsigned pix0 = (unsigned)(oy0 * wo + ox);
     const float* zc = ON ? zt + it_co * UF_ZCS + (it_rg * UF_STEP + 1) * UF_ZS + it_x + 1
                          : zt + (it_co * 32 + it_rg * UF_STEP + 1) * UF_ZS + it_x + 1;   // z row (local) of output row r, tap t: r + 1 + t
@@ -259,6 +286,7 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
 #endif
             if (nrow > 0 && co < p.cout) {
                 const float dd = ep_d[i * 32 + 8 * g + it_co], bi = ep_b[i * 32 + 8 * g + it_co];
+                const float sn = OSP ? ep_s[i * 32 + 8 * g + it_co] : 0.f;
                 const float neg = p.act ? 0.2f : 1.f, gain = p.act ? 1.41421356237309515f : 1.f;
                 // channel-blocked output [cout/8][ho][wo][8]: the 8 channels of this pass are one block, lanes (channel, x) write contiguous bytes
                 const unsigned o0 = ON ? ((unsigned)(co >> 3) * (unsigned)(ho * wo) + pix0) * 8u + (unsigned)(co & 7) : (unsigned)co * (unsigned)(ho * wo) + pix0;
@@ -294,7 +322,17 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
 #ifdef E4S_PHASE_PROF
                             if ((p.exp & 1) && v != 12345.678f) continue;
 #endif
-                            if constexpr (ON) ob[o0 + (unsigned)(ro * wo * 8)] = v;
+                            if constexpr (OSP) {
+                                // lanes (2m, 2m+1) hold channels (2m, 2m+1) of one pixel: both form the pair's split; the even one writes the hi
+                                // dword, the odd one the lo dword — one store per lane and row, as for the fp32 output
+                                const float u = __fmul_rn(v, sn);
+                                const float other = __shfl_xor(u, 1, 64);
+                                unsigned h2, l2;
+                                split2((tid & 1) ? other : u, (tid & 1) ? u : other, h2, l2);
+                                unsigned* osp = reinterpret_cast<unsigned*>(p.out);
+                                const size_t o4 = (((size_t)b * (p.cout >> 3) + (size_t)(co >> 3)) * ho * wo + pix0 + (size_t)ro * wo) * 4 + ((co & 7) >> 1);
+                                osp[(tid & 1) ? (size_t)p.plane_out * 4 + o4 : o4] = (tid & 1) ? l2 : h2;
+                            } else if constexpr (ON) ob[o0 + (unsigned)(ro * wo * 8)] = v;
                             else ob[o0 + (unsigned)(ro * wo)] = v;
                         }
                     }
@@ -308,16 +346,16 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
     E4S_PROF_MARK(g_prof_up, 5);
 }
 
-template <int CB, int MINW, bool XN = false, bool ON = false>
+template <int CB, int MINW, bool XN = false, bool ON = false, bool XSP = false, bool OSP = false>
 int launch_up_fused(UpFusedParams& p, hipStream_t st) {
     using C = UfCfg<CB>;
     dim3 grid(p.tiles_x * p.tiles_y, cdiv(p.cout, C::TN), p.bs);
     if (C::LDS_BYTES > 64 * 1024) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&up_fused_sb_kernel<CB, MINW, XN, ON>),
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&up_fused_sb_kernel<CB, MINW, XN, ON, XSP, OSP>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (attr != hipSuccess) return fail((int)attr, "modconv_up_fused_sb: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
     }
-    hipLaunchKernelGGL((up_fused_sb_kernel<CB, MINW, XN, ON>), grid, dim3(UF_NT), C::LDS_BYTES, st, p);
+    hipLaunchKernelGGL((up_fused_sb_kernel<CB, MINW, XN, ON, XSP, OSP>), grid, dim3(UF_NT), C::LDS_BYTES, st, p);
     return check_launch("modconv_up_fused_sb");
 }
 
@@ -337,14 +375,17 @@ extern "C" E4S_API int e4s_prof_clear_up() {
 
 extern "C" int e4s_modconv_up_fused_sb(float* out, const float* x, const uint16_t* whi, const uint16_t* wlo, const float* s, const float* d,
                                        const float* blur, const float* noise, int noise_bs, const float* noise_weight, const float* act_bias,
-                                       int act, int bs, int cin, int cout, int h, int w, void* stream) {
+                                       int act, int bs, int cin, int cout, int h, int w, const float* s_next, void* stream) {
     E4S_REQUIRE(out && x && whi && wlo && s && blur, "modconv_up_fused_sb: null tensor");
     E4S_REQUIRE(bs >= 0 && bs <= 65535 && cin >= 1 && cout >= 1 && h >= 1 && w >= 1, "modconv_up_fused_sb: bad size");
     E4S_REQUIRE((int64_t)cout * 4 * h * w < ((int64_t)1 << 31) && (int64_t)cin * h * w < ((int64_t)1 << 31), "modconv_up_fused_sb: one sample must stay below 2^31 elements");
     E4S_REQUIRE((((uintptr_t)whi | (uintptr_t)wlo) & 15) == 0, "modconv_up_fused_sb: weight slabs must be 16-byte aligned");
     E4S_REQUIRE(!noise || (noise_weight && (noise_bs == 1 || noise_bs == bs)), "modconv_up_fused_sb: noise needs its weight and batch 1 or bs");
-    const bool x_nhwc = (act & E4S_X_NHWC) != 0, out_nhwc = (act & E4S_OUT_NHWC) != 0;
+    const bool x_nhwc = (act & E4S_X_NHWC) != 0, out_nhwc = (act & E4S_OUT_NHWC) != 0, x_sp = (act & E4S_X_SP) != 0, out_sp = (act & E4S_OUT_SP) != 0;
     act &= 1;
+    E4S_REQUIRE(!(x_sp && x_nhwc) && !(out_sp && out_nhwc), "modconv_up_fused_sb: one layout per side");
+    E4S_REQUIRE(!x_sp || (cin % 16 == 0 && ((uintptr_t)x & 15) == 0), "modconv_up_fused_sb: split-plane input needs cin %% 16 == 0 and a 16-byte aligned tensor");
+    E4S_REQUIRE(!out_sp || (s_next && cout % 8 == 0 && ((uintptr_t)out & 15) == 0), "modconv_up_fused_sb: split-plane output needs s_next, cout %% 8 == 0 and a 16-byte aligned tensor");
     E4S_REQUIRE(!x_nhwc || (cin % 16 == 0 && ((uintptr_t)x & 15) == 0), "modconv_up_fused_sb: channels-last input needs cin %% 16 == 0 and a 16-byte aligned tensor");
     E4S_REQUIRE(!out_nhwc || cout % 8 == 0, "modconv_up_fused_sb: channels-last output needs cout %% 8 == 0");
     if (bs == 0) return 0;
@@ -353,12 +394,17 @@ extern "C" int e4s_modconv_up_fused_sb(float* out, const float* x, const uint16_
     p.blur = blur; p.noise = noise; p.noise_weight = noise_weight; p.act_bias = act_bias;
     p.noise_bstride = (noise && noise_bs > 1) ? 4 * h * w : 0;
     p.act = act; p.bs = bs; p.cin = cin; p.cout = cout; p.h = h; p.w = w;
+    p.s_next = s_next;
+    p.plane_in = (int64_t)bs * (cin / 8) * h * w;
+    p.plane_out = (int64_t)bs * (cout / 8) * 4 * h * w;
     p.tiles_x = cdiv(2 * w, UF_OUT);
     p.tiles_y = cdiv(2 * h, UF_OUT);
     { const char* e = getenv("E4S_UF_EXP"); p.exp = e ? atoi(e) : 0; }
     hipStream_t st = (hipStream_t)stream;
     static const int cb2 = [] { const char* e = getenv("E4S_UPFUSED_CB2"); return e ? atoi(e) : 0; }();
     if (cb2 && cout > 32) return launch_up_fused<2, 2>(p, st);   // 64 co per workgroup: x staged once, 1 workgroup per CU
+    if (x_sp && out_sp) return launch_up_fused<1, 4, false, true, true, true>(p, st);
+    if (x_sp || out_sp) return fail(E4S_ERR_ARG, "modconv_up_fused_sb: split planes are built for both sides together (the chain's up layers)");
     if (x_nhwc && out_nhwc) return launch_up_fused<1, 4, true, true>(p, st);
     if (x_nhwc) return launch_up_fused<1, 4, true, false>(p, st);
     if (out_nhwc) return launch_up_fused<1, 4, false, true>(p, st);

@@ -172,7 +172,18 @@ class ModulatedConv2d(nn.Module):
         return (ops.UP_FUSED and self._two_stage(False)) if self.upsample else True
 
     def forward_regions(self, input, styles, labels, noise=None, noise_weight=None, act_bias=None, act=False, rgb=None, want_out=True,
-                        x_nhwc=False, out_nhwc=False):
+                        x_nhwc=False, out_nhwc=False, x_sp=False, s_next=None):
+        """``x_sp`` / ``s_next`` (engine-internal, inference): the split-plane chain of the single-region stages (csrc/modconv_chain.hip) —
+        ``input`` is split planes already carrying this layer's modulation / the activation is written as split planes modulated by
+        ``s_next`` for the next layer."""
+        if x_sp:
+            if labels is not None or self.kernel_size != 3:
+                raise ValueError("split-plane input is built for the single-region 3x3 layers")
+            wt, s, d = self.tables(styles, masked=False)
+            if self.upsample:
+                return ops.modconv_up_single(input, wt, s, d, self.blur.kernel, noise, noise_weight, act_bias, act, self.out_channel, s_next=s_next)
+            out_sp, rgb_img = ops.chain_conv3x3(input, wt, d, noise, noise_weight, act_bias, act, self.out_channel, s_next=s_next, rgb=rgb)
+            return out_sp if rgb is None else (out_sp, rgb_img)
         if self._two_stage(labels is not None):
             # single-region up layer: transposed conv at 1x its MACs into a pre-blur buffer, then blur + epilogue
             wt, s, d = self.tables(styles, masked=False)
@@ -185,8 +196,8 @@ class ModulatedConv2d(nn.Module):
         wt, s, d = self.tables(styles, masked=labels is not None)
         saved = (s, d, self._weights(labels is not None)[1]) if labels is not None else None
         out = ops.region_modconv3x3(input, wt, s, d, labels, noise, noise_weight, act_bias, act, self.out_channel, self.upsample, rgb=rgb,
-                                    want_out=want_out, x_nhwc=x_nhwc, out_nhwc=out_nhwc)
-        if x_nhwc or out_nhwc:
+                                    want_out=want_out, x_nhwc=x_nhwc, out_nhwc=out_nhwc, s_next=s_next)
+        if x_nhwc or out_nhwc or s_next is not None:
             return out              # inference only (Generator.forward takes this route under no_grad)
         if rgb is not None:
             return tuple(None if o is None else ops._attach("ModulatedConv2d", o, input, styles, self.weight, self.modulation.weight,
@@ -255,17 +266,19 @@ class StyledConv(nn.Module):
         self.activate = FusedLeakyReLU(out_channel)
         self.mask_op = mask_op
 
-    def forward(self, input, style, mask, noise=None, _fused_rgb=None, _want_out=True, _x_nhwc=False, _out_nhwc=False):
+    def forward(self, input, style, mask, noise=None, _fused_rgb=None, _want_out=True, _x_nhwc=False, _out_nhwc=False, _x_sp=False, _s_next=None):
         """``_fused_rgb=(to_rgb, rgb_style [bs,512], skip)`` (engine-internal, used by ``Generator.forward``) also evaluates that
         single-region ToRGB in this layer's epilogue and returns ``(out, rgb)``.  ``_x_nhwc`` / ``_out_nhwc`` (engine-internal): the
         activation comes in / goes out channels-last, ``[bs, H, W, C]``."""
-        if _x_nhwc:
+        if _x_sp:
+            _, bs, _, H, W, _ = input.shape       # split planes [2, bs, C/8, H, W, 8]
+        elif _x_nhwc:
             bs, _, H, W, _ = input.shape          # channel-blocked [bs, C/8, H, W, 8]
         else:
             bs, _, H, W = input.shape
         H_out, W_out = (H * 2, W * 2) if self.conv.upsample else (H, W)
         if noise is None:  # reference :331-333
-            noise = input.new_empty(bs, 1, H_out, W_out).normal_()
+            noise = torch.empty(bs, 1, H_out, W_out, dtype=torch.float32, device=input.device).normal_()
         if self.activate.negative_slope != 0.2 or abs(self.activate.scale - 2 ** 0.5) > 1e-12:
             raise NotImplementedError("fused epilogue implements leaky_relu(0.2) * sqrt(2)")
         if self.mask_op:
@@ -282,7 +295,7 @@ class StyledConv(nn.Module):
             r_wt, r_s, _ = to_rgb.conv.tables(rgb_style[:, None, :])
             rgb = (r_wt, r_s, to_rgb.bias, skip, to_rgb.upsample.kernel if skip is not None else None)
         return self.conv.forward_regions(input, styles, labels, noise, self.noise.weight, self.activate.bias, act=True, rgb=rgb,
-                                         want_out=_want_out or rgb is None, x_nhwc=_x_nhwc, out_nhwc=_out_nhwc)
+                                         want_out=_want_out or rgb is None, x_nhwc=_x_nhwc, out_nhwc=_out_nhwc, x_sp=_x_sp, s_next=_s_next)
 
 
 class ToRGB(nn.Module):
@@ -456,6 +469,27 @@ class Generator(nn.Module):
         # (measured: 1.8 -> 5 TB/s on the staging read pattern, tools/probes/tile_read_probe.hip).  Nothing outside these kernels sees it.
         chain = ops.NHWC_CHAIN and not torch.is_grad_enabled() and out.is_cuda and latent.ndim == 4 and ops.FUSE_RGB
         nhwc = False                           # layout of `out` right now
+        # Split-plane chain (inference): from stage sp_from on, every layer is a single-region layer with a split-plane kernel; the activation
+        # between them is written by its producer already multiplied by the consumer's modulation and split into bf16 hi / lo planes
+        # (csrc/modconv_chain.hip).  The last masked layer hands over in that form too.
+        n_stage = len(self.to_rgbs)
+
+        def sp_stage_ok(jj):
+            cu, c2, tr = self.convs[2 * jj], self.convs[2 * jj + 1], self.to_rgbs[jj]
+            res = 2 ** (jj + 3)
+            return (2 * jj + 1 >= rli and not cu.mask_op and not c2.mask_op and not tr.mask_op and tuple(tr.upsample.kernel.shape) == (4, 4)
+                    and cu.conv.kernel_size == 3 and c2.conv.kernel_size == 3 and cu.conv._two_stage(False)
+                    and ops.chain_supported(cu.conv.in_channel, cu.conv.out_channel, res // 2, res // 2, True)
+                    and ops.chain_supported(c2.conv.in_channel, c2.conv.out_channel, res, res, False)
+                    and ops.can_fuse_rgb(c2.conv.out_channel, res, False, False))
+        sp_from = n_stage
+        if chain and ops.SP_CHAIN and lat is not None and not torch.is_grad_enabled():
+            while sp_from > 0 and sp_stage_ok(sp_from - 1):
+                sp_from -= 1
+        sp = False                             # `out` is split planes right now
+
+        def s_of(layer, k):                    # modulation table [bs, 1, cin] a single-region layer will apply to its input (W+ index k)
+            return layer.conv.tables(lat[k][:, 0][:, None, :], masked=False)[1]
 
         def up_takes_nhwc(jj):                 # may the up-conv of stage jj read channels-last?
             if not chain or jj >= len(self.to_rgbs) or 2 * jj + 1 < rli or not ops.nhwc_link("u", jj):
@@ -471,6 +505,16 @@ class Generator(nn.Module):
             else:
                 code = (lambda k: latent[:, :, k]) if per_region else (lambda k: latent[:, 0, k])
             conv2 = self.convs[2 * j + 1]
+            if j >= sp_from:
+                # ---- a stage of the split-plane chain: up-conv -> conv (+ fused ToRGB), hand-overs as split planes
+                if not sp:                     # (the previous layer could not hand over in split planes: convert once)
+                    out = ops.to_split_planes(out, s_of(self.convs[2 * j], i), x_nhwc=nhwc)
+                    nhwc, sp = False, True
+                out = self.convs[2 * j](out, code(i), mask, noise=noise[1 + 2 * j], _x_sp=True, _s_next=s_of(conv2, i + 1))
+                last = j + 1 == n_stage
+                out, skip = conv2(out, code(i + 1), mask, noise=noise[2 + 2 * j], _fused_rgb=(to_rgb, lat[i + 2][:, 0], skip), _want_out=not last,
+                                  _x_sp=True, _s_next=None if last else s_of(self.convs[2 * j + 2], i + 2))
+                continue
             # this stage's second conv can take channels-last input iff it is a single-region layer whose ToRGB rides in its epilogue
             c2_fused = ((not per_region or (rli != 17 and i + 2 == rli)) and not to_rgb.mask_op and tuple(to_rgb.upsample.kernel.shape) == (4, 4)
                         and ops.can_fuse_rgb(conv2.conv.out_channel, out.shape[3 if nhwc else -1] * 2, False, conv2.mask_op))
@@ -493,10 +537,14 @@ class Generator(nn.Module):
                 # the single-region ToRGB rides in the conv's epilogue: the activation is not read back for the 1x1 conv
                 # (the last layer's own activation is consumed by nothing but this ToRGB: it is not written)
                 last = j + 1 == len(self.to_rgbs)
-                nhwc_out = (not last) and up_takes_nhwc(j + 1) and conv2.conv.out_channel % 8 == 0
+                # the last layer before the split-plane chain hands over in that form (masked fused-ToRGB kernel; otherwise converted there)
+                sp_out = (j + 1 == sp_from and not last and not nhwc and conv2.mask_op and conv2.conv.out_channel % 8 == 0 and ops.MODCONV_MODE == "sb"
+                          and out.shape[-1] >= 32)
+                nhwc_out = (not last) and not sp_out and up_takes_nhwc(j + 1) and conv2.conv.out_channel % 8 == 0
                 out, skip = conv2(out, code(i + 1), mask, noise=noise[2 + 2 * j], _fused_rgb=(to_rgb, lat[i + 2][:, 0] if lat is not None else latent[:, 0, i + 2], skip),
-                                  _want_out=not last, _x_nhwc=nhwc, _out_nhwc=nhwc_out)
-                nhwc = nhwc_out
+                                  _want_out=not last, _x_nhwc=nhwc, _out_nhwc=nhwc_out,
+                                  _s_next=s_of(self.convs[2 * j + 2], i + 2) if sp_out else None)
+                nhwc, sp = nhwc_out, sp_out
             else:
                 assert not nhwc, "channels-last activation reached a layer that cannot read it"
                 out = conv2(out, code(i + 1), mask, noise=noise[2 + 2 * j])

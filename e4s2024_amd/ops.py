@@ -465,9 +465,32 @@ UP_FUSED = os.environ.get("E4S_UP_FUSED", "1") != "0"     # single-region up lay
 UP_TWO_STAGE = os.environ.get("E4S_UP_TWO_STAGE", "1") != "0"
 
 
-def modconv_up_single(x, wt, s, d, blur, noise, noise_weight, act_bias, act: bool, cout: int, x_nhwc: bool = False, out_nhwc: bool = False) -> torch.Tensor:
+def modconv_up_single(x, wt, s, d, blur, noise, noise_weight, act_bias, act: bool, cout: int, x_nhwc: bool = False, out_nhwc: bool = False,
+                      s_next=None) -> torch.Tensor:
     """Single-region up layer: transposed conv (1x MACs) into a pre-blur buffer, then blur + demod + noise + bias + act.
-    ``x_nhwc`` / ``out_nhwc``: channel-blocked activations ``[bs, c/8, h, w, 8]`` (fused kernel only)."""
+    ``x_nhwc`` / ``out_nhwc``: channel-blocked activations ``[bs, c/8, h, w, 8]`` (fused kernel only).
+    ``s_next [bs, 1, cout]``: the chain form — ``x`` is split planes ``[2, bs, cin/8, h, w, 8]`` (already carrying this layer's modulation)
+    and the result is written as split planes modulated for the next layer (csrc/modconv_chain.hip)."""
+    if s_next is not None:
+        _req(x, "x_sp", torch.int16)
+        if x.dim() != 6 or x.shape[0] != 2 or x.shape[-1] != 8 or not x.is_contiguous() or not UP_FUSED:
+            raise ValueError("modconv_up_single: the chain form takes contiguous split planes [2, bs, C/8, H, W, 8] and the fused kernel")
+        _, bs, cb, h, w, _ = x.shape
+        cin = cb * 8
+        sn = _c(s_next, "s_next").reshape(bs, cout)
+        out = _alloc_split_planes(bs, cout, 2 * h, 2 * w, x.device)
+        nz = nbs = None
+        if noise is not None:
+            nz = _c(noise, "noise")
+            nbs = nz.shape[0]
+            if nz.numel() != nbs * 4 * h * w:
+                raise ValueError(f"noise shape {tuple(nz.shape)} does not match output {2 * h}x{2 * w}")
+        ev = _timed("modconv_up_fused_sb")
+        lib().call("e4s_modconv_up_fused_sb", _p(out), _p(x), _p(wt[0]), _p(wt[1]), _p(s), _p(d), _p(_c(blur, "blur kernel")), _p(nz), nbs or 0,
+                   _p(noise_weight) if nz is not None else None, _p(act_bias), (1 if act else 0) | 8 | 16, bs, cin, cout, h, w, _p(sn), _stream())
+        if ev is not None:
+            ev.record()
+        return out
     x = _c(x, "input")
     if x_nhwc:
         bs, cb, h, w, _ = x.shape          # channel-blocked [bs, cin/8, h, w, 8]
@@ -487,7 +510,7 @@ def modconv_up_single(x, wt, s, d, blur, noise, noise_weight, act_bias, act: boo
         ev = _timed("modconv_up_fused_sb")
         lib().call("e4s_modconv_up_fused_sb", _p(out), _p(x), _p(wt[0]), _p(wt[1]), _p(s), _p(d), _p(_c(blur, "blur kernel")), _p(nz), nbs or 0,
                    _p(noise_weight) if nz is not None else None, _p(act_bias), (1 if act else 0) | (2 if x_nhwc else 0) | (4 if out_nhwc else 0),
-                   bs, cin, cout, h, w, _stream())
+                   bs, cin, cout, h, w, None, _stream())
         if ev is not None:
             ev.record()
         return out
@@ -597,6 +620,9 @@ def _workspace(device, floats: int) -> torch.Tensor:
 # 512x512 conv 0.361 -> 0.324); with the hand-overs into the up-sampling kernels as well ("u" links; the kernel reads its patch pixel's two
 # 8-channel blocks with four 16-byte loads) another +1.3 % (fused up-sampling 0.707 -> 0.640 ms).
 NHWC_CHAIN = os.environ.get("E4S_NHWC_CHAIN", "1") != "0"
+# The single-region stages as a split-plane chain (csrc/modconv_chain.hip): each producer writes its activation already multiplied by the
+# consumer's modulation and split into bf16 hi / lo planes; the 512 x 512 and 1024 x 1024 convs then run on persistent, LDS-DMA-fed kernels.
+SP_CHAIN = os.environ.get("E4S_SP_CHAIN", "1") != "0"
 # which hand-overs are channel-blocked: "all" (default), or a list of "c" / "u" (every hand-over into a second conv / into an up-conv),
 # "u<J>" (into the up-conv of stage J, resolution 2^(J+3)) and "c<J>" (into that stage's second conv)
 NHWC_LINKS = os.environ.get("E4S_NHWC_LINKS", "all")
@@ -615,11 +641,12 @@ def can_fuse_rgb(cout: int, w: int, up: bool, masked: bool) -> bool:
 
 
 def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: bool, cout: int, up: bool, rgb=None, want_out: bool = True,
-                      x_nhwc: bool = False, out_nhwc: bool = False):
+                      x_nhwc: bool = False, out_nhwc: bool = False, s_next=None):
     """``rgb = (wt_rgb [cout,3], s_rgb [bs,1,cout], bias [1,3,1,1], skip or None, up_kernel)`` fuses the following single-region
     ToRGB; the call then returns ``(out, rgb_image)``.  ``want_out=False`` (with ``rgb``) skips writing the layer's own activation
     and returns ``(None, rgb_image)``.  ``x_nhwc`` / ``out_nhwc``: the activation is channel-blocked, ``[bs, c/8, h, w, 8]`` (split-bf16
-    kernel, width >= 32; the 256x256-and-up layers can chain in this layout inside ``Generator.forward``)."""
+    kernel, width >= 32; the 256x256-and-up layers can chain in this layout inside ``Generator.forward``).  ``s_next [bs, 1, cout]`` (masked
+    layer with a fused ToRGB): the activation is written as split planes ``[2, bs, cout/8, h, w, 8]`` modulated for a single-region consumer."""
     x = _c(x, "input")
     if x_nhwc:
         bs, cb, h, w, _ = x.shape          # channel-blocked [bs, cin/8, h, w, 8]
@@ -632,7 +659,14 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
         raise ValueError("want_out=False only makes sense together with a fused ToRGB")
     if (x_nhwc or out_nhwc) and not (isinstance(wt, tuple) and w >= 32 and cin % 16 == 0 and cout % 8 == 0):
         raise ValueError("channel-blocked activations need the split-bf16 kernel, width >= 32, cin % 16 == 0 and cout % 8 == 0")
-    out = torch.empty((bs, cout // 8, ho, wo, 8) if out_nhwc else (bs, cout, ho, wo), dtype=torch.float32, device=x.device) if want_out else None
+    sn = None
+    if s_next is not None:
+        if rgb is None or not want_out or out_nhwc or up or cout % 8:
+            raise ValueError("region_modconv3x3: split-plane output goes with the fused ToRGB of a same-resolution layer")
+        sn = _c(s_next, "s_next").reshape(bs, cout)
+        out = _alloc_split_planes(bs, cout, ho, wo, x.device)
+    else:
+        out = torch.empty((bs, cout // 8, ho, wo, 8) if out_nhwc else (bs, cout, ho, wo), dtype=torch.float32, device=x.device) if want_out else None
     lh = lw = 0
     if labels is not None:
         lh, lw = labels.shape[1:]
@@ -645,7 +679,7 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
         if nz.numel() != nbs * ho * wo:
             raise ValueError(f"noise shape {tuple(nz.shape)} does not match output {ho}x{wo}")
     ws, wsn = None, 0
-    if bs * cout * ho * wo <= SPLITK_MAX_OUT_FLOATS:
+    if bs * cout * ho * wo <= SPLITK_MAX_OUT_FLOATS and sn is None:
         wsn = 16 * bs * cout * ho * wo
         ws = _workspace(x.device, wsn)
     sb = isinstance(wt, tuple)
@@ -665,7 +699,8 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
     if sb:
         lib().call("e4s_region_modconv3x3_sb", _p(out), _p(x), _p(wt[0]), _p(wt[1]), _p(s), _p(d), _p(labels), lh, lw, _p(nz), nbs or 0,
                    _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg,
-                   (1 if up else 0) | (2 if x_nhwc else 0) | (4 if out_nhwc else 0), _p(ws), wsn, *rgb_args, _stream())
+                   (1 if up else 0) | (2 if x_nhwc else 0) | (4 if out_nhwc else 0) | (16 if sn is not None else 0), _p(ws), wsn, *rgb_args, _p(sn),
+                   _stream())
     else:
         lib().call("e4s_region_modconv3x3", _p(out), _p(x), _p(wt), _p(s), _p(d), _p(labels), lh, lw, _p(nz), nbs or 0,
                    _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, 1 if up else 0,
@@ -673,6 +708,132 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
     if ev is not None:
         ev.record()
     return out if rgb is None else (out, rgb_out)
+
+
+# ------------------------------------------------------------------------------------ the single-region chain on split planes
+def _alloc_split_planes(bs: int, c: int, h: int, w: int, device) -> torch.Tensor:
+    """Uninitialised split planes ``[2, bs, c/8, h, w, 8]`` int16 — a view of a flat buffer with 16 more bytes behind the second plane, which
+    the producing kernel zeroes (the consumers' padding source; include/e4s_hip.h)."""
+    n = 2 * bs * c * h * w
+    return torch.empty(n + 8, dtype=torch.int16, device=device)[:n].view(2, bs, c // 8, h, w, 8)
+
+
+def to_split_planes(x: torch.Tensor, s: torch.Tensor, x_nhwc: bool = False) -> torch.Tensor:
+    """fp32 activation ``[bs, C, H, W]`` (or channel-blocked ``[bs, C/8, H, W, 8]``) times the consumer's modulation ``s [bs, 1, C]`` ->
+    "split planes" int16 ``[2 (hi, lo), bs, C/8, H, W, 8]`` of bf16 bits (csrc/modconv_chain.hip)."""
+    x = _c(x, "input")
+    if x_nhwc:
+        bs, cb, h, w, _ = x.shape
+        c = cb * 8
+    else:
+        bs, c, h, w = x.shape
+    s2 = _c(s, "s").reshape(bs, -1)
+    if s2.shape[1] != c or c % 8:
+        raise ValueError(f"to_split_planes: modulation {tuple(s.shape)} does not fit {c} channels (multiple of 8)")
+    out = _alloc_split_planes(bs, c, h, w, x.device)
+    lib().call("e4s_to_split_planes", _p(out), _p(x), _p(s2), bs, c, h, w, int(x_nhwc), _stream())
+    return out
+
+
+def from_split_planes(sp: torch.Tensor) -> torch.Tensor:
+    """hi + lo of split planes as fp32 ``[bs, C, H, W]`` (still multiplied by the modulation they were written with); tests / debugging."""
+    v = sp.view(torch.bfloat16).float().sum(0)                      # [bs, C/8, H, W, 8]
+    bs, cb, h, w, _ = v.shape
+    return v.permute(0, 1, 4, 2, 3).reshape(bs, cb * 8, h, w)
+
+
+def chain_supported(cin: int, cout: int, h: int, w: int, up: bool) -> bool:
+    """Is there a persistent split-plane kernel for this single-region layer?  (Generator(1024): 64 -> 64 @ 512, 32 -> 32 @ 1024)"""
+    if MODCONV_MODE != "sb":
+        return False
+    if up:
+        return UP_FUSED and UP_TWO_STAGE and cin % 16 == 0 and cout % 32 == 0
+    return (cin, cout) in ((32, 32), (64, 64)) and h % 16 == 0 and w % 32 == 0
+
+
+def chain_upconv(x_sp: torch.Tensor, wt, d, blur, noise, noise_weight, act_bias, act: bool, cout: int, s_next) -> torch.Tensor:
+    """Single-region up-sampling ``StyledConv`` (transposed conv + blur) on split planes ``[2, bs, cin/8, h, w, 8]`` -> split planes of its
+    ``[bs, cout, 2h, 2w]`` activation, modulated by ``s_next [bs, 1, cout]`` for the next layer.  ``wt`` = bare 3x3 slabs
+    (``PreparedWeights.get(..., tconv=True)``)."""
+    from ._lib import ChainLayer
+    _req(x_sp, "x_sp", torch.int16)
+    if x_sp.dim() != 6 or x_sp.shape[0] != 2 or x_sp.shape[-1] != 8 or not x_sp.is_contiguous():
+        raise ValueError("chain_upconv: x_sp must be contiguous split planes [2, bs, C/8, H, W, 8]")
+    _, bs, cb, h, w, _ = x_sp.shape
+    L = ChainLayer()
+    dd, sn, bk = _c(d, "d").reshape(bs, cout), _c(s_next, "s_next").reshape(bs, cout), _c(blur, "blur kernel")
+    out_sp = _alloc_split_planes(bs, cout, 2 * h, 2 * w, x_sp.device)
+    keep = [x_sp, dd, sn, bk, out_sp]
+    L.x_sp, L.whi, L.wlo, L.d, L.out_sp, L.s_next = x_sp.data_ptr(), wt[0].data_ptr(), wt[1].data_ptr(), dd.data_ptr(), out_sp.data_ptr(), sn.data_ptr()
+    if noise is not None:
+        nz = _c(noise, "noise")
+        if nz.numel() != nz.shape[0] * 4 * h * w or nz.shape[0] not in (1, bs):
+            raise ValueError(f"noise shape {tuple(nz.shape)} does not match output {2 * h}x{2 * w}")
+        keep += [nz, noise_weight]
+        L.noise, L.noise_bs, L.noise_weight = nz.data_ptr(), nz.shape[0], noise_weight.data_ptr()
+    if act_bias is not None:
+        L.act_bias = act_bias.data_ptr()
+    L.act = 1 if act else 0
+    L.bs, L.cin, L.cout, L.h, L.w = bs, cb * 8, cout, h, w
+    ev = _timed(f"chain_upconv<{cb * 8}>")
+    lib().call("e4s_chain_upconv", ctypes.byref(L), _p(bk), _stream())
+    if ev is not None:
+        ev.record()
+    del keep
+    return out_sp
+
+
+def chain_conv3x3(x_sp: torch.Tensor, wt, d, noise, noise_weight, act_bias, act: bool, cout: int, s_next=None, rgb=None):
+    """Single-region ``StyledConv`` (same resolution) on split planes.  ``s_next [bs, 1, cout]``: also write the activation as split planes
+    modulated for the next layer; ``rgb = (wt_rgb, s_rgb, bias, skip or None, up_kernel)``: the following ToRGB fused (as in
+    ``region_modconv3x3``).  Returns ``(out_sp or None, rgb image or None)``."""
+    from ._lib import ChainLayer
+    _req(x_sp, "x_sp", torch.int16)
+    if x_sp.dim() != 6 or x_sp.shape[0] != 2 or x_sp.shape[-1] != 8 or not x_sp.is_contiguous():
+        raise ValueError("chain_conv3x3: x_sp must be contiguous split planes [2, bs, C/8, H, W, 8]")
+    _, bs, cb, h, w, _ = x_sp.shape
+    cin = cb * 8
+    L = ChainLayer()
+    keep = [x_sp]
+    L.x_sp, L.whi, L.wlo = x_sp.data_ptr(), wt[0].data_ptr(), wt[1].data_ptr()
+    if d is not None:
+        dd = _c(d, "d").reshape(bs, cout)
+        keep.append(dd)
+        L.d = dd.data_ptr()
+    if noise is not None:
+        nz = _c(noise, "noise")
+        if nz.numel() != nz.shape[0] * h * w or nz.shape[0] not in (1, bs):
+            raise ValueError(f"noise shape {tuple(nz.shape)} does not match output {h}x{w}")
+        keep += [nz, noise_weight]
+        L.noise, L.noise_bs, L.noise_weight = nz.data_ptr(), nz.shape[0], noise_weight.data_ptr()
+    if act_bias is not None:
+        L.act_bias = act_bias.data_ptr()
+    L.act = 1 if act else 0
+    out_sp = rgb_out = None
+    if s_next is not None:
+        sn = _c(s_next, "s_next").reshape(bs, cout)
+        out_sp = _alloc_split_planes(bs, cout, h, w, x_sp.device)
+        keep += [sn, out_sp]
+        L.out_sp, L.s_next = out_sp.data_ptr(), sn.data_ptr()
+    if rgb is not None:
+        r_wt, r_s, r_bias, r_skip, r_upk = rgb
+        rgb_out = torch.empty((bs, 3, h, w), dtype=torch.float32, device=x_sp.device)
+        rs, rb = _c(r_s, "rgb s").reshape(bs, cout), _c(r_bias.detach(), "rgb bias")
+        keep += [rs, rb, rgb_out]
+        L.rgb_out, L.rgb_wt, L.rgb_s, L.rgb_bias = rgb_out.data_ptr(), r_wt.data_ptr(), rs.data_ptr(), rb.data_ptr()
+        if r_skip is not None:
+            sk, uk = _c(r_skip, "skip"), _c(r_upk, "upsample.kernel")
+            if tuple(sk.shape) != (bs, 3, h // 2, w // 2):
+                raise ValueError(f"skip shape {tuple(sk.shape)} != {(bs, 3, h // 2, w // 2)}")
+            keep += [sk, uk]
+            L.rgb_skip, L.rgb_up_kernel = sk.data_ptr(), uk.data_ptr()
+    L.bs, L.cin, L.cout, L.h, L.w = bs, cin, cout, h, w
+    ev = _timed(f"chain_conv3x3<{cin}>")
+    lib().call("e4s_chain_conv3x3", ctypes.byref(L), _stream())
+    if ev is not None:
+        ev.record()
+    del keep
+    return out_sp, rgb_out
 
 
 def region_torgb(x, wt, s, labels, bias, skip, up_kernel) -> torch.Tensor:

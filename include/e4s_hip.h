@@ -124,13 +124,17 @@ E4S_API int e4s_modconv_prep_weights_sb(uint16_t* whi, uint16_t* wlo, float* wsq
  * cin % 16 == 0 / cout % 8 == 0, w >= 32, single-region layers (input) / any layer (output). */
 #define E4S_X_NHWC 2
 #define E4S_OUT_NHWC 4
+/* ... or a split-plane tensor (see "The single-region chain" below): E4S_X_SP (e4s_modconv_up_fused_sb) = x is split planes already carrying
+ * this layer's modulation (s is then not applied again); E4S_OUT_SP = out is written as split planes modulated by s_next[bs][cout]. */
+#define E4S_X_SP 8
+#define E4S_OUT_SP 16
 E4S_API int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16_t* whi, const uint16_t* wlo, const float* s, const float* d,
                                      const uint8_t* labels, int lh, int lw,
                                      const float* noise, int noise_bs, const float* noise_weight, const float* act_bias, int act,
                                      int bs, int cin, int cout, int h, int w, int nreg, int up,
                                      float* workspace, int64_t workspace_floats,
                                      float* rgb_out, const float* rgb_wt, const float* rgb_s, const float* rgb_bias,
-                                     const float* rgb_skip, const float* rgb_up_kernel, void* stream);
+                                     const float* rgb_skip, const float* rgb_up_kernel, const float* s_next, void* stream);
 /* rgb_* (all NULL = off): fuse the single-region ToRGB that follows this layer (model.py:439-479) into the epilogue — allowed for
  * same-resolution layers of width >= 32 whose Cout fits one workgroup tile (<= 64, or <= 128 on masked layers): rgb_out [bs,3,h,w] =
  * sum_co out[co] * rgb_wt[co][o] * rgb_s[b][co] + rgb_bias[o] + upfirdn2d(rgb_skip, rgb_up_kernel, up=2, pad=(2,1)), so the layer's
@@ -153,7 +157,43 @@ E4S_API int e4s_blur_epilogue(float* out, const float* z, const float* blur, con
  * noise, bias and activation are applied before the only write (no [bs,cout,2h+1,2w+1] round trip).  Arguments as the pair above. */
 E4S_API int e4s_modconv_up_fused_sb(float* out, const float* x, const uint16_t* whi, const uint16_t* wlo, const float* s, const float* d,
                                     const float* blur, const float* noise, int noise_bs, const float* noise_weight,
-                                    const float* act_bias, int act, int bs, int cin, int cout, int h, int w, void* stream);
+                                    const float* act_bias, int act, int bs, int cin, int cout, int h, int w, const float* s_next, void* stream);
+
+/* ---- The single-region chain (layers past remaining_layer_idx) on split planes.
+ * A single-region layer's modulation s[b][ci] belongs to the INPUT channel alone (model.py:276-283 with one style per sample) and all
+ * tables are known up front, so the producer of an activation applies the CONSUMER's modulation and the bf16 hi/lo split in its epilogue
+ * and writes "split planes":  sp[plane hi|lo][bs][c/8][h][w][8 x bf16]  (c % 16 == 0; same bytes as the fp32 tensor), whose 16-byte
+ * element is one lane's MFMA B fragment.  A split-plane buffer carries 16 more bytes behind the second plane, written as zeros by whoever
+ * produces it (the padding source of the consumers' LDS-DMA): allocate 2 * bs * c * h * w * 2 + 16 bytes.  Consumers stage them with LDS-DMA only (no registers, no VALU) from persistent workgroups.
+ * Arithmetic is that of e4s_region_modconv3x3_sb / e4s_modconv_up_fused_sb on the fp32 tensor (fl(x * s), RNE split).
+ *   e4s_to_split_planes : fp32 [bs,c,h,w] (or channel-blocked [bs,c/8,h,w,8] when x_nhwc) times s[bs][c] -> split planes
+ *   e4s_chain_conv3x3   : StyledConv (same resolution) reading split planes; out_sp (optional) = its activation as split planes modulated
+ *                         by s_next[bs][cout]; rgb_* (optional) = the following single-region ToRGB fused as in e4s_region_modconv3x3_sb.
+ *                         h % 16 == 0, w % 32 == 0; built for 32 -> 32 and 64 -> 64 channels (the 1024 / 512 stages of Generator(1024)).
+ *   e4s_chain_upconv    : the up-sampling StyledConv (transposed conv + 4x4 blur, model.py:287-300) reading split planes [bs,cin,h,w],
+ *                         writing its [bs,cout,2h,2w] activation as split planes; built for 128 -> 64 and 64 -> 32 channels.
+ * L is a HOST struct; every pointer inside is a device pointer.  whi / wlo from e4s_modconv_prep_weights_sb(up = 0). */
+typedef struct E4sChainLayer {
+    const uint16_t* x_sp;
+    const uint16_t* whi;
+    const uint16_t* wlo;
+    const float* d;            /* [bs][cout] demodulation or NULL */
+    const float* noise;        /* [noise_bs (1 or bs)][ho*wo] or NULL */
+    const float* noise_weight;
+    const float* act_bias;     /* [cout] or NULL */
+    uint16_t* out_sp;          /* or NULL */
+    const float* s_next;       /* [bs][cout], required with out_sp */
+    float* rgb_out;            /* [bs,3,h,w] or NULL (e4s_chain_conv3x3 only) */
+    const float* rgb_wt;       /* [cout][3]  (e4s_modconv_prep_weights, k = 1) */
+    const float* rgb_s;        /* [bs][cout] */
+    const float* rgb_bias;     /* [3] */
+    const float* rgb_skip;     /* [bs,3,h/2,w/2] or NULL */
+    const float* rgb_up_kernel;/* [4,4] */
+    int noise_bs, act, bs, cin, cout, h, w, _pad;
+} E4sChainLayer;
+E4S_API int e4s_to_split_planes(uint16_t* out_sp, const float* x, const float* s, int bs, int c, int h, int w, int x_nhwc, void* stream);
+E4S_API int e4s_chain_conv3x3(const E4sChainLayer* L, void* stream);
+E4S_API int e4s_chain_upconv(const E4sChainLayer* L, const float* blur, void* stream);
 
 /* ToRGB forward in one pass (model.py:439-479): 1x1 modulated conv without demodulation, + bias, + upsampled skip.
  *   x : [bs, cin, h, w]   wt : [cin, 3] from e4s_modconv_prep_weights(k=1)   s : [bs, nreg, cin]   bias : [3]
