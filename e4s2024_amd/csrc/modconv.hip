@@ -190,33 +190,53 @@ struct JobTable {
     E4sStyleJob j[E4S_MAX_STYLE_JOBS];
 };
 
+constexpr int STYLE_CI = 4;     // input channels per wave: the 8 style rows of a block are loaded once and reused for all of them
+constexpr int DEMOD_ROWS = 8;   // (batch, region) rows per block of the demodulation kernel: wsq is re-read nbr / 8 times instead of nbr times
+
 __global__ __launch_bounds__(256) void style_batched_kernel(const JobTable t, int bs, int sdim, float scale) {
     const E4sStyleJob& J = t.j[blockIdx.z];
     const int lane = threadIdx.x & 63;
-    const int ci = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int ci0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * STYLE_CI;
     const int nbr = bs * J.nreg;
     const int br0 = blockIdx.y * STYLE_ROWS;
-    if (ci >= J.cin || br0 >= nbr) return;
-    const float* wrow = J.mod_weight + (size_t)ci * sdim;
-    const float mb = J.mod_bias ? J.mod_bias[ci] : 0.f;
-    float acc[STYLE_ROWS];
+    if (ci0 >= J.cin || br0 >= nbr) return;
+    const bool vec = sdim == 512 && (J.stride_b & 3) == 0 && (J.stride_r & 3) == 0 && ((((uintptr_t)J.styles | (uintptr_t)J.mod_weight) & 15) == 0);
+    if (vec) {   // the path's shape (style_dim 512): a lane owns 8 of the 512 style entries of every row, in registers
+        float4 sv[STYLE_ROWS][2];
 #pragma unroll
-    for (int q = 0; q < STYLE_ROWS; ++q) acc[q] = 0.f;
-    const bool vec = (sdim & 3) == 0 && (J.stride_b & 3) == 0 && (J.stride_r & 3) == 0 && ((((uintptr_t)J.styles | (uintptr_t)J.mod_weight) & 15) == 0);
-    if (vec) {
-        for (int j = lane * 4; j < sdim; j += 256) {
-            const float4 w4 = *reinterpret_cast<const float4*>(wrow + j);
+        for (int q = 0; q < STYLE_ROWS; ++q) {
+            const int br = br0 + q < nbr ? br0 + q : nbr - 1;
+            const int b = br / J.nreg, r = br - b * J.nreg;
+            const float* sp = J.styles + b * J.stride_b + r * J.stride_r;
+            sv[q][0] = *reinterpret_cast<const float4*>(sp + lane * 4);
+            sv[q][1] = *reinterpret_cast<const float4*>(sp + 256 + lane * 4);
+        }
+#pragma unroll
+        for (int c = 0; c < STYLE_CI; ++c) {
+            const int ci = ci0 + c;
+            if (ci >= J.cin) break;
+            const float* wrow = J.mod_weight + (size_t)ci * sdim;
+            const float4 w0 = *reinterpret_cast<const float4*>(wrow + lane * 4), w1 = *reinterpret_cast<const float4*>(wrow + 256 + lane * 4);
+            const float mb = J.mod_bias ? J.mod_bias[ci] : 0.f;
 #pragma unroll
             for (int q = 0; q < STYLE_ROWS; ++q) {
-                const int br = br0 + q;
-                if (br < nbr) {
-                    const int b = br / J.nreg, r = br - b * J.nreg;
-                    const float4 v = *reinterpret_cast<const float4*>(J.styles + b * J.stride_b + r * J.stride_r + j);
-                    acc[q] += (v.x * w4.x + v.y * w4.y) + (v.z * w4.z + v.w * w4.w);
-                }
+                // (same summation order as the one-channel-per-wave version: two float4 steps of j = lane * 4 and 256 + lane * 4)
+                float a = (sv[q][0].x * w0.x + sv[q][0].y * w0.y) + (sv[q][0].z * w0.z + sv[q][0].w * w0.w);
+                a += (sv[q][1].x * w1.x + sv[q][1].y * w1.y) + (sv[q][1].z * w1.z + sv[q][1].w * w1.w);
+                a = wave_sum(a);
+                if (lane == 0 && br0 + q < nbr) J.s[(size_t)(br0 + q) * J.cin + ci] = a * scale + mb;
             }
         }
-    } else {
+        return;
+    }
+    for (int c = 0; c < STYLE_CI; ++c) {
+        const int ci = ci0 + c;
+        if (ci >= J.cin) break;
+        const float* wrow = J.mod_weight + (size_t)ci * sdim;
+        const float mb = J.mod_bias ? J.mod_bias[ci] : 0.f;
+        float acc[STYLE_ROWS];
+#pragma unroll
+        for (int q = 0; q < STYLE_ROWS; ++q) acc[q] = 0.f;
         for (int j = lane; j < sdim; j += 64) {
             const float wv = wrow[j];
 #pragma unroll
@@ -228,40 +248,56 @@ __global__ __launch_bounds__(256) void style_batched_kernel(const JobTable t, in
                 }
             }
         }
-    }
 #pragma unroll
-    for (int q = 0; q < STYLE_ROWS; ++q) {
-        const float a = wave_sum(acc[q]);
-        if (lane == 0 && br0 + q < nbr) J.s[(size_t)(br0 + q) * J.cin + ci] = a * scale + mb;
+        for (int q = 0; q < STYLE_ROWS; ++q) {
+            const float a = wave_sum(acc[q]);
+            if (lane == 0 && br0 + q < nbr) J.s[(size_t)(br0 + q) * J.cin + ci] = a * scale + mb;
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void demod_batched_kernel(const JobTable t, int bs) {
     const E4sStyleJob& J = t.j[blockIdx.z];
-    __shared__ float part[4][64];
+    __shared__ float part[DEMOD_ROWS][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int co = blockIdx.x * 64 + lane;
-    const int br = blockIdx.y;
-    if (!J.d || br >= bs * J.nreg || blockIdx.x * 64 >= J.cout) return;   // block-uniform exits
-    const float* sv = J.s + (size_t)br * J.cin;
+    const int nbr = bs * J.nreg;
+    const int br0 = blockIdx.y * DEMOD_ROWS;
+    if (!J.d || br0 >= nbr || blockIdx.x * 64 >= J.cout) return;   // block-uniform exits
     const int per = (J.cin + 3) / 4;
     const int c0 = wave * per, c1 = (c0 + per < J.cin) ? c0 + per : J.cin;
-    float a0 = 0.f, a1 = 0.f;
+    // per row the two partial sums (even / odd input channels of this wave's quarter) of the one-row-per-block version, in its order
+    float a0[DEMOD_ROWS], a1[DEMOD_ROWS];
+#pragma unroll
+    for (int q = 0; q < DEMOD_ROWS; ++q) a0[q] = a1[q] = 0.f;
     if (co < J.cout) {
         int ci = c0;
         for (; ci + 1 < c1; ci += 2) {
-            const float t0 = sv[ci], t1 = sv[ci + 1];
-            a0 += t0 * t0 * J.wsq[(size_t)ci * J.cout + co];
-            a1 += t1 * t1 * J.wsq[(size_t)(ci + 1) * J.cout + co];
+            const float w0 = J.wsq[(size_t)ci * J.cout + co], w1 = J.wsq[(size_t)(ci + 1) * J.cout + co];
+#pragma unroll
+            for (int q = 0; q < DEMOD_ROWS; ++q) {
+                const float* sv = J.s + (size_t)(br0 + q < nbr ? br0 + q : nbr - 1) * J.cin;     // wave-uniform: scalar loads
+                const float t0 = sv[ci], t1 = sv[ci + 1];
+                a0[q] += t0 * t0 * w0;
+                a1[q] += t1 * t1 * w1;
+            }
         }
         if (ci < c1) {
-            const float t0 = sv[ci];
-            a0 += t0 * t0 * J.wsq[(size_t)ci * J.cout + co];
+            const float w0 = J.wsq[(size_t)ci * J.cout + co];
+#pragma unroll
+            for (int q = 0; q < DEMOD_ROWS; ++q) {
+                const float t0 = J.s[(size_t)(br0 + q < nbr ? br0 + q : nbr - 1) * J.cin + ci];
+                a0[q] += t0 * t0 * w0;
+            }
         }
     }
-    part[wave][lane] = a0 + a1;
+#pragma unroll
+    for (int q = 0; q < DEMOD_ROWS; ++q) part[q][wave][lane] = a0[q] + a1[q];
     __syncthreads();
-    if (wave == 0 && co < J.cout) J.d[(size_t)br * J.cout + co] = rsqrtf(((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) + 1e-8f);
+    // the four waves finish two rows each
+    for (int q = wave; q < DEMOD_ROWS; q += 4)
+        if (co < J.cout && br0 + q < nbr)
+            J.d[(size_t)(br0 + q) * J.cout + co] = rsqrtf(((part[q][0][lane] + part[q][1][lane]) + (part[q][2][lane] + part[q][3][lane])) + 1e-8f);
 }
 
 extern "C" int e4s_style_demod_batched(const E4sStyleJob* jobs, int n_jobs, int bs, int sdim, void* stream) {
@@ -285,9 +321,9 @@ extern "C" int e4s_style_demod_batched(const E4sStyleJob* jobs, int n_jobs, int 
         }
     }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(style_batched_kernel, dim3(cdiv(max_cin, 4), cdiv(max_nbr, STYLE_ROWS), n_jobs), dim3(256), 0, st, t, bs, sdim,
+    hipLaunchKernelGGL(style_batched_kernel, dim3(cdiv(max_cin, 4 * STYLE_CI), cdiv(max_nbr, STYLE_ROWS), n_jobs), dim3(256), 0, st, t, bs, sdim,
                        1.0f / sqrtf((float)sdim));
-    if (any_d) hipLaunchKernelGGL(demod_batched_kernel, dim3(cdiv(max_cout, 64), max_nbr, n_jobs), dim3(256), 0, st, t, bs);
+    if (any_d) hipLaunchKernelGGL(demod_batched_kernel, dim3(cdiv(max_cout, 64), cdiv(max_nbr, DEMOD_ROWS), n_jobs), dim3(256), 0, st, t, bs);
     return check_launch("style_demod_batched");
 }
 

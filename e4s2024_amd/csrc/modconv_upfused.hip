@@ -287,6 +287,9 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
             if (nrow > 0 && co < p.cout) {
                 const float dd = ep_d[i * 32 + 8 * g + it_co], bi = ep_b[i * 32 + 8 * g + it_co];
                 const float sn = OSP ? ep_s[i * 32 + 8 * g + it_co] : 0.f;
+                // (OSP) dword 0 of this lane's column in its plane: even lanes write the hi plane, odd lanes the lo plane; rows are 32-bit offsets
+                unsigned* osp_row = reinterpret_cast<unsigned*>(p.out) + ((tid & 1) ? (size_t)p.plane_out * 4 : (size_t)0)
+                                    + (((size_t)b * (p.cout >> 3) + (size_t)(co >> 3)) * ho * wo + pix0) * 4 + ((co & 7) >> 1);
                 const float neg = p.act ? 0.2f : 1.f, gain = p.act ? 1.41421356237309515f : 1.f;
                 // channel-blocked output [cout/8][ho][wo][8]: the 8 channels of this pass are one block, lanes (channel, x) write contiguous bytes
                 const unsigned o0 = ON ? ((unsigned)(co >> 3) * (unsigned)(ho * wo) + pix0) * 8u + (unsigned)(co & 7) : (unsigned)co * (unsigned)(ho * wo) + pix0;
@@ -329,9 +332,7 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
                                 const float other = __shfl_xor(u, 1, 64);
                                 unsigned h2, l2;
                                 split2((tid & 1) ? other : u, (tid & 1) ? u : other, h2, l2);
-                                unsigned* osp = reinterpret_cast<unsigned*>(p.out);
-                                const size_t o4 = (((size_t)b * (p.cout >> 3) + (size_t)(co >> 3)) * ho * wo + pix0 + (size_t)ro * wo) * 4 + ((co & 7) >> 1);
-                                osp[(tid & 1) ? (size_t)p.plane_out * 4 + o4 : o4] = (tid & 1) ? l2 : h2;
+                                osp_row[(unsigned)(ro * wo * 4)] = (tid & 1) ? l2 : h2;
                             } else if constexpr (ON) ob[o0 + (unsigned)(ro * wo * 8)] = v;
                             else ob[o0 + (unsigned)(ro * wo)] = v;
                         }

@@ -201,6 +201,7 @@ def test_channels_last_chain_gives_the_same_image(gpu_net3, links):
     codes, mask = _config2_inputs(2)
     codes, mask = codes.to(DEV), mask.to(DEV)
     old = (_ops.NHWC_CHAIN, _ops.NHWC_LINKS, _ops.region_modconv3x3, _ops.modconv_up_single)
+    old_sp, _ops.SP_CHAIN = _ops.SP_CHAIN, False        # the blocked route is what runs when the split-plane chain (tests/test_gpu_chain.py) is off
     blocked_calls = []
 
     def counting(fn):
@@ -218,6 +219,7 @@ def test_channels_last_chain_gives_the_same_image(gpu_net3, links):
             b, _, _ = gpu_net3.gen_img(None, codes, mask, randomize_noise=False)
     finally:
         _ops.NHWC_CHAIN, _ops.NHWC_LINKS, _ops.region_modconv3x3, _ops.modconv_up_single = old
+        _ops.SP_CHAIN = old_sp
     assert a.shape == b.shape and (a - b).abs().max().item() <= 1e-4
     assert len(blocked_calls) >= 2, blocked_calls        # the blocked route was really taken (a producer and a consumer at least)
 
