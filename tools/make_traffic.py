@@ -1,0 +1,58 @@
+"""FETCH_SIZE / WRITE_SIZE passes of tools/final_prof.sh -> profiles/<round>_traffic.json (what bench.py reports as roofline.traffic).
+
+    python tools/make_traffic.py gpurun_out/r02_final_pmc_fetch.txt gpurun_out/r02_final_pmc_write.txt profiles/r02_traffic.json
+
+Keys are the names bench.py's KernelTimer uses.  Counters are in KB (rocprofv3 derived metrics).  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE
+counts a 128-byte request of a wide (16 B per lane) streaming read as 64 bytes — such kernels (the LDS-DMA chain kernels, dwordx4 only) get the
+x2 correction, stated per entry; kernels whose activation loads are dwords (the masked conv: channels-first rows) are reported uncorrected."""
+import json
+import re
+import sys
+
+
+def parse(path):
+    out, cur = {}, None
+    for line in open(path):
+        if not line.startswith(" "):
+            cur = line.strip()
+        else:
+            m = re.match(r"\s+(\S+)\s+calls=\s*(\d+)\s+avg=\s*([\d.]+)", line)
+            if m and cur:
+                out.setdefault(cur, {})[m.group(1)] = (int(m.group(2)), float(m.group(3)))
+    return out
+
+
+# bench.py key -> (substrings the kernel name must contain, FETCH_SIZE correction, note, algorithmic bytes per launch at batch 4 or None)
+KEYS = {
+    "region_modconv_sb_kernel<4,1,1,8,5>": (["region_modconv_sb_kernel<4, 1, 1, 8, 5"], 1.0,
+                                            "7 launches per step (6 plain + 1 with fused ToRGB and split-plane output); dword activation loads: no FETCH correction", 117700000),
+    "chain_conv3x3<32>": (["chain_conv_kernel<1, 2"], 2.0, "LDS-DMA dwordx4 only: FETCH_SIZE x2 (guide)", 4 * (32 * 1024 * 1024 * 4 + 3 * 1024 * 1024 * 4 + 3 * 512 * 512 * 4)),
+    "chain_conv3x3<64>": (["chain_conv_kernel<2, 4"], 2.0, "LDS-DMA dwordx4 only: FETCH_SIZE x2 (guide)", 4 * (2 * 64 * 512 * 512 * 4 + 3 * 512 * 512 * 4 + 3 * 256 * 256 * 4)),
+    "modconv_up_fused_sb": (["up_fused_sb_kernel"], 2.0, "2 launches per step (256->512, 512->1024), split-plane in/out, 16-byte loads: FETCH_SIZE x2 (guide)",
+                            (4 * (128 * 256 * 256 * 4 + 64 * 512 * 512 * 4) + 4 * (64 * 512 * 512 * 4 + 32 * 1024 * 1024 * 4)) // 2),
+}
+
+
+def main(fetch_path, write_path, out_path):
+    f, w = parse(fetch_path), parse(write_path)
+    doc = {}
+    for key, (subs, corr, note, alg) in KEYS.items():
+        fk = [(n, v["FETCH_SIZE"]) for n, v in f.items() if all(s in n for s in subs) and "FETCH_SIZE" in v]
+        wk = [(n, v["WRITE_SIZE"]) for n, v in w.items() if all(s in n for s in subs) and "WRITE_SIZE" in v]
+        if not fk or not wk:
+            continue
+        nf, nw = sum(c for _, (c, _) in fk), sum(c for _, (c, _) in wk)
+        fetch_kb = sum(c * a for _, (c, a) in fk) / nf
+        write_kb = sum(c * a for _, (c, a) in wk) / nw
+        doc[key] = {"fetch_kb_per_launch_raw": round(fetch_kb, 1), "fetch_correction": corr, "write_kb_per_launch": round(write_kb, 1),
+                    "hbm_bytes_per_launch": int((fetch_kb * corr + write_kb) * 1024), "launches_averaged": nf, "algorithmic_bytes_per_launch": alg,
+                    "note": note,
+                    "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around `python3 bench.py --steps 2 --warmup 1 "
+                              f"--no-cpu-baseline --no-full-swap --no-pti --clip 0` (tools/final_prof.sh -> {fetch_path.split('/')[-1]}, {write_path.split('/')[-1]})"}
+    with open(out_path, "w") as fh:
+        json.dump(doc, fh, indent=1)
+    print(json.dumps({k: (v["hbm_bytes_per_launch"], v["algorithmic_bytes_per_launch"]) for k, v in doc.items()}))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])

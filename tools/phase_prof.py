@@ -83,7 +83,7 @@ def run_same(cin, cout, h, bs=4, masked=False, up=False):
     report(f"{'up' if up else 'same'} conv {cin}->{cout} @{h}^2 bs{bs} {'masked' if masked else 'single-region'}", read(n), a.elapsed_time(b))
 
 
-def run_up_fused(cin, cout, h, bs=4):
+def run_up_fused(cin, cout, h, bs=4, sp=False):
     g = torch.Generator(device=dev).manual_seed(0)
     x = torch.randn(bs, cin, h, h, device=dev, generator=g)
     w = torch.randn(1, cout, cin, 3, 3, device=dev, generator=g)
@@ -92,18 +92,23 @@ def run_up_fused(cin, cout, h, bs=4):
     nz = torch.randn(bs, 1, 2 * h, 2 * h, device=dev, generator=g); nw = torch.tensor([0.1], device=dev); ab = torch.zeros(cout, device=dev)
     wt, _ = ops.PreparedWeights().get(w, None, False, True, tconv=True)
     ops.UP_FUSED = True
+    if sp:
+        xs, sn = ops.to_split_planes(x, s), torch.randn(bs, 1, cout, device=dev, generator=g)
+        call = lambda: ops.modconv_up_single(xs, wt, s, d, blur, nz, nw, ab, True, cout, s_next=sn)
+    else:
+        call = lambda: ops.modconv_up_single(x, wt, s, d, blur, nz, nw, ab, True, cout)
     for _ in range(3):
-        ops.modconv_up_single(x, wt, s, d, blur, nz, nw, ab, True, cout)
+        call()
     clear("up")
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record(); ops.modconv_up_single(x, wt, s, d, blur, nz, nw, ab, True, cout); b.record(); torch.cuda.synchronize()
-    report(f"fused up {cin}->{cout} @{h}^2 bs{bs}", read(1 << 17, "up"), a.elapsed_time(b))
+    a.record(); call(); b.record(); torch.cuda.synchronize()
+    report(f"fused up {cin}->{cout} @{h}^2 bs{bs}{' split planes' if sp else ''}", read(1 << 17, "up"), a.elapsed_time(b))
 
 
 def run_conv(cin, cout, h, bs=8):
     x = torch.randn(bs, cin, h, h, device=dev); w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
     mean = torch.zeros(bs, cin, device=dev); rstd = torch.ones(bs, cin, device=dev); slope = torch.full((cout,), 0.25, device=dev)
-    pc = ops.PreparedConv(); pc.get(w)
+    pc = ops.PreparedConv().get(w)
     for _ in range(3):
         ops.conv2d(x, pc, stride=1, pad=1, in_norm=(mean, rstd), prelu=slope)
     clear("conv")
@@ -116,10 +121,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "conv":
         run_conv(256, 256, 64); run_conv(128, 128, 128); run_conv(64, 64, 256); run_conv(512, 512, 32)
         sys.exit(0)
-    run_same(32, 32, 1024)
-    run_same(64, 64, 512)
     run_same(512, 512, 64, masked=True)
+    run_same(256, 256, 128, masked=True)
     run_same(128, 128, 256, masked=True)
     run_same(512, 256, 64, masked=True, up=True)
+    run_same(256, 128, 128, masked=True, up=True)
     run_up_fused(128, 64, 256)
     run_up_fused(64, 32, 512)
+    run_up_fused(128, 64, 256, sp=True)
+    run_up_fused(64, 32, 512, sp=True)
