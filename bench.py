@@ -370,7 +370,22 @@ def main():
                         "trainable_params": int(sum(p.numel() for p in params)), "loss_first": round(l0, 4), "loss_last": round(lN.item(), 4),
                         "how": "whole step (forward, backward, weight re-layout, Adam) as one hipGraph; synthesis gradients from csrc/modconv_bwd.hip "
                                "+ fp32 library GEMMs (BASELINE configs[3], one frame)"}
-            del step, topt, tnet, params
+            # the loop of configs[3] itself on a short clip: passes over the frames, one optimiser step per frame, eroded maps, foreground-weighted
+            # L2 (pti.tune_clip: training/video_swap_ft_coach.py:242-317); the first two steps run eagerly, the rest replays one captured step
+            del step
+            nf, passes = 8, 2
+            vecs = torch.from_numpy(seeded.seeded_array(42, "vecs", (nf, 12, 1280), dist="normal")).to(dev)
+            labs = torch.from_numpy(seeded.blocky_labels(43, nf, 12, 512, 16)).to(dev).to(torch.uint8)
+            imgs = torch.tanh(torch.from_numpy(seeded.seeded_array(44, "imgs", (nf, 3, 1024, 1024), dist="normal"))).to(dev)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            hist = pti.tune_clip(tnet, topt, imgs, labs, vecs, steps=passes, erode_radius=3)
+            torch.cuda.synchronize()
+            pti_info["clip_loop"] = {"frames": nf, "passes": passes, "optimizer_steps": nf * passes, "seconds": round(time.perf_counter() - t2, 4),
+                                     "mean_loss_per_pass": [round(h, 4) for h in hist],
+                                     "what": "pti.tune_clip: erode_mask radius 3 + foreground-weighted L2, the first 2 steps eagerly on the capture stream, then one captured step replayed per frame "
+                                             "(includes the capture); BASELINE configs[3] is 200 passes x 32 frames, sharded over 4 GPUs with averaged gradients"}
+            del topt, tnet, params, vecs, labs, imgs
             torch.cuda.empty_cache()
         except Exception as e:      # noqa: BLE001 - secondary measurement
             pti_info = {"error": f"{type(e).__name__}: {e}"[:300]}

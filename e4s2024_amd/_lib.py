@@ -31,6 +31,8 @@ _PROTOS = {
     "e4s_modconv_up_fused_sb": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr],
     "e4s_swap_head_mask": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
     "e4s_foreground_masks": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr],
+    "e4s_frames_to_tensor": [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
+    "e4s_erode_labels": [c_ptr, c_ptr, c_int, c_int, c_int, c_int, ctypes.c_uint, c_ptr],
     "e4s_pyr_down": [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_resample_u8": [c_ptr] * 5 + [c_int] * 7 + [c_ptr],
     "e4s_pyr_blend_level": [c_ptr] * 7 + [c_int, c_int, c_int, c_ptr],

@@ -324,3 +324,58 @@ extern "C" int e4s_foreground_masks(float* content, float* border, float* full, 
                        hole_mask, h, w, radius);
     return check_launch("foreground_masks");
 }
+
+
+// ============================================================================ f3: uint8 frames -> network input
+// transforms.Compose([ToTensor(), Normalize((.5,.5,.5), (.5,.5,.5))]) (datasets/dataset.py:32, 45; face_swap_video_pipeline.py:338-339):
+// out[b][c][y][x] = (in[b][y][x][c] / 255 - 0.5) / 0.5 in float32 (a true division, as torchvision's ToTensor does).
+__global__ __launch_bounds__(256) void frames_to_tensor_kernel(float* __restrict__ out, const uint8_t* __restrict__ in, int bs, int hw) {
+    const int64_t total = (int64_t)bs * hw;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int b = (int)(i / hw);
+        const int pix = (int)(i - (int64_t)b * hw);
+        const uint8_t* q = in + i * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[((int64_t)b * 3 + c) * hw + pix] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)q[c], 255.f), 0.5f), 0.5f);
+    }
+}
+
+extern "C" int e4s_frames_to_tensor(float* out, const uint8_t* frames_u8, int bs, int h, int w, void* stream) {
+    E4S_REQUIRE(out && frames_u8, "frames_to_tensor: null tensor");
+    E4S_REQUIRE(bs >= 0 && h >= 1 && w >= 1, "frames_to_tensor: bad size");
+    if (bs == 0) return 0;
+    const int64_t total = (int64_t)bs * h * w;
+    const int grid = (int)(cdiv64(total, 256) < 8192 ? cdiv64(total, 256) : 8192);
+    hipLaunchKernelGGL(frames_to_tensor_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, frames_u8, bs, h * w);
+    return check_launch("frames_to_tensor");
+}
+
+// ============================================================================ f1: erode_mask of the PTI loop
+// erode_mask(mask, img, radius) (training/video_swap_ft_coach.py:64-93): face = not {background 0, hair 4, ear-rings 11}; the face mask is
+// eroded with a (2r+1)^2 box (cv2.erode, BORDER_CONSTANT 0: pixels outside the image count as not-face); out = mask where the eroded face
+// mask holds, 0 elsewhere.  A flat erosion is a logical AND over the window — no arithmetic to pin beyond its definition.
+__global__ __launch_bounds__(256) void erode_labels_kernel(uint8_t* __restrict__ out, const uint8_t* __restrict__ in, int h, int w, int radius, unsigned bg_bits) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= w || y >= h) return;
+    const uint8_t* m = in + (size_t)blockIdx.z * h * w;
+    bool keep = true;
+    for (int dy = -radius; dy <= radius && keep; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= h) { keep = false; break; }
+        for (int dx = -radius; dx <= radius; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= w) { keep = false; break; }
+            const unsigned c = m[(size_t)yy * w + xx];
+            if (c < 32 && ((bg_bits >> c) & 1u)) { keep = false; break; }
+        }
+    }
+    out[(size_t)blockIdx.z * h * w + (size_t)y * w + x] = keep ? m[(size_t)y * w + x] : (uint8_t)0;
+}
+
+extern "C" int e4s_erode_labels(uint8_t* out, const uint8_t* labels, int bs, int h, int w, int radius, unsigned bg_class_bits, void* stream) {
+    E4S_REQUIRE(out && labels && out != labels, "erode_labels: null tensor / in-place");
+    E4S_REQUIRE(bs >= 0 && bs <= 65535 && h >= 1 && w >= 1 && radius >= 0 && radius <= 64, "erode_labels: bad size");
+    if (bs == 0) return 0;
+    hipLaunchKernelGGL(erode_labels_kernel, dim3(cdiv(w, 32), cdiv(h, 8), bs), dim3(256), 0, (hipStream_t)stream, out, labels, h, w, radius, bg_class_bits);
+    return check_launch("erode_labels");
+}

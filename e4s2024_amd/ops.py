@@ -1133,6 +1133,35 @@ def foreground_masks(swapped: torch.Tensor, hole_mask: Optional[torch.Tensor] = 
     return content, border, full
 
 
+def frames_to_tensor(frames_u8: torch.Tensor) -> torch.Tensor:
+    """uint8 frames ``[bs, H, W, 3]`` -> ``[bs, 3, H, W]`` float in [-1, 1]: ``Compose([ToTensor(), Normalize(.5, .5)])`` (datasets/dataset.py:32, 45;
+    face_swap_video_pipeline.py:338-339) on the device, bit for bit (``(x / 255 - 0.5) / 0.5`` in float32)."""
+    if not isinstance(frames_u8, torch.Tensor) or frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.shape[-1] != 3:
+        raise ValueError("frames_to_tensor: uint8 [bs, H, W, 3] frames")
+    if not frames_u8.is_cuda:
+        raise RuntimeError("frames must be a CUDA tensor")
+    x = frames_u8.contiguous()
+    bs, h, w, _ = x.shape
+    out = torch.empty((bs, 3, h, w), dtype=torch.float32, device=x.device)
+    lib().call("e4s_frames_to_tensor", _p(out), _p(x), bs, h, w, _stream())
+    return out
+
+
+PTI_BG_CLASSES = (0, 4, 11)        # background, hair, ear-rings: what erode_mask / the PTI foreground leave out (video_swap_ft_coach.py:72, 277)
+
+
+def erode_labels(labels: torch.Tensor, radius: int, bg_classes: Sequence[int] = PTI_BG_CLASSES) -> torch.Tensor:
+    """``erode_mask(mask, img, radius)[0]`` (training/video_swap_ft_coach.py:64-93) for a batch of uint8 ``[bs, H, W]`` 12-class maps."""
+    m = _labels_u8(labels, "labels")
+    bits = 0
+    for c in bg_classes:
+        bits |= 1 << int(c)
+    out = torch.empty_like(m)
+    if m.shape[0]:
+        lib().call("e4s_erode_labels", _p(out), _p(m), m.shape[0], m.shape[1], m.shape[2], int(radius), bits, _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------ f1: native gradients of the masked conv
 NATIVE_BWD = os.environ.get("E4S_NATIVE_BWD", "1") != "0"
 _FOLD_CHUNK_PX = 4096

@@ -343,6 +343,13 @@ E4S_API int e4s_pyr_up(float* out, const float* in, const float* minuend, const 
  * out = up(prev) + la*m_hi + lb*(1 - m_hi);  *_lo and prev are [planes, h, w], *_hi [planes, 2h, 2w]. */
 E4S_API int e4s_pyr_blend_level(float* out, const float* prev, const float* a_hi, const float* a_lo, const float* b_hi, const float* b_lo,
                                 const float* m_hi, int planes, int h, int w, void* stream);
+/* uint8 frames [bs, h, w, 3] -> the network's input [bs, 3, h, w] = (x / 255 - 0.5) / 0.5: transforms.Compose([ToTensor(), Normalize(.5, .5)])
+ * of datasets/dataset.py:32, 45 as used at face_swap_video_pipeline.py:338-339 (float32, true division like torchvision). */
+E4S_API int e4s_frames_to_tensor(float* out, const uint8_t* frames_u8, int bs, int h, int w, void* stream);
+/* erode_mask(mask, img, radius) of the PTI loop (training/video_swap_ft_coach.py:64-93) on uint8 [bs, h, w] 12-class maps: the face mask
+ * (every class whose bit is NOT set in bg_class_bits; the reference's background set {0, 4, 11} = 0x811) is eroded with a (2r+1)^2 box,
+ * pixels outside the image counting as not-face (cv2.erode, BORDER_CONSTANT 0); out = label where the eroded mask holds, 0 elsewhere. */
+E4S_API int e4s_erode_labels(uint8_t* out, const uint8_t* labels, int bs, int h, int w, int radius, unsigned bg_class_bits, void* stream);
 E4S_API int e4s_foreground_masks(float* content, float* border, float* full, const uint8_t* swapped, const uint8_t* hole_mask,
                                  int bs, int h, int w, int radius, void* stream);
 

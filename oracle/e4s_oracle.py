@@ -540,6 +540,32 @@ def swap_comp_style_vector(style_vectors1: Tensor, style_vectors2: Tensor, comp_
     return out
 
 
+def erode_mask(mask: np.ndarray, radius: int = 3) -> np.ndarray:
+    """``erode_mask(mask, img, radius)[0]`` — training/video_swap_ft_coach.py:64-93.  ``mask``: integer 12-class map ``[H, W]``.
+    face = not {0, 4, 11} (:72-73); ``cv2.erode`` with a ``(2r+1)^2`` box of ones, ``BORDER_CONSTANT`` 0 (:79-81) = a flat erosion whose
+    outside-the-image pixels count as not-face; the label survives where the eroded face mask holds (:83-84).
+    cv2 is neither in the reference tree nor in this image: **pinned by definition only** (a flat erosion is a logical AND over the window;
+    checked against scipy.ndimage.binary_erosion, an independent implementation, in tests/test_oracle_golden.py)."""
+    face = ~np.isin(mask, (0, 4, 11))
+    h, w = face.shape
+    pad = np.zeros((h + 2 * radius, w + 2 * radius), dtype=bool)
+    pad[radius: radius + h, radius: radius + w] = face
+    er = np.ones((h, w), dtype=bool)
+    for dy in range(2 * radius + 1):
+        for dx in range(2 * radius + 1):
+            er &= pad[dy: dy + h, dx: dx + w]
+    out = np.zeros_like(mask)
+    out[er] = mask[er]
+    return out
+
+
+def frames_to_tensor(frames_u8: np.ndarray) -> Tensor:
+    """``Compose([ToTensor(), Normalize((.5,.5,.5), (.5,.5,.5))])`` — datasets/dataset.py:32, 45 (face_swap_video_pipeline.py:338-339) on uint8
+    ``[bs, H, W, 3]``: torchvision's ToTensor is ``permute -> float32 -> div(255)``, Normalize ``(x - mean) / std``."""
+    t = torch.from_numpy(np.ascontiguousarray(frames_u8)).permute(0, 3, 1, 2).to(torch.float32).div(255)
+    return t.sub(0.5).div(0.5)
+
+
 def _flat_morph(mask: np.ndarray, radius: int, op) -> np.ndarray:
     """Flat (2r+1)^2 dilation / erosion with the 'geodesic' border of utils/morphology.py:76-81, 150-155: pixels outside the image
     are ignored.  ``mask``: float ``[..., H, W]``."""

@@ -490,3 +490,38 @@ def test_graphed_pti_replay_then_eval_uses_fresh_weights():
         assert torch.equal(got, want), "no_grad forward after a graph replay rendered with stale weight copies"
         previews.append(got)
     assert (previews[0] - previews[1]).abs().max().item() > 1e-4      # the weights really moved between the two previews
+
+
+def test_tune_clip_graphed_matches_eager_and_counts_steps():
+    """BASELINE configs[3] loop (training/video_swap_ft_coach.py:242-317) on a small Net3: `steps` passes over the clip, one optimiser step
+    per frame, eroded region maps, foreground-weighted L2.  The graph-replayed loop (first two steps eager, then one captured step replayed
+    with each frame's inputs) walks the trajectory of the plain eager loop, and the optimiser has taken exactly steps x frames steps."""
+    import types
+    install_dropin()
+    from models.networks import Net3
+    from e4s2024_amd import pti, ops
+    opts = types.SimpleNamespace(fsencoder_type="psp", remaining_layer_idx=5, num_seg_cls=12, out_size=64, train_G=True,
+                                 start_from_latent_avg=True, learn_in_w=False)
+    n = 3
+    vec = T(seeded.seeded_array(41, "vecs", (n, 12, 1280), dist="normal")).to(DEV)
+    lab = T(seeded.blocky_labels(3, n, 12, 64, 8)).to(DEV)
+    img = torch.tanh(T(seeded.seeded_array(5, "imgs", (n, 3, 64, 64), dist="normal"))).to(DEV)
+
+    def make():
+        net = Net3(opts)
+        seeded.apply_seeded(net, 4, "net3")
+        net = net.to(DEV).train()
+        net.latent_avg = seeded.seeded_latent_avg(2, 10).to(DEV)
+        return net
+
+    maps, fg = pti.prepare_clip(lab, 1, (64, 64))
+    assert tuple(fg.shape) == (n, 1, 64, 64) and np.array_equal(maps[1].cpu().numpy(), O.erode_mask(lab[1].cpu().numpy(), 1))
+    hist = {}
+    for graphed in (False, True):
+        net = make()
+        opt = torch.optim.Adam(pti.trainable_parameters(net), lr=1e-3, capturable=True, fused=True)
+        hist[graphed] = pti.tune_clip(net, opt, img, lab, vec, steps=3, erode_radius=1, graphed=graphed, randomize_noise=False)
+        taken = {int(st["step"].item()) for st in opt.state.values() if "step" in st}
+        assert taken == {3 * n}, taken
+    assert hist[False][-1] < hist[False][0]
+    assert np.allclose(hist[True], hist[False], rtol=3e-3), hist

@@ -149,3 +149,26 @@ def test_pil_resize_on_the_device_equals_pillow_bit_for_bit():
     for (h, w), (ow, oh) in [((37, 53), (20, 31)), ((50, 41), (123, 77)), ((9, 7), (3, 2)), ((64, 48), (64, 24))]:
         x = rs.randint(0, 256, (1, h, w, 3)).astype(np.uint8)
         assert np.array_equal(ops.pil_resize(T(x).to(DEV), (ow, oh)).cpu().numpy()[0], np.array(PIL.fromarray(x[0]).resize((ow, oh))))
+
+
+@pytest.mark.parametrize("radius", [0, 1, 3, 5])
+def test_erode_labels_matches_the_oracle(radius):
+    """f1: erode_mask of the PTI loop (training/video_swap_ft_coach.py:64-93) on the device, ragged sizes, a batch, exact."""
+    rs = np.random.RandomState(11 + radius)
+    lab = np.repeat(np.repeat(rs.randint(0, 12, (3, 14, 19)), 5, 1), 5, 2)[:, :67, :93].astype(np.uint8)
+    out = ops.erode_labels(T(lab).to(DEV), radius).cpu().numpy()
+    for b in range(3):
+        assert np.array_equal(out[b], O.erode_mask(lab[b], radius)), (radius, b)
+    full = seeded.blocky_labels(7, 2, 12, 512, 16)
+    assert np.array_equal(ops.erode_labels(T(full).to(DEV), 3).cpu().numpy()[1], O.erode_mask(full[1], 3))
+
+
+def test_frames_to_tensor_bit_exact():
+    """f3: ToTensor + Normalize(.5, .5) of uint8 frames on the device == the float32 expression torchvision evaluates."""
+    rs = np.random.RandomState(5)
+    fr = rs.randint(0, 256, (2, 37, 53, 3)).astype(np.uint8)
+    fr[0, 0, :, 0] = np.arange(53) * 4 % 256
+    got = ops.frames_to_tensor(T(fr).to(DEV)).cpu()
+    assert torch.equal(got, O.frames_to_tensor(fr))
+    with pytest.raises(ValueError):
+        ops.frames_to_tensor(torch.zeros(1, 3, 4, 4, device=DEV))

@@ -285,6 +285,63 @@ def test_pti_gradient_average_world2_gloo(tmp_path):
     assert pti.sync_gradients([torch.nn.Parameter(torch.ones(2))]) == 0      # no process group: nothing to do
 
 
+_TUNE_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[3])
+from e4s2024_amd import pti
+from e4s2024_amd.runner import shard_range
+rank, world, n = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[5])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[4], RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.manual_seed(0)
+net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3)); ref.load_state_dict(net.state_dict())
+xs, ys = torch.randn(n, 1, 6), torch.randn(n, 1, 3)
+opt, ropt = torch.optim.SGD(net.parameters(), lr=0.1), torch.optim.SGD(ref.parameters(), lr=0.1)
+calls = []
+def step_fn(net_, opt_, vec, mp, img, fg, group, active):            # vec = x, img = y of this rank's frame (None: no frame left this round)
+    opt_.zero_grad(set_to_none=True)
+    loss = None
+    if vec is not None:
+        loss = torch.nn.functional.mse_loss(net_(vec[0]), img[0]); loss.backward()
+    calls.append((vec is not None, active))
+    pti.sync_gradients(list(net_.parameters()), group, active_ranks=active)
+    opt_.step()
+    return loss
+hist = pti.tune_clip(net, opt, ys, torch.zeros(n, 1, 1, dtype=torch.uint8), xs, steps=2, group=None, step_fn=step_fn)
+# the same schedule in one process: round i of a pass = the i-th frame of every rank's block, gradients averaged over the ranks that have one
+blocks = [shard_range(n, r, world) for r in range(world)]
+rounds = max(e - s for s, e in blocks)
+for _ in range(2):
+    for i in range(rounds):
+        fr = [s + i for s, e in blocks if s + i < e]
+        ropt.zero_grad()
+        (sum(torch.nn.functional.mse_loss(ref(xs[f]), ys[f]) for f in fr) / len(fr)).backward()
+        ropt.step()
+for a, b in zip(net.parameters(), ref.parameters()):
+    assert torch.allclose(a, b, atol=1e-6), (a - b).abs().max()
+assert len(calls) == 2 * rounds and len(hist) == 2
+lo, hi = blocks[rank]
+assert [c[0] for c in calls[:rounds]] == [lo + i < hi for i in range(rounds)]
+print("TUNE_OK", rank, calls[:rounds])
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("n_frames,port", [(5, 29621), (4, 29622), (1, 29623)])
+def test_tune_clip_rounds_world2_gloo(tmp_path, n_frames, port):
+    """BASELINE configs[3] on several GPUs: `pti.tune_clip` shards the clip's frames in blocks, walks them in rounds (one frame per rank per
+    round, gradients averaged over the ranks that still have one) and keeps every rank's parameters identical to the single-process
+    evaluation of the same schedule — also when the blocks are uneven (a rank sits a round out but still joins the collectives)."""
+    script = tmp_path / "tune_worker.py"
+    script.write_text(_TUNE_WORKER)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", ROOT, str(port), str(n_frames)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "TUNE_OK 0" in outs[0] and "TUNE_OK 1" in outs[1]
+
+
 def test_run_clip_single_process_equals_sharded_result():
     from e4s2024_amd.runner import FrameShardRunner
     r = FrameShardRunner()

@@ -215,3 +215,23 @@ def test_g13_style_vector_mix():
     for below in (False, True):
         assert torch.equal(O.swap_comp_style_vector(t, s, idx, below), T(g[f"batch.out_below{int(below)}"]))
         assert torch.equal(pipeline.mix_style_vectors(t, s, idx, below), T(g[f"batch.out_below{int(below)}"]))
+
+
+def test_erode_mask_restatement_against_an_independent_erosion():
+    """f1: ``erode_mask`` (training/video_swap_ft_coach.py:64-93).  cv2 is not available, so the flat erosion is checked against
+    scipy.ndimage.binary_erosion (box structuring element, border_value 0 = cv2's BORDER_CONSTANT 0) on seeded label maps."""
+    ndi = pytest.importorskip("scipy.ndimage")
+    rs = np.random.RandomState(3)
+    for (h, w), r in (((64, 64), 3), ((40, 57), 1), ((33, 33), 5), ((16, 20), 0)):
+        lab = np.repeat(np.repeat(rs.randint(0, 12, (h // 4 + 1, w // 4 + 1)), 4, 0), 4, 1)[:h, :w].astype(np.uint8)
+        face = ~np.isin(lab, (0, 4, 11))
+        er = ndi.binary_erosion(face, structure=np.ones((2 * r + 1, 2 * r + 1), bool), border_value=0) if r else face
+        want = np.where(er, lab, 0).astype(np.uint8)
+        assert np.array_equal(O.erode_mask(lab, r), want), ((h, w), r)
+
+
+def test_frames_to_tensor_restatement():
+    a = np.arange(256, dtype=np.uint8).reshape(1, 16, 16, 1).repeat(3, 3)
+    t = O.frames_to_tensor(a)
+    assert t.shape == (1, 3, 16, 16) and t.min().item() == -1.0 and t.max().item() == 1.0
+    assert torch.equal(t[0, 0].flatten(), (torch.arange(256, dtype=torch.float32) / 255 - 0.5) / 0.5)
