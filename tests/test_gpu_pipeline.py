@@ -194,3 +194,28 @@ def test_mix_style_vectors_inside_graph_capture():
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, eager)
+
+
+def test_clip_from_reference_style_directory_through_the_swap(gpu_net3, parser, tmp_path):
+    """Row f4 on the device: a directory written the reference's way (RGB PNG crops, uint8 label PNGs) -> ``handoff.load`` onto the GPU ->
+    the batched swap.  The loader's image normalisation equals the device ingest kernel's (``ops.frames_to_tensor``, the ToTensor +
+    Normalize of face_swap_video_pipeline.py:338-339) bit for bit, and the swap on the loaded clip equals the swap on the same tensors
+    built directly."""
+    from PIL import Image
+    from e4s2024_amd import handoff
+    rs = np.random.RandomState(2)
+    os_path = str(tmp_path)
+    import os
+    os.makedirs(os.path.join(os_path, "imgs"))
+    u8 = {}
+    for t in "DT":
+        u8[t] = rs.randint(0, 256, (2, 1024, 1024, 3)).astype(np.uint8)
+        for i in range(2):
+            Image.fromarray(u8[t][i]).save(os.path.join(os_path, "imgs", "%s_%04d.png" % (t, i)))
+    clip = handoff.load(os_path, device=DEV)
+    assert clip.driven_mask is None and clip.target.is_cuda
+    for k, t in (("driven", "D"), ("target", "T")):
+        assert torch.equal(getattr(clip, k), ops.frames_to_tensor(T(u8[t]).to(DEV)))
+    a, lab_a = pipeline.swap_batch(gpu_net3, parser, clip.driven, clip.target)
+    b, lab_b = pipeline.swap_batch(gpu_net3, parser, ops.frames_to_tensor(T(u8["D"]).to(DEV)), ops.frames_to_tensor(T(u8["T"]).to(DEV)))
+    assert torch.equal(a, b) and torch.equal(lab_a, lab_b) and a.dtype == torch.uint8 and tuple(a.shape) == (2, 1024, 1024, 3)

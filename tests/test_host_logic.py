@@ -397,3 +397,38 @@ def test_multi_band_blend_oracle_properties():
     B = rs.rand(64, 64, 3) * 255
     assert np.array_equal(np.clip(O.laplacian_blend(A, B, np.ones((64, 64, 3), np.float32), 6), 0, 255).astype(np.uint8), A)
     assert np.abs(O.laplacian_blend(A, B, np.zeros((64, 64, 3), np.float32), 6) - B).max() <= 1e-3
+
+
+def test_handoff_reads_a_directory_written_the_reference_way(tmp_path):
+    """Row f4: the experiment directory as ``FaceSwapVideoPipeline`` writes it — ``targets[i].save(imgs/T_%04d.png)``,
+    ``Image.fromarray(T_mask[i]).save(mask/T_mask_%04d.png)`` (face_swap_video_pipeline.py:226-229), ``torch.save(driven_style_vector,
+    styleVec/D_style_vec_%04d.pt)`` with ``[1, 12, 1280]`` tensors (:351-354), 512-pixel crops that the reader resizes to 1024 like
+    ``Image.open(...).convert("RGB").resize((1024, 1024))`` (:408-411) — goes through ``handoff.load`` into the tensors the engine takes,
+    and the image normalisation equals the oracle's ToTensor + Normalize restatement."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from e4s2024_amd import handoff
+    from oracle import e4s_oracle as O
+    rs = np.random.RandomState(1)
+    n = 2
+    imgs = {t: [Image.fromarray(rs.randint(0, 256, (512, 512, 3)).astype(np.uint8)) for _ in range(n)] for t in "DT"}
+    masks = {t: [rs.randint(0, 12, (512, 512)).astype(np.uint8) for _ in range(n)] for t in "DT"}
+    vecs = {t: [torch.from_numpy(rs.standard_normal((1, 12, 1280)).astype(np.float32)) for _ in range(n)] for t in "DT"}
+    for sub in ("imgs", "mask", "styleVec"):
+        os.makedirs(tmp_path / sub)
+    for i in range(n):
+        for t in "DT":
+            imgs[t][i].save(os.path.join(tmp_path, "imgs", "%s_%04d.png" % (t, i)))
+            Image.fromarray(masks[t][i]).save(os.path.join(tmp_path, "mask", "%s_mask_%04d.png" % (t, i)))
+            torch.save(vecs[t][i], os.path.join(tmp_path, "styleVec", "%s_style_vec_%04d.pt" % (t, i)))
+    Image.fromarray(masks["D"][0]).save(os.path.join(tmp_path, "mask", "S_mask.png"))           # files the reader must ignore
+    Image.fromarray(rs.randint(0, 256, (512, 512, 3)).astype(np.uint8)).save(os.path.join(tmp_path, "mask", "D_mask_vis_0000.png"))
+    clip = handoff.load(str(tmp_path))
+    assert len(clip) == n and tuple(clip.target.shape) == (n, 3, 1024, 1024) and clip.target_mask.dtype == torch.uint8
+    for k, t in (("driven", "D"), ("target", "T")):
+        want_u8 = np.stack([np.asarray(Image.open(os.path.join(tmp_path, "imgs", "%s_%04d.png" % (t, i))).convert("RGB").resize((1024, 1024))) for i in range(n)])
+        assert torch.equal(getattr(clip, k), O.frames_to_tensor(want_u8))
+        assert np.array_equal(getattr(clip, k + "_mask").numpy(), np.stack(masks[t]))
+        assert torch.equal(getattr(clip, k + "_style"), torch.cat(vecs[t]))
+    assert len(handoff.load(str(tmp_path), first_index=1)) == 1 and len(handoff.load(str(tmp_path), count=1)) == 1
