@@ -39,7 +39,7 @@ def test_abi_signatures_carry_no_torch_types():
         for arg in decl[decl.index("(") + 1: decl.rindex(")")].split(","):
             ty = " ".join(arg.split()[:-1])
             assert ty in ("", "void", "int", "float", "int64_t", "void*", "float*", "const float*", "uint8_t*", "const uint8_t*", "int*", "int32_t*", "const int32_t*",
-                          "const float* const*", "uint16_t*", "const uint16_t*", "const E4sStyleJob*", "const E4sChainLayer*"), (decl.split("(")[0], arg)
+                          "const float* const*", "uint16_t*", "const uint16_t*", "const E4sStyleJob*", "const E4sChainLayer*", "unsigned"), (decl.split("(")[0], arg)
 
 
 def test_argument_validation_without_gpu():
@@ -432,3 +432,27 @@ def test_handoff_reads_a_directory_written_the_reference_way(tmp_path):
         assert np.array_equal(getattr(clip, k + "_mask").numpy(), np.stack(masks[t]))
         assert torch.equal(getattr(clip, k + "_style"), torch.cat(vecs[t]))
     assert len(handoff.load(str(tmp_path), first_index=1)) == 1 and len(handoff.load(str(tmp_path), count=1)) == 1
+
+
+def test_bench_spawns_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` outside a launcher starts torch.distributed.run with N ranks of itself as a CHILD process (never an exec of
+    a process that may have touched the GPU) and exits with its code; inside a launcher (WORLD_SIZE set) it does not spawn."""
+    sys.path.insert(0, ROOT)
+    import subprocess as sp
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(sp, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--warmup", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as ex:
+        bench._spawn_ranks(4)
+    assert ex.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "5", "--warmup", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
