@@ -26,20 +26,7 @@ using namespace e4s;
 
 namespace {
 
-// LDS-DMA with explicit address spaces: a SCALAR 64-bit global base + a 32-bit per-lane byte offset (the saddr form of
-// global_load_lds_*: one VGPR, no 64-bit address arithmetic), and the LDS destination as a plain 32-bit LDS address (M0).  Written with
-// generic pointers, hipcc 7.2 wraps every DMA in null checks of the generic -> LDS conversion, and a per-lane choice between two source
-// pointers (image / zero block) becomes two exec-masked DMAs with a GOT load in between: ~190 cycles per instruction instead of ~10.
 __device__ uint4 g_zero16[4];   // 64 zero bytes (zero-initialised device global): ChainParams::zeros
-typedef __attribute__((address_space(3))) unsigned char lds_byte;
-typedef const __attribute__((address_space(1))) unsigned char gl_byte;
-__device__ __forceinline__ void dma16(const void* gbase, unsigned voff, lds_byte* dst) {
-    __builtin_amdgcn_global_load_lds((gl_byte*)gbase + voff, dst, 16, 0, 0);      // (C-style cast: an address-space cast)
-}
-__device__ __forceinline__ void dma4(const void* gbase, unsigned voff, lds_byte* dst) {
-    __builtin_amdgcn_global_load_lds((gl_byte*)gbase + voff, dst, 4, 0, 0);
-}
-
 #define CH_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 // s_waitcnt vmcnt(n) for an n that is a constant only after unrolling: the switch folds to the one case (vmcnt is a 6-bit field)
 __device__ __forceinline__ void wait_vm(int n) {

@@ -35,6 +35,7 @@ struct UpFusedParams {
     int tiles_x, tiles_y;
     const float* s_next;     // [bs][cout] (OSP): modulation of the NEXT layer, applied before the bf16 split of the output
     int64_t plane_in, plane_out;   // uint4 per split plane (XSP / OSP)
+    const float* zeros;      // >= 64 zero bytes (DMA source of an absent noise / bias operand)
     int exp;                 // tuning experiments of the -DE4S_PHASE_PROF build (E4S_UF_EXP): 1 = no output stores, 2 = no blur, 4 = no z-tile writes
 };
 // channel-blocked activations ([bs, c/8, h, w, 8]) are compile-time variants: XN = input, ON = output (E4S_X_NHWC / E4S_OUT_NHWC in `act`);
@@ -347,6 +348,217 @@ __global__ __launch_bounds__(UF_NT, MINW) void up_fused_sb_kernel(const UpFusedP
     E4S_PROF_MARK(g_prof_up, 5);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The chain's up layer (split planes in, split planes out) with LDS-DMA staging.  Phase timestamps of the register-staged kernel above:
+// first chunk 7 us, K loop 17.5 us for ~3 us of MFMA (every chunk waits a memory round trip for loads issued one short MFMA phase earlier),
+// epilogue 21 us.  Here the chunks land by global_load_lds_dwordx4 into a ring of two stages (two chunks in flight, no registers, no VALU,
+// no ds_write), issued by all eight waves; the workgroup shape (two per CU, so one's blur epilogue overlaps the other's K loop), the tile
+// geometry and the epilogue are those of the kernel above.
+constexpr int UD_XS4 = 4 * UF_PATCH, UD_W4 = 36 * 32, UD_STAGE4 = UD_XS4 + UD_W4;      // uint4 per stage: [hi|lo][half][289] + [hi|lo][tap][half][32]
+constexpr int UD_BODY = 2 * UD_STAGE4 * 16;                                               // 73 856 bytes (the pre-blur tile overlays it afterwards)
+constexpr int UD_EP_D = 0, UD_EP_B = 64, UD_EP_S = 128, UD_EP_N = 192, UD_EP_FLOATS = UD_EP_N + 13 * 64;
+constexpr int UD_LDS_BYTES = UD_BODY + UD_EP_FLOATS * 4;                                  // 77 952: two workgroups per CU
+constexpr int UD_G = 6;                                                                   // DMA instructions per chunk and wave (3 + 3, surplus ones repeat a piece)
+static_assert(UD_LDS_BYTES <= 80 * 1024 && UF_ZCO * UF_ZCS_NHWC * 4 <= UD_BODY, "two workgroups per CU; the pre-blur tile fits the stages");
+
+__global__ __launch_bounds__(UF_NT, 2) void up_fused_dma_kernel(const UpFusedParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint4* lds4 = reinterpret_cast<uint4*>(lds_raw);
+    float* epw = reinterpret_cast<float*>(lds_raw + UD_BODY);
+    lds_byte* const lds_b = (lds_byte*)lds_raw;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l5 = lane & 31, khalf = lane >> 5;
+    E4S_PROF_MARK(g_prof_up, 0);
+    const int tyt = blockIdx.x / p.tiles_x, txt = blockIdx.x - tyt * p.tiles_x;
+    const int p0y = tyt * UF_STEP - 1, p0x = txt * UF_STEP - 1;
+    const int cot = blockIdx.y, co0 = cot * 32;
+    const int b = blockIdx.z;
+    const int hw = p.h * p.w, ho = 2 * p.h, wo = 2 * p.w;
+    const int nchunk = p.cin >> 4, cb8 = p.cin >> 3;
+    const unsigned zero_off = (unsigned)(2 * p.plane_in * 16);             // the 16 zero bytes behind the two input planes
+
+    // ---- this wave's share of a chunk: activation units u = wave, wave + 8, wave + 16 of 20 (5 pieces x 4 (plane, half)); weight pieces
+    // wave, wave + 8, wave + 16 of 18
+    unsigned xoffs[3], xdst[3];
+    bool xin[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int u = wave + 8 * k;
+        u = u < 20 ? u : 19;
+        const int j = u % 5, combo = u / 5;
+        const int e = j * 64 + lane;
+        const int py = e / UF_PW, px = e - py * UF_PW;
+        const int gy = p0y - 1 + py, gx = p0x - 1 + px;
+        xin[k] = e < UF_PATCH && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+        // uint4 index of this lane's pixel in chunk 0 of its (plane, half); a chunk further is 2 * hw on
+        xoffs[k] = (unsigned)((combo >> 1) * p.plane_in) + (unsigned)((b * cb8 + (combo & 1)) * hw + gy * p.w + gx);
+        xdst[k] = (unsigned)((combo * UF_PATCH + j * 64) * 16);
+    }
+    auto issue = [&](int c) __attribute__((always_inline)) {
+        const unsigned st = (unsigned)(c & 1) * (unsigned)(UD_STAGE4 * 16);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int e = ((wave + 8 * k < 20 ? wave + 8 * k : 19) % 5) * 64 + lane;
+            if (e < UF_PATCH) dma16(p.x, xin[k] ? (xoffs[k] + (unsigned)(2 * c * hw)) * 16u : zero_off, lds_b + st + xdst[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int piece = wave + 8 * k;
+            piece = piece < 18 ? piece : 17;
+            const int hl = piece / 9;                                            // 18 x 32 uint4 = 9 pieces per slab
+            const int rem = piece * 64 - hl * 576 + lane;                        // [tap][half][32] index
+            dma16(hl ? p.wlo : p.whi, (unsigned)((((c * 18 + (rem >> 5)) * p.cout) + co0 + (rem & 31)) * 16), lds_b + st + (UD_XS4 + piece * 64) * 16);
+        }
+    };
+    // ---- epilogue operands by DMA as well: noise tile (13 pieces: 2 per wave), d / s_next / bias of the 32 channels (every wave, same bytes)
+    {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            int piece = wave + 8 * k;
+            piece = piece < 13 ? piece : 12;
+            const int e = piece * 64 + lane;
+            const int ry = e / UF_OUT, rx = e - ry * UF_OUT;
+            const int ny = tyt * UF_OUT + ry, nx = txt * UF_OUT + rx;
+            const bool ok = p.noise && e < UF_OUT * UF_OUT && ny < ho && nx < wo;
+            if (ok) dma4(p.noise, (unsigned)((b * p.noise_bstride + ny * wo + nx) * 4), lds_b + UD_BODY + (UD_EP_N + piece * 64) * 4);
+            else dma4(p.zeros, 0u, lds_b + UD_BODY + (UD_EP_N + piece * 64) * 4);
+        }
+        const unsigned co4 = (unsigned)((co0 + l5) * 4);
+        dma4(p.d, (unsigned)(b * p.cout * 4) + co4, lds_b + UD_BODY + UD_EP_D * 4);
+        dma4(p.s_next, (unsigned)(b * p.cout * 4) + co4, lds_b + UD_BODY + UD_EP_S * 4);
+        dma4(p.act_bias ? p.act_bias : p.zeros, p.act_bias ? co4 : 0u, lds_b + UD_BODY + UD_EP_B * 4);
+    }
+    issue(0);
+    if (nchunk > 1) issue(1);
+
+    const int pty = 2 * wave + (l5 >> 4), ptx = l5 & 15;   // this lane's position inside the tile
+    const int xoff = pty * UF_PW + ptx;
+    f32x16 accs[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accs[a][r] = 0.f;
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
+        // chunk c has landed for this wave (only chunk c + 1's instructions may still be in flight), then for all of them
+        if (c + 1 < nchunk) E4S_WAIT_VM(UD_G); else E4S_WAIT_VM(0);
+        E4S_LDS_BARRIER();
+        if (c == 0) E4S_PROF_MARK(g_prof_up, 1);
+        unsigned xb_i = (unsigned)((c & 1) * UD_STAGE4 + khalf * UF_PATCH + xoff);
+        unsigned wb_i = (unsigned)((c & 1) * UD_STAGE4 + UD_XS4 + khalf * 32 + l5);
+        asm volatile("" : "+v"(xb_i), "+v"(wb_i));
+        const uint4* xs = lds4 + xb_i;
+        const uint4* whalf = lds4 + wb_i;
+        uint4 bh[2], bl[2], ah[2], al[2];
+        auto fetch = [&](int tap, int slot) __attribute__((always_inline)) {
+            const int ky = tap / 3, kx = tap % 3;
+            const int eo = (1 - (ky >> 1)) * UF_PW + (1 - (kx >> 1));
+            bh[slot] = xs[eo];
+            bl[slot] = xs[2 * UF_PATCH + eo];
+            ah[slot] = whalf[tap * 64];
+            al[slot] = whalf[18 * 32 + tap * 64];
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int cs = tap & 1;
+            if (tap + 1 < 9) fetch(tap + 1, cs ^ 1);
+            const int ai = 2 * ((tap / 3) & 1) + ((tap % 3) & 1);
+            accs[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[cs]), __builtin_bit_cast(bf16x8, bh[cs]), accs[ai], 0, 0, 0);
+            accs[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[cs]), __builtin_bit_cast(bf16x8, bl[cs]), accs[ai], 0, 0, 0);
+            accs[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[cs]), __builtin_bit_cast(bf16x8, bh[cs]), accs[ai], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        E4S_LDS_BARRIER();                                   // everyone is done with this stage: refill it with chunk c + 2
+        if (c + 2 < nchunk) issue(c + 2);
+    }
+
+    // ---- epilogue (as up_fused_sb_kernel's split-plane variant): 8 output channels per pass through the pre-blur tile, which overlays the stages
+    E4S_PROF_MARK(g_prof_up, 2);
+    float* zt = reinterpret_cast<float*>(lds_raw);
+    const float* ep_d = epw + UD_EP_D;
+    const float* ep_b = epw + UD_EP_B;
+    const float* ep_s = epw + UD_EP_S;
+    const float* ep_n = epw + UD_EP_N;
+    float kf[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) kf[t] = p.blur[15 - t];
+    const float nw = p.noise ? p.noise_weight[0] : 0.f;
+    constexpr int NITEM = UF_ZCO * 2 * UF_OUT;       // 448: lanes = the 8 channels of a pixel, then pixels; 14 rows each
+    const int it_co = tid & 7, it_rem = tid >> 3;
+    const int it_rg = it_rem / UF_OUT, it_x = it_rem - it_rg * UF_OUT;
+    const int oy0 = tyt * UF_OUT + it_rg * UF_STEP, ox = txt * UF_OUT + it_x;
+    const bool it_ok = tid < NITEM && ox < wo && oy0 < ho;
+    const int nrow = it_ok ? (ho - oy0 < UF_STEP ? ho - oy0 : UF_STEP) : 0;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid < 4) reinterpret_cast<unsigned*>(p.out)[(size_t)p.plane_out * 8 + tid] = 0u;   // zero tail
+    const unsigned pix0 = (unsigned)(oy0 * wo + ox);
+    const float* zc = zt + it_co * UF_ZCS_NHWC + (it_rg * UF_STEP + 1) * UF_ZS + it_x + 1;
+    const float* nzp = ep_n + (tid < NITEM ? it_rg * UF_STEP * UF_OUT + it_x : 0);
+    const float neg = p.act ? 0.2f : 1.f, gain = p.act ? 1.41421356237309515f : 1.f;
+    E4S_PROF_MARK(g_prof_up, 3);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int col = 4 * khalf + rr;
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci)
+                *reinterpret_cast<float2*>(&zt[col * UF_ZCS_NHWC + (2 * pty + ci) * UF_ZS + 2 * ptx]) = make_float2(accs[2 * ci][4 * g + rr], accs[2 * ci + 1][4 * g + rr]);
+        }
+        __syncthreads();
+        const int co = co0 + 8 * g + it_co;
+        if (nrow > 0 && co < p.cout) {
+            const float dd = ep_d[8 * g + it_co], bi = ep_b[8 * g + it_co], sn = ep_s[8 * g + it_co];
+            unsigned* osp_row = reinterpret_cast<unsigned*>(p.out) + ((tid & 1) ? (size_t)p.plane_out * 4 : (size_t)0)
+                                + (((size_t)b * (p.cout >> 3) + (size_t)(co >> 3)) * ho * wo + pix0) * 4 + ((co & 7) >> 1);
+            constexpr int HR = UF_STEP / 2;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                float a[HR];
+#pragma unroll
+                for (int r = 0; r < HR; ++r) a[r] = 0.f;
+#pragma unroll
+                for (int zr = 0; zr < HR + 3; ++zr) {
+                    const float* zp = zc + (hf * HR + zr) * UF_ZS;
+                    const float z0 = zp[0], z1 = zp[1], z2 = zp[2], z3 = zp[3];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int r = zr - t;
+                        if (r >= 0 && r < HR) {
+                            a[r] = __builtin_fmaf(z0, kf[t * 4], a[r]);
+                            a[r] = __builtin_fmaf(z1, kf[t * 4 + 1], a[r]);
+                            a[r] = __builtin_fmaf(z2, kf[t * 4 + 2], a[r]);
+                            a[r] = __builtin_fmaf(z3, kf[t * 4 + 3], a[r]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < HR; ++r) {
+                    const int ro = hf * HR + r;
+                    if (ro < nrow) {
+                        float v = __builtin_fmaf(a[r], dd, bi) + __fmul_rn(nw, nzp[ro * UF_OUT]);
+                        v = fmaxf(v, v * neg) * gain;
+                        const float u = __fmul_rn(v, sn);
+                        const float other = __shfl_xor(u, 1, 64);
+                        unsigned h2, l2;
+                        split2((tid & 1) ? other : u, (tid & 1) ? u : other, h2, l2);
+                        osp_row[(unsigned)(ro * wo * 4)] = (tid & 1) ? l2 : h2;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    E4S_PROF_MARK(g_prof_up, 4);
+    E4S_PROF_DRAIN();
+    E4S_PROF_MARK(g_prof_up, 5);
+}
+
+__device__ uint4 g_uf_zero[4];   // 64 zero bytes (UpFusedParams::zeros)
+
 template <int CB, int MINW, bool XN = false, bool ON = false, bool XSP = false, bool OSP = false>
 int launch_up_fused(UpFusedParams& p, hipStream_t st) {
     using C = UfCfg<CB>;
@@ -404,7 +616,22 @@ extern "C" int e4s_modconv_up_fused_sb(float* out, const float* x, const uint16_
     hipStream_t st = (hipStream_t)stream;
     static const int cb2 = [] { const char* e = getenv("E4S_UPFUSED_CB2"); return e ? atoi(e) : 0; }();
     if (cb2 && cout > 32) return launch_up_fused<2, 2>(p, st);   // 64 co per workgroup: x staged once, 1 workgroup per CU
-    if (x_sp && out_sp) return launch_up_fused<1, 4, false, true, true, true>(p, st);
+    if (x_sp && out_sp) {
+        static const int use_dma = [] { const char* e = getenv("E4S_UP_DMA"); return e ? atoi(e) : 1; }();
+        if (use_dma && cout % 32 == 0 && cin % 16 == 0 && d) {
+            static const float* zeros = [] {
+                void* ptr = nullptr;
+                return hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_uf_zero)) == hipSuccess ? static_cast<const float*>(ptr) : nullptr;
+            }();
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&up_fused_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, UD_LDS_BYTES);
+            if (zeros && attr == hipSuccess) {
+                p.zeros = zeros;
+                hipLaunchKernelGGL(up_fused_dma_kernel, dim3(p.tiles_x * p.tiles_y, cout / 32, bs), dim3(UF_NT), UD_LDS_BYTES, st, p);
+                return check_launch("modconv_up_fused_sb");
+            }
+        }
+        return launch_up_fused<1, 4, false, true, true, true>(p, st);
+    }
     if (x_sp || out_sp) return fail(E4S_ERR_ARG, "modconv_up_fused_sb: split planes are built for both sides together (the chain's up layers)");
     if (x_nhwc && out_nhwc) return launch_up_fused<1, 4, true, true>(p, st);
     if (x_nhwc) return launch_up_fused<1, 4, true, false>(p, st);
