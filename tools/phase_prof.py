@@ -118,6 +118,11 @@ def run_conv(cin, cout, h, bs=8):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "small":
+        for h in (4, 8, 16, 32):
+            run_same(512, 512, h, masked=True)
+            run_same(512, 512, h, masked=True, up=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "conv":
         run_conv(256, 256, 64); run_conv(128, 128, 128); run_conv(64, 64, 256); run_conv(512, 512, 32)
         sys.exit(0)
