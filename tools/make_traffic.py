@@ -28,7 +28,7 @@ KEYS = {
                                             "7 launches per step (6 plain + 1 with fused ToRGB and split-plane output); dword activation loads: no FETCH correction", 117700000),
     "chain_conv3x3<32>": (["chain_conv_kernel<1, 2"], 2.0, "LDS-DMA dwordx4 only: FETCH_SIZE x2 (guide)", 4 * (32 * 1024 * 1024 * 4 + 3 * 1024 * 1024 * 4 + 3 * 512 * 512 * 4)),
     "chain_conv3x3<64>": (["chain_conv_kernel<2, 4"], 2.0, "LDS-DMA dwordx4 only: FETCH_SIZE x2 (guide)", 4 * (2 * 64 * 512 * 512 * 4 + 3 * 512 * 512 * 4 + 3 * 256 * 256 * 4)),
-    "modconv_up_fused_sb": (["up_fused_sb_kernel"], 2.0, "2 launches per step (256->512, 512->1024), split-plane in/out, 16-byte loads: FETCH_SIZE x2 (guide)",
+    "modconv_up_fused_sb": (["up_fused"], 2.0, "2 launches per step (256->512, 512->1024), split-plane in/out, 16-byte loads: FETCH_SIZE x2 (guide)",
                             (4 * (128 * 256 * 256 * 4 + 64 * 512 * 512 * 4) + 4 * (64 * 512 * 512 * 4 + 32 * 1024 * 1024 * 4)) // 2),
 }
 
