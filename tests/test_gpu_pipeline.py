@@ -97,17 +97,19 @@ def _check_labels(tag, got, ent, which):
     return n
 
 
-@pytest.mark.parametrize("mode", ["one_stream", "two_streams", "four_chains"])
+@pytest.mark.parametrize("mode", ["batched", "one_stream", "two_streams", "four_chains"])
 def test_swap_batch_bs8_vs_oracle(gpu_net3, parser, faces, oracle_chain, net3_sd, mode):
     drv, tgt = faces[0].to(DEV), faces[1].to(DEV)
     old = pipeline.SWAP_CHAINS
     pipeline.SWAP_CHAINS = 4 if mode == "four_chains" else 2
+    # "batched" = the default route (driven and target as one batch of 16 through parser and encoder)
+    kw = {"batched": True} if mode == "batched" else {"batched": False, "two_streams": mode != "one_stream"}
     try:
         runs = []
         for _ in range(3):            # race detection: the same call three times must give the same bits
-            img, lab = pipeline.swap_batch(gpu_net3, parser, drv, tgt, to_uint8=False, two_streams=mode != "one_stream")
+            img, lab = pipeline.swap_batch(gpu_net3, parser, drv, tgt, to_uint8=False, **kw)
             runs.append((img.clone(), lab.clone()))
-        frames, lab_u8 = pipeline.swap_batch(gpu_net3, parser, drv, tgt, to_uint8=True, two_streams=mode != "one_stream")
+        frames, lab_u8 = pipeline.swap_batch(gpu_net3, parser, drv, tgt, to_uint8=True, **kw)
         torch.cuda.synchronize()
     finally:
         pipeline.SWAP_CHAINS = old

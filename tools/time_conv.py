@@ -13,7 +13,7 @@ tot = 0.0
 for cin, cout, h, s, n in shapes:
     x = torch.randn(bs, cin, h, h, device=dev); w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
     mean = torch.zeros(bs, cin, device=dev); rstd = torch.ones(bs, cin, device=dev); slope = torch.full((cout,), 0.25, device=dev)
-    pc = ops.PreparedConv(); pc.get(w)
+    pc = ops.PreparedConv().get(w)
     for _ in range(3): y = ops.conv2d(x, pc, stride=s, pad=1, in_norm=(mean, rstd), prelu=slope)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
