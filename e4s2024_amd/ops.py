@@ -1195,16 +1195,39 @@ def _sum_dim(t, dim: int):
     return t.select(dim, 0) if t.shape[dim] == 1 else t.sum(dim)
 
 
+GEMM_SPLITK_CAP_FLOATS = 64 << 20     # at most 256 MB of split-K partial products per call
+
+
+def gemm_sb(a: torch.Tensor, b: torch.Tensor, a_kc: bool, b_kc: bool) -> torch.Tensor:
+    """``C[i] = opA(a[i]) @ opB(b[i])`` on the bf16 matrix cores with the three-term split (``e4s_gemm_sb``, csrc/gemm_sb.hip) — the
+    contractions of the backward pass.  ``a``: ``[Ba, M, K]`` if ``a_kc`` else ``[Ba, K, M]``; ``b``: ``[Bb, N, K]`` if ``b_kc`` else
+    ``[Bb, K, N]``; ``Ba``, ``Bb`` are the batch or 1 (shared).  Returns fp32 ``[batch, M, N]``."""
+    a, b = _c(a, "a"), _c(b, "b")
+    if a.dim() != 3 or b.dim() != 3:
+        raise ValueError("gemm_sb takes 3-D operands [batch or 1, rows, cols]")
+    M, K = (a.shape[1], a.shape[2]) if a_kc else (a.shape[2], a.shape[1])
+    N, Kb = (b.shape[1], b.shape[2]) if b_kc else (b.shape[2], b.shape[1])
+    batch = max(a.shape[0], b.shape[0])
+    if K != Kb or a.shape[0] not in (1, batch) or b.shape[0] not in (1, batch):
+        raise ValueError(f"gemm_sb: a {tuple(a.shape)} (a_kc={a_kc}) and b {tuple(b.shape)} (b_kc={b_kc}) do not fit")
+    c = torch.empty((batch, M, N), dtype=torch.float32, device=a.device)
+    # the split of a long K (sizes only: reproducible); the library applies the same rule under the workspace it is given
+    skinny = a_kc and b_kc and M <= 8
+    tm, tn = (32, 256) if skinny else (128, 128)
+    base, nchunk, ks = -(-M // tm) * -(-N // tn) * batch, -(-K // 32), 1
+    while base * ks < 512 and ks * 2 * 4 <= nchunk and ks < 1024 and ks * 2 * batch * M * N <= GEMM_SPLITK_CAP_FLOATS:
+        ks *= 2
+    ws = torch.empty((ks * batch * M * N,), dtype=torch.float32, device=a.device) if ks > 1 else None
+    lib().call("e4s_gemm_sb", _p(c), _p(a), _p(b), M, N, K, int(a_kc), int(b_kc), a.shape[2], b.shape[2],
+               0 if a.shape[0] == 1 and batch > 1 else a.shape[1] * a.shape[2], 0 if b.shape[0] == 1 and batch > 1 else b.shape[1] * b.shape[2],
+               M * N, batch, _p(ws), 0 if ws is None else ws.numel(), _stream())
+    return c
+
+
 def _gemm_nt(a, b):
-    """``a [..., M, K] @ b [..., N, K]ᵀ``.  A long reduction (K = all the pixels of a layer) with a small M x N goes to the library as a
-    batch of K-chunks — a single GEMM would use a handful of workgroups (measured: 1.13 -> 0.36 ms for 32 x 1M x 288)."""
-    k = a.shape[-1]
-    kc = 8192
-    if k < 65536 or k % kc:
-        return torch.matmul(a, b.transpose(-1, -2))
-    a = a.reshape(*a.shape[:-1], k // kc, kc).transpose(-2, -3)                      # [..., nb, M, kc] (views)
-    b = b.reshape(*b.shape[:-1], k // kc, kc).transpose(-2, -3)
-    return torch.matmul(a, b.transpose(-1, -2)).sum(-3)
+    """``a [..., M, K] @ b [..., N, K]ᵀ`` (the weight gradients: K = all the pixels of a layer, split over workgroups inside the kernel)."""
+    lead = a.shape[:-2]
+    return gemm_sb(a.reshape(-1, *a.shape[-2:]), b.reshape(-1, *b.shape[-2:]), True, True).view(*lead, a.shape[-2], b.shape[-2])
 
 
 def unfold2d(x, ks: int, stride: int, pad: int, ho: int, wo: int):
@@ -1223,7 +1246,12 @@ def _mconv_input_grads(gz, wg, x, s, lab, up: int, need_x: bool, need_s: bool, n
     G, cout, ks, nreg = wg.shape[0], wg.shape[1], wg.shape[-1], s.shape[1]
     dx = ds = dw = None
     if need_x or need_s:
-        u = torch.matmul(wg.reshape(G, 1, cout, cin * ks * ks).transpose(2, 3), gz)                  # [G, bs, cin*KK, P]
+        # U_g = W_gᵀ gz_g: [G, bs, cin*KK, P]; the weight is stored [cout][cin*KK] = [K][M], gz [cout][P] = [K][N]
+        w2 = wg.reshape(G, cout, cin * ks * ks)
+        if bs == 1:
+            u = gemm_sb(w2, gz.view(G, cout, -1), False, False).view(G, 1, cin * ks * ks, -1)
+        else:
+            u = torch.stack([gemm_sb(w2[g:g + 1], gz[g], False, False) for g in range(G)])
         dx = torch.empty_like(x) if need_x else None
         nchunk = -(-(h * w) // _FOLD_CHUNK_PX)
         part = torch.empty((nchunk, bs, nreg, cin), dtype=torch.float32, device=x.device) if need_s else None
@@ -1261,7 +1289,7 @@ class _MaskedConvCore(torch.autograd.Function):
         _check_mconv(x, wg, s, d, lab, 1)
         bs, cin, h, wd = x.shape
         cout = wg.shape[1]
-        z = torch.matmul(wg.reshape(1, 1, cout, -1), _mconv_unfold(x, s, lab, wg.shape[-1])).view(bs, cout, h, wd)
+        z = gemm_sb(wg.reshape(1, cout, -1), _mconv_unfold(x, s, lab, wg.shape[-1]).view(bs, -1, h * wd), True, False).view(bs, cout, h, wd)
         y = _mconv_scale(z, None, d, lab, s.shape[1])[0].view(bs, cout, h, wd)        # y = z * d[c(p)], zero where the label is no region
         ctx.save_for_backward(x, wg, s, d, lab, y)
         return y

@@ -392,6 +392,17 @@ E4S_API int e4s_unfold2d(float* cols, const float* x, int bs, int C, int hi, int
 E4S_API int e4s_mconv_fold(float* dx, float* ds_part, const float* U, const float* x, const float* s, const uint8_t* labels, int bs, int cin,
                            int h, int w, int ks, int nreg, int up, int chunk_px, void* stream);
 
+
+/* The contractions of the backward (f1) — replaces the library GEMMs (torch.matmul) behind the reference's autograd of
+ * ModulatedConv2d (models/stylegan2/model.py:276-320 differentiated by PyTorch; training/video_swap_ft_coach.py:268-299 is the loop):
+ *   C[b] (M x N, row-major, dense [batch][M][N] at stride_c) = opA(A[b]) (M x K) * opB(B[b]) (K x N),  fp32 in / out,
+ * each product as three bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulation).  a_kc != 0: A is stored [M][K] with row stride lda,
+ * else [K][M]; b_kc != 0: B is stored [N][K] with row stride ldb, else [K][N].  K-contiguous operands need 16-byte aligned rows and
+ * K % 4 == 0.  Batch strides in floats (0 = one matrix for all b).  workspace (may be NULL): scratch of workspace_floats floats for
+ * the split of a long K over workgroups; partial sums are added in a fixed order. */
+E4S_API int e4s_gemm_sb(float* c, const float* a, const float* b, int M, int N, int K, int a_kc, int b_kc, int lda, int ldb, int64_t stride_a,
+                        int64_t stride_b, int64_t stride_c, int batch, float* workspace, int64_t workspace_floats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

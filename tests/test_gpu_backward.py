@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import install_dropin, template_from_manifest
+from conftest import install_dropin, record_parity, template_from_manifest
 from e4s2024_amd import seeded
 from oracle import e4s_oracle as O
 
@@ -525,3 +525,25 @@ def test_tune_clip_graphed_matches_eager_and_counts_steps():
         assert taken == {3 * n}, taken
     assert hist[False][-1] < hist[False][0]
     assert np.allclose(hist[True], hist[False], rtol=3e-3), hist
+
+
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("M,N,K,batch,share_a", [(128, 128, 64, 1, False), (3, 288, 4096, 2, False), (200, 70, 100, 3, True), (513, 129, 36, 1, False),
+                                                 (128, 1152, 65536, 1, False), (32, 288, 16, 4, True)])
+def test_gemm_sb_against_fp64(a_kc, b_kc, M, N, K, batch, share_a):
+    """``e4s_gemm_sb`` (csrc/gemm_sb.hip), every operand layout, ragged tiles, a K tail, a shared A, the split of a long K: against
+    torch.matmul in float64, and bit-identical from run to run (the split partial sums are added in a fixed order)."""
+    from e4s2024_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(1 if share_a else batch, M, K, generator=g)
+    b = torch.randn(batch, K, N, generator=g)
+    ref = torch.matmul(a.double(), b.double())
+    a_dev = (a if a_kc else a.transpose(1, 2).contiguous()).to(DEV)
+    b_dev = (b.transpose(1, 2).contiguous() if b_kc else b).to(DEV)
+    c1 = ops.gemm_sb(a_dev, b_dev, a_kc, b_kc)
+    c2 = ops.gemm_sb(a_dev, b_dev, a_kc, b_kc)
+    torch.cuda.synchronize()
+    assert tuple(c1.shape) == (batch, M, N) and torch.equal(c1, c2)
+    err = (c1.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    record_parity(f"gemm_sb.{'kc' if a_kc else 'mc'}_{'kc' if b_kc else 'mc'}.{M}x{N}x{K}.rel_vs_fp64", err, 3e-5)
+    assert err <= 3e-5

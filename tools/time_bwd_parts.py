@@ -34,9 +34,11 @@ for cin, cout, h, up in [(128, 128, 256, 1), (256, 128, 128, 2), (256, 256, 128,
     res = {
         "scale": t(lambda: ops._mconv_scale(gy, out, d, lab, 12, up, want_q=True, act=True, want_sums=True)),
         "unfold": t(lambda: ops._mconv_unfold(x, s, lab, 3, up)),
-        "U gemm": t(lambda: torch.matmul(wt, gz)),
-        "fold": t(lambda: ops._mconv_input_grads(gz, wg, x, s, lab, up, True, True, False)) - t(lambda: torch.matmul(wt, gz)),
-        "dW gemm": t(lambda: torch.matmul(gz, cols.transpose(2, 3))),
+        "U gemm (lib)": t(lambda: torch.matmul(wt, gz)),
+        "U gemm_sb": t(lambda: ops.gemm_sb(wg.reshape(G, cout, cin * 9), gz.view(G, cout, -1), False, False)),
+        "U+fold": t(lambda: ops._mconv_input_grads(gz, wg, x, s, lab, up, True, True, False)),
+        "dW gemm (lib)": t(lambda: torch.matmul(gz, cols.transpose(2, 3))),
+        "dW gemm_sb": t(lambda: ops._gemm_nt(gz, cols)),
     }
     for kc in (2048, 8192):
         if P % kc == 0 and P > kc:

@@ -45,5 +45,5 @@ for i in range(args.steps):
     gl, _ = g(vec, lab, target)
 torch.cuda.synchronize()
 print(f"PTI step as one hipGraph: {(time.time() - tg) / args.steps * 1e3:.2f} ms/iter, loss now {gl.item():.4f}")
-print(f"PTI step, eager (fused HIP forward, native gradient kernels + library GEMMs): {eager_s:.3f} s/iter, loss {losses[0]:.4f} -> {losses[-1]:.4f}, "
+print(f"PTI step, eager (fused HIP forward, native gradient kernels + split-bf16 MFMA GEMMs (csrc/gemm_sb.hip)): {eager_s:.3f} s/iter, loss {losses[0]:.4f} -> {losses[-1]:.4f}, "
       f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
