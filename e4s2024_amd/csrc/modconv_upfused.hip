@@ -362,7 +362,7 @@ constexpr int UD_LDS_BYTES = UD_BODY + UD_EP_FLOATS * 4;                        
 constexpr int UD_G = 6;                                                                   // DMA instructions per chunk and wave (3 + 3, surplus ones repeat a piece)
 static_assert(UD_LDS_BYTES <= 80 * 1024 && UF_ZCO * UF_ZCS_NHWC * 4 <= UD_BODY, "two workgroups per CU; the pre-blur tile fits the stages");
 
-__global__ __launch_bounds__(UF_NT, 2) void up_fused_dma_kernel(const UpFusedParams p) {
+__global__ __launch_bounds__(UF_NT, 4) void up_fused_dma_kernel(const UpFusedParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint4* lds4 = reinterpret_cast<uint4*>(lds_raw);
     float* epw = reinterpret_cast<float*>(lds_raw + UD_BODY);
@@ -478,77 +478,104 @@ __global__ __launch_bounds__(UF_NT, 2) void up_fused_dma_kernel(const UpFusedPar
 
     // ---- epilogue (as up_fused_sb_kernel's split-plane variant): 8 output channels per pass through the pre-blur tile, which overlays the stages
     E4S_PROF_MARK(g_prof_up, 2);
-    float* zt = reinterpret_cast<float*>(lds_raw);
+    // Channel PAIRS through the blur: the pre-blur tile is kept as [4 pairs][32 rows][34 columns][2 channels], so one ds_read_b64 feeds
+    // a packed FMA (v_pk_fma_f32: both channels of a pair per instruction) and the thread that finishes a pixel holds exactly the two
+    // values of one bf16 dword of the split planes — no lane exchange, no select.  Thread = (column, pair, group of 7 rows): a wave is
+    // 16 columns x 4 pairs (the four dwords of a pixel's 16 bytes leave in one store instruction), waves = 2 column halves x 4 row groups.
+    // Per output the same FMAs in the same order as the single-channel form (bit-identical results).
+    float2* zt2 = reinterpret_cast<float2*>(lds_raw);
     const float* ep_d = epw + UD_EP_D;
     const float* ep_b = epw + UD_EP_B;
     const float* ep_s = epw + UD_EP_S;
     const float* ep_n = epw + UD_EP_N;
-    float kf[16];
+    // the 16 taps as 8 aligned register pairs: a packed FMA broadcasts either half of a pair to both channels (op_sel), so no tap is ever copied
+    f32x2 kp[8];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) kf[t] = p.blur[15 - t];
+    for (int t = 0; t < 8; ++t) kp[t] = (f32x2){p.blur[15 - 2 * t], p.blur[14 - 2 * t]};
     const float nw = p.noise ? p.noise_weight[0] : 0.f;
-    constexpr int NITEM = UF_ZCO * 2 * UF_OUT;       // 448: lanes = the 8 channels of a pixel, then pixels; 14 rows each
-    const int it_co = tid & 7, it_rem = tid >> 3;
-    const int it_rg = it_rem / UF_OUT, it_x = it_rem - it_rg * UF_OUT;
-    const int oy0 = tyt * UF_OUT + it_rg * UF_STEP, ox = txt * UF_OUT + it_x;
-    const bool it_ok = tid < NITEM && ox < wo && oy0 < ho;
-    const int nrow = it_ok ? (ho - oy0 < UF_STEP ? ho - oy0 : UF_STEP) : 0;
+    constexpr int ZP_ROW = UF_ZS;                       // float2 per row (34)
+    constexpr int ZP_PAIR = 32 * UF_ZS + 16;            // float2 per channel pair: +16 so that the four pairs of a wave fall on the two bank halves
+    static_assert(4 * ZP_PAIR * 8 <= UD_BODY, "the pair-interleaved pre-blur tile fits the stages");
+    constexpr int RG = 7;                               // output rows per thread
+    const int bx = (lane & 15) + 16 * (wave & 1), bcp = (lane >> 4), brg = wave >> 1;
+    const int oy0 = tyt * UF_OUT + brg * RG, ox = txt * UF_OUT + bx;
+    const bool col_ok = bx < UF_OUT && ox < wo;
+    int nrow = ho - oy0;
+    nrow = nrow < 0 ? 0 : (nrow > RG ? RG : nrow);     // wave-uniform
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid < 4) reinterpret_cast<unsigned*>(p.out)[(size_t)p.plane_out * 8 + tid] = 0u;   // zero tail
-    const unsigned pix0 = (unsigned)(oy0 * wo + ox);
-    const float* zc = zt + it_co * UF_ZCS_NHWC + (it_rg * UF_STEP + 1) * UF_ZS + it_x + 1;
-    const float* nzp = ep_n + (tid < NITEM ? it_rg * UF_STEP * UF_OUT + it_x : 0);
+    const float2* zc0 = zt2 + bcp * ZP_PAIR + (brg * RG + 1) * ZP_ROW + (bx < UF_OUT ? bx : 0) + 1;
+    const float* nzp = ep_n + brg * RG * UF_OUT + (bx < UF_OUT ? bx : 0);
     const float neg = p.act ? 0.2f : 1.f, gain = p.act ? 1.41421356237309515f : 1.f;
     E4S_PROF_MARK(g_prof_up, 3);
+    static_assert(2 * 4 * ZP_PAIR * 8 <= UD_BODY, "two passes of the pre-blur tile fit the stages");
+    // Two passes (16 channels) of pre-blur values go to LDS at a time: half the barriers, and half of the accumulators are dead before
+    // the first blur starts — the blur's own registers then fit under 128 without spilling (a spill reload would queue behind the output
+    // stores: one in-order vmcnt).
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int gg = 0; gg < 2; ++gg) {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int col = 4 * khalf + rr;
+        for (int gs = 0; gs < 2; ++gs) {
+            const int g = 2 * gg + gs;
+            // this lane's four channels of the pass (4 khalf + 0..3 = pairs 2 khalf, 2 khalf + 1) at its 2 x 2 pre-blur values
 #pragma unroll
-            for (int ci = 0; ci < 2; ++ci)
-                *reinterpret_cast<float2*>(&zt[col * UF_ZCS_NHWC + (2 * pty + ci) * UF_ZS + 2 * ptx]) = make_float2(accs[2 * ci][4 * g + rr], accs[2 * ci + 1][4 * g + rr]);
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci) {
+                    float2* zd = &zt2[(4 * gs + 2 * khalf + q) * ZP_PAIR + (2 * pty + ci) * ZP_ROW + 2 * ptx];
+                    zd[0] = make_float2(accs[2 * ci][4 * g + 2 * q], accs[2 * ci][4 * g + 2 * q + 1]);            // adjacent registers: 8-byte stores, no copies
+                    zd[1] = make_float2(accs[2 * ci + 1][4 * g + 2 * q], accs[2 * ci + 1][4 * g + 2 * q + 1]);
+                }
         }
         __syncthreads();
-        const int co = co0 + 8 * g + it_co;
+#pragma unroll 1
+        for (int gs = 0; gs < 2; ++gs) {
+        const int g = 2 * gg + gs;
+        const float2* zc = zc0 + gs * 4 * ZP_PAIR;
+        const int cl = 8 * g + 2 * bcp;                 // the pair's first channel inside this workgroup's 32
+        const int co = co0 + cl;
         if (nrow > 0 && co < p.cout) {
-            const float dd = ep_d[8 * g + it_co], bi = ep_b[8 * g + it_co], sn = ep_s[8 * g + it_co];
-            unsigned* osp_row = reinterpret_cast<unsigned*>(p.out) + ((tid & 1) ? (size_t)p.plane_out * 4 : (size_t)0)
-                                + (((size_t)b * (p.cout >> 3) + (size_t)(co >> 3)) * ho * wo + pix0) * 4 + ((co & 7) >> 1);
-            constexpr int HR = UF_STEP / 2;
+            const float2 dd = make_float2(ep_d[cl], ep_d[cl + 1]), bi = make_float2(ep_b[cl], ep_b[cl + 1]), sn = make_float2(ep_s[cl], ep_s[cl + 1]);
+            unsigned* orow = reinterpret_cast<unsigned*>(p.out) + (((size_t)b * (p.cout >> 3) + (size_t)(co >> 3)) * ho * wo + (size_t)oy0 * wo + ox) * 4 + ((co & 7) >> 1);
+            // Four output rows in flight: pre-blur row zr gives its last term (tap row 3) to output row zr - 3, which is finished and stored
+            // at once, then the window moves on.  A rolled loop with a fixed body: 4 accumulator pairs + 2 rows of reads, whatever RG is.
+            f32x2 a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3;
+            f32x2 z[4], zn[4];
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                float a[HR];
+            for (int u = 0; u < 4; ++u) { const float2 t2 = zc[u]; z[u] = (f32x2){t2.x, t2.y}; }
+#pragma unroll 1
+            for (int zr = 0; zr < RG + 3; ++zr) {
+                if (zr + 1 < RG + 3) {
+                    const float2* zp = zc + (zr + 1) * ZP_ROW;
 #pragma unroll
-                for (int r = 0; r < HR; ++r) a[r] = 0.f;
-#pragma unroll
-                for (int zr = 0; zr < HR + 3; ++zr) {
-                    const float* zp = zc + (hf * HR + zr) * UF_ZS;
-                    const float z0 = zp[0], z1 = zp[1], z2 = zp[2], z3 = zp[3];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int r = zr - t;
-                        if (r >= 0 && r < HR) {
-                            a[r] = __builtin_fmaf(z0, kf[t * 4], a[r]);
-                            a[r] = __builtin_fmaf(z1, kf[t * 4 + 1], a[r]);
-                            a[r] = __builtin_fmaf(z2, kf[t * 4 + 2], a[r]);
-                            a[r] = __builtin_fmaf(z3, kf[t * 4 + 3], a[r]);
-                        }
-                    }
+                    for (int u = 0; u < 4; ++u) { const float2 t2 = zp[u]; zn[u] = (f32x2){t2.x, t2.y}; }
                 }
+                a3 = (f32x2){0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < HR; ++r) {
-                    const int ro = hf * HR + r;
-                    if (ro < nrow) {
-                        float v = __builtin_fmaf(a[r], dd, bi) + __fmul_rn(nw, nzp[ro * UF_OUT]);
-                        v = fmaxf(v, v * neg) * gain;
-                        const float u = __fmul_rn(v, sn);
-                        const float other = __shfl_xor(u, 1, 64);
-                        unsigned h2, l2;
-                        split2((tid & 1) ? other : u, (tid & 1) ? u : other, h2, l2);
-                        osp_row[(unsigned)(ro * wo * 4)] = (tid & 1) ? l2 : h2;
-                    }
+                for (int u = 0; u < 4; ++u) {
+                    const f32x2 zz = z[u];
+#define E4S_KB(i) (((i) & 1) ? __builtin_shufflevector(kp[(i) >> 1], kp[(i) >> 1], 1, 1) : __builtin_shufflevector(kp[(i) >> 1], kp[(i) >> 1], 0, 0))
+                    a0 = __builtin_elementwise_fma(zz, E4S_KB(12 + u), a0);
+                    a1 = __builtin_elementwise_fma(zz, E4S_KB(8 + u), a1);
+                    a2 = __builtin_elementwise_fma(zz, E4S_KB(4 + u), a2);
+                    a3 = __builtin_elementwise_fma(zz, E4S_KB(u), a3);
+#undef E4S_KB
                 }
+                const int r = zr - 3;
+                if (r >= 0 && r < nrow && col_ok) {
+                    const float nz = __fmul_rn(nw, nzp[r * UF_OUT]);
+                    float v0 = __builtin_fmaf(a0[0], dd.x, bi.x) + nz, v1 = __builtin_fmaf(a0[1], dd.y, bi.y) + nz;
+                    v0 = fmaxf(v0, v0 * neg) * gain;
+                    v1 = fmaxf(v1, v1 * neg) * gain;
+                    unsigned h2, l2;
+                    split2(__fmul_rn(v0, sn.x), __fmul_rn(v1, sn.y), h2, l2);
+                    orow[(unsigned)(r * wo * 4)] = h2;
+                    orow[(size_t)p.plane_out * 4 + (unsigned)(r * wo * 4)] = l2;
+                }
+                a0 = a1; a1 = a2; a2 = a3;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) z[u] = zn[u];
             }
+        }
         }
         __syncthreads();
     }
@@ -623,10 +650,12 @@ extern "C" int e4s_modconv_up_fused_sb(float* out, const float* x, const uint16_
                 void* ptr = nullptr;
                 return hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_uf_zero)) == hipSuccess ? static_cast<const float*>(ptr) : nullptr;
             }();
-            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&up_fused_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, UD_LDS_BYTES);
+            // tuning knob: E4S_UP_ONE_PER_CU=1 asks for 84 KB of LDS, so that one workgroup per CU stays (phase timings without a neighbour)
+            static const int lds_bytes = [] { const char* e = getenv("E4S_UP_ONE_PER_CU"); return (e && atoi(e)) ? 84 * 1024 : UD_LDS_BYTES; }();
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&up_fused_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
             if (zeros && attr == hipSuccess) {
                 p.zeros = zeros;
-                hipLaunchKernelGGL(up_fused_dma_kernel, dim3(p.tiles_x * p.tiles_y, cout / 32, bs), dim3(UF_NT), UD_LDS_BYTES, st, p);
+                hipLaunchKernelGGL(up_fused_dma_kernel, dim3(p.tiles_x * p.tiles_y, cout / 32, bs), dim3(UF_NT), lds_bytes, st, p);
                 return check_launch("modconv_up_fused_sb");
             }
         }

@@ -126,6 +126,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "conv":
         run_conv(256, 256, 64); run_conv(128, 128, 128); run_conv(64, 64, 256); run_conv(512, 512, 32)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "up":
+        run_up_fused(128, 64, 256, sp=True); run_up_fused(64, 32, 512, sp=True)
+        sys.exit(0)
     run_same(512, 512, 64, masked=True)
     run_same(256, 256, 128, masked=True)
     run_same(128, 128, 256, masked=True)
