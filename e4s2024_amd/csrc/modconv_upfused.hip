@@ -531,6 +531,9 @@ __global__ __launch_bounds__(UF_NT, 4) void up_fused_dma_kernel(const UpFusedPar
         for (int gs = 0; gs < 2; ++gs) {
         const int g = 2 * gg + gs;
         const float2* zc = zc0 + gs * 4 * ZP_PAIR;
+#ifdef E4S_PHASE_PROF
+        if (p.exp & 2) continue;                                         // experiment: no blur
+#endif
         const int cl = 8 * g + 2 * bcp;                 // the pair's first channel inside this workgroup's 32
         const int co = co0 + cl;
         if (nrow > 0 && co < p.cout) {
@@ -568,6 +571,9 @@ __global__ __launch_bounds__(UF_NT, 4) void up_fused_dma_kernel(const UpFusedPar
                     v1 = fmaxf(v1, v1 * neg) * gain;
                     unsigned h2, l2;
                     split2(__fmul_rn(v0, sn.x), __fmul_rn(v1, sn.y), h2, l2);
+#ifdef E4S_PHASE_PROF
+                    if ((p.exp & 1) && v0 != 12345.678f) continue;      // experiment: no output stores
+#endif
                     orow[(unsigned)(r * wo * 4)] = h2;
                     orow[(size_t)p.plane_out * 4 + (unsigned)(r * wo * 4)] = l2;
                 }
