@@ -276,6 +276,204 @@ __global__ __launch_bounds__(GNT, 2) void gemm_sb_skinny_kernel(const GemmParams
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of a (masked) modulated convolution without the unfolded operand:
+//     dW[g][b][co][(ci, k)] = sum_p gz[g][b][co][p] * s[b][c_g(p)][ci] * x[b][ci][p + k - pad]
+// = the GEMM above with A = gz (K-contiguous) and a VIRTUAL B: row n = (ci, k) of the modulated im2col matrix is produced while it is
+// staged — 16 consecutive pixels of one image row per thread: 16 dwords of x (shifted by the tap, zero outside the image), their 16
+// labels (one 16-byte load; two for the up layers, whose labels live at the output resolution: c_g(p) = label[2 py + gy][2 px + gx]) and
+// the modulation from a table in LDS (this tile's input channels — at most 16 for 3x3, 128 for 1x1 — x 16 regions).  Reads x instead of the 9x larger unfolded
+// matrix and needs no unfold pass.  labels == null: one region (s[b][0][ci], or 1 if s == null: a plain convolution).  w % 16 == 0.
+struct WgradParams {
+    GemmParams g;          // a = gz, c / partial / M = cout, N = cin * KK, K = h * w; lda = K; batch = G * bs
+    const float* x;        // [bs][cin][h][w]
+    const float* s;        // [bs][nreg][cin] or null
+    const uint8_t* lab;    // [bs][up h][up w] or null
+    int bs, cin, h, w, nreg, up;
+};
+
+template <int KS>
+__global__ __launch_bounds__(GNT, 2) void mconv_wgrad_kernel(const WgradParams q) {
+    constexpr int KK = KS * KS, PAD = KS / 2;
+    const GemmParams& p = q.g;
+    __shared__ uint4 lds[4 * GT * 4];
+    constexpr int TAB_CI = KS == 1 ? GT : 16;            // distinct input channels among a tile's 128 rows
+    __shared__ float s_tab[TAB_CI * E4S_MAX_REGIONS];
+    uint4* ahi = lds;
+    uint4* alo = lds + GT * 4;
+    uint4* bhi = lds + 2 * GT * 4;
+    uint4* blo = lds + 3 * GT * 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l5 = lane & 31, kg = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bx = blockIdx.x;
+    const int ks = bx % p.ksplit; bx /= p.ksplit;
+    const int tn = bx % p.tiles_n, tm = bx / p.tiles_n;
+    const int bz = blockIdx.z;
+    const int gpar = bz / q.bs, b = bz - gpar * q.bs;
+    const int gy = q.up == 2 ? gpar >> 1 : 0, gx = q.up == 2 ? gpar & 1 : 0;
+    const float* A = p.a + (size_t)bz * p.sa;
+    const int m0 = tm * GT, n0 = tn * GT;
+    const int nchunk = (p.K + GK - 1) / GK;
+    const int ch_begin = ks * p.chunks_per;
+    const int ch_end = ch_begin + p.chunks_per < nchunk ? ch_begin + p.chunks_per : nchunk;
+
+    // the modulation of this tile's input channels (ci0 .. ci0 + 15) for every region
+    const int ci0 = n0 / KK;
+    for (int i = tid; i < TAB_CI * E4S_MAX_REGIONS; i += GNT) {
+        const int cl = i >> 4, r = i & 15;
+        float v = 0.f;
+        if (ci0 + cl < q.cin && r < q.nreg) v = q.s ? q.s[((size_t)b * q.nreg + r) * q.cin + ci0 + cl] : 1.f;
+        s_tab[i] = v;
+    }
+    // this thread's row of the virtual B: n = (ci, tap), 16 pixels from kb
+    const int n = n0 + (tid >> 1);
+    const bool n_ok = n < p.N;
+    const int ci = n_ok ? n / KK : 0, tap = n_ok ? n - ci * KK : 0;
+    const int ky = tap / KS - PAD, kx = tap % KS - PAD;
+    const int cl16 = (ci - ci0) * 16;
+    const float* xc = q.x + ((size_t)b * q.cin + ci) * q.h * q.w;
+    const int lw = q.up * q.w;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float va[16], vb[16], vl = 0.f, vr = 0.f;
+    uint4 lb[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    bool row_ok = false;
+    // 16 pixels of one image row, aligned (w % 16 == 0): four 16-byte loads + the left / right neighbour for the shifted taps
+    auto load_b = [&](int ch) __attribute__((always_inline)) {
+        const int p0 = ch * GK + 16 * (tid & 1);
+        const int py = p0 / q.w, px0 = p0 - py * q.w;
+        const int yy = py + ky;
+        row_ok = n_ok && p0 < p.K && yy >= 0 && yy < q.h;
+        const float* xr = xc + (size_t)(row_ok ? yy : 0) * q.w + (p0 < p.K ? px0 : 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 f = *reinterpret_cast<const float4*>(xr + 4 * j);
+            vb[4 * j] = f.x; vb[4 * j + 1] = f.y; vb[4 * j + 2] = f.z; vb[4 * j + 3] = f.w;
+        }
+        if (KS == 3) {
+            const int pxs = p0 < p.K ? px0 : 0;
+            vl = xr[pxs > 0 ? -1 : 0];
+            vr = xr[pxs + 16 < q.w ? 16 : 15];
+        }
+        if (q.lab) {
+            const int pyc = py < q.h ? py : q.h - 1;
+            const uint8_t* lr = q.lab + ((size_t)b * q.up * q.h + (size_t)q.up * pyc + gy) * lw + q.up * (p0 < p.K ? px0 : 0);
+            lb[0] = *reinterpret_cast<const uint4*>(lr);
+            if (q.up == 2) lb[1] = *reinterpret_cast<const uint4*>(lr + 16);
+        }
+    };
+    auto store_b = [&](int ch) __attribute__((always_inline)) {
+        const int p0 = ch * GK + 16 * (tid & 1);
+        const int px0 = p0 % q.w;
+        unsigned h[8], l[8];
+        float t[16];
+        // the tap's view of the row: element e reads pixel px0 + e + kx
+        float xs[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float ctr = vb[e];
+            const float lft = e > 0 ? vb[e - 1] : vl, rgt = e < 15 ? vb[e + 1] : vr;
+            xs[e] = kx == 0 ? ctr : (kx < 0 ? lft : rgt);
+        }
+        const bool ok_l = row_ok && (px0 + kx >= 0), ok_r = row_ok && (px0 + 15 + kx < q.w);
+        const unsigned lw4[8] = {lb[0].x, lb[0].y, lb[0].z, lb[0].w, lb[1].x, lb[1].y, lb[1].z, lb[1].w};
+        bool uni = true;
+        if (q.lab) {
+            const unsigned b0 = lw4[0] & 0xffu, rep = b0 * 0x01010101u;
+            uni = lw4[0] == rep && lw4[1] == rep && lw4[2] == rep && lw4[3] == rep;
+            if (q.up == 2) uni = uni && lw4[4] == rep && lw4[5] == rep && lw4[6] == rep && lw4[7] == rep;
+        }
+        if (uni) {          // one region under these 16 pixels (or no label map): one table read
+            const int c = q.lab ? (int)(lw4[0] & 0xffu) : 0;
+            const float sv = c < q.nreg ? s_tab[cl16 + (c < E4S_MAX_REGIONS ? c : 0)] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) t[e] = xs[e] * sv;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int byte = q.up == 2 ? 2 * e + gx : e;
+                const int c = (int)((lw4[byte >> 2] >> (8 * (byte & 3))) & 0xffu);
+                t[e] = c < q.nreg ? xs[e] * s_tab[cl16 + (c < E4S_MAX_REGIONS ? c : 0)] : 0.f;
+            }
+        }
+        if (!row_ok) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) t[e] = 0.f;
+        }
+        if (!ok_l) t[0] = 0.f;
+        if (!ok_r) t[15] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) split2(t[2 * c], t[2 * c + 1], h[c], l[c]);
+        const int r = tid >> 1, kh = tid & 1;
+        bhi[g_slot(r, 2 * kh)] = make_uint4(h[0], h[1], h[2], h[3]);
+        bhi[g_slot(r, 2 * kh + 1)] = make_uint4(h[4], h[5], h[6], h[7]);
+        blo[g_slot(r, 2 * kh)] = make_uint4(l[0], l[1], l[2], l[3]);
+        blo[g_slot(r, 2 * kh + 1)] = make_uint4(l[4], l[5], l[6], l[7]);
+    };
+
+    if (ch_begin < ch_end) {
+        g_load<true>(va, A, p.lda, m0, p.M, ch_begin * GK, p.K, tid);
+        load_b(ch_begin);
+    }
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+        __syncthreads();                       // (also orders the s_tab fill before its first use)
+        g_store<true>(va, ahi, alo, ch * GK, p.K, tid);
+        store_b(ch);
+        __syncthreads();
+        if (ch + 1 < ch_end) {
+            g_load<true>(va, A, p.lda, m0, p.M, (ch + 1) * GK, p.K, tid);
+            load_b(ch + 1);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int j = 2 * t + kg;
+            uint4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ra = wm * 64 + i * 32 + l5, rb = wn * 64 + i * 32 + l5;
+                ah[i] = ahi[g_slot(ra, j)]; al[i] = alo[g_slot(ra, j)];
+                bh[i] = bhi[g_slot(rb, j)]; bl[i] = blo[g_slot(rb, j)];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jq = 0; jq < 2; ++jq)
+                    acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[jq]), acc[i][jq], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jq = 0; jq < 2; ++jq)
+                    acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[jq]), acc[i][jq], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jq = 0; jq < 2; ++jq)
+                    acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[jq]), acc[i][jq], 0, 0, 0);
+        }
+    }
+    float* C = p.ksplit > 1 ? p.partial + ((size_t)ks * p.batch + bz) * (size_t)p.M * p.N : p.c + (size_t)bz * p.sc;
+#pragma unroll
+    for (int jq = 0; jq < 2; ++jq) {
+        const int nn = n0 + wn * 64 + jq * 32 + l5;
+        if (nn >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                if (m < p.M) C[(size_t)m * p.N + nn] = acc[i][jq][r];
+            }
+    }
+}
+
 // C = sum of the ksplit partial products, always in the order 0, 1, 2, ... (one thread per element; a workgroup of 256 threads shares
 // the work of an element when there are few elements and many partials: 4 x 64 strided partial sums, then a fixed tree)
 __global__ __launch_bounds__(256) void gemm_sb_finalize_wide_kernel(float* __restrict__ c, const float* __restrict__ partial, long long mn, long long sc, int batch,
@@ -349,4 +547,48 @@ extern "C" int e4s_gemm_sb(float* c, const float* a, const float* b, int M, int 
         }
     }
     return check_launch("gemm_sb");
+}
+
+// dW[g][b][co][(ci, k)] (dense [G * bs][cout][cin * ks * ks]) of the masked modulated convolution, G = up * up (the composed weight of each
+// output parity for up = 2), from gz [G][bs][cout][h * w] (e4s_mconv_scale), x [bs][cin][h][w], s [bs][nreg][cin] (null: 1) and the labels
+// ([bs][up h][up w] uint8; null: one region) — the unfolded operand of e4s_mconv_unfold is never materialised.  w % 16 == 0, ks 1 / 3.
+extern "C" int e4s_mconv_wgrad(float* dw, const float* gz, const float* x, const float* s, const uint8_t* labels, int bs, int cin, int cout, int h,
+                               int w, int ks, int nreg, int up, float* workspace, int64_t workspace_floats, void* stream) {
+    E4S_REQUIRE(dw && gz && x, "mconv_wgrad: null tensor");
+    E4S_REQUIRE(bs >= 0 && cin >= 1 && cout >= 1 && h >= 1 && w >= 16 && (w % 16) == 0, "mconv_wgrad: bad size (w must be a multiple of 16)");
+    E4S_REQUIRE((ks == 1 || ks == 3) && (up == 1 || up == 2) && nreg >= 1 && nreg <= E4S_MAX_REGIONS, "mconv_wgrad: ks 1 / 3, up 1 / 2, nreg 1..%d", E4S_MAX_REGIONS);
+    E4S_REQUIRE(labels || nreg == 1, "mconv_wgrad: several regions need a label map");
+    E4S_REQUIRE(up == 1 || labels, "mconv_wgrad: up = 2 is the masked composed form");
+    E4S_REQUIRE((((uintptr_t)gz | (uintptr_t)labels | (uintptr_t)x) & 15) == 0, "mconv_wgrad: gz, x and labels must be 16-byte aligned");
+    const int G = up * up, batch = G * bs;
+    E4S_REQUIRE(batch <= 65535, "mconv_wgrad: batch too large");
+    if (bs == 0) return 0;
+    WgradParams q;
+    GemmParams& p = q.g;
+    p.c = dw; p.a = gz; p.b = nullptr; p.partial = workspace;
+    p.M = cout; p.N = cin * ks * ks; p.K = h * w; p.lda = p.K; p.ldb = 0;
+    p.sa = (long long)cout * p.K; p.sb = 0; p.sc = (long long)p.M * p.N; p.batch = batch;
+    p.tiles_m = cdiv(p.M, GT); p.tiles_n = cdiv(p.N, GT);
+    q.x = x; q.s = s; q.lab = labels; q.bs = bs; q.cin = cin; q.h = h; q.w = w; q.nreg = nreg; q.up = up;
+    const int nchunk = cdiv(p.K, GK);
+    const int64_t base = (int64_t)p.tiles_m * p.tiles_n * batch;
+    int ksplit = 1;
+    if (workspace)
+        while (base * ksplit < 512 && ksplit * 2 * 4 <= nchunk && (int64_t)(ksplit * 2) * batch * p.M * p.N <= workspace_floats && ksplit < 1024) ksplit *= 2;
+    p.ksplit = ksplit;
+    p.chunks_per = cdiv(nchunk, ksplit);
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n * ksplit), 1, batch);
+    hipStream_t st = (hipStream_t)stream;
+    if (ks == 3) hipLaunchKernelGGL(mconv_wgrad_kernel<3>, grid, dim3(GNT), 0, st, q);
+    else hipLaunchKernelGGL(mconv_wgrad_kernel<1>, grid, dim3(GNT), 0, st, q);
+    if (ksplit > 1) {
+        const int64_t mn = (int64_t)p.M * p.N, total = mn * batch;
+        if (total <= 65536 && ksplit >= 16) {
+            hipLaunchKernelGGL(gemm_sb_finalize_wide_kernel, dim3((unsigned)cdiv64(total, 64)), dim3(256), 0, st, dw, workspace, (long long)mn, (long long)p.sc, batch, ksplit);
+        } else {
+            const int g = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
+            hipLaunchKernelGGL(gemm_sb_finalize_kernel, dim3(g), dim3(256), 0, st, dw, workspace, (long long)mn, (long long)p.sc, batch, ksplit);
+        }
+    }
+    return check_launch("mconv_wgrad");
 }

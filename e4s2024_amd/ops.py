@@ -1260,9 +1260,33 @@ def _mconv_input_grads(gz, wg, x, s, lab, up: int, need_x: bool, need_s: bool, n
         if need_s:
             ds = part.sum(0) if nchunk > 1 else part[0]
     if need_w:
-        cols = _mconv_unfold(x, s, lab, ks, up)
-        dw = _sum_dim(_gemm_nt(gz, cols), 1).view_as(wg)
+        if w % 16 == 0 and w >= 16:
+            dw = _sum_dim(mconv_wgrad(gz, x, s, lab, cout, ks, up).view(G, bs, cout, -1), 1).view_as(wg)
+        else:                                   # the 4x4 / 8x8 maps: explicit unfold (tiny)
+            cols = _mconv_unfold(x, s, lab, ks, up)
+            dw = _sum_dim(_gemm_nt(gz, cols), 1).view_as(wg)
     return dx, ds, dw
+
+
+def mconv_wgrad(gz, x, s, lab, cout: int, ks: int, up: int = 1) -> torch.Tensor:
+    """``dW [G*bs, cout, cin*ks*ks]`` of the (masked) modulated convolution from ``gz [G, bs, cout, h*w]`` (``_mconv_scale``) without the
+    unfolded operand (``e4s_mconv_wgrad``: the modulated im2col rows are produced while the GEMM stages them).  ``s`` / ``lab`` None: a plain
+    convolution / one region."""
+    x, gz = _c(x, "x"), _c(gz, "gz")
+    bs, cin, h, w = x.shape
+    G = up * up
+    nreg = 1 if s is None else s.shape[1]
+    M, N, K, batch = cout, cin * ks * ks, h * w, G * bs
+    if gz.numel() != batch * cout * K:
+        raise ValueError(f"mconv_wgrad: gz {tuple(gz.shape)} is not [{G}, {bs}, {cout}, {K}]")
+    dw = torch.empty((batch, M, N), dtype=torch.float32, device=x.device)
+    base, nchunk, kspl = -(-M // 128) * -(-N // 128) * batch, -(-K // 32), 1
+    while base * kspl < 512 and kspl * 2 * 4 <= nchunk and kspl < 1024 and kspl * 2 * batch * M * N <= GEMM_SPLITK_CAP_FLOATS:
+        kspl *= 2
+    ws = torch.empty((kspl * batch * M * N,), dtype=torch.float32, device=x.device) if kspl > 1 else None
+    lib().call("e4s_mconv_wgrad", _p(dw), _p(gz), _p(x), _p(None if s is None else _c(s, "s")), _p(None if lab is None else _labels_u8(lab, "labels")),
+               bs, cin, cout, h, w, ks, nreg, up, _p(ws), 0 if ws is None else ws.numel(), _stream())
+    return dw
 
 
 def _check_mconv(x, wg, s, d, lab, up):
@@ -1484,7 +1508,9 @@ class _SingleStyledConvGrad(torch.autograd.Function):
         if need_w and k in (1, 3):
             # weight gradient = one unfold + one library GEMM per sample group: dW[o,(i,k)] = Σ_p g'[o,p] · x[i,p+k-pad], or for the
             # transposed conv dWt[i,(o,k)] = Σ_q x[i,q] · gT[o,2q+k]
-            if blur is None:
+            if blur is None and w % 16 == 0:
+                dw = mconv_wgrad(g.reshape(1, bs, cout, h * w), x, None, None, cout, k).view(bs, cout, cin, k, k)
+            elif blur is None:
                 dw = _gemm_nt(g.reshape(bs, cout, h * w), unfold2d(x, k, 1, k // 2, h, w)).view(bs, cout, cin, k, k)
             else:
                 dw = _gemm_nt(x.reshape(bs, cin, h * w), unfold2d(g, k, 2, 0, h, w)).view(bs, cin, cout, k, k).transpose(1, 2)

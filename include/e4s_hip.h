@@ -403,6 +403,13 @@ E4S_API int e4s_mconv_fold(float* dx, float* ds_part, const float* U, const floa
 E4S_API int e4s_gemm_sb(float* c, const float* a, const float* b, int M, int N, int K, int a_kc, int b_kc, int lda, int ldb, int64_t stride_a,
                         int64_t stride_b, int64_t stride_c, int batch, float* workspace, int64_t workspace_floats, void* stream);
 
+/* Weight gradient of the (masked) modulated convolution as one implicit GEMM — the modulated im2col operand of e4s_mconv_unfold is produced
+ * while it is staged, never stored:  dW[g][b][co][(ci, k)] = sum_p gz[g][b][co][p] * s[b][c_g(p)][ci] * x[b][ci][p + k - pad],
+ * g < up * up (composed weights of the four output parities for up = 2, labels at the output resolution).  s == NULL: no modulation;
+ * labels == NULL: one region.  dw: dense [up * up * bs][cout][cin * ks * ks].  w % 16 == 0.  workspace as for e4s_gemm_sb. */
+E4S_API int e4s_mconv_wgrad(float* dw, const float* gz, const float* x, const float* s, const uint8_t* labels, int bs, int cin, int cout, int h,
+                            int w, int ks, int nreg, int up, float* workspace, int64_t workspace_floats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

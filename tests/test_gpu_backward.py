@@ -547,3 +547,35 @@ def test_gemm_sb_against_fp64(a_kc, b_kc, M, N, K, batch, share_a):
     err = (c1.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
     record_parity(f"gemm_sb.{'kc' if a_kc else 'mc'}_{'kc' if b_kc else 'mc'}.{M}x{N}x{K}.rel_vs_fp64", err, 3e-5)
     assert err <= 3e-5
+
+
+@pytest.mark.parametrize("cin,cout,h,ks,up,masked,bs", [(32, 48, 16, 3, 1, True, 2), (20, 130, 32, 3, 2, True, 1), (64, 3, 32, 1, 1, True, 2), (16, 32, 48, 3, 1, False, 2),
+                                                    (144, 64, 16, 3, 1, True, 1)])
+def test_implicit_weight_gradient_against_unfold_and_fp64(cin, cout, h, ks, up, masked, bs):
+    """``e4s_mconv_wgrad`` (the modulated im2col rows produced inside the GEMM) == ``e4s_mconv_unfold`` followed by the explicit GEMM, and
+    both agree with a float64 evaluation: plain / masked, 3x3 / 1x1, the composed up-sampling form (labels at the output resolution, four
+    parities), labels outside the region range, ragged channel counts (tiles that straddle input channels)."""
+    from e4s2024_amd import ops
+    nreg = 5 if masked else 1
+    g = torch.Generator().manual_seed(cin * 3 + cout + h)
+    x = torch.randn(bs, cin, h, h, generator=g).to(DEV)
+    G = up * up
+    gz = torch.randn(G, bs, cout, h * h, generator=g).to(DEV)
+    s = (torch.randn(bs, nreg, cin, generator=g) if masked else None)
+    lab = None
+    if masked:
+        lab = torch.randint(0, nreg + 1, (bs, up * h, up * h), generator=g).to(torch.uint8)       # value nreg = "no region"
+        lab[:, : up * h // 4] = 2                                                                  # a coherent part as well
+        lab, s = lab.to(DEV), s.to(DEV)
+    got = ops.mconv_wgrad(gz, x, s, lab, cout, ks, up)
+    again = ops.mconv_wgrad(gz, x, s, lab, cout, ks, up)
+    if masked:
+        cols = ops._mconv_unfold(x, s, lab, ks, up)                                                # [G, bs, cin*KK, P]
+    else:
+        cols = ops.unfold2d(x, ks, 1, ks // 2, h, h)[None]
+    ref64 = torch.matmul(gz.double(), cols.double().transpose(-1, -2)).reshape(G * bs, cout, cin * ks * ks)
+    torch.cuda.synchronize()
+    assert torch.equal(got, again)
+    err = (got.double() - ref64).abs().max().item() / ref64.abs().max().item()
+    record_parity(f"mconv_wgrad.cin{cin}_cout{cout}_h{h}_k{ks}_up{up}_{'masked' if masked else 'plain'}.rel_vs_fp64", err, 3e-5)
+    assert err <= 3e-5
