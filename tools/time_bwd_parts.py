@@ -39,6 +39,7 @@ for cin, cout, h, up in [(128, 128, 256, 1), (256, 128, 128, 2), (256, 256, 128,
         "U+fold": t(lambda: ops._mconv_input_grads(gz, wg, x, s, lab, up, True, True, False)),
         "dW gemm (lib)": t(lambda: torch.matmul(gz, cols.transpose(2, 3))),
         "dW gemm_sb": t(lambda: ops._gemm_nt(gz, cols)),
+        "dW implicit": t(lambda: ops.mconv_wgrad(gz, x, s, lab, cout, 3, up)),
     }
     for kc in (2048, 8192):
         if P % kc == 0 and P > kc:
