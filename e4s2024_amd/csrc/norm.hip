@@ -165,6 +165,126 @@ extern "C" int e4s_norm_gate_add(float* out, const float* x, const float* mean, 
     return check_launch("norm_gate_add");
 }
 
+// ------------------------------------------------------------------------------------ squeeze-excite gate in one launch
+// gate[b, o] = sigmoid( sum_j W2[o, j] * relu( sum_i W1[j, i] * pooled[b, i] ) )      (W1 [H, C], W2 [C, H], no biases; H <= 64)
+// Workgroup = (64 outputs, image): its four waves first compute the H hidden units (every workgroup of an image repeats them: H*C MACs),
+// then 16 outputs each.  Per value the same lane-strided products and wave reduction as vec_fc_kernel: bit-identical to the two launches.
+__global__ __launch_bounds__(256) void se_gate_kernel(float* __restrict__ gate, const float* __restrict__ pooled, const float* __restrict__ W1,
+                                                      const float* __restrict__ W2, int C, int H) {
+    __shared__ float hid[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const float* xr = pooled + (size_t)b * C;
+    for (int j = wave; j < H; j += 4) {
+        const float* wr = W1 + (size_t)j * C;
+        float a = 0.f;
+        for (int i = lane; i < C; i += 64) a += wr[i] * xr[i];
+        a = wave_sum(a);
+        if (lane == 0) hid[j] = fmaxf(a, 0.f);
+    }
+    __syncthreads();
+    for (int k = 0; k < 16; ++k) {
+        const int o = blockIdx.x * 64 + wave * 16 + k;
+        if (o >= C) break;
+        const float* wr = W2 + (size_t)o * H;
+        float a = 0.f;
+        for (int i = lane; i < H; i += 64) a += wr[i] * hid[i];
+        a = wave_sum(a);
+        if (lane == 0) gate[(size_t)b * C + o] = 1.0f / (1.0f + expf(-a));
+    }
+}
+
+extern "C" int e4s_se_gate(float* gate, const float* pooled, const float* w1, const float* w2, int bs, int C, int H, void* stream) {
+    E4S_REQUIRE(gate && pooled && w1 && w2, "se_gate: null tensor");
+    E4S_REQUIRE(bs >= 0 && bs <= 65535 && C >= 1 && H >= 1 && H <= 64, "se_gate: bad size (hidden width 1..64)");
+    if (bs == 0) return 0;
+    hipLaunchKernelGGL(se_gate_kernel, dim3(cdiv(C, 64), bs), dim3(256), 0, (hipStream_t)stream, gate, pooled, w1, w2, C, H);
+    return check_launch("se_gate");
+}
+
+// ------------------------------------------------------------------------------------ norm_gate_add that also returns the statistics of its OUTPUT
+// The next IR-SE unit starts with an InstanceNorm of this output: one workgroup per plane keeps the plane's output values in registers
+// (IT float4 per thread: planes up to 1024 * IT pixels) and produces mean / rstd with the very sums of plane_stats_kernel (same thread ->
+// element mapping, same two passes), so a unit no longer needs a statistics launch of its own.
+template <int IT>
+__global__ __launch_bounds__(256) void norm_gate_add_stats_kernel(float* __restrict__ out, float* __restrict__ omean, float* __restrict__ orstd,
+                                                                  const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  const float* __restrict__ gate, const float* __restrict__ sc, const float* __restrict__ sc_mean,
+                                                                  const float* __restrict__ sc_rstd, int ss, const float* __restrict__ prelu, int C, int h, int w,
+                                                                  float eps) {
+    __shared__ float sh[4];
+    const int plane = blockIdx.x;  // b*C + c
+    const int c = plane % C;
+    const int hw = h * w;
+    const float m = mean ? mean[plane] : 0.f, r = rstd ? rstd[plane] : 1.f, g = gate ? gate[plane] : 1.f;
+    const float sm = sc_mean ? sc_mean[plane] : 0.f, sr = sc_rstd ? sc_rstd[plane] : 1.f;
+    const float sl = prelu ? prelu[c] : 1.f;
+    const float* xp = x + (size_t)plane * hw;
+    float* op = out + (size_t)plane * hw;
+    const float* sp = sc ? sc + (size_t)plane * hw * ss * ss : nullptr;
+    const int ws_ = w * ss;
+    float4 v[IT];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int i = threadIdx.x * 4 + it * 1024;
+        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < hw) {
+            const float4 t = *reinterpret_cast<const float4*>(xp + i);
+            float e[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float u = (e[j] - m) * r * g;
+                if (sp) {
+                    const int yy = (i + j) / w, xx = (i + j) - yy * w;
+                    const float sv = (ss == 1) ? sp[i + j] : sp[(size_t)yy * ss * ws_ + xx * ss];
+                    u += (sv - sm) * sr;
+                }
+                e[j] = u > 0.f ? u : u * sl;
+            }
+            v[it] = make_float4(e[0], e[1], e[2], e[3]);
+            *reinterpret_cast<float4*>(op + i) = v[it];
+            s += (e[0] + e[1]) + (e[2] + e[3]);
+        }
+    }
+    const float mo = block_sum(s, sh) / (float)hw;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int i = threadIdx.x * 4 + it * 1024;
+        if (i < hw) {
+            const float a = v[it].x - mo, b2 = v[it].y - mo, c2 = v[it].z - mo, d = v[it].w - mo;
+            q += (a * a + b2 * b2) + (c2 * c2 + d * d);
+        }
+    }
+    const float var = block_sum(q, sh) / (float)hw;
+    if (threadIdx.x == 0) {
+        omean[plane] = mo;
+        orstd[plane] = 1.0f / sqrtf(var + eps);
+    }
+}
+
+extern "C" int e4s_norm_gate_add_stats(float* out, float* out_mean, float* out_rstd, const float* x, const float* mean, const float* rstd,
+                                       const float* gate, const float* shortcut, const float* sc_mean, const float* sc_rstd, int sc_stride,
+                                       const float* prelu, int bs, int C, int h, int w, float eps, void* stream) {
+    E4S_REQUIRE(out && out_mean && out_rstd && x, "norm_gate_add_stats: null tensor");
+    E4S_REQUIRE(bs >= 0 && C >= 1 && h >= 1 && w >= 1 && (int64_t)bs * C <= 0x7fffffff, "norm_gate_add_stats: bad size");
+    E4S_REQUIRE(((h * w) & 3) == 0 && h * w <= 16384, "norm_gate_add_stats: planes of 4 .. 16384 pixels, a multiple of 4 (use norm_gate_add + plane_stats otherwise)");
+    E4S_REQUIRE((mean == nullptr) == (rstd == nullptr) && (sc_mean == nullptr) == (sc_rstd == nullptr), "norm_gate_add_stats: mean/rstd go together");
+    E4S_REQUIRE(!shortcut || sc_stride >= 1, "norm_gate_add_stats: bad shortcut stride");
+    if (bs == 0) return 0;
+    const int hw = h * w, ss = shortcut ? sc_stride : 1;
+    const dim3 grid(bs * C), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (hw <= 1024)
+        hipLaunchKernelGGL(norm_gate_add_stats_kernel<1>, grid, block, 0, st, out, out_mean, out_rstd, x, mean, rstd, gate, shortcut, sc_mean, sc_rstd, ss, prelu, C, h, w, eps);
+    else if (hw <= 4096)
+        hipLaunchKernelGGL(norm_gate_add_stats_kernel<4>, grid, block, 0, st, out, out_mean, out_rstd, x, mean, rstd, gate, shortcut, sc_mean, sc_rstd, ss, prelu, C, h, w, eps);
+    else
+        hipLaunchKernelGGL(norm_gate_add_stats_kernel<16>, grid, block, 0, st, out, out_mean, out_rstd, x, mean, rstd, gate, shortcut, sc_mean, sc_rstd, ss, prelu, C, h, w, eps);
+    return check_launch("norm_gate_add_stats");
+}
+
 // ------------------------------------------------------------------------------------ masked average pooling per region
 // out[b, r, c] = mean over {p : label(p) == r} of feats[b, c, p]  (0 when the region is empty); labels sampled 'nearest'.
 // One block per (b, c); the label row is re-read from L1 for each region pass.

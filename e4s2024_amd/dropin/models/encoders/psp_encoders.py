@@ -42,7 +42,9 @@ class SEModule(Module):
         self.sigmoid = Sigmoid()
 
     def gate(self, pooled):
-        """pooled ``[bs, C]`` -> gate ``[bs, C]``."""
+        """pooled ``[bs, C]`` -> gate ``[bs, C]`` (one launch; the hidden width of the reference's reduction 16 is at most 32)."""
+        if self.fc1.weight.shape[0] <= 64:
+            return ops.se_gate(pooled, self.fc1.weight, self.fc2.weight)
         return ops.vec_fc(ops.vec_fc(pooled, self.fc1.weight, act=ops.ACT_RELU), self.fc2.weight, act=ops.ACT_SIGMOID)
 
     def forward(self, x):
@@ -72,7 +74,13 @@ class bottleneck_IR_SE_Ours(Module):
 
     def forward(self, x):
         rl = self.res_layer
-        mean, rstd = ops.plane_stats(x, rl[0].eps)                                      # InstanceNorm2d(in_channel) statistics
+        # InstanceNorm2d(in_channel) statistics: the producer of x (the previous unit's / the input layer's norm_gate_add) computed them
+        # in its own launch and left them on the tensor; anything else is measured here
+        st = getattr(x, "_e4s_in_stats", None)
+        if st is not None and st[2] == rl[0].eps and not torch.is_grad_enabled():
+            mean, rstd = st[0], st[1]
+        else:
+            mean, rstd = ops.plane_stats(x, rl[0].eps)
         r = ops.conv2d(x, self._w[0].get(rl[1].weight), 1, 1, in_norm=(mean, rstd), prelu=rl[2].weight)
         r = ops.conv2d(r, self._w[1].get(rl[3].weight), self.stride, 1)
         m2, r2, pooled = ops.plane_stats(r, rl[4].eps, want_nmean=True)                 # IN statistics + mean of the normalised map
@@ -82,8 +90,12 @@ class bottleneck_IR_SE_Ours(Module):
         else:
             sc = ops.conv2d(x, self._w[2].get(self.shortcut_layer[0].weight), self.stride, 0)
             sc_stats, sc_stride = ops.plane_stats(sc, self.shortcut_layer[1].eps), 1
-        out = ops.norm_gate_add(r, m2, r2, gate, sc, sc_stats, sc_stride)
-        return ops._attach("bottleneck_IR_SE_Ours", out, x, *[p for p in self.parameters()])
+        if torch.is_grad_enabled():
+            out = ops.norm_gate_add(r, m2, r2, gate, sc, sc_stats, sc_stride)
+            return ops._attach("bottleneck_IR_SE_Ours", out, x, *[p for p in self.parameters()])
+        out, om, orr = ops.norm_gate_add(r, m2, r2, gate, sc, sc_stats, sc_stride, stats_eps=rl[0].eps)
+        out._e4s_in_stats = (om, orr, rl[0].eps)        # every unit's first InstanceNorm has the default eps
+        return out
 
 
 class FSEncoder_PSP(Module):
@@ -118,7 +130,11 @@ class FSEncoder_PSP(Module):
         il = self.input_layer
         y = ops.conv2d(x, self._w_in.get(il[0].weight), 1, 1)
         mean, rstd = ops.plane_stats(y, il[1].eps)
-        x = ops.norm_gate_add(y, mean, rstd, prelu=il[2].weight)
+        if torch.is_grad_enabled():
+            x = ops.norm_gate_add(y, mean, rstd, prelu=il[2].weight)
+        else:
+            x, om, orr = ops.norm_gate_add(y, mean, rstd, prelu=il[2].weight, stats_eps=il[1].eps)
+            x._e4s_in_stats = (om, orr, il[1].eps)
         taps = {}
         for i, unit in enumerate(self.body):
             x = unit(x)

@@ -1007,7 +1007,26 @@ def vec_fc(x: torch.Tensor, weight: torch.Tensor, bn=None, act: int = ACT_NONE) 
     return y
 
 
-def norm_gate_add(x, mean=None, rstd=None, gate=None, shortcut=None, sc_stats=None, sc_stride: int = 1, prelu=None) -> torch.Tensor:
+def se_gate(pooled: torch.Tensor, fc1_weight: torch.Tensor, fc2_weight: torch.Tensor) -> torch.Tensor:
+    """``sigmoid(fc2 . relu(fc1 . pooled))`` for ``pooled [bs, C]`` and the two bias-free 1x1 conv weights of an SEModule, one launch
+    (``e4s_se_gate``); value for value the two ``vec_fc`` calls."""
+    x = _c(pooled, "pooled")
+    w1, w2 = _c(fc1_weight.detach(), "fc1.weight"), _c(fc2_weight.detach(), "fc2.weight")
+    bs, C = x.shape
+    H = w1.shape[0]
+    if w1.numel() != H * C or w2.numel() != C * H or w2.shape[0] != C or H > 64:
+        raise ValueError(f"se_gate: fc1 {tuple(w1.shape)} / fc2 {tuple(w2.shape)} do not fit {C} channels (hidden width <= 64)")
+    gate = torch.empty((bs, C), dtype=torch.float32, device=x.device)
+    lib().call("e4s_se_gate", _p(gate), _p(x), _p(w1), _p(w2), bs, C, H, _stream())
+    return gate
+
+
+NGA_STATS_MAX_PIXELS = 16384          # planes a single workgroup holds in registers (e4s_norm_gate_add_stats)
+
+
+def norm_gate_add(x, mean=None, rstd=None, gate=None, shortcut=None, sc_stats=None, sc_stride: int = 1, prelu=None, stats_eps: Optional[float] = None):
+    """``prelu(((x - mean) * rstd) * gate + shortcut')``.  With ``stats_eps`` the InstanceNorm statistics of the RESULT come back as well:
+    ``(out, mean_out, rstd_out)`` — from the same launch for planes of up to 16384 pixels, from ``plane_stats`` otherwise."""
     x = _c(x, "input")
     bs, C, h, w = x.shape
     out = torch.empty_like(x)
@@ -1018,8 +1037,16 @@ def norm_gate_add(x, mean=None, rstd=None, gate=None, shortcut=None, sc_stats=No
             raise ValueError(f"shortcut shape {tuple(sc.shape)} != {(bs, C, h * sc_stride, w * sc_stride)}")
         if sc_stats is not None:
             scm, scr = _c(sc_stats[0], "sc_mean"), _c(sc_stats[1], "sc_rstd")
-    lib().call("e4s_norm_gate_add", _p(out), _p(x), _p(mean), _p(rstd), _p(gate), _p(sc), _p(scm), _p(scr), sc_stride,
-               _p(_c(prelu.detach(), "prelu")) if prelu is not None else None, bs, C, h, w, _stream())
+    pr = _p(_c(prelu.detach(), "prelu")) if prelu is not None else None
+    if stats_eps is not None and (h * w) % 4 == 0 and h * w <= NGA_STATS_MAX_PIXELS:
+        om = torch.empty((bs, C), dtype=torch.float32, device=x.device)
+        orr = torch.empty_like(om)
+        lib().call("e4s_norm_gate_add_stats", _p(out), _p(om), _p(orr), _p(x), _p(mean), _p(rstd), _p(gate), _p(sc), _p(scm), _p(scr), sc_stride, pr,
+                   bs, C, h, w, float(stats_eps), _stream())
+        return out, om, orr
+    lib().call("e4s_norm_gate_add", _p(out), _p(x), _p(mean), _p(rstd), _p(gate), _p(sc), _p(scm), _p(scr), sc_stride, pr, bs, C, h, w, _stream())
+    if stats_eps is not None:
+        return (out,) + tuple(plane_stats(out, stats_eps))
     return out
 
 

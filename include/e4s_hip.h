@@ -279,6 +279,14 @@ E4S_API int e4s_vec_fc(float* y, const float* x, const float* W, const float* bn
 E4S_API int e4s_norm_gate_add(float* out, const float* x, const float* mean, const float* rstd, const float* gate,
                               const float* shortcut, const float* sc_mean, const float* sc_rstd, int sc_stride, const float* prelu,
                               int bs, int C, int h, int w, void* stream);
+/* SEModule's gate (helpers.py:56-72) in one launch: gate[b, o] = sigmoid(fc2 . relu(fc1 . pooled[b])), fc1 [H, C], fc2 [C, H], no biases, H <= 64;
+ * value for value what two e4s_vec_fc calls give. */
+E4S_API int e4s_se_gate(float* gate, const float* pooled, const float* w1, const float* w2, int bs, int C, int H, void* stream);
+/* e4s_norm_gate_add that also returns InstanceNorm statistics (mean, 1/sqrt(var + eps), as e4s_plane_stats computes them) of its OUTPUT planes:
+ * the next bottleneck_IR_SE unit (helpers.py:122-144) normalises exactly that tensor.  Planes of at most 16384 pixels, a multiple of 4. */
+E4S_API int e4s_norm_gate_add_stats(float* out, float* out_mean, float* out_rstd, const float* x, const float* mean, const float* rstd,
+                                    const float* gate, const float* shortcut, const float* sc_mean, const float* sc_rstd, int sc_stride,
+                                    const float* prelu, int bs, int C, int h, int w, float eps, void* stream);
 
 /* Masked average pooling per region (psp_encoders.py:355-375): out[bs,nreg,C] = mean of feats[bs,C,h,w] over the pixels whose
  * label (uint8 [bs,lh,lw], sampled nearest at h x w) equals the region, zeros for an empty region. */

@@ -155,3 +155,31 @@ def test_net3_forward_end_to_end(gpu_net3, net3_sd):
         structure, style_codes = gpu_net3.get_style(img.to(DEV), mask.to(DEV))
     assert maxdiff(style_codes, codes) <= 1e-3
     assert maxdiff(out, ref_img) <= 1e-3 and maxdiff(feats, ref_feats) <= 1e-3
+
+
+def test_fused_se_gate_and_statistics_emitting_norm_gate_add_match_the_separate_launches():
+    """The encoder's fused glue against the launches it replaces: ``se_gate`` == two ``vec_fc`` calls; ``norm_gate_add(stats_eps=...)`` ==
+    ``norm_gate_add`` followed by ``plane_stats`` of its result (output and mean bit for bit, rstd to an ulp or two; every plane-size class
+    of the kernel, with and without a strided / normalised shortcut and PReLU)."""
+    from e4s2024_amd import ops
+    g = torch.Generator().manual_seed(7)
+    for bs, C in ((3, 512), (2, 64), (1, 130)):
+        pooled = torch.randn(bs, C, generator=g).to(DEV)
+        H = max(1, C // 16)
+        w1, w2 = (torch.randn(H, C, 1, 1, generator=g) * 0.1).to(DEV), (torch.randn(C, H, 1, 1, generator=g) * 0.1).to(DEV)
+        ref = ops.vec_fc(ops.vec_fc(pooled, w1, act=ops.ACT_RELU), w2, act=ops.ACT_SIGMOID)
+        assert torch.equal(ops.se_gate(pooled, w1, w2), ref)
+    for (bs, C, h, ss, use_sc, use_scn, use_prelu) in ((2, 24, 16, 1, True, False, False), (2, 16, 32, 2, True, True, False), (1, 8, 64, 1, True, False, True),
+                                                      (1, 4, 128, 2, True, True, False), (2, 6, 32, 1, False, False, True), (1, 2, 256, 1, False, False, True)):
+        x = torch.randn(bs, C, h, h, generator=g).to(DEV)
+        mean, rstd = ops.plane_stats(x, 1e-5)
+        gate = torch.rand(bs, C, generator=g).to(DEV)
+        sc = torch.randn(bs, C, h * ss, h * ss, generator=g).to(DEV) if use_sc else None
+        scs = ops.plane_stats(sc, 1e-5) if use_scn else None
+        pr = torch.rand(C, generator=g).to(DEV) if use_prelu else None
+        ref = ops.norm_gate_add(x, mean, rstd, gate, sc, scs, ss, pr)
+        rm, rr = ops.plane_stats(ref, 1e-5)
+        out, om, orr = ops.norm_gate_add(x, mean, rstd, gate, sc, scs, ss, pr, stats_eps=1e-5)
+        assert torch.equal(out, ref) and torch.equal(om, rm), (bs, C, h, ss)
+        # rstd: the same sums, but the compiler contracts the squares into FMAs differently in the two kernels: an ulp or two
+        assert ((orr - rr).abs() <= 4e-7 * rr.abs()).all(), (bs, C, h, ss, ((orr - rr).abs() / rr.abs()).max().item())
