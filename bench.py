@@ -76,6 +76,21 @@ def conv3x3_flops_per_face(size=1024, want_executed=False):
     return out
 
 
+def _by_layer(kt, kernel, bs, peak):
+    """Per-layer split of the dominant kernel's launches: ms per launch, algorithmic TFLOP/s and fraction of `peak`, executed / algorithmic."""
+    rows = []
+    for detail, (calls, ms) in sorted(kt.by_detail(kernel).items(), key=lambda kv: -kv[1][1]):
+        chans, res = detail.split(" @")
+        cin, cout = (int(v) for v in chans.split("->"))
+        up = res.endswith(" up")
+        h = int(res.split()[0])
+        gflop = 2.0 * cin * cout * 9 * h * h * bs / 1e9            # per launch; up layers counted on the input grid (transposed conv)
+        t = ms / calls
+        rows.append({"layer": detail, "ms_per_launch": round(t, 4), "algorithmic_tflops": round(gflop / t, 1), "frac": round(gflop / t / peak, 4),
+                     "executed_over_algorithmic": 4.0 if up else 1.0})
+    return rows
+
+
 TRAFFIC_FILE = "profiles/r02_traffic.json"
 
 
@@ -191,6 +206,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
     ksum = kt.summary()
+    kt_for_layers = kt
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -420,6 +436,9 @@ def main():
                     "executed_over_algorithmic": round(fl_exec[dom] / fl[dom], 3),
                     "executed_frac_of_nominal_peak": round(ach * fl_exec[dom] / fl[dom] / peak, 4) if sb else None,
                     "executed_frac_of_measured_sustained": round(ach * fl_exec[dom] / fl[dom] / (SUSTAINED_BF16_TFLOPS_RANDOM_DATA / 3.0), 4) if sb else None,
+                    # the same ratio layer by layer (one launch per layer and step): the same-resolution layers run every algorithmic MAC once,
+                    # the up-sampling layers execute the parity-composed form at 4x their algorithmic (transposed-conv) MACs
+                    "by_layer": _by_layer(kt_for_layers, dom, bs, peak),
                     "all_modconv3x3": {"achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 2), "ms_per_step": round(all_ms / args.steps, 3),
                                        "by_kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(ksum.items())}}}
         # ---- CPU baseline: the faithful 12-pass oracle on one face

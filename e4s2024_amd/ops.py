@@ -683,7 +683,7 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
         wsn = 16 * bs * cout * ho * wo
         ws = _workspace(x.device, wsn)
     sb = isinstance(wt, tuple)
-    ev = _timed(modconv_kernel_name(cout, w, sb, labels is not None))
+    ev = _timed(modconv_kernel_name(cout, w, sb, labels is not None), f"{cin}->{cout} @{h}{' up' if up else ''}")
     rgb_out = None
     if rgb is not None:
         if not sb:
@@ -1725,19 +1725,29 @@ class KernelTimer:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, a, b in self.events:
+        for name, a, b, _ in self.events:
             c, t = out.get(name, (0, 0.0))
             out[name] = (c + 1, t + a.elapsed_time(b))
         return out
 
+    def by_detail(self, name: str):
+        """{detail: (calls, total_ms)} of one kernel's launches (detail = the layer a launch belongs to)."""
+        torch.cuda.synchronize()
+        out = {}
+        for n, a, b, detail in self.events:
+            if n == name and detail is not None:
+                c, t = out.get(detail, (0, 0.0))
+                out[detail] = (c + 1, t + a.elapsed_time(b))
+        return out
 
-def _timed(name: str):
+
+def _timed(name: str, detail: Optional[str] = None):
     kt = KernelTimer.active
     if kt is None:
         return None
     a = torch.cuda.Event(enable_timing=True)
     b = torch.cuda.Event(enable_timing=True)
-    kt.events.append((name, a, b))
+    kt.events.append((name, a, b, detail))
     a.record()
     return b
 
