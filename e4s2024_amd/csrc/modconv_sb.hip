@@ -137,6 +137,9 @@ struct SbParams {
     // optional split-plane output (modconv_chain.hip): out = [hi|lo][bs][cout/8][ho][wo][8 x bf16] of act * s_next[b][co], for a single-region consumer
     const float* s_next;     // [bs][cout]
     int64_t plane_out;       // uint4 per plane
+    // optional (masked up layer): [bs][ho/16][wo/16] map of region-uniform 16 x 16 output blocks (modconv_upblock.hip computes those: value <
+    // nreg); this kernel then skips them — whole workgroups where all their blocks are uniform, single pixels otherwise
+    const uint8_t* uni_blocks;
 };
 
 template <int CB, int PB, int WC, int WP, int LOG_TW>
@@ -211,6 +214,22 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
     const int hw = p.h * p.w;
     const int ho = p.up ? 2 * p.h : p.h, wo = p.up ? 2 * p.w : p.w;
     const int nchunk = (p.cin + CKS - 1) / CKS;
+    // the uniform 16 x 16 output blocks under this tile (up layer: outputs (2y + pa, 2x + pb) of an 8 x 32 input tile = one block row, four blocks)
+    unsigned ub_skip = 0;       // bit j: block j of this tile is computed by the block kernel
+    if constexpr (C::TH == 8 && C::TW == 32 && !TCONV && !UNI) {
+        if (p.up && p.uni_blocks) {
+            const int nbx = wo >> 4, nby = ho >> 4;
+            const int by = (2 * y0) >> 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int bxk = ((2 * x0) >> 4) + j;
+                const bool uni = by < nby && bxk < nbx && p.uni_blocks[((size_t)b * nby + by) * nbx + bxk] < p.nreg;
+                const bool outside = by >= nby || bxk >= nbx;
+                if (uni || outside) ub_skip |= 1u << j;
+            }
+            if (ub_skip == 0xfu) return;
+        }
+    }
 
     int goff[C::EPT];
     bool ginb[C::EPT];
@@ -527,7 +546,7 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
     for (int q = 0; q < PB; ++q) {
         const int pbk = wp * PB + q;
         const int y = y0 + C::blk_y(pbk, l5), x = x0 + C::blk_x(pbk, l5);
-        const bool pix_ok = y < p.h && x < p.w;
+        const bool pix_ok = y < p.h && x < p.w && !((ub_skip >> ((x - x0) >> 3)) & 1u);
         const int oy = p.up ? 2 * y + pa : y, ox = p.up ? 2 * x + pb_ : x;
         const size_t opix = (size_t)oy * wo + ox;
         const float nz = nzq[q];
@@ -648,6 +667,7 @@ static int launch_sb(SbParams& p, hipStream_t st, float* workspace, int64_t work
         if (WC != 1 || p.cout > C::TN || p.up) return fail(E4S_ERR_ARG, "region_modconv3x3_sb: fused ToRGB needs all %d output channels in one workgroup tile", p.cout);
         ksplit = 1;
     }
+    if (p.uni_blocks) ksplit = 1;       // (the skipped blocks are decided per workgroup / lane in the one-pass epilogue)
     p.ksplit = ksplit;
     p.chunks_per = cdiv(nchunk, ksplit);
     p.partial = workspace;
@@ -713,7 +733,8 @@ extern "C" int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16
                                         const uint8_t* labels, int lh, int lw, const float* noise, int noise_bs, const float* noise_weight,
                                         const float* act_bias, int act, int bs, int cin, int cout, int h, int w, int nreg, int up,
                                         float* workspace, int64_t workspace_floats, float* rgb_out, const float* rgb_wt, const float* rgb_s,
-                                        const float* rgb_bias, const float* rgb_skip, const float* rgb_up_kernel, const float* s_next, void* stream) {
+                                        const float* rgb_bias, const float* rgb_skip, const float* rgb_up_kernel, const float* s_next,
+                                        const uint8_t* uniform_blocks, void* stream) {
     const int layout = up & (E4S_X_NHWC | E4S_OUT_NHWC | E4S_OUT_SP);
     up &= 1;
     E4S_REQUIRE(!(layout & E4S_OUT_SP) || (s_next && rgb_out && out && cout % 8 == 0 && !(layout & E4S_OUT_NHWC) && ((uintptr_t)out & 15) == 0),
@@ -745,6 +766,9 @@ extern "C" int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16
     p.rgb_out = rgb_out; p.rgb_wt = rgb_wt; p.rgb_s = rgb_s; p.rgb_bias = rgb_bias; p.rgb_skip = rgb_skip; p.rgb_upk = rgb_up_kernel;
     p.s_next = (layout & E4S_OUT_SP) ? s_next : nullptr;
     p.plane_out = (int64_t)bs * (cout / 8) * ho * wo;
+    E4S_REQUIRE(!uniform_blocks || (up && labels && w >= 32 && cout >= 128 && (h % 8) == 0 && (w % 8) == 0 && !layout),
+                "region_modconv3x3_sb: the uniform-block map goes with a masked up layer of width >= 32, cout >= 128, h and w multiples of 8");
+    p.uni_blocks = uniform_blocks;
     hipStream_t st = (hipStream_t)stream;
     float* ws = p.out_nhwc ? nullptr : workspace;     // the split-K partial sums are laid out channels-first
     const int64_t wf = p.out_nhwc ? 0 : workspace_floats;

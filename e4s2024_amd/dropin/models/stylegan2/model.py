@@ -195,8 +195,13 @@ class ModulatedConv2d(nn.Module):
                                act_bias, ref=self._torch_ref(labels, noise, act))
         wt, s, d = self.tables(styles, masked=labels is not None)
         saved = (s, d, self._weights(labels is not None)[1]) if labels is not None else None
+        up_blocks = None
+        if (self.upsample and labels is not None and ops.UP_BLOCKS and ops.MODCONV_MODE == "sb" and self.kernel_size == 3 and input.shape[-1] >= 32
+                and self.out_channel >= 128 and not torch.is_grad_enabled()):
+            # region-uniform 16 x 16 output blocks run in the transposed-conv form (a second preparation of the same weight)
+            up_blocks = (self._prepared_tconv.get(self.weight, None, False, self.demodulate, tconv=True)[0], self.blur.kernel)
         out = ops.region_modconv3x3(input, wt, s, d, labels, noise, noise_weight, act_bias, act, self.out_channel, self.upsample, rgb=rgb,
-                                    want_out=want_out, x_nhwc=x_nhwc, out_nhwc=out_nhwc, s_next=s_next)
+                                    want_out=want_out, x_nhwc=x_nhwc, out_nhwc=out_nhwc, s_next=s_next, up_blocks=up_blocks)
         if x_nhwc or out_nhwc or s_next is not None:
             return out              # inference only (Generator.forward takes this route under no_grad)
         if rgb is not None:

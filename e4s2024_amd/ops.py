@@ -640,13 +640,29 @@ def can_fuse_rgb(cout: int, w: int, up: bool, masked: bool) -> bool:
     return FUSE_RGB and MODCONV_MODE == "sb" and not up and w >= 32 and (cout <= 64 or (masked and wide and cout == 128))
 
 
+UP_BLOCKS = os.environ.get("E4S_UP_BLOCKS", "1") != "0"    # masked up layers: region-uniform 16 x 16 output blocks in the transposed-conv form
+UP_BLOCK = 16
+
+
+def uniform_blocks(labels: torch.Tensor, ho: int, wo: int, nreg: int) -> torch.Tensor:
+    """uint8 ``[bs, ho/16, wo/16]``: the region shared by all pixels of a 16 x 16 output block (labels sampled 'nearest' at ``ho`` x ``wo``),
+    255 where a block mixes regions (``e4s_uniform_blocks``)."""
+    lab = _labels_u8(labels, "labels")
+    bs, lh, lw = lab.shape
+    out = torch.empty((bs, -(-ho // UP_BLOCK), -(-wo // UP_BLOCK)), dtype=torch.uint8, device=lab.device)
+    lib().call("e4s_uniform_blocks", _p(out), _p(lab), bs, lh, lw, ho, wo, nreg, UP_BLOCK, _stream())
+    return out
+
+
 def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: bool, cout: int, up: bool, rgb=None, want_out: bool = True,
-                      x_nhwc: bool = False, out_nhwc: bool = False, s_next=None):
+                      x_nhwc: bool = False, out_nhwc: bool = False, s_next=None, up_blocks=None):
     """``rgb = (wt_rgb [cout,3], s_rgb [bs,1,cout], bias [1,3,1,1], skip or None, up_kernel)`` fuses the following single-region
     ToRGB; the call then returns ``(out, rgb_image)``.  ``want_out=False`` (with ``rgb``) skips writing the layer's own activation
     and returns ``(None, rgb_image)``.  ``x_nhwc`` / ``out_nhwc``: the activation is channel-blocked, ``[bs, c/8, h, w, 8]`` (split-bf16
     kernel, width >= 32; the 256x256-and-up layers can chain in this layout inside ``Generator.forward``).  ``s_next [bs, 1, cout]`` (masked
-    layer with a fused ToRGB): the activation is written as split planes ``[2, bs, cout/8, h, w, 8]`` modulated for a single-region consumer."""
+    layer with a fused ToRGB): the activation is written as split planes ``[2, bs, cout/8, h, w, 8]`` modulated for a single-region consumer.
+    ``up_blocks = (wt_tconv, blur_kernel)`` (masked up layer, inference): the 16 x 16 output blocks under ONE region are computed in the
+    transposed-conv form (``e4s_masked_upconv_blocks``, a quarter of the composed form's MACs per block), the composed kernel keeps the rest."""
     x = _c(x, "input")
     if x_nhwc:
         bs, cb, h, w, _ = x.shape          # channel-blocked [bs, cin/8, h, w, 8]
@@ -683,6 +699,16 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
         wsn = 16 * bs * cout * ho * wo
         ws = _workspace(x.device, wsn)
     sb = isinstance(wt, tuple)
+    blocks = None
+    if (up_blocks is not None and UP_BLOCKS and sb and up and labels is not None and w >= 32 and cout >= 128 and h % 8 == 0 and w % 8 == 0
+            and cin % 16 == 0 and rgb is None and not (x_nhwc or out_nhwc) and sn is None):
+        wt_t, blur_k = up_blocks
+        blocks = uniform_blocks(labels, ho, wo, nreg)
+        evb = _timed("masked_upconv_blocks", f"{cin}->{cout} @{h} up")
+        lib().call("e4s_masked_upconv_blocks", _p(out), _p(x), _p(wt_t[0]), _p(wt_t[1]), _p(s), _p(d), _p(blocks), _p(_c(blur_k, "blur kernel")), _p(nz),
+                   nbs or 0, _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, _stream())
+        if evb is not None:
+            evb.record()
     ev = _timed(modconv_kernel_name(cout, w, sb, labels is not None), f"{cin}->{cout} @{h}{' up' if up else ''}")
     rgb_out = None
     if rgb is not None:
@@ -700,7 +726,7 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
         lib().call("e4s_region_modconv3x3_sb", _p(out), _p(x), _p(wt[0]), _p(wt[1]), _p(s), _p(d), _p(labels), lh, lw, _p(nz), nbs or 0,
                    _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg,
                    (1 if up else 0) | (2 if x_nhwc else 0) | (4 if out_nhwc else 0) | (16 if sn is not None else 0), _p(ws), wsn, *rgb_args, _p(sn),
-                   _stream())
+                   _p(blocks), _stream())
     else:
         lib().call("e4s_region_modconv3x3", _p(out), _p(x), _p(wt), _p(s), _p(d), _p(labels), lh, lw, _p(nz), nbs or 0,
                    _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, 1 if up else 0,

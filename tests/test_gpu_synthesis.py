@@ -310,3 +310,50 @@ def test_masked_layers_ragged_shapes_against_oracle(sg2, shape, upsample):
             yr = rgb(x.to(DEV), st.to(DEV), T(lab).to(DEV), None)
         refr = O.to_rgb(sdr, "", x, st, onehot, None, masked=True)
         assert maxdiff(yr, refr) <= 3e-5 * max(1.0, float(refr.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 128, 32, 32, 5, 64, 64), (1, 48, 136, 40, 32, 12, 160, 128), (1, 16, 128, 32, 48, 3, 32, 48)])
+def test_masked_up_layer_uniform_blocks_against_oracle_and_composed_form(sg2, shape):
+    """Masked up-sampling StyledConv with the region-uniform 16 x 16 output blocks in the transposed-conv form (``e4s_masked_upconv_blocks``) and
+    the mixed ones in the composed form: label maps made of uniform blocks, mixed blocks, blocks without a region and a label map at another
+    resolution — against the oracle, against the all-composed route, and each output block written by exactly one kernel (NaN-prefilled)."""
+    bs, cin, cout, h, w, nreg, lh, lw = shape
+    rs = np.random.RandomState(17 * cin + h)
+    ry, rx = lh // 4, lw // 4                                                # coarse cells -> large uniform areas
+    cells = rs.randint(0, nreg, (bs, 4, 4)).astype(np.uint8)
+    lab = np.repeat(np.repeat(cells, ry, axis=1), rx, axis=2)
+    lab[:, : lh // 4, : lw // 4] = rs.randint(0, nreg, (bs, lh // 4, lw // 4))  # a corner of per-pixel noise: mixed blocks
+    lab[:, lh - ry // 2:, lw - rx // 2:] = 255                                # an area that belongs to no region
+    onehot = torch.zeros(bs, nreg, lh, lw)
+    for c in range(nreg):
+        onehot[:, c] = T((lab == c).astype(np.float32))
+    m = sg2.StyledConv(cin, cout, 3, 512, upsample=True, mask_op=True)
+    with torch.no_grad():
+        m.conv.weight.copy_(T(rs.standard_normal(m.conv.weight.shape).astype(np.float32)))
+        m.conv.modulation.weight.copy_(T(rs.standard_normal(m.conv.modulation.weight.shape).astype(np.float32)))
+        m.noise.weight.fill_(0.21)
+        m.activate.bias.copy_(T(0.1 * rs.standard_normal(cout).astype(np.float32)))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = T(rs.standard_normal((bs, cin, h, w)).astype(np.float32))
+    st = T(rs.standard_normal((bs, nreg, 512)).astype(np.float32))
+    nz = T(rs.standard_normal((bs, 1, 2 * h, 2 * w)).astype(np.float32))
+    m = m.to(DEV)
+    labd = T(lab).to(DEV)
+    blocks = _ops.uniform_blocks(labd, 2 * h, 2 * w, nreg).cpu().numpy()
+    assert (blocks < nreg).any() and (blocks == 255).any()                    # both kinds of block are present
+    old = _ops.UP_BLOCKS
+    try:
+        with torch.no_grad():
+            _ops.UP_BLOCKS = True
+            y = m(x.to(DEV), st.to(DEV), labd, noise=nz.to(DEV))
+            y2 = m(x.to(DEV), st.to(DEV), labd, noise=nz.to(DEV))
+            _ops.UP_BLOCKS = False
+            yc = m(x.to(DEV), st.to(DEV), labd, noise=nz.to(DEV))
+    finally:
+        _ops.UP_BLOCKS = old
+    ref = O.styled_conv(sd, "", x, st, onehot, nz, masked=True, upsample=True)
+    scale = max(1.0, float(ref.abs().max()))
+    assert torch.equal(y, y2)
+    d_or, d_co = maxdiff(y, ref), (y - yc).abs().max().item()
+    record_parity(f"masked_up_blocks.{cin}to{cout}_{h}x{w}.vs_oracle", d_or / scale, LAYER_TOL)
+    assert d_or <= LAYER_TOL * scale and d_co <= 2e-5 * scale, (shape, d_or, d_co, scale)
