@@ -43,9 +43,11 @@ SWAP_BATCH = 8                    # BASELINE configs[2]: full swap at batch 8
 SUSTAINED_BF16_TFLOPS_RANDOM_DATA = 1255.0
 
 
-def conv3x3_flops_per_face(size=1024, want_executed=False):
+def conv3x3_flops_per_face(size=1024, want_executed=False, uniform_frac=None):
     """Algorithmic FLOPs of the 3x3 modulated convs per face, each counted once, keyed by the kernel that runs them
-    (the transposed convs are counted per INPUT pixel).  Layers up to 256x256 are masked (12 regions)."""
+    (the transposed convs are counted per INPUT pixel).  Layers up to 256x256 are masked (12 regions).
+    ``uniform_frac[out_res]``: share of a masked up layer's 16 x 16 output blocks that lie under one region — those run in the block kernel
+    (csrc/modconv_upblock.hip, 2.0x their algorithmic MACs), the rest in the composed form (4x)."""
     from e4s2024_amd import ops as _ops
     from e4s2024_amd.ops import modconv_kernel_name
     ch = {4: 512, 8: 512, 16: 512, 32: 512, 64: 512, 128: 256, 256: 128, 512: 64, 1024: 32}
@@ -61,9 +63,14 @@ def conv3x3_flops_per_face(size=1024, want_executed=False):
             k = f"chain_conv3x3<{cout}>"          # the split-plane chain's persistent kernel (csrc/modconv_chain.hip)
         else:
             k = modconv_kernel_name(cout, w_in, None, masked)
-        out[k] = out.get(k, 0.0) + fl
+        f = 0.0
+        if up and masked and uniform_frac and _ops.UP_BLOCKS and _ops.MODCONV_MODE == "sb" and w_in >= 32 and cout >= 128:
+            f = float(uniform_frac.get(out_res, 0.0))
+            out["masked_upconv_blocks"] = out.get("masked_upconv_blocks", 0.0) + fl * f
+            executed["masked_upconv_blocks"] = executed.get("masked_upconv_blocks", 0.0) + fl * f * 2.0
+        out[k] = out.get(k, 0.0) + fl * (1.0 - f)
         # MACs the kernel really executes: the parity-composed up-conv spends 4x the transposed conv's, the fused one 1.31x (tile overlap)
-        executed[k] = executed.get(k, 0.0) + fl * ((1.31 if _ops.UP_FUSED else 1.0) if two_stage else (4.0 if up else 1.0))
+        executed[k] = executed.get(k, 0.0) + fl * (1.0 - f) * ((1.31 if _ops.UP_FUSED else 1.0) if two_stage else (4.0 if up else 1.0))
     add(512, 4, 2 * 512 * 512 * 9 * 16, 4, False)
     cin, r = 512, 8
     while r <= size:
@@ -76,18 +83,26 @@ def conv3x3_flops_per_face(size=1024, want_executed=False):
     return out
 
 
-def _by_layer(kt, kernel, bs, peak):
-    """Per-layer split of the dominant kernel's launches: ms per launch, algorithmic TFLOP/s and fraction of `peak`, executed / algorithmic."""
+def _by_layer(kt, kernel, bs, peak, uniform_frac):
+    """Per-layer split of the dominant kernel's launches (plus, for the masked up layers, their region-uniform blocks in the block kernel): ms per
+    layer and step, algorithmic TFLOP/s and fraction of `peak`, executed / algorithmic."""
+    per = {}
+    for name in (kernel, "masked_upconv_blocks"):
+        for detail, (calls, ms) in kt.by_detail(name).items():
+            c, t = per.get(detail, (0, 0.0))
+            per[detail] = (max(c, calls), t + ms)
     rows = []
-    for detail, (calls, ms) in sorted(kt.by_detail(kernel).items(), key=lambda kv: -kv[1][1]):
+    for detail, (calls, ms) in sorted(per.items(), key=lambda kv: -kv[1][1]):
         chans, res = detail.split(" @")
         cin, cout = (int(v) for v in chans.split("->"))
         up = res.endswith(" up")
         h = int(res.split()[0])
         gflop = 2.0 * cin * cout * 9 * h * h * bs / 1e9            # per launch; up layers counted on the input grid (transposed conv)
         t = ms / calls
-        rows.append({"layer": detail, "ms_per_launch": round(t, 4), "algorithmic_tflops": round(gflop / t, 1), "frac": round(gflop / t / peak, 4),
-                     "executed_over_algorithmic": 4.0 if up else 1.0})
+        f = float(uniform_frac.get(2 * h, 0.0)) if (up and uniform_frac and h >= 32 and cout >= 128) else 0.0
+        rows.append({"layer": detail, "ms_per_step": round(t, 4), "algorithmic_tflops": round(gflop / t, 1), "frac": round(gflop / t / peak, 4),
+                     "executed_over_algorithmic": round(f * 2.0 + (1.0 - f) * 4.0, 2) if up else 1.0,
+                     **({"uniform_block_share": round(f, 3)} if up else {})})
     return rows
 
 
@@ -411,7 +426,14 @@ def main():
         faces = bs * world * args.steps
         value = faces / elapsed
         # ---- roofline of the dominant kernel
-        fl, fl_exec = conv3x3_flops_per_face(want_executed=True)
+        # share of region-uniform 16 x 16 output blocks of the masked up layers under THESE masks (they run in the block kernel)
+        ufrac = {}
+        if ops.UP_BLOCKS and ops.MODCONV_MODE == "sb":
+            labd = ops.mask_to_labels(mask)
+            for res in (64, 128, 256):
+                ub = ops.uniform_blocks(labd, res, res, 12)
+                ufrac[res] = float((ub < 12).float().mean().item())
+        fl, fl_exec = conv3x3_flops_per_face(want_executed=True, uniform_frac=ufrac)
         dom = max(ksum, key=lambda k: ksum[k][1]) if ksum else None
         roof = None
         if dom:
@@ -438,7 +460,7 @@ def main():
                     "executed_frac_of_measured_sustained": round(ach * fl_exec[dom] / fl[dom] / (SUSTAINED_BF16_TFLOPS_RANDOM_DATA / 3.0), 4) if sb else None,
                     # the same ratio layer by layer (one launch per layer and step): the same-resolution layers run every algorithmic MAC once,
                     # the up-sampling layers execute the parity-composed form at 4x their algorithmic (transposed-conv) MACs
-                    "by_layer": _by_layer(kt_for_layers, dom, bs, peak),
+                    "by_layer": _by_layer(kt_for_layers, dom, bs, peak, ufrac),
                     "all_modconv3x3": {"achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 2), "ms_per_step": round(all_ms / args.steps, 3),
                                        "by_kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(ksum.items())}}}
         # ---- CPU baseline: the faithful 12-pass oracle on one face
