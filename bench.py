@@ -150,7 +150,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--labels", choices=["blocky", "iid"], default="blocky")
+    ap.add_argument("--no-mask-sensitivity", action="store_true", help="skip the two short runs under coarse / i.i.d. region maps")
+    ap.add_argument("--labels", choices=["blocky", "coarse", "iid"], default="blocky",
+                    help="region maps: 16 x 16 constant cells on the 512 x 512 map (default, BASELINE configs[1]), 4 x 4 cells (face-sized regions), or i.i.d. per pixel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-swap", action="store_true", help="skip the secondary full-swap p50 measurement")
     ap.add_argument("--no-pti", action="store_true", help="skip the secondary PTI step measurement (BASELINE configs[3])")
@@ -195,7 +197,7 @@ def main():
     bs = args.batch
     # codes = latent_avg + 0.5 N(0,1) (seed 1 + rank), blocky 16x16-cell label maps (seed 3 + rank)
     codes = seeded.seeded_codes(1 + rank, bs, 12, 18, la).to(dev)
-    lab = (seeded.blocky_labels(3 + rank, bs, 12, 512, 16) if args.labels == "blocky" else seeded.iid_labels(9 + rank, bs, 12, 512))
+    lab = (seeded.blocky_labels(3 + rank, bs, 12, 512, 16 if args.labels == "blocky" else 4) if args.labels != "iid" else seeded.iid_labels(9 + rank, bs, 12, 512))
     mask = seeded.labels_to_onehot(lab, 12).to(dev)
     ops.STRICT_MASK = False                                       # the one-hot check costs a host sync; masks here are one-hot by construction
 
@@ -222,6 +224,23 @@ def main():
         elapsed = time.perf_counter() - t0
     ksum = kt.summary()
     kt_for_layers = kt
+    # how much of `value` depends on the region maps: the same batch under face-sized regions (4 x 4 cells: every 16 x 16 block of the masked up
+    # layers lies under one region) and under i.i.d. per-pixel labels (none does); single-GPU runs only, 10 steps each, outside the timed region
+    mask_sens = None
+    if world == 1 and args.labels == "blocky" and not args.no_mask_sensitivity:
+        mask_sens = {}
+        for name, lb in (("coarse_4x4_cells", seeded.blocky_labels(3, bs, 12, 512, 4)), ("iid_per_pixel", seeded.iid_labels(9, bs, 12, 512))):
+            m2 = seeded.labels_to_onehot(lb, 12).to(dev)
+            with torch.no_grad():
+                for _ in range(2):
+                    net.gen_img(None, codes, m2.view_as(m2), randomize_noise=False)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    net.gen_img(None, codes, m2.view_as(m2), randomize_noise=False)
+                torch.cuda.synchronize()
+            mask_sens[name] = {"faces_per_s": round(10 * bs / (time.perf_counter() - t1), 1)}
+            del m2
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -493,7 +512,7 @@ def main():
                                    + ("split-bf16: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate (max-abs pixel error "
                                       "6e-5 vs the reference; plain bf16 would miss the 1e-3 bar)" if ops.MODCONV_MODE == "sb" else "exact fp32 MFMA"),
                        "batch_per_gpu": bs, "global_batch": bs * world, "resolution": 1024, "regions": 12, "parallelism": f"frames x{world}"},
-            "roofline": roof, "cpu_baseline": cpu, "full_swap": full_swap, "pti": pti_info, "clip": clip_info,
+            "roofline": roof, "cpu_baseline": cpu, "full_swap": full_swap, "pti": pti_info, "clip": clip_info, "mask_sensitivity": mask_sens,
             "algorithmic_gflop_per_face": 148.52,
             "job_algorithmic_tflops_per_gpu": round(value * 148.52e9 / 1e12 / world, 2),
         }
