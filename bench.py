@@ -65,9 +65,10 @@ def conv3x3_flops_per_face(size=1024, want_executed=False, uniform_frac=None):
             k = modconv_kernel_name(cout, w_in, None, masked)
         f = 0.0
         if up and masked and uniform_frac and _ops.UP_BLOCKS and _ops.MODCONV_MODE == "sb" and w_in >= 32 and cout >= 128:
-            f = float(uniform_frac.get(out_res, 0.0))
+            f1, f2 = uniform_frac.get(out_res, (0.0, 0.0))
+            f = f1 + f2
             out["masked_upconv_blocks"] = out.get("masked_upconv_blocks", 0.0) + fl * f
-            executed["masked_upconv_blocks"] = executed.get("masked_upconv_blocks", 0.0) + fl * f * 2.0
+            executed["masked_upconv_blocks"] = executed.get("masked_upconv_blocks", 0.0) + fl * (f1 * 2.0 + f2 * 2.5)
         out[k] = out.get(k, 0.0) + fl * (1.0 - f)
         # MACs the kernel really executes: the parity-composed up-conv spends 4x the transposed conv's, the fused one 1.31x (tile overlap)
         executed[k] = executed.get(k, 0.0) + fl * (1.0 - f) * ((1.31 if _ops.UP_FUSED else 1.0) if two_stage else (4.0 if up else 1.0))
@@ -99,10 +100,10 @@ def _by_layer(kt, kernel, bs, peak, uniform_frac):
         h = int(res.split()[0])
         gflop = 2.0 * cin * cout * 9 * h * h * bs / 1e9            # per launch; up layers counted on the input grid (transposed conv)
         t = ms / calls
-        f = float(uniform_frac.get(2 * h, 0.0)) if (up and uniform_frac and h >= 32 and cout >= 128) else 0.0
+        f1, f2 = uniform_frac.get(2 * h, (0.0, 0.0)) if (up and uniform_frac and h >= 32 and cout >= 128) else (0.0, 0.0)
         rows.append({"layer": detail, "ms_per_step": round(t, 4), "algorithmic_tflops": round(gflop / t, 1), "frac": round(gflop / t / peak, 4),
-                     "executed_over_algorithmic": round(f * 2.0 + (1.0 - f) * 4.0, 2) if up else 1.0,
-                     **({"uniform_block_share": round(f, 3)} if up else {})})
+                     "executed_over_algorithmic": round(f1 * 2.0 + f2 * 2.5 + (1.0 - f1 - f2) * 4.0, 2) if up else 1.0,
+                     **({"uniform_block_share": round(f1, 3), "uniform_sub_block_share": round(f2, 3)} if up else {})})
     return rows
 
 
@@ -450,8 +451,9 @@ def main():
         if ops.UP_BLOCKS and ops.MODCONV_MODE == "sb":
             labd = ops.mask_to_labels(mask)
             for res in (64, 128, 256):
-                ub = ops.uniform_blocks(labd, res, res, 12)
-                ufrac[res] = float((ub < 12).float().mean().item())
+                ub, _ = ops.uniform_blocks(labd, res, res, 12)
+                # (share under one region, share made of four uniform 8 x 8 sub-blocks): 2.0x / 2.5x their algorithmic MACs
+                ufrac[res] = (float((ub < 12).float().mean().item()), float((ub == ops.UP_BLOCK_QUAD).float().mean().item()))
         fl, fl_exec = conv3x3_flops_per_face(want_executed=True, uniform_frac=ufrac)
         dom = max(ksum, key=lambda k: ksum[k][1]) if ksum else None
         roof = None

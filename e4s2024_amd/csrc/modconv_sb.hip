@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int bxk = ((2 * x0) >> 4) + j;
-                const bool uni = by < nby && bxk < nbx && p.uni_blocks[((size_t)b * nby + by) * nbx + bxk] < p.nreg;
+                const bool uni = by < nby && bxk < nbx && p.uni_blocks[((size_t)b * nby + by) * nbx + bxk] != 255;   // one region, or four uniform sub-blocks
                 const bool outside = by >= nby || bxk >= nbx;
                 if (uni || outside) ub_skip |= 1u << j;
             }

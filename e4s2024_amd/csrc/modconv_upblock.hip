@@ -16,14 +16,9 @@ using namespace e4s;
 
 namespace {
 
-constexpr int MB_T = 10;                   // positions per block side
 constexpr int MB_OUT = 16;                 // output pixels per block side
-constexpr int MB_PW = MB_T + 1;            // activation patch side (a position reads x[a-1], x[a])
-constexpr int MB_PATCH = MB_PW * MB_PW;    // 121
-constexpr int MB_NT = 256;
-constexpr int MB_ZR = 2 * MB_T;            // 20 pre-blur rows / columns
-constexpr int MB_ZS = MB_ZR + 2;           // row stride of the pre-blur tile
 constexpr int MB_ZCO = 8;
+constexpr int MB_QUAD = 254;               // block map value: four region-uniform 8 x 8 sub-blocks with different regions (SUB = 2 variant)
 
 struct UpBlockParams {
     float* out;
@@ -32,7 +27,8 @@ struct UpBlockParams {
     const uint4* wlo;
     const float* s;            // [bs][nreg][cin]
     const float* d;            // [bs][nreg][cout]
-    const uint8_t* blocks;     // [bs][nby][nbx]: region of a uniform block, 255 = mixed (left to the composed kernel)
+    const uint8_t* blocks;     // [bs][nby][nbx]: region of a uniform block, MB_QUAD = four uniform 8 x 8 sub-blocks, 255 = mixed (composed kernel)
+    const uint8_t* sub;        // [bs][2 nby][2 nbx]: region of every 8 x 8 sub-block (255 = mixed); read by the SUB = 2 variant
     const float* blur;         // [4][4]
     const float* noise;
     const float* noise_weight;
@@ -42,55 +38,77 @@ struct UpBlockParams {
     int nbx, nby;
 };
 
-template <int CB>
+// SUB = 1: the block is one region (10 x 10 positions); SUB = 2: its four 8 x 8 sub-blocks are each one region (4 x 6 x 6 positions, every
+// sub-block with its own activation patch, modulation and demodulation: 2.5x the algorithmic MACs)
+template <int CB, int SUB>
 struct UbCfg {
     static constexpr int TN = CB * 32;
+    static constexpr int NSB = SUB * SUB;
+    static constexpr int SBO = MB_OUT / SUB;               // output pixels per sub-block side
+    static constexpr int T = SBO / 2 + 2;                  // positions per sub-block side
+    static constexpr int PW = T + 1;                       // activation patch side of a sub-block (a position reads x[a-1], x[a])
+    static constexpr int PATCH = NSB * PW * PW;            // 121 / 196 staged pixels
+    static constexpr int NPOS = NSB * T * T;               // 100 / 144
+    static constexpr int NWAVE = (NPOS + 31) / 32;         // 4 / 5
+    static constexpr int NT = 64 * NWAVE;
+    static constexpr int ZR = 2 * T;                       // pre-blur rows / columns of a sub-block
+    static constexpr int ZS = ZR + 2;
     static constexpr int W4 = 2 * 9 * 2 * TN;
-    static constexpr int WPT = (W4 + MB_NT - 1) / MB_NT;
-    static constexpr int MAIN_BYTES = W4 * 16 + MB_PATCH * 64;
-    static constexpr int ZT_BYTES = MB_ZCO * MB_ZR * MB_ZS * 4;
+    static constexpr int WPT = (W4 + NT - 1) / NT;
+    static constexpr int MAIN_BYTES = W4 * 16 + PATCH * 64;
+    static constexpr int ZT_BYTES = MB_ZCO * NSB * ZR * ZS * 4;
     static constexpr int BODY = MAIN_BYTES > ZT_BYTES ? MAIN_BYTES : ZT_BYTES;
-    static constexpr int EP_FLOATS = 2 * TN + MB_OUT * MB_OUT;
+    static constexpr int EP_FLOATS = (NSB + 1) * TN + MB_OUT * MB_OUT;
     static constexpr int LDS_BYTES = BODY + EP_FLOATS * 4;
+    static_assert(PATCH <= NT && MB_OUT * MB_OUT <= NT, "one staging thread per patch pixel, one per noise value");
 };
 
-template <int CB>
-__global__ __launch_bounds__(MB_NT, 2) void masked_up_block_kernel(const UpBlockParams p) {
-    using C = UbCfg<CB>;
+template <int CB, int SUB>
+__global__ __launch_bounds__(64 * ((SUB * SUB * (MB_OUT / SUB / 2 + 2) * (MB_OUT / SUB / 2 + 2) + 31) / 32), 2) void masked_up_block_kernel(const UpBlockParams p) {
+    using C = UbCfg<CB, SUB>;
     const int tyt = blockIdx.x / p.nbx, txt = blockIdx.x - tyt * p.nbx;
     const int b = blockIdx.z;
-    const int reg = p.blocks[((size_t)b * p.nby + tyt) * p.nbx + txt];
-    if (reg >= p.nreg) return;                                           // a mixed block (or one without a region)
+    const int flag = p.blocks[((size_t)b * p.nby + tyt) * p.nbx + txt];
+    if (SUB == 1 ? flag >= p.nreg : flag != MB_QUAD) return;            // not this variant's block
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint4* wsm = reinterpret_cast<uint4*>(lds_raw);
     uint4* xh4 = reinterpret_cast<uint4*>(lds_raw + C::W4 * 16);
-    uint4* xl4 = xh4 + 2 * MB_PATCH;
-    float* ep_d = reinterpret_cast<float*>(lds_raw + C::BODY);
-    float* ep_b = ep_d + C::TN;
+    uint4* xl4 = xh4 + 2 * C::PATCH;
+    float* ep_d = reinterpret_cast<float*>(lds_raw + C::BODY);           // [NSB][TN] demodulation of each sub-block's region
+    float* ep_b = ep_d + C::NSB * C::TN;
     float* ep_n = ep_b + C::TN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l5 = lane & 31, khalf = lane >> 5;
-    const int p0y = tyt * (MB_OUT / 2) - 1, p0x = txt * (MB_OUT / 2) - 1;   // first position of the block
     const int co0 = blockIdx.y * C::TN;
     const int hw = p.h * p.w;
     const int ho = 2 * p.h, wo = 2 * p.w;
     const int nchunk = (p.cin + CKS - 1) / CKS;
+    // region of sub-block j of this block
+    auto region_of = [&](int j) -> int {
+        if (SUB == 1) return flag;
+        return p.sub[((size_t)b * 2 * p.nby + 2 * tyt + (j >> 1)) * (2 * p.nbx) + 2 * txt + (j & 1)];
+    };
 
-    const int se_y = tid / MB_PW, se_x = tid - se_y * MB_PW;
-    const int sgy = p0y - 1 + se_y, sgx = p0x - 1 + se_x;
-    const bool s_in = tid < MB_PATCH && sgy >= 0 && sgy < p.h && sgx >= 0 && sgx < p.w;
+    // staging element of this thread: one patch pixel of one sub-block, 16 channels per chunk
+    const int ssb = tid < C::PATCH ? tid / (C::PW * C::PW) : 0;
+    const int se = tid - ssb * C::PW * C::PW;
+    const int se_y = se / C::PW, se_x = se - se_y * C::PW;
+    // first position of the sub-block: (block origin + sub-block offset) / 2 - 1; patch row 0 is one further up
+    const int sgy = tyt * (MB_OUT / 2) + (ssb / SUB) * (C::SBO / 2) - 2 + se_y, sgx = txt * (MB_OUT / 2) + (ssb % SUB) * (C::SBO / 2) - 2 + se_x;
+    const bool s_in = tid < C::PATCH && sgy >= 0 && sgy < p.h && sgx >= 0 && sgx < p.w;
     const int sgoff = s_in ? sgy * p.w + sgx : 0;
     const float* xb = p.x + (size_t)b * p.cin * hw;
-    const float* sb = p.s + ((size_t)b * p.nreg + reg) * p.cin;
+    const float* sb = p.s + ((size_t)b * p.nreg + region_of(ssb)) * p.cin;
 
     const int pos = wave * 32 + l5;
-    const bool pos_ok = pos < MB_T * MB_T;
-    const int posc = pos_ok ? pos : MB_T * MB_T - 1;
-    const int pty = posc / MB_T, ptx = posc - pty * MB_T;
-    const int xoff = pty * MB_PW + ptx;
+    const bool pos_ok = pos < C::NPOS;
+    const int posc = pos_ok ? pos : C::NPOS - 1;
+    const int psb = posc / (C::T * C::T), plp = posc - psb * C::T * C::T;
+    const int pty = plp / C::T, ptx = plp - pty * C::T;
+    const int xoff = psb * C::PW * C::PW + pty * C::PW + ptx;
 
     f32x16 accs[4][CB];
 #pragma unroll
@@ -111,7 +129,7 @@ __global__ __launch_bounds__(MB_NT, 2) void masked_up_block_kernel(const UpBlock
         const size_t wbase = (size_t)chunk * 18 * p.cout;
 #pragma unroll
         for (int v = 0; v < C::WPT; ++v) {
-            int idx = tid + v * MB_NT;
+            int idx = tid + v * C::NT;
             idx = idx < C::W4 ? idx : C::W4 - 1;
             const int hl = idx / (18 * C::TN);
             const int rem = idx - hl * 18 * C::TN;
@@ -122,12 +140,12 @@ __global__ __launch_bounds__(MB_NT, 2) void masked_up_block_kernel(const UpBlock
         }
     };
     auto store_chunk = [&](int chunk) __attribute__((always_inline)) {
-        if (tid < MB_PATCH) {
+        if (tid < C::PATCH) {
             unsigned hi[8], lo[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const int c0 = chunk * CKS + 2 * c;
-                const float s0 = c0 < p.cin ? sb[c0] : 0.f, s1 = c0 + 1 < p.cin ? sb[c0 + 1] : 0.f;   // workgroup-uniform
+                const float s0 = c0 < p.cin ? sb[c0] : 0.f, s1 = c0 + 1 < p.cin ? sb[c0 + 1] : 0.f;   // the sub-block's region (SUB = 1: workgroup-uniform)
                 split2(s_in ? xr[2 * c] * s0 : 0.f, s_in ? xr[2 * c + 1] * s1 : 0.f, hi[c], lo[c]);
             }
             const int sw = (tid >> 3) & 1;
@@ -138,20 +156,19 @@ __global__ __launch_bounds__(MB_NT, 2) void masked_up_block_kernel(const UpBlock
         }
 #pragma unroll
         for (int v = 0; v < C::WPT; ++v) {
-            const int idx = tid + v * MB_NT;
+            const int idx = tid + v * C::NT;
             if (idx < C::W4) wsm[idx] = make_uint4(wr[v][0], wr[v][1], wr[v][2], wr[v][3]);
         }
     };
 
     // epilogue operands, fetched next to the first chunk's loads and parked in LDS (no global load after a store)
-    float ep_r0 = 1.f, ep_r1 = 0.f, ep_r2 = 0.f;
+    float ep_r0[C::NSB], ep_r1 = 0.f, ep_r2 = 0.f;
     {
         const int co = co0 + tid;
-        if (tid < C::TN && co < p.cout) {
-            if (p.d) ep_r0 = p.d[((size_t)b * p.nreg + reg) * p.cout + co];
-            if (p.act_bias) ep_r1 = p.act_bias[co];
-        }
-        if (p.noise) {
+#pragma unroll
+        for (int j = 0; j < C::NSB; ++j) ep_r0[j] = (tid < C::TN && co < p.cout && p.d) ? p.d[((size_t)b * p.nreg + region_of(j)) * p.cout + co] : 1.f;
+        if (tid < C::TN && co < p.cout && p.act_bias) ep_r1 = p.act_bias[co];
+        if (p.noise && tid < MB_OUT * MB_OUT) {
             const int ny = tyt * MB_OUT + (tid >> 4), nx = txt * MB_OUT + (tid & 15);
             if (ny < ho && nx < wo) ep_r2 = p.noise_weight[0] * p.noise[(size_t)b * p.noise_bstride + (size_t)ny * wo + nx];
         }
@@ -161,8 +178,12 @@ __global__ __launch_bounds__(MB_NT, 2) void masked_up_block_kernel(const UpBlock
         __syncthreads();
         store_chunk(chunk);
         if (chunk == 0) {
-            if (tid < C::TN) { ep_d[tid] = ep_r0; ep_b[tid] = ep_r1; }
-            ep_n[tid] = ep_r2;
+            if (tid < C::TN) {
+#pragma unroll
+                for (int j = 0; j < C::NSB; ++j) ep_d[j * C::TN + tid] = ep_r0[j];
+                ep_b[tid] = ep_r1;
+            }
+            if (tid < MB_OUT * MB_OUT) ep_n[tid] = ep_r2;
         }
         __syncthreads();
         if (chunk + 1 < nchunk) load_chunk(chunk + 1);
@@ -170,7 +191,7 @@ __global__ __launch_bounds__(MB_NT, 2) void masked_up_block_kernel(const UpBlock
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
-            const int e = xoff + (1 - (ky >> 1)) * MB_PW + (1 - (kx >> 1));
+            const int e = xoff + (1 - (ky >> 1)) * C::PW + (1 - (kx >> 1));
             const int ai = 2 * (ky & 1) + (kx & 1);
             const int slot = e * 2 + (khalf ^ ((e >> 3) & 1));
             const uint4 bh = xh4[slot], bl = xl4[slot];
@@ -192,18 +213,23 @@ __global__ __launch_bounds__(MB_NT, 2) void masked_up_block_kernel(const UpBlock
         }
     }
 
-    // ---- epilogue: the pre-blur tile of 8 channels, z[2 pty + i][2 ptx + j]; output pixel (y, x) of the block = sum_{t,u} k[t][u] z[y + 1 + t][x + 1 + u]
+    // ---- epilogue: the pre-blur tiles of 8 channels, per sub-block z[2 pty + i][2 ptx + j]; output pixel (y, x) of a sub-block =
+    // sum_{t,u} k[t][u] z[y + 1 + t][x + 1 + u]
     __syncthreads();
-    float* zt = reinterpret_cast<float*>(lds_raw);       // [8][20][22]
+    float* zt = reinterpret_cast<float*>(lds_raw);       // [8][NSB][ZR][ZS]
     float kf[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) kf[t] = p.blur[15 - t];
-    const int bx = tid & 15, bco = (tid >> 4) & 7, byg = tid >> 7;           // blur item: column bx, channel bco of the pass, rows 8 byg .. +7
+    // blur item (threads 0..255): column bx of the block, channel bco of the pass, rows 8 byg .. +7
+    const int bx = tid & 15, bco = (tid >> 4) & 7, byg = (tid >> 7) & 1;
+    const bool blur_thread = tid < 256;
+    const int bsb = SUB == 1 ? 0 : 2 * byg + (bx >> 3);                       // sub-block of these 8 rows / this column
+    const int brow0 = SUB == 1 ? 8 * byg : 0, blx = SUB == 1 ? bx : (bx & 7);  // first row / column inside the sub-block
     const int oy0 = tyt * MB_OUT + 8 * byg, ox = txt * MB_OUT + bx;
     int nrow = ho - oy0;
-    nrow = nrow < 0 ? 0 : (nrow > 8 ? 8 : nrow);
+    nrow = (!blur_thread || nrow < 0) ? 0 : (nrow > 8 ? 8 : nrow);
     const bool col_ok = ox < wo;
-    const float* zc = zt + (bco * MB_ZR + 8 * byg + 1) * MB_ZS + bx + 1;
+    const float* zc = zt + ((bco * C::NSB + bsb) * C::ZR + brow0 + 1) * C::ZS + blx + 1;
     const float* nzp = ep_n + 8 * byg * MB_OUT + bx;
     const float neg = p.act ? 0.2f : 1.f, gain = p.act ? 1.41421356237309515f : 1.f;
 #pragma unroll
@@ -216,19 +242,20 @@ __global__ __launch_bounds__(MB_NT, 2) void masked_up_block_kernel(const UpBlock
                     const int col = 4 * khalf + rr;
 #pragma unroll
                     for (int ci = 0; ci < 2; ++ci)
-                        *reinterpret_cast<float2*>(&zt[(col * MB_ZR + 2 * pty + ci) * MB_ZS + 2 * ptx]) = make_float2(accs[2 * ci][i][4 * g + rr], accs[2 * ci + 1][i][4 * g + rr]);
+                        *reinterpret_cast<float2*>(&zt[((col * C::NSB + psb) * C::ZR + 2 * pty + ci) * C::ZS + 2 * ptx]) =
+                            make_float2(accs[2 * ci][i][4 * g + rr], accs[2 * ci + 1][i][4 * g + rr]);
                 }
             }
             __syncthreads();
             const int cl = i * 32 + 8 * g + bco;
             const int co = co0 + cl;
             if (nrow > 0 && col_ok && co < p.cout) {
-                const float dd = ep_d[cl], bi = ep_b[cl];
+                const float dd = ep_d[bsb * C::TN + cl], bi = ep_b[cl];
                 float* orow = p.out + ((size_t)b * p.cout + co) * ho * wo + (size_t)oy0 * wo + ox;
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3;
 #pragma unroll 1
                 for (int zr = 0; zr < 8 + 3; ++zr) {
-                    const float* zp = zc + zr * MB_ZS;
+                    const float* zp = zc + zr * C::ZS;
                     const float z0 = zp[0], z1 = zp[1], z2 = zp[2], z3 = zp[3];
                     a3 = 0.f;
                     a0 = __builtin_fmaf(z0, kf[12], a0); a1 = __builtin_fmaf(z0, kf[8], a1); a2 = __builtin_fmaf(z0, kf[4], a2); a3 = __builtin_fmaf(z0, kf[0], a3);
@@ -249,57 +276,74 @@ __global__ __launch_bounds__(MB_NT, 2) void masked_up_block_kernel(const UpBlock
     }
 }
 
-// flags[b][by][bx] = the region shared by all block x block output pixels of block (by, bx) (labels sampled 'nearest' at ho x wo exactly as
-// the masked kernels do), 255 if they differ or the shared label is no region (>= nreg)
-__global__ __launch_bounds__(256) void uniform_blocks_kernel(uint8_t* __restrict__ flags, const uint8_t* __restrict__ labels, int lh, int lw, int ho, int wo,
-                                                             float lsy, float lsx, int nreg, int block) {
+// One workgroup per 16 x 16 output block, one thread per output pixel (labels sampled 'nearest' at ho x wo exactly as the masked kernels do):
+//   sub[b][2 by + sy][2 bx + sx] = the region shared by the 8 x 8 sub-block's pixels, 255 if they differ or are no region (>= nreg);
+//   blocks[b][by][bx] = that region if all four sub-blocks share one, MB_QUAD if each sub-block is uniform but they differ, else 255.
+__global__ __launch_bounds__(256) void uniform_blocks_kernel(uint8_t* __restrict__ blocks, uint8_t* __restrict__ sub, const uint8_t* __restrict__ labels, int lh,
+                                                             int lw, int ho, int wo, float lsy, float lsx, int nreg, int want_quad) {
+    __shared__ int ref[4];
     const int b = blockIdx.z, by = blockIdx.y, bxk = blockIdx.x;
-    int first = -1;
-    bool same = true;
-    for (int i = threadIdx.x; i < block * block; i += 256) {
-        int oy = by * block + i / block, ox = bxk * block + i % block;
-        oy = oy < ho ? oy : ho - 1; ox = ox < wo ? ox : wo - 1;
-        const int c = labels[((size_t)b * lh + nearest_src(oy, lsy, lh)) * lw + nearest_src(ox, lsx, lw)];
-        if (first < 0) first = c;
-        same = same && c == first;
-    }
-    __shared__ int ref;
-    if (threadIdx.x == 0) ref = first;
+    const int y = threadIdx.x >> 4, x = threadIdx.x & 15;
+    int oy = by * MB_OUT + y, ox = bxk * MB_OUT + x;
+    oy = oy < ho ? oy : ho - 1; ox = ox < wo ? ox : wo - 1;
+    const int c = labels[((size_t)b * lh + nearest_src(oy, lsy, lh)) * lw + nearest_src(ox, lsx, lw)];
+    const int j = (y >> 3) * 2 + (x >> 3);
+    if ((y & 7) == 0 && (x & 7) == 0) ref[j] = c;
     __syncthreads();
-    const int ok = __syncthreads_and(same && (first < 0 || first == ref));
-    if (threadIdx.x == 0) flags[((size_t)b * gridDim.y + by) * gridDim.x + bxk] = (ok && ref < nreg) ? (uint8_t)ref : (uint8_t)255;
+    int r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ok = __syncthreads_and(j != k || c == ref[k]);
+        r[k] = (ok && ref[k] < nreg) ? ref[k] : 255;
+    }
+    if (threadIdx.x == 0) {
+        const size_t nbx = gridDim.x, nby = gridDim.y;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sub[((size_t)b * 2 * nby + 2 * by + (k >> 1)) * (2 * nbx) + 2 * bxk + (k & 1)] = (uint8_t)r[k];
+        const bool all_uni = r[0] != 255 && r[1] != 255 && r[2] != 255 && r[3] != 255;
+        const bool one = all_uni && r[0] == r[1] && r[0] == r[2] && r[0] == r[3];
+        blocks[((size_t)b * nby + by) * nbx + bxk] = one ? (uint8_t)r[0] : ((all_uni && want_quad) ? (uint8_t)MB_QUAD : (uint8_t)255);
+    }
 }
 
 }  // namespace
 
-extern "C" int e4s_uniform_blocks(uint8_t* flags, const uint8_t* labels, int bs, int lh, int lw, int ho, int wo, int nreg, int block, void* stream) {
-    E4S_REQUIRE(flags && labels, "uniform_blocks: null tensor");
-    E4S_REQUIRE(bs >= 0 && bs <= 65535 && lh >= 1 && lw >= 1 && ho >= 1 && wo >= 1 && block >= 1 && block <= 64 && nreg >= 1 && nreg <= E4S_MAX_REGIONS,
-                "uniform_blocks: bad size");
+extern "C" int e4s_uniform_blocks(uint8_t* blocks, uint8_t* sub, const uint8_t* labels, int bs, int lh, int lw, int ho, int wo, int nreg, int want_quad,
+                                  void* stream) {
+    E4S_REQUIRE(blocks && sub && labels, "uniform_blocks: null tensor");
+    E4S_REQUIRE(bs >= 0 && bs <= 65535 && lh >= 1 && lw >= 1 && ho >= 16 && wo >= 16 && (ho % 16) == 0 && (wo % 16) == 0 && nreg >= 1 && nreg <= E4S_MAX_REGIONS,
+                "uniform_blocks: bad size (output height / width multiples of 16)");
     if (bs == 0) return 0;
-    hipLaunchKernelGGL(uniform_blocks_kernel, dim3(cdiv(wo, block), cdiv(ho, block), bs), dim3(256), 0, (hipStream_t)stream, flags, labels, lh, lw, ho, wo,
-                       (float)lh / (float)ho, (float)lw / (float)wo, nreg, block);
+    hipLaunchKernelGGL(uniform_blocks_kernel, dim3(wo / 16, ho / 16, bs), dim3(256), 0, (hipStream_t)stream, blocks, sub, labels, lh, lw, ho, wo,
+                       (float)lh / (float)ho, (float)lw / (float)wo, nreg, want_quad);
     return check_launch("uniform_blocks");
 }
 
-// The region-uniform 16 x 16 output blocks of a masked up-sampling StyledConv (blocks[b][by][bx] < nreg; others are left untouched for
-// e4s_region_modconv3x3_sb with the same block map).  Weights: the transposed-conv preparation (e4s_modconv_prep_weights_sb, k = 3, not composed).
+// The 16 x 16 output blocks of a masked up-sampling StyledConv that lie under one region, or whose four 8 x 8 sub-blocks each do (blocks[b][by][bx]
+// != 255; the others are left untouched for e4s_region_modconv3x3_sb with the same block map).  Weights: the transposed-conv preparation (e4s_modconv_prep_weights_sb, k = 3, not composed).
 extern "C" int e4s_masked_upconv_blocks(float* out, const float* x, const uint16_t* whi, const uint16_t* wlo, const float* s, const float* d,
-                                        const uint8_t* blocks, const float* blur, const float* noise, int noise_bs, const float* noise_weight,
-                                        const float* act_bias, int act, int bs, int cin, int cout, int h, int w, int nreg, void* stream) {
-    E4S_REQUIRE(out && x && whi && wlo && s && blocks && blur, "masked_upconv_blocks: null tensor");
+                                        const uint8_t* blocks, const uint8_t* sub, const float* blur, const float* noise, int noise_bs,
+                                        const float* noise_weight, const float* act_bias, int act, int bs, int cin, int cout, int h, int w, int nreg,
+                                        int sub_blocks, void* stream) {
+    E4S_REQUIRE(out && x && whi && wlo && s && blocks && sub && blur, "masked_upconv_blocks: null tensor");
     E4S_REQUIRE(bs >= 0 && bs <= 65535 && cin >= 1 && cout >= 1 && h >= 8 && w >= 8 && (h % 8) == 0 && (w % 8) == 0, "masked_upconv_blocks: bad size (h, w multiples of 8)");
     E4S_REQUIRE(nreg >= 1 && nreg <= E4S_MAX_REGIONS, "masked_upconv_blocks: %d regions (max %d)", nreg, E4S_MAX_REGIONS);
     E4S_REQUIRE(!noise || (noise_weight && (noise_bs == 1 || noise_bs == bs)), "masked_upconv_blocks: noise needs its weight and batch 1 or bs");
     E4S_REQUIRE((((uintptr_t)whi | (uintptr_t)wlo) & 15) == 0, "masked_upconv_blocks: weight slabs must be 16-byte aligned");
     if (bs == 0) return 0;
     UpBlockParams p;
-    p.out = out; p.x = x; p.whi = reinterpret_cast<const uint4*>(whi); p.wlo = reinterpret_cast<const uint4*>(wlo); p.s = s; p.d = d; p.blocks = blocks;
+    p.out = out; p.x = x; p.whi = reinterpret_cast<const uint4*>(whi); p.wlo = reinterpret_cast<const uint4*>(wlo); p.s = s; p.d = d; p.blocks = blocks; p.sub = sub;
     p.blur = blur; p.noise = noise; p.noise_weight = noise_weight; p.act_bias = act_bias;
     p.noise_bstride = (noise && noise_bs == bs) ? 4 * h * w : 0; p.act = act;
     p.bs = bs; p.cin = cin; p.cout = cout; p.h = h; p.w = w; p.nreg = nreg;
     p.nbx = 2 * w / MB_OUT; p.nby = 2 * h / MB_OUT;
-    using C = UbCfg<2>;
-    hipLaunchKernelGGL(masked_up_block_kernel<2>, dim3(p.nbx * p.nby, cdiv(cout, C::TN), bs), dim3(MB_NT), C::LDS_BYTES, (hipStream_t)stream, p);
+    using C1 = UbCfg<2, 1>;
+    using C2 = UbCfg<2, 2>;
+    const dim3 grid(p.nbx * p.nby, cdiv(cout, C1::TN), bs);
+    hipLaunchKernelGGL((masked_up_block_kernel<2, 1>), grid, dim3(C1::NT), C1::LDS_BYTES, (hipStream_t)stream, p);   // blocks under one region
+    // blocks of four uniform 8 x 8 sub-blocks (only present in a map made with want_quad).  Measured on the benchmark maps (the 64 -> 128 layer,
+    // 8-pixel cells): 0.57 ms against the composed form's 0.47 — 144 positions are five waves on four SIMDs at 252 registers, one workgroup per
+    // CU; kept behind E4S_UP_SUBBLOCKS for masks where it is the 16 x 16 blocks that are rare.
+    if (sub_blocks) hipLaunchKernelGGL((masked_up_block_kernel<2, 2>), grid, dim3(C2::NT), C2::LDS_BYTES, (hipStream_t)stream, p);
     return check_launch("masked_upconv_blocks");
 }

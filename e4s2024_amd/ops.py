@@ -642,16 +642,24 @@ def can_fuse_rgb(cout: int, w: int, up: bool, masked: bool) -> bool:
 
 UP_BLOCKS = os.environ.get("E4S_UP_BLOCKS", "1") != "0"    # masked up layers: region-uniform 16 x 16 output blocks in the transposed-conv form
 UP_BLOCK = 16
+UP_SUBBLOCKS = os.environ.get("E4S_UP_SUBBLOCKS", "0") != "0"   # also blocks made of four uniform 8 x 8 sub-blocks (slower than the composed form on the benchmark maps)
 
 
-def uniform_blocks(labels: torch.Tensor, ho: int, wo: int, nreg: int) -> torch.Tensor:
-    """uint8 ``[bs, ho/16, wo/16]``: the region shared by all pixels of a 16 x 16 output block (labels sampled 'nearest' at ``ho`` x ``wo``),
-    255 where a block mixes regions (``e4s_uniform_blocks``)."""
+UP_BLOCK_QUAD = 254      # block map value: four region-uniform 8 x 8 sub-blocks with different regions
+
+
+def uniform_blocks(labels: torch.Tensor, ho: int, wo: int, nreg: int):
+    """``(blocks [bs, ho/16, wo/16], sub [bs, ho/8, wo/8])`` uint8 (``e4s_uniform_blocks``): ``sub`` = the region shared by all pixels of an
+    8 x 8 output sub-block (labels sampled 'nearest' at ``ho`` x ``wo``), 255 if they differ; ``blocks`` = the region of a 16 x 16 block whose
+    four sub-blocks share one, 254 if each sub-block is uniform but they differ, 255 otherwise."""
     lab = _labels_u8(labels, "labels")
     bs, lh, lw = lab.shape
-    out = torch.empty((bs, -(-ho // UP_BLOCK), -(-wo // UP_BLOCK)), dtype=torch.uint8, device=lab.device)
-    lib().call("e4s_uniform_blocks", _p(out), _p(lab), bs, lh, lw, ho, wo, nreg, UP_BLOCK, _stream())
-    return out
+    if ho % UP_BLOCK or wo % UP_BLOCK:
+        raise ValueError("uniform_blocks: output size must be a multiple of 16")
+    blocks = torch.empty((bs, ho // UP_BLOCK, wo // UP_BLOCK), dtype=torch.uint8, device=lab.device)
+    sub = torch.empty((bs, ho // 8, wo // 8), dtype=torch.uint8, device=lab.device)
+    lib().call("e4s_uniform_blocks", _p(blocks), _p(sub), _p(lab), bs, lh, lw, ho, wo, nreg, int(UP_SUBBLOCKS), _stream())
+    return blocks, sub
 
 
 def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: bool, cout: int, up: bool, rgb=None, want_out: bool = True,
@@ -703,10 +711,10 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
     if (up_blocks is not None and UP_BLOCKS and sb and up and labels is not None and w >= 32 and cout >= 128 and h % 8 == 0 and w % 8 == 0
             and cin % 16 == 0 and rgb is None and not (x_nhwc or out_nhwc) and sn is None):
         wt_t, blur_k = up_blocks
-        blocks = uniform_blocks(labels, ho, wo, nreg)
+        blocks, sub = uniform_blocks(labels, ho, wo, nreg)
         evb = _timed("masked_upconv_blocks", f"{cin}->{cout} @{h} up")
-        lib().call("e4s_masked_upconv_blocks", _p(out), _p(x), _p(wt_t[0]), _p(wt_t[1]), _p(s), _p(d), _p(blocks), _p(_c(blur_k, "blur kernel")), _p(nz),
-                   nbs or 0, _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, _stream())
+        lib().call("e4s_masked_upconv_blocks", _p(out), _p(x), _p(wt_t[0]), _p(wt_t[1]), _p(s), _p(d), _p(blocks), _p(sub), _p(_c(blur_k, "blur kernel")), _p(nz),
+                   nbs or 0, _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, int(UP_SUBBLOCKS), _stream())
         if evb is not None:
             evb.record()
     ev = _timed(modconv_kernel_name(cout, w, sb, labels is not None), f"{cin}->{cout} @{h}{' up' if up else ''}")

@@ -136,16 +136,20 @@ E4S_API int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16_t*
                                      float* rgb_out, const float* rgb_wt, const float* rgb_s, const float* rgb_bias,
                                      const float* rgb_skip, const float* rgb_up_kernel, const float* s_next,
                                      const uint8_t* uniform_blocks, void* stream);
-/* Masked up-sampling layers, region-uniform output blocks (model.py:287-300 per region == one transposed conv + blur where a 16 x 16 block
- * of output pixels has ONE region):
- *   e4s_uniform_blocks: blocks[b][by][bx] = that region (labels uint8 [bs][lh][lw] sampled 'nearest' at ho x wo), 255 = mixed / no region;
- *   e4s_masked_upconv_blocks: computes exactly the blocks with a region, in the transposed-conv form (weights: e4s_modconv_prep_weights_sb
- *   of the bare 3x3 weight), s [bs][nreg][cin], d [bs][nreg][cout], blur [4][4], out fp32 [bs][cout][2h][2w];
- *   e4s_region_modconv3x3_sb(..., uniform_blocks = the same map) then computes the remaining blocks in the composed form. */
-E4S_API int e4s_uniform_blocks(uint8_t* blocks, const uint8_t* labels, int bs, int lh, int lw, int ho, int wo, int nreg, int block, void* stream);
+/* Masked up-sampling layers, region-uniform output blocks (model.py:287-300 per region == one transposed conv + blur where a block of output
+ * pixels has ONE region):
+ *   e4s_uniform_blocks: sub[b][2by+sy][2bx+sx] = the region of an 8 x 8 output sub-block (labels uint8 [bs][lh][lw] sampled 'nearest' at
+ *   ho x wo), 255 = mixed / no region; blocks[b][by][bx] = the region of a 16 x 16 block if its four sub-blocks share one, 254 if each of
+ *   them is uniform but they differ (only with want_quad; e4s_masked_upconv_blocks then needs sub_blocks = 1), 255 otherwise;
+ *   e4s_masked_upconv_blocks: computes exactly the blocks != 255 in the transposed-conv form (weights: e4s_modconv_prep_weights_sb of the
+ *   bare 3x3 weight), s [bs][nreg][cin], d [bs][nreg][cout], blur [4][4], out fp32 [bs][cout][2h][2w];
+ *   e4s_region_modconv3x3_sb(..., uniform_blocks = the same block map) then computes the remaining blocks in the composed form. */
+E4S_API int e4s_uniform_blocks(uint8_t* blocks, uint8_t* sub, const uint8_t* labels, int bs, int lh, int lw, int ho, int wo, int nreg, int want_quad,
+                               void* stream);
 E4S_API int e4s_masked_upconv_blocks(float* out, const float* x, const uint16_t* whi, const uint16_t* wlo, const float* s, const float* d,
-                                     const uint8_t* blocks, const float* blur, const float* noise, int noise_bs, const float* noise_weight,
-                                     const float* act_bias, int act, int bs, int cin, int cout, int h, int w, int nreg, void* stream);
+                                     const uint8_t* blocks, const uint8_t* sub, const float* blur, const float* noise, int noise_bs,
+                                     const float* noise_weight, const float* act_bias, int act, int bs, int cin, int cout, int h, int w, int nreg,
+                                     int sub_blocks, void* stream);
 /* rgb_* (all NULL = off): fuse the single-region ToRGB that follows this layer (model.py:439-479) into the epilogue — allowed for
  * same-resolution layers of width >= 32 whose Cout fits one workgroup tile (<= 64, or <= 128 on masked layers): rgb_out [bs,3,h,w] =
  * sum_co out[co] * rgb_wt[co][o] * rgb_s[b][co] + rgb_bias[o] + upfirdn2d(rgb_skip, rgb_up_kernel, up=2, pad=(2,1)), so the layer's

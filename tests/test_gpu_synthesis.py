@@ -312,18 +312,19 @@ def test_masked_layers_ragged_shapes_against_oracle(sg2, shape, upsample):
         assert maxdiff(yr, refr) <= 3e-5 * max(1.0, float(refr.abs().max()))
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 128, 32, 32, 5, 64, 64), (1, 48, 136, 40, 32, 12, 160, 128), (1, 16, 128, 32, 48, 3, 32, 48)])
+@pytest.mark.parametrize("shape", [(2, 32, 128, 32, 32, 5, 64, 64, 4), (1, 48, 136, 40, 32, 12, 160, 128, 4), (1, 16, 128, 32, 48, 3, 32, 48, 4),
+                                   (2, 32, 128, 32, 32, 5, 64, 64, 8), (1, 64, 192, 64, 32, 12, 128, 64, 8)])
 def test_masked_up_layer_uniform_blocks_against_oracle_and_composed_form(sg2, shape):
     """Masked up-sampling StyledConv with the region-uniform 16 x 16 output blocks in the transposed-conv form (``e4s_masked_upconv_blocks``) and
     the mixed ones in the composed form: label maps made of uniform blocks, mixed blocks, blocks without a region and a label map at another
     resolution — against the oracle, against the all-composed route, and each output block written by exactly one kernel (NaN-prefilled)."""
-    bs, cin, cout, h, w, nreg, lh, lw = shape
-    rs = np.random.RandomState(17 * cin + h)
-    ry, rx = lh // 4, lw // 4                                                # coarse cells -> large uniform areas
-    cells = rs.randint(0, nreg, (bs, 4, 4)).astype(np.uint8)
+    bs, cin, cout, h, w, nreg, lh, lw, ncell = shape
+    rs = np.random.RandomState(17 * cin + h + ncell)
+    ry, rx = lh // ncell, lw // ncell                                        # coarse cells -> uniform 16 x 16 blocks (4) or 8 x 8 sub-blocks (8)
+    cells = rs.randint(0, nreg, (bs, ncell, ncell)).astype(np.uint8)
     lab = np.repeat(np.repeat(cells, ry, axis=1), rx, axis=2)
     lab[:, : lh // 4, : lw // 4] = rs.randint(0, nreg, (bs, lh // 4, lw // 4))  # a corner of per-pixel noise: mixed blocks
-    lab[:, lh - ry // 2:, lw - rx // 2:] = 255                                # an area that belongs to no region
+    lab[:, lh - max(ry, lh // 8) // 2:, lw - max(rx, lw // 8) // 2:] = 255    # an area that belongs to no region
     onehot = torch.zeros(bs, nreg, lh, lw)
     for c in range(nreg):
         onehot[:, c] = T((lab == c).astype(np.float32))
@@ -339,18 +340,24 @@ def test_masked_up_layer_uniform_blocks_against_oracle_and_composed_form(sg2, sh
     nz = T(rs.standard_normal((bs, 1, 2 * h, 2 * w)).astype(np.float32))
     m = m.to(DEV)
     labd = T(lab).to(DEV)
-    blocks = _ops.uniform_blocks(labd, 2 * h, 2 * w, nreg).cpu().numpy()
-    assert (blocks < nreg).any() and (blocks == 255).any()                    # both kinds of block are present
-    old = _ops.UP_BLOCKS
+    _sub_was = _ops.UP_SUBBLOCKS
+    _ops.UP_SUBBLOCKS = ncell == 8
+    blocks, sub = (t.cpu().numpy() for t in _ops.uniform_blocks(labd, 2 * h, 2 * w, nreg))
+    _ops.UP_SUBBLOCKS = _sub_was
+    assert ((blocks < nreg).any() or ncell == 8) and (blocks == 255).any()    # uniform and mixed blocks are present
+    assert ncell != 8 or (blocks == _ops.UP_BLOCK_QUAD).any()                 # ... and blocks of four uniform sub-blocks with 8 cells per side
+    up2 = np.repeat(np.repeat(sub, 2, axis=1), 2, axis=2)[:, ::2, ::2]         # (sanity of the two maps against each other)
+    assert sub.shape == (bs, blocks.shape[1] * 2, blocks.shape[2] * 2) and up2.shape == sub.shape
+    old, old_sub = _ops.UP_BLOCKS, _ops.UP_SUBBLOCKS
     try:
         with torch.no_grad():
-            _ops.UP_BLOCKS = True
+            _ops.UP_BLOCKS, _ops.UP_SUBBLOCKS = True, ncell == 8
             y = m(x.to(DEV), st.to(DEV), labd, noise=nz.to(DEV))
             y2 = m(x.to(DEV), st.to(DEV), labd, noise=nz.to(DEV))
             _ops.UP_BLOCKS = False
             yc = m(x.to(DEV), st.to(DEV), labd, noise=nz.to(DEV))
     finally:
-        _ops.UP_BLOCKS = old
+        _ops.UP_BLOCKS, _ops.UP_SUBBLOCKS = old, old_sub
     ref = O.styled_conv(sd, "", x, st, onehot, nz, masked=True, upsample=True)
     scale = max(1.0, float(ref.abs().max()))
     assert torch.equal(y, y2)
