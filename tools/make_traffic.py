@@ -28,8 +28,9 @@ KEYS = {
                                             "7 launches per step (6 plain + 1 with fused ToRGB and split-plane output; on the benchmark maps the 128->256 up "
                                             "layer's launch leaves at once: its blocks are all region-uniform and run in masked_up_block_kernel); dword activation "
                                             "loads: no FETCH correction", (823900000 - 4 * (256 * 128 * 128 * 4 + 128 * 256 * 256 * 4)) // 7),
-    "masked_upconv_blocks": (["masked_up_block_kernel"], 1.0, "the region-uniform blocks of the masked up layers (benchmark maps: the 128->256 layer); dword loads",
-                             4 * (256 * 128 * 128 * 4 + 128 * 256 * 256 * 4)),
+    "masked_upconv_blocks": (["masked_up_block_kernel"], 1.0, "3 launches per step (the masked up layers of width >= 32); on the benchmark maps only the 128->256 "
+                             "layer has region-uniform blocks, the other two launches leave at once: averages over all three; dword loads",
+                             4 * (256 * 128 * 128 * 4 + 128 * 256 * 256 * 4) // 3),
     "chain_conv3x3<32>": (["chain_conv_kernel<1, 2"], 2.0, "LDS-DMA dwordx4 only: FETCH_SIZE x2 (guide)", 4 * (32 * 1024 * 1024 * 4 + 3 * 1024 * 1024 * 4 + 3 * 512 * 512 * 4)),
     "chain_conv3x3<64>": (["chain_conv_kernel<2, 4"], 2.0, "LDS-DMA dwordx4 only: FETCH_SIZE x2 (guide)", 4 * (2 * 64 * 512 * 512 * 4 + 3 * 512 * 512 * 4 + 3 * 256 * 256 * 4)),
     "modconv_up_fused_sb": (["up_fused"], 2.0, "2 launches per step (256->512, 512->1024), split-plane in/out, 16-byte loads: FETCH_SIZE x2 (guide)",
