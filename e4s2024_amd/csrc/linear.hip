@@ -93,3 +93,102 @@ extern "C" int e4s_grouped_linear(float* out, int64_t out_stride_b, int64_t out_
                            gp, addend, scale, bias_mul, act, slope, bs, in_dim, out_dim);
     return check_launch("grouped_linear");
 }
+
+// ------------------------------------------------------------------------------------ backward of the grouped linear (f1: the PTI loop trains the MLPs)
+// y[b,g,o] = act(scale * sum_i W[g][o][i] x[b,g,i] + bias_mul * bias[g][o]);  gy = dL/dy, already multiplied by act'(y) by the caller's kernel below.
+//
+// (1) weight / bias gradients: dW[g][o][i] = scale * sum_b gy[b,g,o] x[b,g,i]  (an outer product per group: written once, 16-byte stores),
+//     db[g][o] = bias_mul * sum_b gy[b,g,o].  dW / db are dense [groups][out][in] / [groups][out]: the caller hands out per-group views.
+__global__ __launch_bounds__(256) void grouped_linear_wgrad_kernel(float* __restrict__ dW, float* __restrict__ db, const float* __restrict__ gy,
+                                                                   const float* __restrict__ x, float scale, float bias_mul, int bs, int groups, int in_dim,
+                                                                   int out_dim) {
+    const int g = blockIdx.y;
+    const int o0 = blockIdx.x * 8;
+    const int n4 = in_dim >> 2;
+    for (int i4 = threadIdx.x; i4 < n4; i4 += 256) {
+        float4 acc[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b = 0; b < bs; ++b) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + ((size_t)b * groups + g) * in_dim + 4 * i4);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float gv = o0 + r < out_dim ? gy[((size_t)b * groups + g) * out_dim + o0 + r] : 0.f;
+                acc[r].x += gv * xv.x; acc[r].y += gv * xv.y; acc[r].z += gv * xv.z; acc[r].w += gv * xv.w;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (o0 + r < out_dim)
+                *reinterpret_cast<float4*>(dW + ((size_t)g * out_dim + o0 + r) * in_dim + 4 * i4) = make_float4(acc[r].x * scale, acc[r].y * scale, acc[r].z * scale, acc[r].w * scale);
+    }
+    if (db && threadIdx.x < 8 && o0 + (int)threadIdx.x < out_dim) {
+        float a = 0.f;
+        for (int b = 0; b < bs; ++b) a += gy[((size_t)b * groups + g) * out_dim + o0 + threadIdx.x];
+        db[(size_t)g * out_dim + o0 + threadIdx.x] = a * bias_mul;
+    }
+}
+
+// (2) input gradient: dx[b,g,i] = scale * sum_o W[g][o][i] gy[b,g,o], optionally times lrelu'(h[b,g,i]) of the PREVIOUS layer's output h (the
+//     sign of a leaky-relu output is the sign of its input).  The sum over o is split over `osplit` workgroups per (group, 1024 inputs); the
+//     partial sums are added in a fixed order by the finishing kernel (no atomics).
+constexpr int LIN_BWD_BT = 8;
+__global__ __launch_bounds__(256) void grouped_linear_dgrad_kernel(float* __restrict__ part, const float* __restrict__ gy, const GroupPtrs gp, int bs, int groups,
+                                                                   int in_dim, int out_dim, int osplit) {
+    const int g = blockIdx.y, os = blockIdx.x, i4 = blockIdx.z * 256 + threadIdx.x;
+    const int n4 = in_dim >> 2;
+    if (i4 >= n4) return;
+    const int per = (out_dim + osplit - 1) / osplit;
+    const int o_begin = os * per, o_end = o_begin + per < out_dim ? o_begin + per : out_dim;
+    const float* __restrict__ W = gp.W[g];
+    float4 acc[LIN_BWD_BT];
+#pragma unroll
+    for (int b = 0; b < LIN_BWD_BT; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int o = o_begin; o < o_end; ++o) {
+        const float4 w = *reinterpret_cast<const float4*>(W + (size_t)o * in_dim + 4 * i4);
+#pragma unroll
+        for (int b = 0; b < LIN_BWD_BT; ++b)
+            if (b < bs) {
+                const float gv = gy[((size_t)b * groups + g) * out_dim + o];
+                acc[b].x += gv * w.x; acc[b].y += gv * w.y; acc[b].z += gv * w.z; acc[b].w += gv * w.w;
+            }
+    }
+#pragma unroll
+    for (int b = 0; b < LIN_BWD_BT; ++b)
+        if (b < bs) *reinterpret_cast<float4*>(part + ((((size_t)os * bs + b) * groups + g) * in_dim) + 4 * i4) = acc[b];
+}
+
+__global__ __launch_bounds__(256) void grouped_linear_dgrad_finish_kernel(float* __restrict__ dx, const float* __restrict__ part, const float* __restrict__ h, float scale,
+                                                                          float slope, long long total, int osplit) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    float a = 0.f;
+    for (int k = 0; k < osplit; ++k) a += part[(size_t)k * total + i];
+    a *= scale;
+    if (h) a *= h[i] > 0.f ? 1.f : slope;
+    dx[i] = a;
+}
+
+extern "C" int e4s_grouped_linear_bwd(float* dW, float* db, float* dx, float* scratch, const float* gy, const float* x, const float* const* W, const float* h_prev,
+                                      float scale, float bias_mul, float slope, int bs, int groups, int in_dim, int out_dim, int osplit, void* stream) {
+    E4S_REQUIRE(gy && x, "grouped_linear_bwd: null tensor");
+    E4S_REQUIRE(bs >= 1 && bs <= LIN_BWD_BT && groups >= 1 && groups <= LIN_MAX_GROUPS && in_dim >= 4 && (in_dim % 4) == 0 && out_dim >= 1 && osplit >= 1 && osplit <= 256,
+                "grouped_linear_bwd: bad size (batch <= %d, groups <= %d, in_dim a multiple of 4)", LIN_BWD_BT, LIN_MAX_GROUPS);
+    E4S_REQUIRE(!dx || (W && scratch), "grouped_linear_bwd: the input gradient needs the weights and a scratch of osplit * bs * groups * in_dim floats");
+    E4S_REQUIRE((((uintptr_t)x | (uintptr_t)dW | (uintptr_t)scratch) & 15) == 0, "grouped_linear_bwd: tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (dW)
+        hipLaunchKernelGGL(grouped_linear_wgrad_kernel, dim3(cdiv(out_dim, 8), groups), dim3(256), 0, st, dW, db, gy, x, scale, bias_mul, bs, groups, in_dim, out_dim);
+    if (dx) {
+        GroupPtrs gp;
+        for (int g = 0; g < LIN_MAX_GROUPS; ++g) {
+            gp.W[g] = g < groups ? W[g] : nullptr;
+            gp.bias[g] = nullptr;
+            if (g < groups) E4S_REQUIRE(W[g] && ((uintptr_t)W[g] & 15) == 0, "grouped_linear_bwd: null / unaligned weight pointer for group %d", g);
+        }
+        hipLaunchKernelGGL(grouped_linear_dgrad_kernel, dim3(osplit, groups, cdiv(in_dim / 4, 256)), dim3(256), 0, st, scratch, gy, gp, bs, groups, in_dim, out_dim, osplit);
+        const long long total = (long long)bs * groups * in_dim;
+        hipLaunchKernelGGL(grouped_linear_dgrad_finish_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, dx, scratch, h_prev, scale, slope, total, osplit);
+    }
+    return check_launch("grouped_linear_bwd");
+}

@@ -42,6 +42,11 @@ def local_mlps(mlps, x, addend=None):
     out = ops.grouped_linear(h, [l.weight for l in l2], [l.bias for l in l2], scale=l2[0].scale, bias_mul=l2[0].lr_mul, act=0, addend=addend)
     deps = [x] + [p for l in l0 + l2 for p in (l.weight, l.bias)]
     n = len(mlps)
+    if (torch.is_grad_enabled() and ops.NATIVE_BWD and any(d.requires_grad for d in deps) and x.shape[0] <= 8 and x.shape[2] % 4 == 0
+            and h.shape[2] % 4 == 0 and x.is_contiguous() and all(l.bias is not None for l in l0 + l2)):
+        # gradients from the grouped-linear backward kernels (no re-evaluation, no stacked copy of the weights)
+        return ops.local_mlps_grad(x, out, h, [l.weight for l in l0], [l.bias for l in l0], [l.weight for l in l2], [l.bias for l in l2],
+                                   l0[0].scale, l2[0].scale, l0[0].lr_mul, l2[0].lr_mul, slope)
 
     def ref(xr, *ps):     # ps: (w, b) of the n first layers, then of the n second layers
         return torch_ref.local_mlps(xr, ps[0:2 * n:2], ps[1:2 * n:2], ps[2 * n::2], ps[2 * n + 1::2], l0[0].scale, l2[0].scale, l0[0].lr_mul,

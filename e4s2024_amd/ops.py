@@ -1739,6 +1739,51 @@ def grouped_linear(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Opt
     return out
 
 
+class _LocalMLPsGrad(torch.autograd.Function):
+    """The per-region LocalMLP stack (networks.py:23-49, 236-244) with known forward values: ``h = lrelu(scale0 W0 x + lr0 b0)`` and
+    ``out = scale2 W2 h + lr2 b2 (+ addend)`` came from two ``grouped_linear`` launches; the gradients of x and of the 4 n parameters come from
+    ``e4s_grouped_linear_bwd`` (outer products for the weights, a split transposed mat-vec for the inputs): no stacking of the 12 x 13.6 MB
+    weights, no library GEMM, no re-evaluation."""
+
+    @staticmethod
+    def forward(ctx, x, out, h, scale0, scale2, lr0, lr2, slope, *params):
+        n = len(params) // 4
+        ctx.save_for_backward(x, h, *params[:n], *params[2 * n:3 * n])          # x, h, W0 (n), W2 (n)
+        ctx.consts = (n, float(scale0), float(scale2), float(lr0), float(lr2), float(slope))
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        n, scale0, scale2, lr0, lr2, slope = ctx.consts
+        x, h = ctx.saved_tensors[0], ctx.saved_tensors[1]
+        w0, w2 = ctx.saved_tensors[2:2 + n], ctx.saved_tensors[2 + n:2 + 2 * n]
+        bs, _, in0 = x.shape
+        hid, out2 = h.shape[2], g.shape[2]
+        g = g.contiguous()
+        xc, hc = x.contiguous(), h.contiguous()
+        dev = g.device
+        PtrArr = ctypes.c_void_p * n
+        # layer 2: dW2, db2, and dL/d(pre-activation of layer 0) = scale2 W2^T g * lrelu'(h)
+        dW2 = torch.empty((n, out2, hid), dtype=torch.float32, device=dev)
+        db2 = torch.empty((n, out2), dtype=torch.float32, device=dev)
+        gy0 = torch.empty((bs, n, hid), dtype=torch.float32, device=dev)
+        os2 = 32
+        scratch = torch.empty((os2 * bs * n * max(hid, in0),), dtype=torch.float32, device=dev)
+        lib().call("e4s_grouped_linear_bwd", _p(dW2), _p(db2), _p(gy0), _p(scratch), _p(g), _p(hc), PtrArr(*[w.data_ptr() for w in w2]), _p(hc),
+                   scale2, lr2, slope, bs, n, hid, out2, os2, _stream())
+        # layer 0: dW0, db0, dx
+        dW0 = torch.empty((n, hid, in0), dtype=torch.float32, device=dev)
+        db0 = torch.empty((n, hid), dtype=torch.float32, device=dev)
+        dx = torch.empty_like(xc) if ctx.needs_input_grad[0] else None
+        lib().call("e4s_grouped_linear_bwd", _p(dW0), _p(db0), _p(dx), _p(scratch), _p(gy0), _p(xc), PtrArr(*[w.data_ptr() for w in w0]), None,
+                   scale0, lr0, slope, bs, n, in0, hid, 8, _stream())
+        return (dx, None, None, None, None, None, None, None) + tuple(dW0.unbind(0)) + tuple(db0.unbind(0)) + tuple(dW2.unbind(0)) + tuple(db2.unbind(0))
+
+
+def local_mlps_grad(x, out, h, w0, b0, w2, b2, scale0, scale2, lr0, lr2, slope):
+    return _LocalMLPsGrad.apply(x, out, h, scale0, scale2, lr0, lr2, slope, *w0, *b0, *w2, *b2)
+
+
 # ----------------------------------------------------------------------------- kernel timing hook
 class KernelTimer:
     """Optional HIP-event timing of individual launches on the current stream (used by bench.py for the roofline of

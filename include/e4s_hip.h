@@ -235,6 +235,15 @@ E4S_API int e4s_grouped_linear(float* out, int64_t out_stride_b, int64_t out_str
                        float scale, float bias_mul, int act, float slope,
                        int bs, int groups, int in_dim, int out_dim, void* stream);
 
+/* Backward of e4s_grouped_linear for dense [bs][groups][...] tensors (f1: PTI trains the LocalMLPs, training/video_swap_ft_coach.py:297-299).
+ * gy = dL/d(pre-activation) [bs][groups][out_dim].  dW [groups][out_dim][in_dim] = scale * sum_b gy x^T and db [groups][out_dim] =
+ * bias_mul * sum_b gy (either may be NULL);  dx [bs][groups][in_dim] = scale * W^T gy, times leaky_relu'(h_prev) when h_prev (the previous
+ * layer's OUTPUT, same shape as dx) is given — or NULL for no input gradient.  scratch: osplit * bs * groups * in_dim floats (the sum over
+ * out_dim is split over osplit workgroups and finished in a fixed order).  bs <= 8, in_dim % 4 == 0. */
+E4S_API int e4s_grouped_linear_bwd(float* dW, float* db, float* dx, float* scratch, const float* gy, const float* x, const float* const* W,
+                                   const float* h_prev, float scale, float bias_mul, float slope, int bs, int groups, int in_dim, int out_dim,
+                                   int osplit, void* stream);
+
 /* ------------------------------------------------------------------------------------ a8 / a9: plain convolutions
  * Replaces the F.conv2d calls of the regional-style encoder (models/encoders/psp_encoders.py:334, helpers.py:128-139)
  * and of BiSeNet / ResNet-18 (swap_face_fine/face_parsing/model.py:23-35, resnet.py:15-49) with one implicit-GEMM kernel on

@@ -579,3 +579,41 @@ def test_implicit_weight_gradient_against_unfold_and_fp64(cin, cout, h, ks, up, 
     err = (got.double() - ref64).abs().max().item() / ref64.abs().max().item()
     record_parity(f"mconv_wgrad.cin{cin}_cout{cout}_h{h}_k{ks}_up{up}_{'masked' if masked else 'plain'}.rel_vs_fp64", err, 3e-5)
     assert err <= 3e-5
+
+
+@pytest.mark.parametrize("bs,n,dim_in,dim_style,layers", [(1, 12, 1280, 512, 13), (2, 3, 40, 32, 2), (8, 5, 64, 128, 1)])
+def test_local_mlps_native_backward_against_autograd(bs, n, dim_in, dim_style, layers):
+    """The per-region LocalMLP stack: gradients of the input and of all 4 n parameters from ``e4s_grouped_linear_bwd`` (``ops._LocalMLPsGrad``)
+    against autograd through the stock-PyTorch form (``torch_ref.local_mlps``), at the real size (12 x [512, 1280] + 12 x [6656, 512]) and small ones."""
+    install_dropin()
+    from models import networks
+    from e4s2024_amd import ops, torch_ref
+    torch.manual_seed(bs * 100 + n)
+    mlps = [networks.LocalMLP(dim_in, dim_style, layers).to(DEV) for _ in range(n)]
+    for m in mlps:
+        for p in m.parameters():
+            p.data.normal_(0, 0.5)
+    x = torch.randn(bs, n, dim_in, device=DEV, requires_grad=True)
+    add = torch.randn(layers * dim_style, device=DEV)
+    wgt = torch.randn(bs, n, layers * dim_style, device=DEV)
+    assert ops.NATIVE_BWD
+    out = networks.local_mlps(mlps, x, addend=add)
+    assert "LocalMLPsGrad" in type(out.grad_fn).__name__
+    (out * wgt).sum().backward()
+    got = [x.grad.clone()] + [p.grad.clone() for m in mlps for p in m.parameters()]
+    x.grad = None
+    for m in mlps:
+        for p in m.parameters():
+            p.grad = None
+    l0, l2 = [m.mlp[0] for m in mlps], [m.mlp[2] for m in mlps]
+    ref = torch_ref.local_mlps(x, [l.weight for l in l0], [l.bias for l in l0], [l.weight for l in l2], [l.bias for l in l2], l0[0].scale, l2[0].scale,
+                               l0[0].lr_mul, l2[0].lr_mul, mlps[0].mlp[1].negative_slope, add)
+    assert (out - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+    (ref * wgt).sum().backward()
+    want = [x.grad] + [p.grad for m in mlps for p in m.parameters()]
+    worst = 0.0
+    for a, b in zip(got, want):
+        assert a.shape == b.shape
+        worst = max(worst, (a - b).abs().max().item() / max(1e-6, b.abs().max().item()))
+    record_parity(f"local_mlps.native_backward.bs{bs}_n{n}_{dim_in}x{dim_style}x{layers}.rel_vs_autograd", worst, 2e-4)
+    assert worst <= 2e-4
