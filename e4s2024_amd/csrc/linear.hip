@@ -192,3 +192,43 @@ extern "C" int e4s_grouped_linear_bwd(float* dW, float* db, float* dx, float* sc
     }
     return check_launch("grouped_linear_bwd");
 }
+
+// ------------------------------------------------------------------------------------ small constant linear map over a long axis
+// out[j][n] = sum_k T[j][k] * w[n][k]      (trans = 0: w [N][K] -> out [J][N];   the parity composition of an up layer's 3x3 weight with its blur:
+//                                           J = 36 composed taps, K = 9, N = cout * cin, T a constant of the blur kernel)
+// dw[n][k]  = sum_j T[j][k] * g[j][n]      (trans = 1: its transpose, the gradient of w)
+// J, K <= 36: T lives in LDS, one thread per n.
+constexpr int SM_MAX = 36;
+__global__ __launch_bounds__(256) void small_map_kernel(float* __restrict__ out, const float* __restrict__ T, const float* __restrict__ in, int J, int K, long long N,
+                                                        int trans) {
+    __shared__ float t[SM_MAX * SM_MAX];
+    for (int i = threadIdx.x; i < J * K; i += 256) t[i] = T[i];
+    __syncthreads();
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    if (!trans) {
+        float w[SM_MAX];
+        for (int k = 0; k < K; ++k) w[k] = in[n * K + k];
+        for (int j = 0; j < J; ++j) {
+            float a = 0.f;
+            for (int k = 0; k < K; ++k) a += t[j * K + k] * w[k];
+            out[(long long)j * N + n] = a;
+        }
+    } else {
+        float a[SM_MAX];
+        for (int k = 0; k < K; ++k) a[k] = 0.f;
+        for (int j = 0; j < J; ++j) {
+            const float gv = in[(long long)j * N + n];
+            for (int k = 0; k < K; ++k) a[k] += t[j * K + k] * gv;
+        }
+        for (int k = 0; k < K; ++k) out[n * K + k] = a[k];
+    }
+}
+
+extern "C" int e4s_small_map(float* out, const float* T, const float* in, int J, int K, int64_t N, int trans, void* stream) {
+    E4S_REQUIRE(out && T && in, "small_map: null tensor");
+    E4S_REQUIRE(J >= 1 && J <= SM_MAX && K >= 1 && K <= SM_MAX && N >= 0, "small_map: J, K in 1..%d", SM_MAX);
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(small_map_kernel, dim3((unsigned)cdiv64(N, 256)), dim3(256), 0, (hipStream_t)stream, out, T, in, J, K, (long long)N, trans);
+    return check_launch("small_map");
+}

@@ -1780,6 +1780,70 @@ class _LocalMLPsGrad(torch.autograd.Function):
         return (dx, None, None, None, None, None, None, None) + tuple(dW0.unbind(0)) + tuple(db0.unbind(0)) + tuple(dW2.unbind(0)) + tuple(db2.unbind(0))
 
 
+class _SmallMap(torch.autograd.Function):
+    """``out[j, ...] = sum_k T[j, k] * w[..., k]`` for a constant ``T [J, K]`` (J, K <= 36) — the parity composition of an up layer's weight
+    (``torch_ref._parity_weights``) — and its gradient, one launch each (``e4s_small_map``)."""
+
+    @staticmethod
+    def forward(ctx, w, T):
+        w, T = _c(w, "w"), _c(T, "T")
+        J, K = T.shape
+        if w.shape[-1] != K:
+            raise ValueError(f"small_map: last dimension {w.shape[-1]} != {K}")
+        n = w.numel() // K
+        out = torch.empty((J,) + tuple(w.shape[:-1]), dtype=torch.float32, device=w.device)
+        lib().call("e4s_small_map", _p(out), _p(T), _p(w), J, K, n, 0, _stream())
+        ctx.save_for_backward(T)
+        ctx.wshape = tuple(w.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (T,) = ctx.saved_tensors
+        J, K = T.shape
+        g = g.contiguous()
+        dw = torch.empty(ctx.wshape, dtype=torch.float32, device=g.device)
+        lib().call("e4s_small_map", _p(dw), _p(T), _p(g), J, K, dw.numel() // K, 1, _stream())
+        return dw, None
+
+
+def small_map(w, T):
+    return _SmallMap.apply(w, T)
+
+
+class _EqualLinearGrad(torch.autograd.Function):
+    """``scale * x @ W^T + lr_mul * bias`` (EqualLinear without activation, model.py:154-162) for ``x [bs <= 8, in]`` with the grouped-linear
+    kernels in both directions (one group): the modulation vectors of the single-region layers under autograd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, scale, lr_mul):
+        xc = _c(x, "x")
+        out = grouped_linear(xc[:, None, :], [weight], [bias], scale=scale, bias_mul=lr_mul, act=0)[:, 0]
+        ctx.save_for_backward(xc, weight)
+        ctx.consts = (float(scale), float(lr_mul))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        scale, lr = ctx.consts
+        bs, in_dim = x.shape
+        out_dim = w.shape[0]
+        g = g.contiguous()
+        dW = torch.empty((1, out_dim, in_dim), dtype=torch.float32, device=g.device)
+        db = torch.empty((1, out_dim), dtype=torch.float32, device=g.device)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        osplit = 8
+        scratch = torch.empty((osplit * bs * in_dim,), dtype=torch.float32, device=g.device)
+        lib().call("e4s_grouped_linear_bwd", _p(dW), _p(db), _p(dx), _p(scratch), _p(g), _p(x), (ctypes.c_void_p * 1)(_c(w, "weight").data_ptr()), None,
+                   scale, lr, 0.0, bs, 1, in_dim, out_dim, osplit, _stream())
+        return dx, dW[0], db[0], None, None
+
+
+def equal_linear_grad(x, weight, bias, scale, lr_mul):
+    return _EqualLinearGrad.apply(x, weight, bias, scale, lr_mul)
+
+
 def local_mlps_grad(x, out, h, w0, b0, w2, b2, scale0, scale2, lr0, lr2, slope):
     return _LocalMLPsGrad.apply(x, out, h, scale0, scale2, lr0, lr2, slope, *w0, *b0, *w2, *b2)
 

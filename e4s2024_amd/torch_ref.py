@@ -106,7 +106,13 @@ def _composed_up_weights(ws, blur, dtype):
 def _parity_weights(ws, blur, dtype):
     """The composed 3x3 weight of each output parity g = 2a+b of an up-sampling layer, ``[4, cout, cin, 3, 3]``:
     ``W_g[dy,dx] = C2[4-2dy+a][4-2dx+b]`` (= ``C2[:, :, a::2, b::2].flip(2, 3)``), as one contraction with a cached constant."""
-    return torch.einsum("gyxkl,oikl->goiyx", _blur_shift(blur, dtype)[1], ws)
+    par = _blur_shift(blur, dtype)[1]
+    if ws.is_cuda and ws.dtype == torch.float32:
+        from . import ops
+        if ops.NATIVE_BWD:      # one launch (and one for its gradient) instead of a library GEMM of 36 x 9 x (cout cin)
+            co, ci = ws.shape[:2]
+            return ops.small_map(ws.reshape(co, ci, 9), par.reshape(36, 9)).view(4, 3, 3, co, ci).permute(0, 3, 4, 1, 2)
+    return torch.einsum("gyxkl,oikl->goiyx", par, ws)
 
 
 def _region_sum(x, styles, labels, weight, mod_w, mod_b, mod_scale, mod_lr, demodulate, upsample, blur):
@@ -278,7 +284,10 @@ def styled_conv(x, styles, weight, mod_w, mod_b, noise_weight, act_bias, *, labe
         from . import ops
         if ops.NATIVE_BWD:
             bs, cin, k = x.shape[0], x.shape[1], weight.shape[-1]
-            s = F.linear(styles[:, 0], mod_w * mod_scale, mod_b * mod_lr)
+            if bs <= 8 and styles.shape[-1] % 4 == 0 and mod_b is not None:
+                s = ops.equal_linear_grad(styles[:, 0], mod_w, mod_b, mod_scale, mod_lr)
+            else:
+                s = F.linear(styles[:, 0], mod_w * mod_scale, mod_b * mod_lr)
             wm = (weight * (1.0 / math.sqrt(cin * k * k))) * s.view(bs, 1, cin, 1, 1)                    # model.py:276-281
             if demodulate:
                 wm = wm * torch.rsqrt(wm.pow(2).sum((2, 3, 4), keepdim=True) + 1e-8)

@@ -21,7 +21,7 @@ from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     pti.pti_step(net, opt, vec, lab, target)
     torch.cuda.synchronize()
-rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in ("aten::copy_", "aten::contiguous", "aten::clone", "aten::mul", "aten::add", "aten::sum", "aten::fill_", "aten::zero_")]
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in ("aten::copy_", "aten::contiguous", "aten::clone", "aten::mul", "aten::add", "aten::sum", "aten::fill_", "aten::zero_", "aten::mm", "aten::bmm", "aten::addmm", "aten::baddbmm", "aten::matmul")]
 rows.sort(key=lambda e: -e.self_device_time_total)
 for e in rows[:28]:
     print(f"{e.key:18s} x{e.count:3d} device {e.self_device_time_total:8.1f} us  shapes {str(e.input_shapes)[:110]}")
