@@ -31,6 +31,14 @@ static inline int ilog2(int v) {
 }
 static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// an odd stride near n / golden ratio that is coprime with n: i -> (i * stride) % n is a permutation of 0..n-1 that sends neighbours far apart
+static inline unsigned coprime_stride(unsigned n) {
+    if (n < 3) return 1u;
+    unsigned s = (unsigned)(n * 0.6180339887) | 1u;
+    auto gcd = [](unsigned a, unsigned b) { while (b) { const unsigned t = a % b; a = b; b = t; } return a; };
+    while (gcd(s, n) != 1u) s += 2u;
+    return s % n ? s % n : 1u;
+}
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // wave64 sum via DPP-lowered shuffles

@@ -140,6 +140,10 @@ struct SbParams {
     // optional (masked up layer): [bs][ho/16][wo/16] map of region-uniform 16 x 16 output blocks (modconv_upblock.hip computes those: value <
     // nreg); this kernel then skips them — whole workgroups where all their blocks are uniform, single pixels otherwise
     const uint8_t* uni_blocks;
+    const int* uni_ctrl;     // uni_ctrl[2] == 0: the map is not in use for this layer (too few blocks qualify)
+    unsigned perm_mul;       // (with uni_blocks) workgroup i works on tile slot (i * perm_mul) % gridDim.x: consecutive workgroups go to the 8 XCDs
+                             // round-robin, so a skip pattern with a period of 2 / 4 / 8 tiles would idle whole XCDs; a golden-ratio stride
+                             // coprime with the grid spreads any spatially coherent skip set evenly
 };
 
 template <int CB, int PB, int WC, int WP, int LOG_TW>
@@ -203,8 +207,9 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
 
     const int ntile = p.tiles_x * p.tiles_y;
     const int npar = p.up ? 4 : 1;
-    const int ks = blockIdx.x / (ntile * npar);
-    const int bx = blockIdx.x - ks * ntile * npar;
+    const unsigned bxp = p.perm_mul ? (unsigned)(((unsigned long long)blockIdx.x * p.perm_mul) % gridDim.x) : blockIdx.x;
+    const int ks = bxp / (ntile * npar);
+    const int bx = bxp - ks * ntile * npar;
     const int tile = bx % ntile;
     const int par = bx / ntile;
     const int pa = par >> 1, pb_ = par & 1;
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
     // the uniform 16 x 16 output blocks under this tile (up layer: outputs (2y + pa, 2x + pb) of an 8 x 32 input tile = one block row, four blocks)
     unsigned ub_skip = 0;       // bit j: block j of this tile is computed by the block kernel
     if constexpr (C::TH == 8 && C::TW == 32 && !TCONV && !UNI) {
-        if (p.up && p.uni_blocks) {
+        if (p.up && p.uni_blocks && p.uni_ctrl[2] != 0) {
             const int nbx = wo >> 4, nby = ho >> 4;
             const int by = (2 * y0) >> 4;
 #pragma unroll
@@ -672,6 +677,7 @@ static int launch_sb(SbParams& p, hipStream_t st, float* workspace, int64_t work
     p.chunks_per = cdiv(nchunk, ksplit);
     p.partial = workspace;
     dim3 grid(p.tiles_x * p.tiles_y * npar * ksplit, cdiv(p.cout, C::TN), p.bs);
+    p.perm_mul = p.uni_blocks ? coprime_stride(grid.x) : 0u;
     // tuning knob (A/B in one process): E4S_SB_MINWAVES=1 lets the register allocator use > 256 registers (1 wave/SIMD)
     static const int minw = [] { const char* e = getenv("E4S_SB_MINWAVES"); return e ? atoi(e) : 2; }();
     static const int uni_ok = [] { const char* e = getenv("E4S_SB_UNI"); return e ? atoi(e) : 1; }();
@@ -734,7 +740,7 @@ extern "C" int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16
                                         const float* act_bias, int act, int bs, int cin, int cout, int h, int w, int nreg, int up,
                                         float* workspace, int64_t workspace_floats, float* rgb_out, const float* rgb_wt, const float* rgb_s,
                                         const float* rgb_bias, const float* rgb_skip, const float* rgb_up_kernel, const float* s_next,
-                                        const uint8_t* uniform_blocks, void* stream) {
+                                        const uint8_t* uniform_blocks, const int* uniform_ctrl, void* stream) {
     const int layout = up & (E4S_X_NHWC | E4S_OUT_NHWC | E4S_OUT_SP);
     up &= 1;
     E4S_REQUIRE(!(layout & E4S_OUT_SP) || (s_next && rgb_out && out && cout % 8 == 0 && !(layout & E4S_OUT_NHWC) && ((uintptr_t)out & 15) == 0),
@@ -768,7 +774,10 @@ extern "C" int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16
     p.plane_out = (int64_t)bs * (cout / 8) * ho * wo;
     E4S_REQUIRE(!uniform_blocks || (up && labels && w >= 32 && cout >= 128 && (h % 8) == 0 && (w % 8) == 0 && !layout),
                 "region_modconv3x3_sb: the uniform-block map goes with a masked up layer of width >= 32, cout >= 128, h and w multiples of 8");
+    E4S_REQUIRE(!uniform_blocks || uniform_ctrl, "region_modconv3x3_sb: the uniform-block map comes with its control words (e4s_uniform_blocks)");
     p.uni_blocks = uniform_blocks;
+    p.uni_ctrl = uniform_ctrl;
+    p.perm_mul = 0;
     hipStream_t st = (hipStream_t)stream;
     float* ws = p.out_nhwc ? nullptr : workspace;     // the split-K partial sums are laid out channels-first
     const int64_t wf = p.out_nhwc ? 0 : workspace_floats;

@@ -29,6 +29,7 @@ struct UpBlockParams {
     const float* d;            // [bs][nreg][cout]
     const uint8_t* blocks;     // [bs][nby][nbx]: region of a uniform block, MB_QUAD = four uniform 8 x 8 sub-blocks, 255 = mixed (composed kernel)
     const uint8_t* sub;        // [bs][2 nby][2 nbx]: region of every 8 x 8 sub-block (255 = mixed); read by the SUB = 2 variant
+    const int* ctrl;           // ctrl[2] == 0: too few blocks qualify, the layer stays in the composed form (e4s_uniform_blocks)
     const float* blur;         // [4][4]
     const float* noise;
     const float* noise_weight;
@@ -36,6 +37,7 @@ struct UpBlockParams {
     int noise_bstride, act;
     int bs, cin, cout, h, w, nreg;
     int nbx, nby;
+    unsigned perm_mul;         // workgroup i works on block (i * perm_mul) % (nbx * nby): see SbParams::perm_mul
 };
 
 // SUB = 1: the block is one region (10 x 10 positions); SUB = 2: its four 8 x 8 sub-blocks are each one region (4 x 6 x 6 positions, every
@@ -66,8 +68,10 @@ struct UbCfg {
 template <int CB, int SUB>
 __global__ __launch_bounds__(64 * ((SUB * SUB * (MB_OUT / SUB / 2 + 2) * (MB_OUT / SUB / 2 + 2) + 31) / 32), 2) void masked_up_block_kernel(const UpBlockParams p) {
     using C = UbCfg<CB, SUB>;
-    const int tyt = blockIdx.x / p.nbx, txt = blockIdx.x - tyt * p.nbx;
+    const int blk = (int)(((unsigned long long)blockIdx.x * p.perm_mul) % gridDim.x);
+    const int tyt = blk / p.nbx, txt = blk - tyt * p.nbx;
     const int b = blockIdx.z;
+    if (p.ctrl[2] == 0) return;
     const int flag = p.blocks[((size_t)b * p.nby + tyt) * p.nbx + txt];
     if (SUB == 1 ? flag >= p.nreg : flag != MB_QUAD) return;            // not this variant's block
 
@@ -276,67 +280,104 @@ __global__ __launch_bounds__(64 * ((SUB * SUB * (MB_OUT / SUB / 2 + 2) * (MB_OUT
     }
 }
 
-// One workgroup per 16 x 16 output block, one thread per output pixel (labels sampled 'nearest' at ho x wo exactly as the masked kernels do):
+// One workgroup per ROW OF FOUR 16 x 16 output blocks (= the 64 x 16 output pixels of one tile of the composed kernel, modconv_sb.hip: an
+// 8 x 32 input tile at the four parities), one thread per pixel column of each block (labels sampled 'nearest' at ho x wo exactly as the
+// masked kernels do):
 //   sub[b][2 by + sy][2 bx + sx] = the region shared by the 8 x 8 sub-block's pixels, 255 if they differ or are no region (>= nreg);
-//   blocks[b][by][bx] = that region if all four sub-blocks share one, MB_QUAD if each sub-block is uniform but they differ, else 255.
+//   blocks[b][by][bx] = that region if all four sub-blocks share one, MB_QUAD (with want_quad) if each sub-block is uniform but they differ,
+//   else 255 — and 255 for ALL FOUR blocks of the row unless every one of them qualifies: the composed kernel can only leave a tile out as
+//   a whole, so a tile with one mixed block is cheaper entirely in the composed form than partly in both.
 __global__ __launch_bounds__(256) void uniform_blocks_kernel(uint8_t* __restrict__ blocks, uint8_t* __restrict__ sub, const uint8_t* __restrict__ labels, int lh,
-                                                             int lw, int ho, int wo, float lsy, float lsx, int nreg, int want_quad) {
-    __shared__ int ref[4];
-    const int b = blockIdx.z, by = blockIdx.y, bxk = blockIdx.x;
-    const int y = threadIdx.x >> 4, x = threadIdx.x & 15;
-    int oy = by * MB_OUT + y, ox = bxk * MB_OUT + x;
-    oy = oy < ho ? oy : ho - 1; ox = ox < wo ? ox : wo - 1;
-    const int c = labels[((size_t)b * lh + nearest_src(oy, lsy, lh)) * lw + nearest_src(ox, lsx, lw)];
-    const int j = (y >> 3) * 2 + (x >> 3);
-    if ((y & 7) == 0 && (x & 7) == 0) ref[j] = c;
-    __syncthreads();
+                                                             int lw, int ho, int wo, float lsy, float lsx, int nreg, int want_quad, int* __restrict__ ctrl,
+                                                             int min_percent) {
+    // wave k = block k of the row; lane = (sub-block q = lane >> 4, its pixel column x8 = lane & 7, rows 4 yh .. 4 yh + 3 with yh = (lane >> 3) & 1):
+    // four labels per lane, everything else with wave ballots — one barrier in the whole kernel
+    __shared__ int flag[4];
+    const int b = blockIdx.z, by = blockIdx.y, tile = blockIdx.x;
+    const int nbx = wo / MB_OUT, nby = ho / MB_OUT;
+    const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+    const int q = lane >> 4, x8 = lane & 7, yh = (lane >> 3) & 1;
+    const int bxk = tile * 4 + k;
+    int ox = bxk * MB_OUT + (q & 1) * 8 + x8;
+    ox = ox < wo ? ox : wo - 1;
+    const int sx = nearest_src(ox, lsx, lw);
+    int c0 = -1;
+    bool same = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int oy = by * MB_OUT + (q >> 1) * 8 + yh * 4 + i;
+        oy = oy < ho ? oy : ho - 1;
+        const int c = labels[((size_t)b * lh + nearest_src(oy, lsy, lh)) * lw + sx];
+        if (i == 0) c0 = c;
+        same = same && c == c0;
+    }
+    const int refq = __shfl(c0, q * 16, 64);                              // the sub-block's first label
+    const unsigned long long okm = __ballot(same && c0 == refq);
     int r[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int ok = __syncthreads_and(j != k || c == ref[k]);
-        r[k] = (ok && ref[k] < nreg) ? ref[k] : 255;
+    for (int j = 0; j < 4; ++j) {
+        const int rj = __shfl(c0, j * 16, 64);
+        r[j] = (((okm >> (16 * j)) & 0xffffull) == 0xffffull && rj < nreg) ? rj : 255;
     }
-    if (threadIdx.x == 0) {
-        const size_t nbx = gridDim.x, nby = gridDim.y;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) sub[((size_t)b * 2 * nby + 2 * by + (k >> 1)) * (2 * nbx) + 2 * bxk + (k & 1)] = (uint8_t)r[k];
+    int f = 255;
+    if (bxk < nbx) {
         const bool all_uni = r[0] != 255 && r[1] != 255 && r[2] != 255 && r[3] != 255;
         const bool one = all_uni && r[0] == r[1] && r[0] == r[2] && r[0] == r[3];
-        blocks[((size_t)b * nby + by) * nbx + bxk] = one ? (uint8_t)r[0] : ((all_uni && want_quad) ? (uint8_t)MB_QUAD : (uint8_t)255);
+        f = one ? r[0] : ((all_uni && want_quad) ? MB_QUAD : 255);
+        if (lane < 4) sub[((size_t)b * 2 * nby + 2 * by + (lane >> 1)) * (2 * nbx) + 2 * bxk + (lane & 1)] = (uint8_t)r[lane];
+    }
+    if (lane == 0) flag[k] = bxk < nbx ? f : 0;                           // (a block beyond the edge does not veto its row)
+    __syncthreads();
+    const bool all = flag[0] != 255 && flag[1] != 255 && flag[2] != 255 && flag[3] != 255;
+    if (lane == 0 && bxk < nbx) blocks[((size_t)b * nby + by) * nbx + bxk] = (uint8_t)(all ? f : 255);
+    // ctrl (zeroed by the caller): [0] = rows of four blocks that qualify, [1] = workgroups done, [2] = the verdict for the two consumers: 1 if
+    // at least min_percent of the rows qualify.  Below that the transposed-conv form does not pay (measured: scattered blocks run at half
+    // the rate of contiguous ones in both kernels) and the whole layer stays in the composed form.
+    if (threadIdx.x == 0) {
+        if (all) atomicAdd(&ctrl[0], 1);
+        __threadfence();
+        const int total = gridDim.x * gridDim.y * gridDim.z;
+        if (atomicAdd(&ctrl[1], 1) == total - 1) {
+            __threadfence();
+            const int q = atomicAdd(&ctrl[0], 0);
+            ctrl[2] = (q * 100 >= min_percent * total) ? 1 : 0;
+        }
     }
 }
 
 }  // namespace
 
-extern "C" int e4s_uniform_blocks(uint8_t* blocks, uint8_t* sub, const uint8_t* labels, int bs, int lh, int lw, int ho, int wo, int nreg, int want_quad,
-                                  void* stream) {
-    E4S_REQUIRE(blocks && sub && labels, "uniform_blocks: null tensor");
+extern "C" int e4s_uniform_blocks(uint8_t* blocks, uint8_t* sub, int* ctrl, const uint8_t* labels, int bs, int lh, int lw, int ho, int wo, int nreg, int want_quad,
+                                  int min_percent, void* stream) {
+    E4S_REQUIRE(blocks && sub && labels && ctrl, "uniform_blocks: null tensor");
+    E4S_REQUIRE(min_percent >= 0 && min_percent <= 100, "uniform_blocks: min_percent in 0..100");
     E4S_REQUIRE(bs >= 0 && bs <= 65535 && lh >= 1 && lw >= 1 && ho >= 16 && wo >= 16 && (ho % 16) == 0 && (wo % 16) == 0 && nreg >= 1 && nreg <= E4S_MAX_REGIONS,
                 "uniform_blocks: bad size (output height / width multiples of 16)");
     if (bs == 0) return 0;
-    hipLaunchKernelGGL(uniform_blocks_kernel, dim3(wo / 16, ho / 16, bs), dim3(256), 0, (hipStream_t)stream, blocks, sub, labels, lh, lw, ho, wo,
-                       (float)lh / (float)ho, (float)lw / (float)wo, nreg, want_quad);
+    hipLaunchKernelGGL(uniform_blocks_kernel, dim3(cdiv(wo, 64), ho / 16, bs), dim3(256), 0, (hipStream_t)stream, blocks, sub, labels, lh, lw, ho, wo,
+                       (float)lh / (float)ho, (float)lw / (float)wo, nreg, want_quad, ctrl, min_percent);
     return check_launch("uniform_blocks");
 }
 
 // The 16 x 16 output blocks of a masked up-sampling StyledConv that lie under one region, or whose four 8 x 8 sub-blocks each do (blocks[b][by][bx]
 // != 255; the others are left untouched for e4s_region_modconv3x3_sb with the same block map).  Weights: the transposed-conv preparation (e4s_modconv_prep_weights_sb, k = 3, not composed).
 extern "C" int e4s_masked_upconv_blocks(float* out, const float* x, const uint16_t* whi, const uint16_t* wlo, const float* s, const float* d,
-                                        const uint8_t* blocks, const uint8_t* sub, const float* blur, const float* noise, int noise_bs,
+                                        const uint8_t* blocks, const uint8_t* sub, const int* ctrl, const float* blur, const float* noise, int noise_bs,
                                         const float* noise_weight, const float* act_bias, int act, int bs, int cin, int cout, int h, int w, int nreg,
                                         int sub_blocks, void* stream) {
-    E4S_REQUIRE(out && x && whi && wlo && s && blocks && sub && blur, "masked_upconv_blocks: null tensor");
+    E4S_REQUIRE(out && x && whi && wlo && s && blocks && sub && ctrl && blur, "masked_upconv_blocks: null tensor");
     E4S_REQUIRE(bs >= 0 && bs <= 65535 && cin >= 1 && cout >= 1 && h >= 8 && w >= 8 && (h % 8) == 0 && (w % 8) == 0, "masked_upconv_blocks: bad size (h, w multiples of 8)");
     E4S_REQUIRE(nreg >= 1 && nreg <= E4S_MAX_REGIONS, "masked_upconv_blocks: %d regions (max %d)", nreg, E4S_MAX_REGIONS);
     E4S_REQUIRE(!noise || (noise_weight && (noise_bs == 1 || noise_bs == bs)), "masked_upconv_blocks: noise needs its weight and batch 1 or bs");
     E4S_REQUIRE((((uintptr_t)whi | (uintptr_t)wlo) & 15) == 0, "masked_upconv_blocks: weight slabs must be 16-byte aligned");
     if (bs == 0) return 0;
     UpBlockParams p;
-    p.out = out; p.x = x; p.whi = reinterpret_cast<const uint4*>(whi); p.wlo = reinterpret_cast<const uint4*>(wlo); p.s = s; p.d = d; p.blocks = blocks; p.sub = sub;
+    p.out = out; p.x = x; p.whi = reinterpret_cast<const uint4*>(whi); p.wlo = reinterpret_cast<const uint4*>(wlo); p.s = s; p.d = d; p.blocks = blocks; p.sub = sub; p.ctrl = ctrl;
     p.blur = blur; p.noise = noise; p.noise_weight = noise_weight; p.act_bias = act_bias;
     p.noise_bstride = (noise && noise_bs == bs) ? 4 * h * w : 0; p.act = act;
     p.bs = bs; p.cin = cin; p.cout = cout; p.h = h; p.w = w; p.nreg = nreg;
     p.nbx = 2 * w / MB_OUT; p.nby = 2 * h / MB_OUT;
+    p.perm_mul = coprime_stride((unsigned)(p.nbx * p.nby));
     using C1 = UbCfg<2, 1>;
     using C2 = UbCfg<2, 2>;
     const dim3 grid(p.nbx * p.nby, cdiv(cout, C1::TN), bs);

@@ -127,6 +127,11 @@ class FSEncoder_PSP(Module):
         return ops.masked_avg_pool(style_feats, ops.mask_to_labels(segmap), nreg)
 
     def forward(self, x, segmap):
+        return self.codes(self.features(x), segmap)
+
+    def features(self, x):
+        """The feature maps the style codes are pooled from (after units 6, 20 and 23) — everything of ``forward`` that does not depend on the
+        region map, so that a caller can run the face parser next to it (``pipeline.swap_batch``)."""
         il = self.input_layer
         y = ops.conv2d(x, self._w_in.get(il[0].weight), 1, 1)
         mean, rstd = ops.plane_stats(y, il[1].eps)
@@ -140,7 +145,11 @@ class FSEncoder_PSP(Module):
             x = unit(x)
             if i in (6, 20, 23):
                 taps[i] = x
-        structure_feats = torch.zeros_like(x)                                           # reference :392
+        taps["last"] = x
+        return taps
+
+    def codes(self, taps, segmap):
+        structure_feats = torch.zeros_like(taps["last"])                                # reference :392
         codes_vector = torch.cat([self.get_per_comp_styleCode(taps[6], segmap),
                                   self.get_per_comp_styleCode(taps[20], segmap),
                                   self.get_per_comp_styleCode(taps[23], segmap)], dim=2)

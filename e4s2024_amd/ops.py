@@ -648,18 +648,24 @@ UP_SUBBLOCKS = os.environ.get("E4S_UP_SUBBLOCKS", "0") != "0"   # also blocks ma
 UP_BLOCK_QUAD = 254      # block map value: four region-uniform 8 x 8 sub-blocks with different regions
 
 
-def uniform_blocks(labels: torch.Tensor, ho: int, wo: int, nreg: int):
+UP_BLOCKS_MIN_PERCENT = int(os.environ.get("E4S_UP_BLOCKS_MIN", "40"))   # below this share of qualifying tiles a layer stays entirely in the composed form
+
+
+def uniform_blocks(labels: torch.Tensor, ho: int, wo: int, nreg: int, with_ctrl: bool = False):
     """``(blocks [bs, ho/16, wo/16], sub [bs, ho/8, wo/8])`` uint8 (``e4s_uniform_blocks``): ``sub`` = the region shared by all pixels of an
     8 x 8 output sub-block (labels sampled 'nearest' at ``ho`` x ``wo``), 255 if they differ; ``blocks`` = the region of a 16 x 16 block whose
-    four sub-blocks share one, 254 if each sub-block is uniform but they differ, 255 otherwise."""
+    four sub-blocks share one, 254 if each sub-block is uniform but they differ, 255 otherwise — and 255 for a whole row of four blocks (a tile
+    of the composed kernel) unless all four qualify.  ``with_ctrl``: also the control words (``ctrl[2]`` = 1 if at least
+    ``UP_BLOCKS_MIN_PERCENT`` of those rows qualify: the consumers leave the layer in the composed form otherwise)."""
     lab = _labels_u8(labels, "labels")
     bs, lh, lw = lab.shape
     if ho % UP_BLOCK or wo % UP_BLOCK:
         raise ValueError("uniform_blocks: output size must be a multiple of 16")
     blocks = torch.empty((bs, ho // UP_BLOCK, wo // UP_BLOCK), dtype=torch.uint8, device=lab.device)
     sub = torch.empty((bs, ho // 8, wo // 8), dtype=torch.uint8, device=lab.device)
-    lib().call("e4s_uniform_blocks", _p(blocks), _p(sub), _p(lab), bs, lh, lw, ho, wo, nreg, int(UP_SUBBLOCKS), _stream())
-    return blocks, sub
+    ctrl = torch.zeros((4,), dtype=torch.int32, device=lab.device)
+    lib().call("e4s_uniform_blocks", _p(blocks), _p(sub), _p(ctrl), _p(lab), bs, lh, lw, ho, wo, nreg, int(UP_SUBBLOCKS), UP_BLOCKS_MIN_PERCENT, _stream())
+    return (blocks, sub, ctrl) if with_ctrl else (blocks, sub)
 
 
 def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: bool, cout: int, up: bool, rgb=None, want_out: bool = True,
@@ -707,13 +713,13 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
         wsn = 16 * bs * cout * ho * wo
         ws = _workspace(x.device, wsn)
     sb = isinstance(wt, tuple)
-    blocks = None
+    blocks = bctrl = None
     if (up_blocks is not None and UP_BLOCKS and sb and up and labels is not None and w >= 32 and cout >= 128 and h % 8 == 0 and w % 8 == 0
             and cin % 16 == 0 and rgb is None and not (x_nhwc or out_nhwc) and sn is None):
         wt_t, blur_k = up_blocks
-        blocks, sub = uniform_blocks(labels, ho, wo, nreg)
+        blocks, sub, bctrl = uniform_blocks(labels, ho, wo, nreg, with_ctrl=True)
         evb = _timed("masked_upconv_blocks", f"{cin}->{cout} @{h} up")
-        lib().call("e4s_masked_upconv_blocks", _p(out), _p(x), _p(wt_t[0]), _p(wt_t[1]), _p(s), _p(d), _p(blocks), _p(sub), _p(_c(blur_k, "blur kernel")), _p(nz),
+        lib().call("e4s_masked_upconv_blocks", _p(out), _p(x), _p(wt_t[0]), _p(wt_t[1]), _p(s), _p(d), _p(blocks), _p(sub), _p(bctrl), _p(_c(blur_k, "blur kernel")), _p(nz),
                    nbs or 0, _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, int(UP_SUBBLOCKS), _stream())
         if evb is not None:
             evb.record()
@@ -734,7 +740,7 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
         lib().call("e4s_region_modconv3x3_sb", _p(out), _p(x), _p(wt[0]), _p(wt[1]), _p(s), _p(d), _p(labels), lh, lw, _p(nz), nbs or 0,
                    _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg,
                    (1 if up else 0) | (2 if x_nhwc else 0) | (4 if out_nhwc else 0) | (16 if sn is not None else 0), _p(ws), wsn, *rgb_args, _p(sn),
-                   _p(blocks), _stream())
+                   _p(blocks), _p(bctrl) if blocks is not None else None, _stream())
     else:
         lib().call("e4s_region_modconv3x3", _p(out), _p(x), _p(wt), _p(s), _p(d), _p(labels), lh, lw, _p(nz), nbs or 0,
                    _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, 1 if up else 0,

@@ -28,6 +28,7 @@ SWAP_CHAINS = int(os.environ.get("E4S_SWAP_CHAINS", "2"))     # 2 = driven | tar
 # launch-bound glue between its convolutions fill the chip better at twice the batch than as two concurrent chains (measured at bs 8:
 # parse + encode 4.3 + 13.7 ms for 16 images against 2 x (2.5 + 8.1) ms on one stream and 21.0 ms on two streams).
 SWAP_BATCHED = os.environ.get("E4S_SWAP_BATCHED", "1") != "0"
+PARSE_BESIDE_ENCODE = os.environ.get("E4S_PARSE_BESIDE_ENCODE", "1") != "0"    # (batched route) the face parser on a side stream next to the encoder body
 
 
 def _side_stream(device, idx=0):
@@ -84,8 +85,22 @@ def swap_batch(net, parser, driven: torch.Tensor, target: torch.Tensor, comp_ind
     if batched:
         bs = driven.shape[0]
         both = torch.cat([driven, target])
-        lab = parser.parse_batch((both + 1) / 2, seg12=True)              # uint8 [2 bs, 512, 512]
-        vec, _ = net.get_style_vectors(both, lab)
+        enc = getattr(net, "encoder", None)
+        if PARSE_BESIDE_ENCODE and hasattr(enc, "features"):
+            # the encoder needs the region maps only for its last step (masked average pooling): the parser runs on a side stream next to
+            # the encoder's body
+            main, side = torch.cuda.current_stream(), _side_stream(driven.device, 0)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                lab = parser.parse_batch((both + 1) / 2, seg12=True)      # uint8 [2 bs, 512, 512]
+            both.record_stream(side)
+            taps = enc.features(ops.bilinear_resize(both, (256, 256), align_corners=False))      # Net3._encode (networks.py:217)
+            main.wait_stream(side)
+            lab.record_stream(main)
+            vec, _ = enc.codes(taps, lab)
+        else:
+            lab = parser.parse_batch((both + 1) / 2, seg12=True)          # uint8 [2 bs, 512, 512]
+            vec, _ = net.get_style_vectors(both, lab)
         lab_d, lab_t, vec_d, vec_t = lab[:bs], lab[bs:], vec[:bs], vec[bs:]
         mark("parse+encode_x2")
     elif two_streams:

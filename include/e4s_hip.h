@@ -135,19 +135,21 @@ E4S_API int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16_t*
                                      float* workspace, int64_t workspace_floats,
                                      float* rgb_out, const float* rgb_wt, const float* rgb_s, const float* rgb_bias,
                                      const float* rgb_skip, const float* rgb_up_kernel, const float* s_next,
-                                     const uint8_t* uniform_blocks, void* stream);
+                                     const uint8_t* uniform_blocks, const int* uniform_ctrl, void* stream);
 /* Masked up-sampling layers, region-uniform output blocks (model.py:287-300 per region == one transposed conv + blur where a block of output
  * pixels has ONE region):
  *   e4s_uniform_blocks: sub[b][2by+sy][2bx+sx] = the region of an 8 x 8 output sub-block (labels uint8 [bs][lh][lw] sampled 'nearest' at
  *   ho x wo), 255 = mixed / no region; blocks[b][by][bx] = the region of a 16 x 16 block if its four sub-blocks share one, 254 if each of
- *   them is uniform but they differ (only with want_quad; e4s_masked_upconv_blocks then needs sub_blocks = 1), 255 otherwise;
+ *   them is uniform but they differ (only with want_quad; e4s_masked_upconv_blocks then needs sub_blocks = 1), 255 otherwise — and 255 for a
+ *   whole row of four blocks (one tile of the composed kernel) unless all four qualify; ctrl: four ints zeroed by the caller, ctrl[2] becomes 1
+ *   if at least min_percent of those rows qualify, else 0 (both consumers then leave the layer in the composed form);
  *   e4s_masked_upconv_blocks: computes exactly the blocks != 255 in the transposed-conv form (weights: e4s_modconv_prep_weights_sb of the
  *   bare 3x3 weight), s [bs][nreg][cin], d [bs][nreg][cout], blur [4][4], out fp32 [bs][cout][2h][2w];
  *   e4s_region_modconv3x3_sb(..., uniform_blocks = the same block map) then computes the remaining blocks in the composed form. */
-E4S_API int e4s_uniform_blocks(uint8_t* blocks, uint8_t* sub, const uint8_t* labels, int bs, int lh, int lw, int ho, int wo, int nreg, int want_quad,
-                               void* stream);
+E4S_API int e4s_uniform_blocks(uint8_t* blocks, uint8_t* sub, int* ctrl, const uint8_t* labels, int bs, int lh, int lw, int ho, int wo, int nreg,
+                               int want_quad, int min_percent, void* stream);
 E4S_API int e4s_masked_upconv_blocks(float* out, const float* x, const uint16_t* whi, const uint16_t* wlo, const float* s, const float* d,
-                                     const uint8_t* blocks, const uint8_t* sub, const float* blur, const float* noise, int noise_bs,
+                                     const uint8_t* blocks, const uint8_t* sub, const int* ctrl, const float* blur, const float* noise, int noise_bs,
                                      const float* noise_weight, const float* act_bias, int act, int bs, int cin, int cout, int h, int w, int nreg,
                                      int sub_blocks, void* stream);
 /* rgb_* (all NULL = off): fuse the single-region ToRGB that follows this layer (model.py:439-479) into the epilogue — allowed for

@@ -320,11 +320,17 @@ def test_masked_up_layer_uniform_blocks_against_oracle_and_composed_form(sg2, sh
     resolution — against the oracle, against the all-composed route, and each output block written by exactly one kernel (NaN-prefilled)."""
     bs, cin, cout, h, w, nreg, lh, lw, ncell = shape
     rs = np.random.RandomState(17 * cin + h + ncell)
-    ry, rx = lh // ncell, lw // ncell                                        # coarse cells -> uniform 16 x 16 blocks (4) or 8 x 8 sub-blocks (8)
-    cells = rs.randint(0, nreg, (bs, ncell, ncell)).astype(np.uint8)
-    lab = np.repeat(np.repeat(cells, ry, axis=1), rx, axis=2)
-    lab[:, : lh // 4, : lw // 4] = rs.randint(0, nreg, (bs, lh // 4, lw // 4))  # a corner of per-pixel noise: mixed blocks
-    lab[:, lh - max(ry, lh // 8) // 2:, lw - max(rx, lw // 8) // 2:] = 255    # an area that belongs to no region
+    # region maps built at block granularity: every 16 x 16 (ncell = 4) or 8 x 8 (ncell = 8) output block gets one region, then one row of
+    # blocks gets per-pixel noise in its left half (mixed blocks: the whole 64-pixel tile row falls back to the composed form) and the last
+    # block row a corner that belongs to no region
+    ho, wo = 2 * h, 2 * w
+    cell = 16 if ncell == 4 else 8
+    cy, cx = cell * lh // ho, cell * lw // wo                                 # a block in label pixels
+    cells = rs.randint(0, nreg, (bs, ho // cell, wo // cell)).astype(np.uint8)
+    lab = np.repeat(np.repeat(cells, cy, axis=1), cx, axis=2)
+    by = 16 * lh // ho
+    lab[:, by:2 * by, : lw // 2] = rs.randint(0, nreg, (bs, by, lw // 2))       # second row of 16 x 16 blocks: noise
+    lab[:, lh - by // 2:, lw - cx // 2:] = 255                                  # no region
     onehot = torch.zeros(bs, nreg, lh, lw)
     for c in range(nreg):
         onehot[:, c] = T((lab == c).astype(np.float32))
