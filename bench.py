@@ -152,7 +152,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-mask-sensitivity", action="store_true", help="skip the two short runs under coarse / i.i.d. region maps")
-    ap.add_argument("--labels", choices=["blocky", "coarse", "iid"], default="blocky",
+    ap.add_argument("--labels", choices=["blocky", "coarse", "portrait", "iid"], default="blocky",
                     help="region maps: 16 x 16 constant cells on the 512 x 512 map (default, BASELINE configs[1]), 4 x 4 cells (face-sized regions), or i.i.d. per pixel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-swap", action="store_true", help="skip the secondary full-swap p50 measurement")
@@ -198,7 +198,8 @@ def main():
     bs = args.batch
     # codes = latent_avg + 0.5 N(0,1) (seed 1 + rank), blocky 16x16-cell label maps (seed 3 + rank)
     codes = seeded.seeded_codes(1 + rank, bs, 12, 18, la).to(dev)
-    lab = (seeded.blocky_labels(3 + rank, bs, 12, 512, 16 if args.labels == "blocky" else 4) if args.labels != "iid" else seeded.iid_labels(9 + rank, bs, 12, 512))
+    lab = (seeded.facelike_labels(5 + rank, bs, 512) if args.labels == "portrait" else
+           seeded.blocky_labels(3 + rank, bs, 12, 512, 16 if args.labels == "blocky" else 4) if args.labels != "iid" else seeded.iid_labels(9 + rank, bs, 12, 512))
     mask = seeded.labels_to_onehot(lab, 12).to(dev)
     ops.STRICT_MASK = False                                       # the one-hot check costs a host sync; masks here are one-hot by construction
 
@@ -225,12 +226,14 @@ def main():
         elapsed = time.perf_counter() - t0
     ksum = kt.summary()
     kt_for_layers = kt
-    # how much of `value` depends on the region maps: the same batch under face-sized regions (4 x 4 cells: every 16 x 16 block of the masked up
-    # layers lies under one region) and under i.i.d. per-pixel labels (none does); single-GPU runs only, 10 steps each, outside the timed region
+    # how much of `value` depends on the region maps: the same batch under portrait-shaped maps (ellipses: hair, skin, eyes, ...: what the face
+    # parser produces on photographs), under 4 x 4 cells (every 16 x 16 block of the masked up layers lies under one region) and under i.i.d.
+    # per-pixel labels (none does); single-GPU runs only, 10 steps each, outside the timed region
     mask_sens = None
     if world == 1 and args.labels == "blocky" and not args.no_mask_sensitivity:
         mask_sens = {}
-        for name, lb in (("coarse_4x4_cells", seeded.blocky_labels(3, bs, 12, 512, 4)), ("iid_per_pixel", seeded.iid_labels(9, bs, 12, 512))):
+        for name, lb in (("portrait_like_ellipses", seeded.facelike_labels(5, bs, 512)), ("coarse_4x4_cells", seeded.blocky_labels(3, bs, 12, 512, 4)),
+                         ("iid_per_pixel", seeded.iid_labels(9, bs, 12, 512))):
             m2 = seeded.labels_to_onehot(lb, 12).to(dev)
             with torch.no_grad():
                 for _ in range(2):

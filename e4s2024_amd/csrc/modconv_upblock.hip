@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void uniform_blocks_kernel(uint8_t* __restrict
     __syncthreads();
     const bool all = flag[0] != 255 && flag[1] != 255 && flag[2] != 255 && flag[3] != 255;
     if (lane == 0 && bxk < nbx) blocks[((size_t)b * nby + by) * nbx + bxk] = (uint8_t)(all ? f : 255);
-    // ctrl (zeroed by the caller): [0] = rows of four blocks that qualify, [1] = workgroups done, [2] = the verdict for the two consumers: 1 if
+    // ctrl (zeroed once by the caller, left zeroed by every launch): [0] = rows of four blocks that qualify, [1] = workgroups done, [2] = the verdict for the two consumers: 1 if
     // at least min_percent of the rows qualify.  Below that the transposed-conv form does not pay (measured: scattered blocks run at half
     // the rate of contiguous ones in both kernels) and the whole layer stays in the composed form.
     if (threadIdx.x == 0) {
@@ -341,6 +341,8 @@ __global__ __launch_bounds__(256) void uniform_blocks_kernel(uint8_t* __restrict
             __threadfence();
             const int q = atomicAdd(&ctrl[0], 0);
             ctrl[2] = (q * 100 >= min_percent * total) ? 1 : 0;
+            ctrl[0] = 0;        // ready for the next layer on this stream (its map kernel runs after this layer's consumers)
+            ctrl[1] = 0;
         }
     }
 }

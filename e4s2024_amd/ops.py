@@ -237,10 +237,10 @@ class _StreamCtx:
     model: ONE host thread per stream; the prepared weight copies, which ARE shared, publish themselves atomically and are ordered across
     streams by an event, see ``_Prepared``)."""
 
-    __slots__ = ("label_cache", "table_plan", "forward_stamp", "workspace")
+    __slots__ = ("label_cache", "table_plan", "forward_stamp", "workspace", "up_ctrl")
 
     def __init__(self):
-        self.label_cache, self.table_plan, self.forward_stamp, self.workspace = {}, {}, None, None
+        self.label_cache, self.table_plan, self.forward_stamp, self.workspace, self.up_ctrl = {}, {}, None, None, None
 
 
 _ctxs = {}
@@ -663,7 +663,10 @@ def uniform_blocks(labels: torch.Tensor, ho: int, wo: int, nreg: int, with_ctrl:
         raise ValueError("uniform_blocks: output size must be a multiple of 16")
     blocks = torch.empty((bs, ho // UP_BLOCK, wo // UP_BLOCK), dtype=torch.uint8, device=lab.device)
     sub = torch.empty((bs, ho // 8, wo // 8), dtype=torch.uint8, device=lab.device)
-    ctrl = torch.zeros((4,), dtype=torch.int32, device=lab.device)
+    ctx = _ctx()
+    ctrl = getattr(ctx, "up_ctrl", None)
+    if ctrl is None or ctrl.device != lab.device:
+        ctrl = ctx.up_ctrl = torch.zeros((4,), dtype=torch.int32, device=lab.device)      # per stream; every launch leaves its counters zeroed
     lib().call("e4s_uniform_blocks", _p(blocks), _p(sub), _p(ctrl), _p(lab), bs, lh, lw, ho, wo, nreg, int(UP_SUBBLOCKS), UP_BLOCKS_MIN_PERCENT, _stream())
     return (blocks, sub, ctrl) if with_ctrl else (blocks, sub)
 

@@ -169,6 +169,34 @@ def blocky_labels(seed: int, bs: int, n_cls: int = 12, size: int = 512, cells: i
     return np.repeat(np.repeat(small, rep, axis=1), rep, axis=2)
 
 
+def facelike_labels(seed: int, bs: int, size: int = 512) -> np.ndarray:
+    """uint8 [bs, size, size] region maps shaped like a parsed portrait (12 classes as in CelebAMask-HQ's merged set: 0 background, 1 lips,
+    2 eyebrows, 3 eyes, 4 hair, 5 nose, 6 skin, 7 ears, 8 neck, 9 mouth, 10 eye glasses unused, 11 ear rings): ellipses with a few pixels of
+    per-sample jitter — large coherent regions with curved borders, the kind of map the face parser produces on real photographs."""
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32) / size
+
+    def ell(cx, cy, rx, ry):
+        return ((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2 <= 1.0
+
+    out = np.zeros((bs, size, size), dtype=np.uint8)
+    for b in range(bs):
+        j = lambda s=0.015: float(rs.uniform(-s, s))          # noqa: E731
+        cx, cy = 0.5 + j(), 0.5 + j()
+        m = out[b]
+        m[ell(cx, cy + 0.42, 0.34, 0.22)] = 8                                   # neck / shoulders
+        m[ell(cx, cy - 0.06, 0.36 + j(), 0.44 + j())] = 4                       # hair
+        m[ell(cx - 0.30, cy + 0.02, 0.035, 0.07)] = 7; m[ell(cx + 0.30, cy + 0.02, 0.035, 0.07)] = 7   # ears
+        m[ell(cx - 0.30, cy + 0.10, 0.012, 0.02)] = 11                          # ear ring
+        m[ell(cx, cy + 0.04, 0.27 + j(), 0.36 + j())] = 6                       # skin
+        m[ell(cx - 0.11, cy - 0.07, 0.06, 0.012)] = 2; m[ell(cx + 0.11, cy - 0.07, 0.06, 0.012)] = 2   # eyebrows
+        m[ell(cx - 0.11, cy - 0.02, 0.045, 0.02)] = 3; m[ell(cx + 0.11, cy - 0.02, 0.045, 0.02)] = 3   # eyes
+        m[ell(cx, cy + 0.08, 0.04, 0.07)] = 5                                   # nose
+        m[ell(cx, cy + 0.21, 0.085, 0.035)] = 1                                 # lips
+        m[ell(cx, cy + 0.21, 0.055, 0.012)] = 9                                 # mouth
+    return out
+
+
 def iid_labels(seed: int, bs: int, n_cls: int = 12, size: int = 512) -> np.ndarray:
     """uint8 [bs, size, size] i.i.d. per-pixel labels — the adversarial case where
     every tile sees all regions."""

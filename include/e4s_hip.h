@@ -141,7 +141,7 @@ E4S_API int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16_t*
  *   e4s_uniform_blocks: sub[b][2by+sy][2bx+sx] = the region of an 8 x 8 output sub-block (labels uint8 [bs][lh][lw] sampled 'nearest' at
  *   ho x wo), 255 = mixed / no region; blocks[b][by][bx] = the region of a 16 x 16 block if its four sub-blocks share one, 254 if each of
  *   them is uniform but they differ (only with want_quad; e4s_masked_upconv_blocks then needs sub_blocks = 1), 255 otherwise — and 255 for a
- *   whole row of four blocks (one tile of the composed kernel) unless all four qualify; ctrl: four ints zeroed by the caller, ctrl[2] becomes 1
+ *   whole row of four blocks (one tile of the composed kernel) unless all four qualify; ctrl: four ints, [0] and [1] zero on entry (every launch leaves them zero again: one buffer per stream serves all layers), ctrl[2] becomes 1
  *   if at least min_percent of those rows qualify, else 0 (both consumers then leave the layer in the composed form);
  *   e4s_masked_upconv_blocks: computes exactly the blocks != 255 in the transposed-conv form (weights: e4s_modconv_prep_weights_sb of the
  *   bare 3x3 weight), s [bs][nreg][cin], d [bs][nreg][cout], blur [4][4], out fp32 [bs][cout][2h][2w];
