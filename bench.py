@@ -64,7 +64,7 @@ def conv3x3_flops_per_face(size=1024, want_executed=False, uniform_frac=None):
         else:
             k = modconv_kernel_name(cout, w_in, None, masked)
         f = 0.0
-        if up and masked and uniform_frac and _ops.UP_BLOCKS and _ops.MODCONV_MODE == "sb" and w_in >= 32 and cout >= 128:
+        if up and masked and uniform_frac and _ops.UP_BLOCKS and _ops.MODCONV_MODE == "sb" and w_in >= max(32, _ops.UP_BLOCKS_MIN_WIDTH) and cout >= 128:
             f1, f2 = uniform_frac.get(out_res, (0.0, 0.0))
             f = f1 + f2
             out["masked_upconv_blocks"] = out.get("masked_upconv_blocks", 0.0) + fl * f
@@ -100,7 +100,8 @@ def _by_layer(kt, kernel, bs, peak, uniform_frac):
         h = int(res.split()[0])
         gflop = 2.0 * cin * cout * 9 * h * h * bs / 1e9            # per launch; up layers counted on the input grid (transposed conv)
         t = ms / calls
-        f1, f2 = uniform_frac.get(2 * h, (0.0, 0.0)) if (up and uniform_frac and h >= 32 and cout >= 128) else (0.0, 0.0)
+        from e4s2024_amd import ops as _o
+        f1, f2 = uniform_frac.get(2 * h, (0.0, 0.0)) if (up and uniform_frac and h >= max(32, _o.UP_BLOCKS_MIN_WIDTH) and cout >= 128) else (0.0, 0.0)
         rows.append({"layer": detail, "ms_per_step": round(t, 4), "algorithmic_tflops": round(gflop / t, 1), "frac": round(gflop / t / peak, 4),
                      "executed_over_algorithmic": round(f1 * 2.0 + f2 * 2.5 + (1.0 - f1 - f2) * 4.0, 2) if up else 1.0,
                      **({"uniform_block_share": round(f1, 3), "uniform_sub_block_share": round(f2, 3)} if up else {})})

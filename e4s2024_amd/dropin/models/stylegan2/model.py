@@ -196,7 +196,8 @@ class ModulatedConv2d(nn.Module):
         wt, s, d = self.tables(styles, masked=labels is not None)
         saved = (s, d, self._weights(labels is not None)[1]) if labels is not None else None
         up_blocks = None
-        if (self.upsample and labels is not None and ops.UP_BLOCKS and ops.MODCONV_MODE == "sb" and self.kernel_size == 3 and input.shape[-1] >= 32
+        if (self.upsample and labels is not None and ops.UP_BLOCKS and ops.MODCONV_MODE == "sb" and self.kernel_size == 3
+                and input.shape[-1] >= max(32, ops.UP_BLOCKS_MIN_WIDTH)
                 and self.out_channel >= 128 and not torch.is_grad_enabled()):
             # region-uniform 16 x 16 output blocks run in the transposed-conv form (a second preparation of the same weight)
             up_blocks = (self._prepared_tconv.get(self.weight, None, False, self.demodulate, tconv=True)[0], self.blur.kernel)

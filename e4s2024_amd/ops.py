@@ -642,6 +642,11 @@ def can_fuse_rgb(cout: int, w: int, up: bool, masked: bool) -> bool:
 
 UP_BLOCKS = os.environ.get("E4S_UP_BLOCKS", "1") != "0"    # masked up layers: region-uniform 16 x 16 output blocks in the transposed-conv form
 UP_BLOCK = 16
+# smallest input width of a masked up layer that tries the block path (64: the 64 -> 128 and 128 -> 256 layers).  A layer that tries costs two
+# small launches and gives up its K split; the 32 -> 64 layer's tiles are the full width of its map and almost never qualify.  Measured, faces/s
+# at batch 4 with the path off / from width 32 / 64 / 128: portrait-shaped maps 1086 / 1080 / 1082 / 1084, 4 x 4-cell maps 1092 / 1229 / 1203 /
+# 1139, the bench's blocky maps 1084 / 1113 / 1126 / 1127 (tools/sweep_blocks_minw.sh)
+UP_BLOCKS_MIN_WIDTH = int(os.environ.get("E4S_UP_BLOCKS_MINW", "64"))
 UP_SUBBLOCKS = os.environ.get("E4S_UP_SUBBLOCKS", "0") != "0"   # also blocks made of four uniform 8 x 8 sub-blocks (slower than the composed form on the benchmark maps)
 
 
@@ -717,7 +722,7 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
         ws = _workspace(x.device, wsn)
     sb = isinstance(wt, tuple)
     blocks = bctrl = None
-    if (up_blocks is not None and UP_BLOCKS and sb and up and labels is not None and w >= 32 and cout >= 128 and h % 8 == 0 and w % 8 == 0
+    if (up_blocks is not None and UP_BLOCKS and sb and up and labels is not None and w >= max(32, UP_BLOCKS_MIN_WIDTH) and cout >= 128 and h % 8 == 0 and w % 8 == 0
             and cin % 16 == 0 and rgb is None and not (x_nhwc or out_nhwc) and sn is None):
         wt_t, blur_k = up_blocks
         blocks, sub, bctrl = uniform_blocks(labels, ho, wo, nreg, with_ctrl=True)
