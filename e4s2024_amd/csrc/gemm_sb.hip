@@ -292,9 +292,13 @@ struct WgradParams {
     int bs, cin, h, w, nreg, up;
 };
 
-template <int KS>
+// TM = rows (output channels) of a tile: 128 (waves 2 x 2, 64 x 64 each), 64 (waves 1 x 4, 64 x 32 each) or 32 (1 x 4, 32 x 32 each).  The
+// 64- and 32-channel layers at 512^2 / 1024^2 fill a 128-row tile to a half / a quarter: their MFMAs, not the building of B, were the time.
+template <int KS, int TM>
 __global__ __launch_bounds__(GNT, 2) void mconv_wgrad_kernel(const WgradParams q) {
     constexpr int KK = KS * KS, PAD = KS / 2;
+    constexpr int WAVES_M = TM == GT ? 2 : 1, WAVES_N = 4 / WAVES_M;
+    constexpr int MI = TM / WAVES_M / 32, NJ = GT / WAVES_N / 32;     // 32 x 32 blocks per wave: 2 x 2, 2 x 1, 1 x 1
     const GemmParams& p = q.g;
     __shared__ uint4 lds[4 * GT * 4];
     constexpr int TAB_CI = KS == 1 ? GT : 16;            // distinct input channels among a tile's 128 rows
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(GNT, 2) void mconv_wgrad_kernel(const WgradParams q
     uint4* blo = lds + 3 * GT * 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l5 = lane & 31, kg = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = WAVES_M == 2 ? wave >> 1 : 0, wn = WAVES_M == 2 ? wave & 1 : wave;
     int bx = blockIdx.x;
     const int ks = bx % p.ksplit; bx /= p.ksplit;
     const int tn = bx % p.tiles_n, tm = bx / p.tiles_n;
@@ -313,7 +317,8 @@ __global__ __launch_bounds__(GNT, 2) void mconv_wgrad_kernel(const WgradParams q
     const int gpar = bz / q.bs, b = bz - gpar * q.bs;
     const int gy = q.up == 2 ? gpar >> 1 : 0, gx = q.up == 2 ? gpar & 1 : 0;
     const float* A = p.a + (size_t)bz * p.sa;
-    const int m0 = tm * GT, n0 = tn * GT;
+    const int m0 = tm * TM, n0 = tn * GT;
+    const bool a_thr = (tid >> 1) < TM;                  // threads that stage a row of A
     const int nchunk = (p.K + GK - 1) / GK;
     const int ch_begin = ks * p.chunks_per;
     const int ch_end = ch_begin + p.chunks_per < nchunk ? ch_begin + p.chunks_per : nchunk;
@@ -335,11 +340,11 @@ __global__ __launch_bounds__(GNT, 2) void mconv_wgrad_kernel(const WgradParams q
     const float* xc = q.x + ((size_t)b * q.cin + ci) * q.h * q.w;
     const int lw = q.up * q.w;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -420,52 +425,56 @@ __global__ __launch_bounds__(GNT, 2) void mconv_wgrad_kernel(const WgradParams q
     };
 
     if (ch_begin < ch_end) {
-        g_load<true>(va, A, p.lda, m0, p.M, ch_begin * GK, p.K, tid);
+        if (a_thr) g_load<true>(va, A, p.lda, m0, p.M, ch_begin * GK, p.K, tid);
         load_b(ch_begin);
     }
     for (int ch = ch_begin; ch < ch_end; ++ch) {
         __syncthreads();                       // (also orders the s_tab fill before its first use)
-        g_store<true>(va, ahi, alo, ch * GK, p.K, tid);
+        if (a_thr) g_store<true>(va, ahi, alo, ch * GK, p.K, tid);
         store_b(ch);
         __syncthreads();
         if (ch + 1 < ch_end) {
-            g_load<true>(va, A, p.lda, m0, p.M, (ch + 1) * GK, p.K, tid);
+            if (a_thr) g_load<true>(va, A, p.lda, m0, p.M, (ch + 1) * GK, p.K, tid);
             load_b(ch + 1);
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int j = 2 * t + kg;
-            uint4 ah[2], al[2], bh[2], bl[2];
+            uint4 ah[MI], al[MI], bh[NJ], bl[NJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int ra = wm * 64 + i * 32 + l5, rb = wn * 64 + i * 32 + l5;
+            for (int i = 0; i < MI; ++i) {
+                const int ra = wm * 64 + i * 32 + l5;
                 ah[i] = ahi[g_slot(ra, j)]; al[i] = alo[g_slot(ra, j)];
+            }
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) {
+                const int rb = wn * 32 * NJ + i * 32 + l5;
                 bh[i] = bhi[g_slot(rb, j)]; bl[i] = blo[g_slot(rb, j)];
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int jq = 0; jq < 2; ++jq)
+                for (int jq = 0; jq < NJ; ++jq)
                     acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[jq]), acc[i][jq], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int jq = 0; jq < 2; ++jq)
+                for (int jq = 0; jq < NJ; ++jq)
                     acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[jq]), acc[i][jq], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int jq = 0; jq < 2; ++jq)
+                for (int jq = 0; jq < NJ; ++jq)
                     acc[i][jq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[jq]), acc[i][jq], 0, 0, 0);
         }
     }
     float* C = p.ksplit > 1 ? p.partial + ((size_t)ks * p.batch + bz) * (size_t)p.M * p.N : p.c + (size_t)bz * p.sc;
 #pragma unroll
-    for (int jq = 0; jq < 2; ++jq) {
-        const int nn = n0 + wn * 64 + jq * 32 + l5;
+    for (int jq = 0; jq < NJ; ++jq) {
+        const int nn = n0 + wn * 32 * NJ + jq * 32 + l5;
         if (nn >= p.N) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
@@ -568,7 +577,8 @@ extern "C" int e4s_mconv_wgrad(float* dw, const float* gz, const float* x, const
     p.c = dw; p.a = gz; p.b = nullptr; p.partial = workspace;
     p.M = cout; p.N = cin * ks * ks; p.K = h * w; p.lda = p.K; p.ldb = 0;
     p.sa = (long long)cout * p.K; p.sb = 0; p.sc = (long long)p.M * p.N; p.batch = batch;
-    p.tiles_m = cdiv(p.M, GT); p.tiles_n = cdiv(p.N, GT);
+    const int tm_rows = p.M <= 32 ? 32 : (p.M <= 64 ? 64 : GT);
+    p.tiles_m = cdiv(p.M, tm_rows); p.tiles_n = cdiv(p.N, GT);
     q.x = x; q.s = s; q.lab = labels; q.bs = bs; q.cin = cin; q.h = h; q.w = w; q.nreg = nreg; q.up = up;
     const int nchunk = cdiv(p.K, GK);
     const int64_t base = (int64_t)p.tiles_m * p.tiles_n * batch;
@@ -579,8 +589,10 @@ extern "C" int e4s_mconv_wgrad(float* dw, const float* gz, const float* x, const
     p.chunks_per = cdiv(nchunk, ksplit);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n * ksplit), 1, batch);
     hipStream_t st = (hipStream_t)stream;
-    if (ks == 3) hipLaunchKernelGGL(mconv_wgrad_kernel<3>, grid, dim3(GNT), 0, st, q);
-    else hipLaunchKernelGGL(mconv_wgrad_kernel<1>, grid, dim3(GNT), 0, st, q);
+#define E4S_WGRAD(KS_, TM_) hipLaunchKernelGGL((mconv_wgrad_kernel<KS_, TM_>), grid, dim3(GNT), 0, st, q)
+    if (ks == 3) { if (tm_rows == 32) E4S_WGRAD(3, 32); else if (tm_rows == 64) E4S_WGRAD(3, 64); else E4S_WGRAD(3, 128); }
+    else { if (tm_rows == 32) E4S_WGRAD(1, 32); else if (tm_rows == 64) E4S_WGRAD(1, 64); else E4S_WGRAD(1, 128); }
+#undef E4S_WGRAD
     if (ksplit > 1) {
         const int64_t mn = (int64_t)p.M * p.N, total = mn * batch;
         if (total <= 65536 && ksplit >= 16) {

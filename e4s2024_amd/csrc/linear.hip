@@ -225,10 +225,57 @@ __global__ __launch_bounds__(256) void small_map_kernel(float* __restrict__ out,
     }
 }
 
+// The shapes the parity composition has (J = 36, K = 9) with everything unrolled and the K-strided side staged through LDS so that both global
+// sides are whole-line accesses: 256 columns n per workgroup, w / dw rows [n][9] move as 2304 consecutive floats.
+template <int J, int K>
+__global__ __launch_bounds__(256) void small_map_fixed_kernel(float* __restrict__ out, const float* __restrict__ T, const float* __restrict__ in, long long N, int trans) {
+    __shared__ float t[J * K];
+    __shared__ float rows[256 * K];
+    for (int i = threadIdx.x; i < J * K; i += 256) t[i] = T[i];
+    const long long n0 = (long long)blockIdx.x * 256;
+    const int cnt = (int)((N - n0 < 256 ? N - n0 : 256) * K);           // floats of the [n][K] side this workgroup owns
+    const long long n = n0 + threadIdx.x;
+    if (!trans) {
+        for (int i = threadIdx.x; i < cnt; i += 256) rows[i] = in[n0 * K + i];
+        __syncthreads();
+        if (n >= N) return;
+        float w[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) w[k] = rows[threadIdx.x * K + k];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) a += t[j * K + k] * w[k];
+            out[(long long)j * N + n] = a;
+        }
+    } else {
+        __syncthreads();
+        float a[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) a[k] = 0.f;
+        if (n < N) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const float gv = in[(long long)j * N + n];
+#pragma unroll
+                for (int k = 0; k < K; ++k) a[k] += t[j * K + k] * gv;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) rows[threadIdx.x * K + k] = a[k];
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += 256) out[n0 * K + i] = rows[i];
+    }
+}
+
 extern "C" int e4s_small_map(float* out, const float* T, const float* in, int J, int K, int64_t N, int trans, void* stream) {
     E4S_REQUIRE(out && T && in, "small_map: null tensor");
     E4S_REQUIRE(J >= 1 && J <= SM_MAX && K >= 1 && K <= SM_MAX && N >= 0, "small_map: J, K in 1..%d", SM_MAX);
     if (N == 0) return 0;
-    hipLaunchKernelGGL(small_map_kernel, dim3((unsigned)cdiv64(N, 256)), dim3(256), 0, (hipStream_t)stream, out, T, in, J, K, (long long)N, trans);
+    if (J == 36 && K == 9)
+        hipLaunchKernelGGL((small_map_fixed_kernel<36, 9>), dim3((unsigned)cdiv64(N, 256)), dim3(256), 0, (hipStream_t)stream, out, T, in, (long long)N, trans);
+    else
+        hipLaunchKernelGGL(small_map_kernel, dim3((unsigned)cdiv64(N, 256)), dim3(256), 0, (hipStream_t)stream, out, T, in, J, K, (long long)N, trans);
     return check_launch("small_map");
 }

@@ -1314,13 +1314,28 @@ def unfold2d(x, ks: int, stride: int, pad: int, ho: int, wo: int):
     return cols
 
 
+# the data / style gradient of a masked 3x3 layer as one kernel instead of the GEMM that writes U + the fold that reads it twice.  Off by default:
+# measured slower on all but the two largest masked layers (csrc/mconv_dgrad.hip, STATUS)
+DGRAD_FUSED = os.environ.get("E4S_DGRAD_FUSED", "0") != "0"
+DGRAD_FUSED_MIN_WIDTH = int(os.environ.get("E4S_DGRAD_FUSED_MINW", "32"))
+
+
 def _mconv_input_grads(gz, wg, x, s, lab, up: int, need_x: bool, need_s: bool, need_w: bool):
     """The part of the backward that follows ``gz``: U_g = W_gᵀ gz_g (library GEMM), dx / ds from one pass over U (``e4s_mconv_fold``), and
     dW_g = gz_g cols_gᵀ (unfold kernel + library GEMM)."""
     bs, cin, h, w = x.shape
     G, cout, ks, nreg = wg.shape[0], wg.shape[1], wg.shape[-1], s.shape[1]
     dx = ds = dw = None
-    if need_x or need_s:
+    if (need_x or need_s) and DGRAD_FUSED and ks == 3 and w >= DGRAD_FUSED_MIN_WIDTH:
+        # one kernel: the nine taps' U in accumulators, modulated and summed with their shifts in LDS (csrc/mconv_dgrad.hip)
+        dx = torch.empty_like(x) if need_x else None
+        ntile = lib().cdll.e4s_mconv_dgrad_tiles(h, w)
+        part = torch.empty((ntile, bs, nreg, cin), dtype=torch.float32, device=x.device) if need_s else None
+        lib().call("e4s_mconv_dgrad", _p(dx), _p(part), _p(_c(gz, "gz")), _p(_c(wg, "wg")), _p(x), _p(s), _p(lab), bs, cin, cout, h, w, nreg, up,
+                   _stream())
+        if need_s:
+            ds = _sum_dim(part.view(ntile, -1), 0).view(bs, nreg, cin) if ntile > 1 else part[0]
+    elif need_x or need_s:
         # U_g = W_gᵀ gz_g: [G, bs, cin*KK, P]; the weight is stored [cout][cin*KK] = [K][M], gz [cout][P] = [K][N]
         w2 = wg.reshape(G, cout, cin * ks * ks)
         if bs == 1:

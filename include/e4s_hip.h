@@ -449,6 +449,16 @@ E4S_API int e4s_gemm_sb(float* c, const float* a, const float* b, int M, int N, 
 E4S_API int e4s_mconv_wgrad(float* dw, const float* gz, const float* x, const float* s, const uint8_t* labels, int bs, int cin, int cout, int h,
                             int w, int ks, int nreg, int up, float* workspace, int64_t workspace_floats, void* stream);
 
+/* Data and style gradient of the masked modulated 3x3 convolution in one kernel — e4s_gemm_sb (U = W^T gz) + e4s_mconv_fold without U in memory
+ * (same reference path: autograd through ModulatedConv2d.forward, models/stylegan2/model.py:276-320):
+ *     dx[b,i,q]            = sum_g sum_k s[b,c_g(q-k+1),i] * sum_o wg[g,o,i,k] * gz[g,b,o,q-k+1]               (may be NULL)
+ *     ds_part[t,b,r,i]     = tile t's part of sum_g sum_{p: c_g(p) = r} sum_k (sum_o wg[g,o,i,k] gz[g,b,o,p]) * x[b,i,p+k-1]   (may be NULL)
+ * gz [up*up, bs, cout, h*w] (e4s_mconv_scale), wg [up*up, cout, cin, 3, 3] fp32, labels as for e4s_mconv_fold (NULL = one region), w >= 32.
+ * t < e4s_mconv_dgrad_tiles(h, w); dL/ds = ds_part.sum(0).  Every product as three bf16 MFMAs with fp32 accumulation; sums in a fixed order. */
+E4S_API int e4s_mconv_dgrad_tiles(int h, int w);
+E4S_API int e4s_mconv_dgrad(float* dx, float* ds_part, const float* gz, const float* wg, const float* x, const float* s, const uint8_t* labels,
+                            int bs, int cin, int cout, int h, int w, int nreg, int up, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

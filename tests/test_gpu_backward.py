@@ -617,3 +617,61 @@ def test_local_mlps_native_backward_against_autograd(bs, n, dim_in, dim_style, l
         worst = max(worst, (a - b).abs().max().item() / max(1e-6, b.abs().max().item()))
     record_parity(f"local_mlps.native_backward.bs{bs}_n{n}_{dim_in}x{dim_style}x{layers}.rel_vs_autograd", worst, 2e-4)
     assert worst <= 2e-4
+
+
+@pytest.mark.parametrize("cin,cout,h,w,up,bs", [(32, 32, 16, 32, 1, 2), (48, 24, 20, 64, 1, 1), (64, 40, 14, 96, 2, 1), (40, 16, 32, 32, 2, 2), (32, 64, 64, 128, 1, 1)])
+def test_fused_data_and_style_gradient_against_fp64_and_the_unfused_pair(cin, cout, h, w, up, bs):
+    """``e4s_mconv_dgrad`` (U = Wᵀ gz kept in accumulators, modulated by the source position's region, summed with its shifts in LDS) against a
+    float64 evaluation of the same sums and against ``e4s_gemm_sb`` + ``e4s_mconv_fold``: 32-wide maps (one tile column that owns every
+    column), widths that are no multiple of the 30 owned columns, heights that are no multiple of the 6 owned rows, ragged channel counts,
+    the composed up-sampling form (four parities, labels at the output resolution), labels outside the region range; bit-identical reruns."""
+    from e4s2024_amd import ops
+    nreg, G = 5, up * up
+    g = torch.Generator().manual_seed(cin + 7 * cout + h + w)
+    x = torch.randn(bs, cin, h, w, generator=g).to(DEV)
+    gz = torch.randn(G, bs, cout, h * w, generator=g).to(DEV)
+    wg = (torch.randn(G, cout, cin, 3, 3, generator=g) / (3 * cout ** 0.5)).to(DEV)
+    s = torch.randn(bs, nreg, cin, generator=g).to(DEV)
+    lab = torch.randint(0, nreg + 1, (bs, up * h, up * w), generator=g).to(torch.uint8)           # value nreg = "no region"
+    lab[:, : up * h // 3] = 2
+    lab[:, :, up * w // 2:] = torch.where(lab[:, :, up * w // 2:] == 1, torch.tensor(3, dtype=torch.uint8), lab[:, :, up * w // 2:])
+    lab = lab.to(DEV)
+
+    def run(fused):
+        old = ops.DGRAD_FUSED
+        ops.DGRAD_FUSED = fused
+        try:
+            return ops._mconv_input_grads(gz, wg, x, s, lab, up, True, True, False)[:2]
+        finally:
+            ops.DGRAD_FUSED = old
+    dx, ds = run(True)
+    dx2, ds2 = run(True)
+    dxu, dsu = run(False)
+    # float64
+    U = torch.einsum("goik,gbop->gbikp", wg.double().view(G, cout, cin, 9), gz.double()).view(G, bs, cin, 9, h, w)
+    xp = torch.nn.functional.pad(x.double(), (1, 1, 1, 1))
+    dx64 = torch.zeros(bs, cin, h + 2, w + 2, dtype=torch.float64, device=DEV)
+    ds64 = torch.zeros(bs, nreg, cin, dtype=torch.float64, device=DEV)
+    s64 = torch.cat([s.double(), torch.zeros(bs, 1, cin, dtype=torch.float64, device=DEV)], 1)        # row nreg = no region
+    for gi in range(G):
+        ga, gb = gi // up, gi % up
+        c = lab[:, ga::up, gb::up].long().clamp(max=nreg)                                              # [bs, h, w]
+        smod = torch.gather(s64, 1, c.view(bs, -1, 1).expand(-1, -1, cin)).view(bs, h, w, cin).permute(0, 3, 1, 2)
+        onehot = torch.nn.functional.one_hot(c, nreg + 1)[..., :nreg].double()                         # [bs, h, w, nreg]
+        for ky in range(3):
+            for kx in range(3):
+                Uk = U[gi, :, :, ky * 3 + kx]                                                          # [bs, cin, h, w] at source positions p
+                dx64[:, :, ky:ky + h, kx:kx + w] += Uk * smod                                          # lands on q = p + k - 1 (padded by one)
+                ds64 += torch.einsum("bihw,bhwr->bri", Uk * xp[:, :, ky:ky + h, kx:kx + w], onehot)
+    dx64 = dx64[:, :, 1:-1, 1:-1]
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx2) and torch.equal(ds, ds2)
+    e_dx = (dx.double() - dx64).abs().max().item() / dx64.abs().max().item()
+    e_ds = (ds.double() - ds64).abs().max().item() / ds64.abs().max().item()
+    e_dxu = (dxu.double() - dx64).abs().max().item() / dx64.abs().max().item()
+    e_dsu = (dsu.double() - ds64).abs().max().item() / ds64.abs().max().item()
+    tag = f"mconv_dgrad.cin{cin}_cout{cout}_{h}x{w}_up{up}"
+    record_parity(tag + ".dx_rel_vs_fp64", e_dx, 3e-5)
+    record_parity(tag + ".ds_rel_vs_fp64", e_ds, 3e-5)
+    assert e_dx <= 3e-5 and e_ds <= 3e-5, (e_dx, e_ds, e_dxu, e_dsu)
+    assert e_dxu <= 3e-5 and e_dsu <= 3e-5

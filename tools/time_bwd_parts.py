@@ -18,7 +18,7 @@ def t(fn, n=5):
 
 
 # (cin, cout, h(out of plain / in of up), up)
-for cin, cout, h, up in [(128, 128, 256, 1), (256, 128, 128, 2), (256, 256, 128, 1), (512, 512, 64, 1), (32, 32, 1024, 1), (64, 64, 512, 1)]:
+for cin, cout, h, up in [(128, 128, 256, 1), (256, 128, 128, 2), (256, 256, 128, 1), (512, 256, 64, 2), (512, 512, 64, 1), (512, 512, 32, 2), (512, 512, 32, 1), (32, 32, 1024, 1), (64, 64, 512, 1)]:
     G, P = up * up, h * h
     x = torch.randn(1, cin, h, h, device=dev)
     s = torch.randn(1, 12, cin, device=dev)
@@ -36,7 +36,8 @@ for cin, cout, h, up in [(128, 128, 256, 1), (256, 128, 128, 2), (256, 256, 128,
         "unfold": t(lambda: ops._mconv_unfold(x, s, lab, 3, up)),
         "U gemm (lib)": t(lambda: torch.matmul(wt, gz)),
         "U gemm_sb": t(lambda: ops.gemm_sb(wg.reshape(G, cout, cin * 9), gz.view(G, cout, -1), False, False)),
-        "U+fold": t(lambda: ops._mconv_input_grads(gz, wg, x, s, lab, up, True, True, False)),
+        "U+fold": t(lambda: (setattr(ops, "DGRAD_FUSED", False), ops._mconv_input_grads(gz, wg, x, s, lab, up, True, True, False))),
+        "dgrad fused": t(lambda: (setattr(ops, "DGRAD_FUSED", True), ops._mconv_input_grads(gz, wg, x, s, lab, up, True, True, False))),
         "dW gemm (lib)": t(lambda: torch.matmul(gz, cols.transpose(2, 3))),
         "dW gemm_sb": t(lambda: ops._gemm_nt(gz, cols)),
         "dW implicit": t(lambda: ops.mconv_wgrad(gz, x, s, lab, cout, 3, up)),
