@@ -225,42 +225,78 @@ __global__ __launch_bounds__(256) void small_map_kernel(float* __restrict__ out,
     }
 }
 
-// The shapes the parity composition has (J = 36, K = 9) with everything unrolled and the K-strided side staged through LDS so that both global
-// sides are whole-line accesses: 256 columns n per workgroup, w / dw rows [n][9] move as 2304 consecutive floats.
-template <int J, int K>
+// The shapes the parity composition has (J = 36, K = 9) with everything unrolled and the K-strided sides staged through LDS so that every global
+// access is a whole line: 256 columns n per workgroup, w / dw rows [n][9] move as 2304 consecutive floats.  GROUPED: the J side is stored
+// [J / 9][N][9] (out[g][n][t] for j = 9 g + t) instead of [J][N] — the four parity weights as [4][cout][cin][3][3], no permuted copy after it.
+template <int J, int K, bool GROUPED>
 __global__ __launch_bounds__(256) void small_map_fixed_kernel(float* __restrict__ out, const float* __restrict__ T, const float* __restrict__ in, long long N, int trans) {
     __shared__ float t[J * K];
     __shared__ float rows[256 * K];
+    constexpr int KO = 9, G = J / KO;
+    static_assert(!GROUPED || (K == KO && J % KO == 0), "the grouped layout shares the staging rows: groups of 9");
     for (int i = threadIdx.x; i < J * K; i += 256) t[i] = T[i];
     const long long n0 = (long long)blockIdx.x * 256;
-    const int cnt = (int)((N - n0 < 256 ? N - n0 : 256) * K);           // floats of the [n][K] side this workgroup owns
+    const int cols = (int)(N - n0 < 256 ? N - n0 : 256);
+    const int cnt = cols * K;                                            // floats of the [n][K] side this workgroup owns
     const long long n = n0 + threadIdx.x;
     if (!trans) {
         for (int i = threadIdx.x; i < cnt; i += 256) rows[i] = in[n0 * K + i];
         __syncthreads();
-        if (n >= N) return;
         float w[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) w[k] = rows[threadIdx.x * K + k];
+        if (!GROUPED) {
+            if (n >= N) return;
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
-            float a = 0.f;
+            for (int j = 0; j < J; ++j) {
+                float a = 0.f;
 #pragma unroll
-            for (int k = 0; k < K; ++k) a += t[j * K + k] * w[k];
-            out[(long long)j * N + n] = a;
+                for (int k = 0; k < K; ++k) a += t[j * K + k] * w[k];
+                out[(long long)j * N + n] = a;
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                __syncthreads();                                         // (rows is reused as the output stage of group g)
+#pragma unroll
+                for (int q = 0; q < KO; ++q) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) a += t[(g * KO + q) * K + k] * w[k];
+                    rows[threadIdx.x * KO + q] = a;
+                }
+                __syncthreads();
+                for (int i = threadIdx.x; i < cols * KO; i += 256) out[((long long)g * N + n0) * KO + i] = rows[i];
+            }
         }
     } else {
         __syncthreads();
         float a[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) a[k] = 0.f;
-        if (n < N) {
+        if (!GROUPED) {
+            if (n < N) {
 #pragma unroll
-            for (int j = 0; j < J; ++j) {
-                const float gv = in[(long long)j * N + n];
+                for (int j = 0; j < J; ++j) {
+                    const float gv = in[(long long)j * N + n];
 #pragma unroll
-                for (int k = 0; k < K; ++k) a[k] += t[j * K + k] * gv;
+                    for (int k = 0; k < K; ++k) a[k] += t[j * K + k] * gv;
+                }
             }
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                __syncthreads();
+                for (int i = threadIdx.x; i < cols * KO; i += 256) rows[i] = in[((long long)g * N + n0) * KO + i];
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < KO; ++q) {
+                    const float gv = rows[threadIdx.x * KO + q];         // (columns beyond N read stale LDS and are never written out)
+#pragma unroll
+                    for (int k = 0; k < K; ++k) a[k] += t[(g * KO + q) * K + k] * gv;
+                }
+            }
+            __syncthreads();
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) rows[threadIdx.x * K + k] = a[k];
@@ -269,13 +305,17 @@ __global__ __launch_bounds__(256) void small_map_fixed_kernel(float* __restrict_
     }
 }
 
-extern "C" int e4s_small_map(float* out, const float* T, const float* in, int J, int K, int64_t N, int trans, void* stream) {
+extern "C" int e4s_small_map(float* out, const float* T, const float* in, int J, int K, int64_t N, int trans, int grouped, void* stream) {
     E4S_REQUIRE(out && T && in, "small_map: null tensor");
     E4S_REQUIRE(J >= 1 && J <= SM_MAX && K >= 1 && K <= SM_MAX && N >= 0, "small_map: J, K in 1..%d", SM_MAX);
+    E4S_REQUIRE(!grouped || (J == 36 && K == 9), "small_map: the grouped layout is built for J = 36, K = 9");
     if (N == 0) return 0;
-    if (J == 36 && K == 9)
-        hipLaunchKernelGGL((small_map_fixed_kernel<36, 9>), dim3((unsigned)cdiv64(N, 256)), dim3(256), 0, (hipStream_t)stream, out, T, in, (long long)N, trans);
+    const dim3 grid((unsigned)cdiv64(N, 256));
+    if (J == 36 && K == 9 && grouped)
+        hipLaunchKernelGGL((small_map_fixed_kernel<36, 9, true>), grid, dim3(256), 0, (hipStream_t)stream, out, T, in, (long long)N, trans);
+    else if (J == 36 && K == 9)
+        hipLaunchKernelGGL((small_map_fixed_kernel<36, 9, false>), grid, dim3(256), 0, (hipStream_t)stream, out, T, in, (long long)N, trans);
     else
-        hipLaunchKernelGGL(small_map_kernel, dim3((unsigned)cdiv64(N, 256)), dim3(256), 0, (hipStream_t)stream, out, T, in, J, K, (long long)N, trans);
+        hipLaunchKernelGGL(small_map_kernel, grid, dim3(256), 0, (hipStream_t)stream, out, T, in, J, K, (long long)N, trans);
     return check_launch("small_map");
 }

@@ -1811,19 +1811,23 @@ class _LocalMLPsGrad(torch.autograd.Function):
 
 class _SmallMap(torch.autograd.Function):
     """``out[j, ...] = sum_k T[j, k] * w[..., k]`` for a constant ``T [J, K]`` (J, K <= 36) — the parity composition of an up layer's weight
-    (``torch_ref._parity_weights``) — and its gradient, one launch each (``e4s_small_map``)."""
+    (``torch_ref._parity_weights``) — and its gradient, one launch each (``e4s_small_map``).  ``grouped`` (J = 36, K = 9): the result is laid out
+    ``[4, ..., 9]`` (``out[g, ..., t]`` for ``j = 9 g + t``), the four parity weights in the layout their consumers read."""
 
     @staticmethod
-    def forward(ctx, w, T):
+    def forward(ctx, w, T, grouped):
         w, T = _c(w, "w"), _c(T, "T")
         J, K = T.shape
         if w.shape[-1] != K:
             raise ValueError(f"small_map: last dimension {w.shape[-1]} != {K}")
+        if grouped and (J, K) != (36, 9):
+            raise ValueError("small_map: the grouped layout is built for T [36, 9]")
         n = w.numel() // K
-        out = torch.empty((J,) + tuple(w.shape[:-1]), dtype=torch.float32, device=w.device)
-        lib().call("e4s_small_map", _p(out), _p(T), _p(w), J, K, n, 0, _stream())
+        shape = (J // 9,) + tuple(w.shape[:-1]) + (9,) if grouped else (J,) + tuple(w.shape[:-1])
+        out = torch.empty(shape, dtype=torch.float32, device=w.device)
+        lib().call("e4s_small_map", _p(out), _p(T), _p(w), J, K, n, 0, int(grouped), _stream())
         ctx.save_for_backward(T)
-        ctx.wshape = tuple(w.shape)
+        ctx.wshape, ctx.grouped = tuple(w.shape), bool(grouped)
         return out
 
     @staticmethod
@@ -1832,12 +1836,12 @@ class _SmallMap(torch.autograd.Function):
         J, K = T.shape
         g = g.contiguous()
         dw = torch.empty(ctx.wshape, dtype=torch.float32, device=g.device)
-        lib().call("e4s_small_map", _p(dw), _p(T), _p(g), J, K, dw.numel() // K, 1, _stream())
-        return dw, None
+        lib().call("e4s_small_map", _p(dw), _p(T), _p(g), J, K, dw.numel() // K, 1, int(ctx.grouped), _stream())
+        return dw, None, None
 
 
-def small_map(w, T):
-    return _SmallMap.apply(w, T)
+def small_map(w, T, grouped: bool = False):
+    return _SmallMap.apply(w, T, grouped)
 
 
 class _EqualLinearGrad(torch.autograd.Function):

@@ -111,7 +111,7 @@ def _parity_weights(ws, blur, dtype):
         from . import ops
         if ops.NATIVE_BWD:      # one launch (and one for its gradient) instead of a library GEMM of 36 x 9 x (cout cin)
             co, ci = ws.shape[:2]
-            return ops.small_map(ws.reshape(co, ci, 9), par.reshape(36, 9)).view(4, 3, 3, co, ci).permute(0, 3, 4, 1, 2)
+            return ops.small_map(ws.reshape(co, ci, 9), par.reshape(36, 9), grouped=True).view(4, co, ci, 3, 3)    # written in this layout: no copy
     return torch.einsum("gyxkl,oikl->goiyx", par, ws)
 
 

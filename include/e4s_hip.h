@@ -248,8 +248,9 @@ E4S_API int e4s_grouped_linear_bwd(float* dW, float* db, float* dx, float* scrat
 
 /* out[j][n] = sum_k T[j][k] w[n][k] (trans = 0; w [N][K], out [J][N]) or its transpose dw[n][k] = sum_j T[j][k] g[j][n] (trans = 1): a constant
  * J x K map (J, K <= 36) along a long axis — the composition of an up layer's 3x3 weight with its blur kernel into the four parity weights
- * (J = 36, K = 9, N = cout * cin; models/stylegan2/model.py:287-300 composed) and its gradient. */
-E4S_API int e4s_small_map(float* out, const float* T, const float* in, int J, int K, int64_t N, int trans, void* stream);
+ * (J = 36, K = 9, N = cout * cin; models/stylegan2/model.py:287-300 composed) and its gradient.  grouped != 0 (J = 36, K = 9 only):
+ * the J side is stored [4][N][9] — out[g][n][t] for j = 9 g + t — i.e. the four parity weights as [4][cout][cin][3][3]. */
+E4S_API int e4s_small_map(float* out, const float* T, const float* in, int J, int K, int64_t N, int trans, int grouped, void* stream);
 
 /* ------------------------------------------------------------------------------------ a8 / a9: plain convolutions
  * Replaces the F.conv2d calls of the regional-style encoder (models/encoders/psp_encoders.py:334, helpers.py:128-139)

@@ -675,3 +675,28 @@ def test_fused_data_and_style_gradient_against_fp64_and_the_unfused_pair(cin, co
     record_parity(tag + ".ds_rel_vs_fp64", e_ds, 3e-5)
     assert e_dx <= 3e-5 and e_ds <= 3e-5, (e_dx, e_ds, e_dxu, e_dsu)
     assert e_dxu <= 3e-5 and e_dsu <= 3e-5
+
+
+@pytest.mark.parametrize("co,ci", [(8, 40), (64, 33), (512, 512)])
+def test_parity_composition_map_both_layouts_and_its_gradient(co, ci):
+    """``e4s_small_map`` with T [36, 9] (the composition of an up layer's 3x3 weight with its blur into four parity weights,
+    ``torch_ref._parity_weights``): the plain [36, N] layout and the grouped [4, N, 9] one the backward consumes, forward and gradient, against
+    the einsum they replace; N = cout * cin not a multiple of the 256 columns of a workgroup."""
+    from e4s2024_amd import ops, torch_ref
+    g = torch.Generator().manual_seed(co + ci)
+    ws = torch.randn(co, ci, 3, 3, generator=g).to(DEV).requires_grad_(True)
+    blur = torch.tensor([1., 3., 3., 1.])
+    blur = (blur[:, None] * blur[None, :] / blur.sum() ** 2 * 4).to(DEV)
+    par = torch_ref._blur_shift(blur, torch.float32)[1]
+    ref = torch.einsum("gyxkl,oikl->goiyx", par.double(), ws.double())
+    gout = torch.randn(4, co, ci, 3, 3, generator=g).to(DEV)
+    gref = torch.einsum("gyxkl,goiyx->oikl", par.double(), gout.double())
+    plain = ops.small_map(ws.reshape(co, ci, 9), par.reshape(36, 9)).view(4, 3, 3, co, ci).permute(0, 3, 4, 1, 2)
+    grouped = ops.small_map(ws.reshape(co, ci, 9), par.reshape(36, 9), grouped=True).view(4, co, ci, 3, 3)
+    assert torch.equal(plain.contiguous(), grouped)
+    assert (grouped.double() - ref).abs().max().item() <= 1e-6 * ref.abs().max().item()
+    (gw,) = torch.autograd.grad(grouped, ws, gout)
+    (gw_plain,) = torch.autograd.grad(plain, ws, gout)
+    assert (gw - gw_plain).abs().max().item() <= 1e-6 * gw.abs().max().item()       # (same sums, the compiler contracts them differently)
+    assert (gw.double() - gref).abs().max().item() <= 1e-6 * gref.abs().max().item()
+    assert torch.equal(torch_ref._parity_weights(ws, blur, torch.float32), grouped)
