@@ -465,7 +465,11 @@ class Generator(nn.Module):
             ops.style_demod_plan(self._table_jobs(latent))     # every layer's modulation / demodulation table in two launches
         out = self.input(latent)
         # one view per W+ index: under autograd the 18 views are one unbind (its backward one stack), not 26 zero-filled slice gradients
-        lat = latent.unbind(2) if latent.ndim == 4 else None
+        if latent.ndim == 4 and latent.is_cuda and torch.is_grad_enabled():
+            # (the layers' gradient kernels want dense [bs, regions, 512] codes: one transposed copy here instead of one per layer)
+            lat = latent.permute(2, 0, 1, 3).contiguous().unbind(0)
+        else:
+            lat = latent.unbind(2) if latent.ndim == 4 else None
         out = self.conv1(out, lat[0] if lat is not None else latent[:, :, 0], mask, noise=noise[0])
         skip = self.to_rgb1(out, lat[1] if lat is not None else latent[:, :, 1], mask)
 
