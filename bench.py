@@ -424,7 +424,7 @@ def main():
             pti_info = {"s_per_iter": round(dt, 5), "iters": n_it, "batch": 1, "resolution": 1024, "loss": "L2", "optimizer": "Adam (fused, capturable)",
                         "trainable_params": int(sum(p.numel() for p in params)), "loss_first": round(l0, 4), "loss_last": round(lN.item(), 4),
                         "how": "whole step (forward, backward, weight re-layout, Adam) as one hipGraph; synthesis gradients from csrc/modconv_bwd.hip "
-                               "+ fp32 library GEMMs (BASELINE configs[3], one frame)"}
+                               "+ csrc/gemm_sb.hip (hand-written split-bf16 MFMA GEMM, implicit weight gradient; no library GEMM in the step) (BASELINE configs[3], one frame)"}
             # the loop of configs[3] itself on a short clip: passes over the frames, one optimiser step per frame, eroded maps, foreground-weighted
             # L2 (pti.tune_clip: training/video_swap_ft_coach.py:242-317); the first two steps run eagerly, the rest replays one captured step
             del step

@@ -1321,8 +1321,9 @@ DGRAD_FUSED_MIN_WIDTH = int(os.environ.get("E4S_DGRAD_FUSED_MINW", "32"))
 
 
 def _mconv_input_grads(gz, wg, x, s, lab, up: int, need_x: bool, need_s: bool, need_w: bool):
-    """The part of the backward that follows ``gz``: U_g = W_gᵀ gz_g (library GEMM), dx / ds from one pass over U (``e4s_mconv_fold``), and
-    dW_g = gz_g cols_gᵀ (unfold kernel + library GEMM)."""
+    """The part of the backward that follows ``gz``: U_g = W_gᵀ gz_g (``e4s_gemm_sb``), dx / ds from one pass over U (``e4s_mconv_fold``) — or both
+    from ``e4s_mconv_dgrad`` without U in memory (``DGRAD_FUSED``) — and dW_g = gz_g cols_gᵀ as an implicit GEMM (``e4s_mconv_wgrad``; the 4x4 / 8x8
+    maps: unfold kernel + ``e4s_gemm_sb``)."""
     bs, cin, h, w = x.shape
     G, cout, ks, nreg = wg.shape[0], wg.shape[1], wg.shape[-1], s.shape[1]
     dx = ds = dw = None
@@ -1390,7 +1391,7 @@ def _check_mconv(x, wg, s, d, lab, up):
 
 class _MaskedConvCore(torch.autograd.Function):
     """``y[b,o,p] = d[b,c(p),o] · Σ_{i,k} W[o,i,k] · s[b,c(p),i] · x[b,i,p+k-pad]`` evaluated AND differentiated with the kernels of
-    ``csrc/modconv_bwd.hip`` and fp32 library GEMMs — the differentiable core ``torch_ref._region_sum`` uses on the
+    ``csrc/modconv_bwd.hip`` and the split-bf16 MFMA GEMM of ``csrc/gemm_sb.hip`` — the differentiable core ``torch_ref._region_sum`` uses on the
     device when a backward pass has to re-evaluate a masked layer (ToRGB).  The inference forward is the fused MFMA kernel, not this.
 
     ``x [bs,cin,h,w]``, ``w [cout,cin,ks,ks]`` (already scaled), ``s [bs,nreg,cin]``, ``d [bs,nreg,cout]`` or None, ``lab`` uint8 ``[bs,h,w]``."""
@@ -1423,7 +1424,7 @@ def masked_conv_core(x, w, s, d, lab):
 
 class _MaskedStyledConvGrad(torch.autograd.Function):
     """A masked ``StyledConv`` whose forward value is already known (``out``, from the fused MFMA kernel) and whose gradients come from
-    ``csrc/modconv_bwd.hip`` + fp32 library GEMMs — no re-evaluation of the layer:
+    ``csrc/modconv_bwd.hip`` + ``csrc/gemm_sb.hip`` — no re-evaluation of the layer, no library GEMM:
 
         out = leaky_relu(d[c(p)] · Σ W_g · s[c(p)] · x  +  noise_weight · noise  +  act_bias) · √2
 
@@ -1596,7 +1597,7 @@ class _SingleStyledConvGrad(torch.autograd.Function):
                 dx = torch.cat([conv2d(g[b:b + 1], PreparedConv(exact="sb3").get(wd[b].contiguous()), 1 if blur is None else 2,
                                        k // 2 if blur is None else 0) for b in range(bs)])
         if need_w and k in (1, 3):
-            # weight gradient = one unfold + one library GEMM per sample group: dW[o,(i,k)] = Σ_p g'[o,p] · x[i,p+k-pad], or for the
+            # weight gradient as an implicit GEMM (e4s_mconv_wgrad; odd widths: one unfold + e4s_gemm_sb per sample group): dW[o,(i,k)] = Σ_p g'[o,p] · x[i,p+k-pad], or for the
             # transposed conv dWt[i,(o,k)] = Σ_q x[i,q] · gT[o,2q+k]
             if blur is None and w % 16 == 0:
                 dw = mconv_wgrad(g.reshape(1, bs, cout, h * w), x, None, None, cout, k).view(bs, cout, cin, k, k)

@@ -3,7 +3,7 @@
 Mirrors one inner iteration of ``VideoSwapPTICoach.train_e4s`` (training/video_swap_ft_coach.py:253-299) for the part that lives on the
 hot path: ``cal_style_codes`` -> ``gen_img`` -> pixel loss -> ``backward`` -> optimiser step, with the style vectors and region map of a
 frame as fixed inputs.  The forward runs on the fused HIP kernels; the backward of the synthesis layers differentiates from their
-outputs with the gradient kernels of ``csrc/modconv_bwd.hip`` + library GEMMs (``ops._MaskedStyledConvGrad`` /
+outputs with the gradient kernels of ``csrc/modconv_bwd.hip`` + ``csrc/gemm_sb.hip`` (``ops._MaskedStyledConvGrad`` /
 ``ops._SingleStyledConvGrad``), only the small per-layer style tables go through autograd (``torch_ref.py``).  The perceptual /
 identity / parsing losses of ``calc_loss`` (:176-223) are separate networks outside the path (LPIPS-alex, ArcFace, a UNet parser) and
 plug in through ``extra_loss``.

@@ -130,7 +130,7 @@ def _region_sum(x, styles, labels, weight, mod_w, mod_b, mod_scale, mod_lr, demo
     lab = _labels_at(labels, ho, wo)
     if x.is_cuda:
         from . import ops
-        if ops.NATIVE_BWD:                                                        # §8 f1: HIP gradient kernels + two library GEMMs
+        if ops.NATIVE_BWD:                                                        # §8 f1: HIP gradient kernels + the split-bf16 MFMA GEMM
             lab8 = _labels_at(labels, ho, wo, as_u8=True)
             if not upsample:
                 return ops.masked_conv_core(x, ws, s, d, lab8)
