@@ -207,7 +207,11 @@ __global__ __launch_bounds__(64 * WC * WP, MINW) void region_modconv_sb_kernel(c
 
     const int ntile = p.tiles_x * p.tiles_y;
     const int npar = p.up ? 4 : 1;
-    const unsigned bxp = p.perm_mul ? (unsigned)(((unsigned long long)blockIdx.x * p.perm_mul) % gridDim.x) : blockIdx.x;
+    unsigned bxp = p.perm_mul ? (unsigned)(((unsigned long long)blockIdx.x * p.perm_mul) % gridDim.x) : blockIdx.x;
+    // A multiplication keeps residues: workgroups i = j (mod 8) — one XCD — would all get tile slots of one residue mod 8, i.e. the same one or two
+    // tile COLUMNS of a map that is 4 or 8 tiles wide, and a skip set made of columns (face in the middle, background left and right) idles half the
+    // XCDs.  Rotating the slot inside its group of eight by the group's index gives every XCD every column.
+    if (p.perm_mul && (gridDim.x & 7u) == 0) bxp = (bxp & ~7u) | ((bxp + (bxp >> 3)) & 7u);
     const int ks = bxp / (ntile * npar);
     const int bx = bxp - ks * ntile * npar;
     const int tile = bx % ntile;
