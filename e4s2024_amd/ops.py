@@ -642,21 +642,23 @@ def can_fuse_rgb(cout: int, w: int, up: bool, masked: bool) -> bool:
 
 UP_BLOCKS = os.environ.get("E4S_UP_BLOCKS", "1") != "0"    # masked up layers: region-uniform 16 x 16 output blocks in the transposed-conv form
 UP_BLOCK = 16
-# smallest input width of a masked up layer that tries the block path (64: the 64 -> 128 and 128 -> 256 layers).  A layer that tries costs two
-# small launches and gives up its K split; the 32 -> 64 layer's tiles are the full width of its map and almost never qualify.  Measured, faces/s
-# at batch 4 with the path off / from width 32 / 64 / 128: portrait-shaped maps 1086 / 1080 / 1082 / 1084, 4 x 4-cell maps 1092 / 1229 / 1203 /
-# 1139, the bench's blocky maps 1084 / 1113 / 1126 / 1127 (tools/sweep_blocks_minw.sh)
-UP_BLOCKS_MIN_WIDTH = int(os.environ.get("E4S_UP_BLOCKS_MINW", "64"))
+# smallest input width of a masked up layer that tries the block path (128: the 128 -> 256 layer only).  A layer that tries costs two small
+# launches and gives up its K split, and below 128 a tile of the composed kernel is half or all of the map's width: on portrait-shaped and
+# parser-made maps those layers never qualify (0 % of their tiles).  Measured, faces/s at batch 4 with the path off / from width 32 / 64 / 128:
+# portrait-shaped maps 1086 / 1080 / 1082 / 1084 (a second box: 1044 / - / 1031 / -), 4 x 4-cell maps 1092 / 1229 / 1203 / 1139, the bench's
+# blocky maps 1084 / 1113 / 1126 / 1127 (tools/sweep_blocks_minw.sh).  E4S_UP_BLOCKS_MINW=64 / 32 for maps made of large cells.
+UP_BLOCKS_MIN_WIDTH = int(os.environ.get("E4S_UP_BLOCKS_MINW", "128"))
 UP_SUBBLOCKS = os.environ.get("E4S_UP_SUBBLOCKS", "0") != "0"   # also blocks made of four uniform 8 x 8 sub-blocks (slower than the composed form on the benchmark maps)
 
 
 UP_BLOCK_QUAD = 254      # block map value: four region-uniform 8 x 8 sub-blocks with different regions
 
 
+UP_BLOCKS_MIN_PERCENT_SMALL = int(os.environ.get("E4S_UP_BLOCKS_MIN_SMALL", "90"))   # the same for a layer whose composed launch fits the chip at once
 UP_BLOCKS_MIN_PERCENT = int(os.environ.get("E4S_UP_BLOCKS_MIN", "40"))   # below this share of qualifying tiles a layer stays entirely in the composed form
 
 
-def uniform_blocks(labels: torch.Tensor, ho: int, wo: int, nreg: int, with_ctrl: bool = False):
+def uniform_blocks(labels: torch.Tensor, ho: int, wo: int, nreg: int, with_ctrl: bool = False, min_percent: int = None):
     """``(blocks [bs, ho/16, wo/16], sub [bs, ho/8, wo/8])`` uint8 (``e4s_uniform_blocks``): ``sub`` = the region shared by all pixels of an
     8 x 8 output sub-block (labels sampled 'nearest' at ``ho`` x ``wo``), 255 if they differ; ``blocks`` = the region of a 16 x 16 block whose
     four sub-blocks share one, 254 if each sub-block is uniform but they differ, 255 otherwise — and 255 for a whole row of four blocks (a tile
@@ -672,7 +674,8 @@ def uniform_blocks(labels: torch.Tensor, ho: int, wo: int, nreg: int, with_ctrl:
     ctrl = getattr(ctx, "up_ctrl", None)
     if ctrl is None or ctrl.device != lab.device:
         ctrl = ctx.up_ctrl = torch.zeros((4,), dtype=torch.int32, device=lab.device)      # per stream; every launch leaves its counters zeroed
-    lib().call("e4s_uniform_blocks", _p(blocks), _p(sub), _p(ctrl), _p(lab), bs, lh, lw, ho, wo, nreg, int(UP_SUBBLOCKS), UP_BLOCKS_MIN_PERCENT, _stream())
+    lib().call("e4s_uniform_blocks", _p(blocks), _p(sub), _p(ctrl), _p(lab), bs, lh, lw, ho, wo, nreg, int(UP_SUBBLOCKS),
+               UP_BLOCKS_MIN_PERCENT if min_percent is None else int(min_percent), _stream())
     return (blocks, sub, ctrl) if with_ctrl else (blocks, sub)
 
 
@@ -725,7 +728,11 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
     if (up_blocks is not None and UP_BLOCKS and sb and up and labels is not None and w >= max(32, UP_BLOCKS_MIN_WIDTH) and cout >= 128 and h % 8 == 0 and w % 8 == 0
             and cin % 16 == 0 and rgb is None and not (x_nhwc or out_nhwc) and sn is None):
         wt_t, blur_k = up_blocks
-        blocks, sub, bctrl = uniform_blocks(labels, ho, wo, nreg, with_ctrl=True)
+        # A layer whose composed launch is one round of workgroups (two per CU) gains nothing from losing some of them — `tools/time_blocks.py 4 tophalf`:
+        # 64 -> 128 at batch 4 with half its tiles moved to the block kernel costs 0.42 + 0.21 ms against 0.47 — so it needs (nearly) all tiles to qualify
+        composed_wgs = (wo // 64) * (ho // 16) * 4 * -(-cout // 128) * bs
+        blocks, sub, bctrl = uniform_blocks(labels, ho, wo, nreg, with_ctrl=True,
+                                            min_percent=max(UP_BLOCKS_MIN_PERCENT, UP_BLOCKS_MIN_PERCENT_SMALL) if composed_wgs <= 512 else UP_BLOCKS_MIN_PERCENT)
         evb = _timed("masked_upconv_blocks", f"{cin}->{cout} @{h} up")
         lib().call("e4s_masked_upconv_blocks", _p(out), _p(x), _p(wt_t[0]), _p(wt_t[1]), _p(s), _p(d), _p(blocks), _p(sub), _p(bctrl), _p(_c(blur_k, "blur kernel")), _p(nz),
                    nbs or 0, _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, int(UP_SUBBLOCKS), _stream())

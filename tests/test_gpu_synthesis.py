@@ -354,8 +354,9 @@ def test_masked_up_layer_uniform_blocks_against_oracle_and_composed_form(sg2, sh
     assert ncell != 8 or (blocks == _ops.UP_BLOCK_QUAD).any()                 # ... and blocks of four uniform sub-blocks with 8 cells per side
     up2 = np.repeat(np.repeat(sub, 2, axis=1), 2, axis=2)[:, ::2, ::2]         # (sanity of the two maps against each other)
     assert sub.shape == (bs, blocks.shape[1] * 2, blocks.shape[2] * 2) and up2.shape == sub.shape
-    old, old_sub, old_w = _ops.UP_BLOCKS, _ops.UP_SUBBLOCKS, _ops.UP_BLOCKS_MIN_WIDTH
-    _ops.UP_BLOCKS_MIN_WIDTH = 32                                             # (the default tries the path from width 128 up only)
+    old, old_sub, old_w, old_pc = _ops.UP_BLOCKS, _ops.UP_SUBBLOCKS, _ops.UP_BLOCKS_MIN_WIDTH, (_ops.UP_BLOCKS_MIN_PERCENT, _ops.UP_BLOCKS_MIN_PERCENT_SMALL)
+    _ops.UP_BLOCKS_MIN_WIDTH = 32                                             # (the default tries the path from width 64 up only)
+    _ops.UP_BLOCKS_MIN_PERCENT = _ops.UP_BLOCKS_MIN_PERCENT_SMALL = 1        # ... and only where most tiles qualify: here both kernels must run
     try:
         with torch.no_grad():
             _ops.UP_BLOCKS, _ops.UP_SUBBLOCKS = True, ncell == 8
@@ -365,6 +366,7 @@ def test_masked_up_layer_uniform_blocks_against_oracle_and_composed_form(sg2, sh
             yc = m(x.to(DEV), st.to(DEV), labd, noise=nz.to(DEV))
     finally:
         _ops.UP_BLOCKS, _ops.UP_SUBBLOCKS, _ops.UP_BLOCKS_MIN_WIDTH = old, old_sub, old_w
+        _ops.UP_BLOCKS_MIN_PERCENT, _ops.UP_BLOCKS_MIN_PERCENT_SMALL = old_pc
     ref = O.styled_conv(sd, "", x, st, onehot, nz, masked=True, upsample=True)
     scale = max(1.0, float(ref.abs().max()))
     assert torch.equal(y, y2)
