@@ -1892,12 +1892,14 @@ def local_mlps_grad(x, out, h, w0, b0, w2, b2, scale0, scale2, lr0, lr2, slope):
 # ----------------------------------------------------------------------------- kernel timing hook
 class KernelTimer:
     """Optional HIP-event timing of individual launches on the current stream (used by bench.py for the roofline of
-    the dominant kernel).  ``with KernelTimer() as kt: ...`` then ``kt.summary()`` → {name: (calls, total_ms)}."""
+    the dominant kernel).  ``with KernelTimer() as kt: ...`` then ``kt.summary()`` → {name: (calls, total_ms)}.  ``only``: time these kernel
+    names only (two event records per launch cost ~4 % of a step when every launch is timed)."""
 
     active = None
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.events = []
+        self.only = None if only is None else set(only)       # names to time (None: every instrumented launch)
 
     def __enter__(self):
         KernelTimer.active = self
@@ -1927,7 +1929,7 @@ class KernelTimer:
 
 def _timed(name: str, detail: Optional[str] = None):
     kt = KernelTimer.active
-    if kt is None:
+    if kt is None or (kt.only is not None and name not in kt.only):
         return None
     a = torch.cuda.Event(enable_timing=True)
     b = torch.cuda.Event(enable_timing=True)

@@ -95,7 +95,7 @@ class FrameShardRunner:
     # ---- the clip loop -------------------------------------------------------------------------------------------
     def run_clip_streamed(self, n_frames: int, shared, frame_inputs: Callable[[int, int], object],
                           synth_fn: Callable[[object, object], torch.Tensor], batch: int = 4, dst: int = 0,
-                          out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+                          out: Optional[torch.Tensor] = None, streams: int = 2) -> Optional[torch.Tensor]:
         """Like ``run_clip`` but the finished frames travel to rank ``dst`` batch by batch while the next batch is being computed, instead
         of in one padded gather at the end (face_swap_video_pipeline.py:404-486 writes each frame out as soon as it is done).
 
@@ -103,15 +103,21 @@ class FrameShardRunner:
         ``async_op``: the collective runs on the backend's own stream); a rank whose block has no ``k``-th batch, or a short last one,
         sends padding.  Rank ``dst`` scatters each round's buffers into ``out [n_frames, H, W, 3]`` (allocated on first use; pass a
         preallocated one to keep the allocation out of a timed region) after the round's gather has completed — at the latest when the
-        next but one round is issued, so at most two rounds of frames are in flight."""
+        next but one round is issued, so at most two rounds of frames are in flight.
+
+        ``streams`` (GPU only): consecutive rounds run on that many alternating HIP streams (``StreamPipeline``): the latency-bound small layers
+        of one batch overlap the large ones of the batch before (+4–6 % swaps/s at batch 8, ``tools/time_swap_pipeline.py``); a round's gather is
+        issued from the round's own stream, so it waits for that round's frames only."""
         start, stop = shard_range(n_frames, self.rank, self.world)
         blocks = [shard_range(n_frames, r, self.world) for r in range(self.world)]
         rounds = max(-(-(e - s) // batch) for s, e in blocks) if n_frames > 0 else 0
-        pending = []          # (work, send buffer, receive buffers, round)
+        pending = []          # (work, send buffer, receive buffers, round, event recorded on the round's stream)
 
         def finish(item):
             nonlocal out
-            work, send, bufs, k = item
+            work, send, bufs, k, ev = item
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)     # the round ran on its own stream
             if work is not None:
                 work.wait()
             if self.rank != dst:
@@ -124,9 +130,13 @@ class FrameShardRunner:
                     if out is None:
                         out = torch.empty((n_frames,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
                     out[lo:hi].copy_(src[: hi - lo])
+                    if src.is_cuda:
+                        src.record_stream(torch.cuda.current_stream())     # (allocated on the round's stream, read here)
 
         shape = None
-        for k in range(rounds):
+
+        def one_round(k):
+            nonlocal shape
             lo = start + k * batch
             hi = min(lo + batch, stop)
             frames = None
@@ -145,13 +155,22 @@ class FrameShardRunner:
                     send[: frames.shape[0]] = frames
             if self.distributed and self.world > 1:
                 bufs = [torch.empty_like(send) for _ in range(self.world)] if self.rank == dst else None
-                work = dist.gather(send, bufs, dst=dst, group=self.group, async_op=True)
+                work = dist.gather(send, bufs, dst=dst, group=self.group, async_op=True)       # (ordered after this round's stream)
             else:
                 bufs, work = None, None
-            pending.append((work, send, bufs, k))
-            if len(pending) > 2:
-                finish(pending.pop(0))
-        while pending:
+            ev = None
+            if send.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record()
+            return work, send, bufs, k, ev
+
+        on_gpu = torch.device(self.device).type == "cuda"
+        with StreamPipeline(streams if on_gpu else 1, device=self.device if on_gpu else None) as pipe:
+            for k in range(rounds):
+                pending.append(pipe.submit(one_round, k))
+                if len(pending) > 2:
+                    finish(pending.pop(0))
+        while pending:                          # (after the pipeline's exit the current stream has waited for every round's stream)
             finish(pending.pop(0))
         return out if self.rank == dst else None
 
@@ -173,6 +192,48 @@ class FrameShardRunner:
             probe = synth_fn(shared, frame_inputs(0, min(1, n_frames)))
             local = probe[:0]
         return self.gather_frames(local, n_frames, dst=dst)
+
+
+class StreamPipeline:
+    """Independent batches on alternating HIP streams of one GPU.
+
+    A batch through ``gen_img`` starts with the 4²–32² layers: a dozen small launches that depend on one another and leave most of the chip
+    idle (≈ 0.4 of 3.5 ms at batch 4).  Batches are independent units (the reference loops over frames, ``face_swap_video_pipeline.py:406``),
+    so the next batch's latency-bound head can run under the previous batch's large layers: ``submit`` puts consecutive calls on ``n`` streams
+    round-robin — kernels of one call stay in order on their stream, calls on different streams overlap.  Measured (``tools/time_pipeline.py``,
+    1024² synthesis): 1 127 → 1 221 faces/s at batch 4 with two streams (1 233 with three), 1 169 → 1 248 at batch 8; outputs bit-identical.
+
+    ``with StreamPipeline(2) as sp: outs = [sp.submit(fn, x) for x in batches]`` — on entry the side streams wait for the work already queued
+    on the current stream (inputs are ready), on exit the current stream waits for all of them (outputs are ready for whatever follows).  The
+    host state of the ops (split-K workspace, control words) is per stream (``ops._StreamCtx``).  ``n <= 1``: plain calls on the current stream.
+    Tensors returned by ``submit`` belong to their stream's allocator pool: drop or consume them after the ``with`` block."""
+
+    def __init__(self, n: int = 2, device=None):
+        self.n = int(n)
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(self.n)] if self.n > 1 else []
+        self._i = 0
+
+    def __enter__(self):
+        if self.streams:
+            main = torch.cuda.current_stream()
+            for st in self.streams:
+                st.wait_stream(main)
+        return self
+
+    def submit(self, fn, *args, **kwargs):
+        if not self.streams:
+            return fn(*args, **kwargs)
+        st = self.streams[self._i % self.n]
+        self._i += 1
+        with torch.cuda.stream(st):
+            return fn(*args, **kwargs)
+
+    def __exit__(self, *exc):
+        if self.streams:
+            main = torch.cuda.current_stream()
+            for st in self.streams:
+                main.wait_stream(st)
+        return False
 
 
 def gen_img_frames(net, codes: torch.Tensor, labels: torch.Tensor, randomize_noise: bool = False) -> torch.Tensor:

@@ -221,3 +221,32 @@ def test_clip_from_reference_style_directory_through_the_swap(gpu_net3, parser, 
     a, lab_a = pipeline.swap_batch(gpu_net3, parser, clip.driven, clip.target)
     b, lab_b = pipeline.swap_batch(gpu_net3, parser, ops.frames_to_tensor(T(u8["D"]).to(DEV)), ops.frames_to_tensor(T(u8["T"]).to(DEV)))
     assert torch.equal(a, b) and torch.equal(lab_a, lab_b) and a.dtype == torch.uint8 and tuple(a.shape) == (2, 1024, 1024, 3)
+
+
+def test_batches_on_alternating_streams_equal_one_stream(gpu_net3):
+    """``runner.StreamPipeline``: six ``gen_img`` batches with DIFFERENT codes and region maps on two and on three alternating streams — every
+    image bit-identical to the same call on one stream (a race on the per-stream host state, the shared prepared weights or the region-map
+    cache would mix batches up), twice in a row."""
+    from e4s2024_amd.runner import StreamPipeline
+    net = gpu_net3
+    la = net.latent_avg.cpu()
+    batches = []
+    for i in range(6):
+        codes = seeded.seeded_codes(70 + i, 2, 12, 18, la).to(DEV)
+        lab = seeded.blocky_labels(80 + i, 2, 12, 512, 16 if i % 2 else 4)
+        batches.append((codes, seeded.labels_to_onehot(lab, 12).to(DEV)))
+    strict = ops.STRICT_MASK
+    ops.STRICT_MASK = False                      # (the one-hot check is a host sync: it would serialise the streams)
+    try:
+        with torch.no_grad():
+            ref = [net.gen_img(None, c, m, randomize_noise=False)[0] for c, m in batches]
+            for n in (2, 3, 2):
+                with StreamPipeline(n, device=DEV) as sp:
+                    outs = [sp.submit(net.gen_img, None, c, m, randomize_noise=False)[0] for c, m in batches]
+                torch.cuda.synchronize()
+                for i, (o, r) in enumerate(zip(outs, ref)):
+                    assert torch.equal(o, r), (n, i, (o - r).abs().max().item())
+                del outs
+    finally:
+        ops.STRICT_MASK = strict
+    assert not torch.equal(ref[0], ref[1])

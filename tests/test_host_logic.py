@@ -456,3 +456,12 @@ def test_bench_spawns_its_own_ranks(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "5", "--warmup", "2"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def test_stream_pipeline_with_one_stream_is_a_plain_call():
+    """``runner.StreamPipeline(1)`` needs no device: ``submit`` is the call itself, in order."""
+    from e4s2024_amd.runner import StreamPipeline
+    seen = []
+    with StreamPipeline(1) as sp:
+        out = [sp.submit(lambda a, b=0: seen.append((a, b)) or a + b, i, b=10) for i in range(4)]
+    assert out == [10, 11, 12, 13] and seen == [(0, 10), (1, 10), (2, 10), (3, 10)]
