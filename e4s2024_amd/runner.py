@@ -206,19 +206,32 @@ class StreamPipeline:
     ``with StreamPipeline(2) as sp: outs = [sp.submit(fn, x) for x in batches]`` — on entry the side streams wait for the work already queued
     on the current stream (inputs are ready), on exit the current stream waits for all of them (outputs are ready for whatever follows).  The
     host state of the ops (split-K workspace, control words) is per stream (``ops._StreamCtx``).  ``n <= 1``: plain calls on the current stream.
-    Tensors returned by ``submit`` belong to their stream's allocator pool: drop or consume them after the ``with`` block."""
+    Tensors returned by ``submit`` (directly or in a tuple / list) are marked as used by the entering stream (``record_stream``), so they can be read
+    and dropped there after the ``with`` block like any other tensor."""
 
     def __init__(self, n: int = 2, device=None):
         self.n = int(n)
         self.streams = [torch.cuda.Stream(device=device) for _ in range(self.n)] if self.n > 1 else []
         self._i = 0
+        self._main = None
 
     def __enter__(self):
+        self._main = None
         if self.streams:
-            main = torch.cuda.current_stream()
+            self._main = main = torch.cuda.current_stream()
             for st in self.streams:
                 st.wait_stream(main)
         return self
+
+    def _hand_over(self, out, depth=0):
+        # results are read on the entering stream after the block: tell the allocator, or a block freed there could be handed out again on its
+        # own stream while that read is still queued
+        if isinstance(out, torch.Tensor):
+            if out.is_cuda and self._main is not None:
+                out.record_stream(self._main)
+        elif isinstance(out, (tuple, list)) and depth < 2:
+            for o in out:
+                self._hand_over(o, depth + 1)
 
     def submit(self, fn, *args, **kwargs):
         if not self.streams:
@@ -226,7 +239,9 @@ class StreamPipeline:
         st = self.streams[self._i % self.n]
         self._i += 1
         with torch.cuda.stream(st):
-            return fn(*args, **kwargs)
+            out = fn(*args, **kwargs)
+        self._hand_over(out)
+        return out
 
     def __exit__(self, *exc):
         if self.streams:
