@@ -102,6 +102,9 @@ class _Lib:
             raise ImportError(
                 f"{SO_PATH} not found: build the HIP library first (python -m e4s2024_amd.build). "
                 "e4s2024_amd has no CPU fallback.")
+        # torch first: its wheel carries its own libamdhip64, and the process must end up with ONE HIP runtime — the library loaded before torch
+        # brings in /opt/rocm's copy, torch then its own, and the kernels launch into a runtime that has no device ("no ROCm-capable device")
+        import torch  # noqa: F401
         self.cdll = ctypes.CDLL(SO_PATH)
         self.cdll.e4s_last_error.restype = ctypes.c_char_p
         self.cdll.e4s_last_error.argtypes = []
