@@ -1025,6 +1025,69 @@ def conv2d(x: torch.Tensor, prepared: PreparedConv, stride: int = 1, pad: int = 
     return out
 
 
+# ---- Winograd F(2x2, 3x3) route of the encoder's stride-1 3x3 convolutions (csrc/winograd.hip + the batched split-bf16 GEMM)
+WINOGRAD = os.environ.get("E4S_WINOGRAD", "1") != "0"
+WINOGRAD_MIN_CIN = int(os.environ.get("E4S_WINOGRAD_MIN_CIN", "256"))
+# Where it pays (tools/time_winograd.py, tools/time_swap.py): the direct kernel runs at the board's sustained MFMA rate once a launch fills the chip
+# (16 faces: 0.255 ms per 512 -> 512 @32^2 launch against 0.239 for Winograd, and slower end to end with its three launches and 268 MB of
+# transformed operands), the 16 GEMMs on e4s_gemm_sb reach two thirds of it — so Winograd is the route of SMALL batches, where the direct launch is
+# latency-bound: one swap (two faces) 7.61 -> 6.65 ms, two swaps 10.04 -> 8.75, four 14.16 -> 13.83, eight 25.3 -> 25.5 (off).
+WINOGRAD_MIN_TILES = int(os.environ.get("E4S_WINOGRAD_MIN_TILES", "256"))
+WINOGRAD_MAX_TILES = int(os.environ.get("E4S_WINOGRAD_MAX_TILES", "2048"))
+
+
+class PreparedWinograd(_Prepared):
+    """``U [16, cout, cin] = G g G^T`` of a 3x3 conv weight, rebuilt when the parameter changes version or storage (``e4s_wino_weight``)."""
+
+    __slots__ = ()
+
+    def get(self, weight: torch.Tensor) -> torch.Tensor:
+        key = None if _volatile(weight) else ((weight.data_ptr(), weight._version), weight.device)
+        hit = self._lookup(key)
+        if hit is not None:
+            return hit[0]
+        w = _c(weight.detach(), "weight")
+        cout, cin, kh, kw = w.shape
+        if (kh, kw) != (3, 3):
+            raise ValueError("PreparedWinograd: 3x3 kernels only")
+        U = torch.empty((16, cout, cin), dtype=torch.float32, device=w.device)
+        lib().call("e4s_wino_weight", _p(U), _p(w), cout, cin, _stream())
+        return self._publish(key, (U,))[0]
+
+
+def winograd_applies(x: torch.Tensor, cin: int, stride: int) -> bool:
+    """Is ``conv2d_winograd`` the faster route for a 3x3, pad-1 convolution of ``x``?  (stride 1, even maps, enough channels, and a tile count
+    between the point where 16 GEMMs fill the chip and the point where the direct kernel does; inference only.)"""
+    bs, _, h, w = x.shape
+    return (WINOGRAD and stride == 1 and x.is_cuda and not torch.is_grad_enabled() and cin >= WINOGRAD_MIN_CIN and h % 2 == 0 and w % 2 == 0
+            and WINOGRAD_MIN_TILES <= bs * (h // 2) * (w // 2) <= WINOGRAD_MAX_TILES)
+
+
+def conv2d_winograd(x: torch.Tensor, U: torch.Tensor, *, in_norm=None, prelu: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``act(conv2d(norm(x), W, stride 1, pad 1))`` for a 3x3 kernel through Winograd F(2x2, 3x3): input transform (with the InstanceNorm
+    of ``in_norm=(mean, rstd)`` applied on load), 16 GEMMs ``U_k [cout, cin] @ V_k [cin, tiles]`` on the split-bf16 MFMA GEMM, output
+    transform with the PReLU.  2.25x fewer multiplications than the direct kernel; same results to ~1e-5 relative."""
+    x = _c(x, "input")
+    bs, cin, h, w = x.shape
+    if U.dim() != 3 or U.shape[0] != 16 or U.shape[2] != cin:
+        raise ValueError(f"conv2d_winograd: U {tuple(U.shape)} does not fit {cin} input channels")
+    cout = U.shape[1]
+    T = bs * (h // 2) * (w // 2)
+    mean = rstd = None
+    if in_norm is not None:
+        mean, rstd = _c(in_norm[0], "in_mean"), _c(in_norm[1], "in_rstd")
+    V = torch.empty((16, cin, T), dtype=torch.float32, device=x.device)
+    ev = _timed("conv2d_winograd<3,1>")
+    lib().call("e4s_wino_input", _p(V), _p(x), _p(mean), _p(rstd), bs, cin, h, w, _stream())
+    M = gemm_sb(U, V, True, False, split_k=False)                                    # [16, cout, T]; no K split: a face's result does not depend on the batch
+    del V
+    out = torch.empty((bs, cout, h, w), dtype=torch.float32, device=x.device)
+    lib().call("e4s_wino_output", _p(out), _p(M), _p(_c(prelu.detach(), "prelu")) if prelu is not None else None, bs, cout, h, w, _stream())
+    if ev is not None:
+        ev.record()
+    return out
+
+
 def plane_stats(x: torch.Tensor, eps: Optional[float] = None, want_nmean: bool = False):
     """Per-(b, c) mean [bs, C] (``eps=None``: mean only = global average pooling), or (mean, rstd[, nmean])."""
     x = _c(x, "input")
@@ -1280,10 +1343,11 @@ def _sum_dim(t, dim: int):
 GEMM_SPLITK_CAP_FLOATS = 64 << 20     # at most 256 MB of split-K partial products per call
 
 
-def gemm_sb(a: torch.Tensor, b: torch.Tensor, a_kc: bool, b_kc: bool) -> torch.Tensor:
+def gemm_sb(a: torch.Tensor, b: torch.Tensor, a_kc: bool, b_kc: bool, split_k: bool = True) -> torch.Tensor:
     """``C[i] = opA(a[i]) @ opB(b[i])`` on the bf16 matrix cores with the three-term split (``e4s_gemm_sb``, csrc/gemm_sb.hip) — the
     contractions of the backward pass.  ``a``: ``[Ba, M, K]`` if ``a_kc`` else ``[Ba, K, M]``; ``b``: ``[Bb, N, K]`` if ``b_kc`` else
-    ``[Bb, K, N]``; ``Ba``, ``Bb`` are the batch or 1 (shared).  Returns fp32 ``[batch, M, N]``."""
+    ``[Bb, K, N]``; ``Ba``, ``Bb`` are the batch or 1 (shared).  Returns fp32 ``[batch, M, N]``.  ``split_k=False``: every output element is one
+    pass over K in a fixed order whatever the other dimensions are (a column's value does not depend on how many columns there are)."""
     a, b = _c(a, "a"), _c(b, "b")
     if a.dim() != 3 or b.dim() != 3:
         raise ValueError("gemm_sb takes 3-D operands [batch or 1, rows, cols]")
@@ -1297,7 +1361,7 @@ def gemm_sb(a: torch.Tensor, b: torch.Tensor, a_kc: bool, b_kc: bool) -> torch.T
     skinny = a_kc and b_kc and M <= 8
     tm, tn = (32, 256) if skinny else (128, 128)
     base, nchunk, ks = -(-M // tm) * -(-N // tn) * batch, -(-K // 32), 1
-    while base * ks < 512 and ks * 2 * 4 <= nchunk and ks < 1024 and ks * 2 * batch * M * N <= GEMM_SPLITK_CAP_FLOATS:
+    while split_k and base * ks < 512 and ks * 2 * 4 <= nchunk and ks < 1024 and ks * 2 * batch * M * N <= GEMM_SPLITK_CAP_FLOATS:
         ks *= 2
     ws = torch.empty((ks * batch * M * N,), dtype=torch.float32, device=a.device) if ks > 1 else None
     lib().call("e4s_gemm_sb", _p(c), _p(a), _p(b), M, N, K, int(a_kc), int(b_kc), a.shape[2], b.shape[2],

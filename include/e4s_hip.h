@@ -460,6 +460,18 @@ E4S_API int e4s_mconv_dgrad_tiles(int h, int w);
 E4S_API int e4s_mconv_dgrad(float* dx, float* ds_part, const float* gz, const float* wg, const float* x, const float* s, const uint8_t* labels,
                             int bs, int cin, int cout, int h, int w, int nreg, int up, void* stream);
 
+/* Winograd F(2x2, 3x3) pieces around e4s_gemm_sb(batch = 16) for stride-1, pad-1 3x3 convolutions (the regional-style encoder's IR-SE units,
+ * models/encoders/helpers.py:122-144: Conv2d(c, d, 3, 1, 1) after InstanceNorm2d / before PReLU):
+ *   e4s_wino_weight : U[16][cout][cin] = G g G^T of w [cout][cin][3][3]
+ *   e4s_wino_input  : V[16][C][T]      = B^T d B of every 4x4 patch (stride 2) of x [bs][C][H][W], T = bs * H/2 * W/2, tile t = (b * H/2 + ty) * W/2 + tx;
+ *                     mean / rstd [bs][C] (both or neither): the patch is taken from (x - mean) * rstd, zero beyond the border
+ *   then M[k] (cout x T) = U[k] (cout x cin) * V[k] (cin x T) for k < 16 — e4s_gemm_sb(M, U, V, cout, T, cin, 1, 0, cin, T, cout*cin, cin*T, cout*T, 16, ...)
+ *   e4s_wino_output : y [bs][cout][H][W] = act(A^T m A) of m = M[.][co][t]; prelu [cout] or NULL (no activation)
+ * H, W even. */
+E4S_API int e4s_wino_weight(float* U, const float* w, int cout, int cin, void* stream);
+E4S_API int e4s_wino_input(float* V, const float* x, const float* mean, const float* rstd, int bs, int C, int H, int W, void* stream);
+E4S_API int e4s_wino_output(float* y, const float* M, const float* prelu, int bs, int cout, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

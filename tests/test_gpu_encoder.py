@@ -183,3 +183,32 @@ def test_fused_se_gate_and_statistics_emitting_norm_gate_add_match_the_separate_
         assert torch.equal(out, ref) and torch.equal(om, rm), (bs, C, h, ss)
         # rstd: the same sums, but the compiler contracts the squares into FMAs differently in the two kernels: an ulp or two
         assert ((orr - rr).abs() <= 4e-7 * rr.abs()).all(), (bs, C, h, ss, ((orr - rr).abs() / rr.abs()).max().item())
+
+
+@pytest.mark.parametrize("bs,cin,cout,h,w,norm,act", [(2, 32, 48, 8, 12, True, True), (1, 64, 64, 32, 32, False, False), (3, 40, 24, 6, 10, True, False),
+                                                      (16, 512, 512, 32, 32, True, True)])
+def test_winograd_route_of_the_stride1_3x3_convolutions(bs, cin, cout, h, w, norm, act):
+    """``ops.conv2d_winograd`` (F(2x2, 3x3): input transform with the InstanceNorm on load, 16 split-bf16 GEMMs, output transform with the
+    PReLU) against float64 ``F.conv2d`` of the normalised input and against the direct kernel, on ragged channel counts and non-square maps
+    and on the shape the encoder's 27 launches have; border tiles see the conv's zero padding of the NORMALISED map."""
+    g = torch.Generator().manual_seed(bs + cin + cout + h)
+    x = (torch.randn(bs, cin, h, w, generator=g) * 1.7 + 0.4).to(DEV)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(DEV)
+    slope = (torch.rand(cout, generator=g) * 0.5).to(DEV) if act else None
+    stats = _ops.plane_stats(x, 1e-5) if norm else None
+    U = _ops.PreparedWinograd().get(wt)
+    out = _ops.conv2d_winograd(x, U, in_norm=stats, prelu=slope)
+    again = _ops.conv2d_winograd(x, U, in_norm=stats, prelu=slope)
+    direct = _ops.conv2d(x, _ops.PreparedConv().get(wt), 1, 1, in_norm=stats, prelu=slope)
+    xn = x.double()
+    if norm:
+        xn = (xn - xn.mean((2, 3), keepdim=True)) / torch.sqrt(xn.var((2, 3), unbiased=False, keepdim=True) + 1e-5)
+    ref = F.conv2d(xn, wt.double(), padding=1)
+    if act:
+        ref = torch.where(ref >= 0, ref, ref * slope.double().view(1, -1, 1, 1))
+    torch.cuda.synchronize()
+    assert torch.equal(out, again)
+    scale = max(1.0, ref.abs().max().item())
+    e_w, e_d = (out.double() - ref).abs().max().item() / scale, (direct.double() - ref).abs().max().item() / scale
+    record_parity(f"conv2d_winograd.{bs}x{cin}to{cout}_{h}x{w}.rel_vs_fp64", e_w, CONV_RTOL, f"direct kernel {e_d:.2e}")
+    assert e_w <= CONV_RTOL and e_d <= CONV_RTOL, (e_w, e_d)
