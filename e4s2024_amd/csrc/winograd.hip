@@ -10,7 +10,7 @@
 //     e4s_wino_input  : V[k][ci][t]  = (B^T d B)[k], d = the (optionally instance-normalised) input patch with the conv's zero padding
 //     e4s_wino_output : y[b][co][2ty+i][2tx+j] = act( (A^T m A)[i][j] ),  m = M[.][co][t];  act = PReLU(co) or none
 // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  A^T = [1 1 1 0; 0 1 -1 -1].
-#include "common.h"
+#include "sb_common.h"
 
 using namespace e4s;
 
@@ -84,6 +84,69 @@ __global__ __launch_bounds__(256) void wino_input_kernel(float* __restrict__ V, 
     }
 }
 
+// The same transform for e4s_gemm_pre: one thread = one tile x EIGHT channels, V written as bf16 hi / lo in channel blocks [16][C / 8][T][8]
+// (16-byte pieces, consecutive threads = consecutive tiles).
+__global__ __launch_bounds__(256) void wino_input_pre_kernel(uint4* __restrict__ Vhi, uint4* __restrict__ Vlo, const float* __restrict__ x,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd, int bs, int C, int H, int W) {
+    const int th = H >> 1, tw = W >> 1;
+    const int T = bs * th * tw;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int c8 = blockIdx.y;
+    if (t >= T) return;
+    const int tx = t % tw, ty = (t / tw) % th, b = t / (tw * th);
+    unsigned oh[16][4], ol[16][4];
+    float prev[16];
+#pragma unroll
+    for (int cj = 0; cj < 8; ++cj) {
+        const int c = c8 * 8 + cj;
+        const bool cok = c < C;
+        const float* xp = x + ((size_t)b * C + (cok ? c : C - 1)) * H * W;
+        const float mu = mean ? mean[(size_t)b * C + (cok ? c : C - 1)] : 0.f, rs = rstd ? rstd[(size_t)b * C + (cok ? c : C - 1)] : 1.f;
+        float d[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int y = 2 * ty - 1 + i;
+            const bool row = cok && y >= 0 && y < H;
+            const float* r = xp + (size_t)((y >= 0 && y < H) ? y : 0) * W + 2 * tx;
+            const float2 mid = *reinterpret_cast<const float2*>(r);
+            const float lft = tx > 0 ? r[-1] : 0.f, rgt = 2 * tx + 2 < W ? r[2] : 0.f;
+            d[i][0] = (row && tx > 0) ? (lft - mu) * rs : 0.f;
+            d[i][1] = row ? (mid.x - mu) * rs : 0.f;
+            d[i][2] = row ? (mid.y - mu) * rs : 0.f;
+            d[i][3] = (row && 2 * tx + 2 < W) ? (rgt - mu) * rs : 0.f;
+        }
+        float e[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            e[0][j] = d[0][j] - d[2][j];
+            e[1][j] = d[1][j] + d[2][j];
+            e[2][j] = d[2][j] - d[1][j];
+            e[3][j] = d[1][j] - d[3][j];
+        }
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[4 * i + 0] = e[i][0] - e[i][2];
+            v[4 * i + 1] = e[i][1] + e[i][2];
+            v[4 * i + 2] = e[i][2] - e[i][1];
+            v[4 * i + 3] = e[i][1] - e[i][3];
+        }
+        if (cj & 1) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) split2(prev[k], v[k], oh[k][cj >> 1], ol[k][cj >> 1]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) prev[k] = v[k];
+        }
+    }
+    const size_t plane = (size_t)gridDim.y * T;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        Vhi[(size_t)k * plane + (size_t)c8 * T + t] = make_uint4(oh[k][0], oh[k][1], oh[k][2], oh[k][3]);
+        Vlo[(size_t)k * plane + (size_t)c8 * T + t] = make_uint4(ol[k][0], ol[k][1], ol[k][2], ol[k][3]);
+    }
+}
+
 __global__ __launch_bounds__(256) void wino_output_kernel(float* __restrict__ y, const float* __restrict__ M, const float* __restrict__ prelu, int bs, int CO,
                                                           int H, int W) {
     const int th = H >> 1, tw = W >> 1;
@@ -148,4 +211,17 @@ extern "C" int e4s_wino_output(float* y, const float* M, const float* prelu, int
     const int T = bs * (H / 2) * (W / 2);
     hipLaunchKernelGGL(wino_output_kernel, dim3(cdiv(T, 256), cout), dim3(256), 0, (hipStream_t)stream, y, M, prelu, bs, cout, H, W);
     return check_launch("wino_output");
+}
+
+// V as bf16 hi / lo [16][ceil(C / 8)][T][8] for e4s_gemm_pre (channels beyond C are zero).  NOT on the default path: see ops.WINOGRAD_PRE.
+extern "C" int e4s_wino_input_pre(uint16_t* V_hi, uint16_t* V_lo, const float* x, const float* mean, const float* rstd, int bs, int C, int H, int W, void* stream) {
+    E4S_REQUIRE(V_hi && V_lo && x && (!mean == !rstd), "wino_input_pre: null tensor (mean and rstd come together)");
+    E4S_REQUIRE(bs >= 0 && C >= 1 && C <= 8 * 65535 && H >= 2 && W >= 2 && (H % 2) == 0 && (W % 2) == 0 && (int64_t)bs * H * W / 4 < ((int64_t)1 << 30),
+                "wino_input_pre: even height and width");
+    E4S_REQUIRE((((uintptr_t)x) & 7) == 0 && (((uintptr_t)V_hi | (uintptr_t)V_lo) & 15) == 0, "wino_input_pre: unaligned tensor");
+    if (bs == 0) return 0;
+    const int T = bs * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(wino_input_pre_kernel, dim3(cdiv(T, 256), cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<uint4*>(V_hi),
+                       reinterpret_cast<uint4*>(V_lo), x, mean, rstd, bs, C, H, W);
+    return check_launch("wino_input_pre");
 }

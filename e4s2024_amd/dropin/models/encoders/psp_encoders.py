@@ -71,7 +71,8 @@ class bottleneck_IR_SE_Ours(Module):
             SEModule(depth, 16),
         )
         self._w = [ops.PreparedConv() for _ in range(3)]
-        self._wino = [ops.PreparedWinograd() for _ in range(2)]          # the two 3x3 convolutions' Winograd-domain weights (stride 1 only)
+        # the two 3x3 convolutions' Winograd-domain weights (stride 1 only): fp32 and split to bf16 hi / lo
+        self._wino = [(self._w[i], ops.PreparedWinograd(), ops.PreparedWinogradSplit()) for i in range(2)]
 
     def forward(self, x):
         rl = self.res_layer
@@ -82,12 +83,9 @@ class bottleneck_IR_SE_Ours(Module):
             mean, rstd = st[0], st[1]
         else:
             mean, rstd = ops.plane_stats(x, rl[0].eps)
-        if ops.winograd_applies(x, x.shape[1], 1):
-            r = ops.conv2d_winograd(x, self._wino[0].get(rl[1].weight), in_norm=(mean, rstd), prelu=rl[2].weight)
-        else:
-            r = ops.conv2d(x, self._w[0].get(rl[1].weight), 1, 1, in_norm=(mean, rstd), prelu=rl[2].weight)
-        if ops.winograd_applies(r, r.shape[1], self.stride):
-            r = ops.conv2d_winograd(r, self._wino[1].get(rl[3].weight))
+        r = ops.conv3x3_s1(x, rl[1].weight, self._wino[0], in_norm=(mean, rstd), prelu=rl[2].weight)      # direct kernel or Winograd (ops.winograd_route)
+        if self.stride == 1:
+            r = ops.conv3x3_s1(r, rl[3].weight, self._wino[1])
         else:
             r = ops.conv2d(r, self._w[1].get(rl[3].weight), self.stride, 1)
         m2, r2, pooled = ops.plane_stats(r, rl[4].eps, want_nmean=True)                 # IN statistics + mean of the normalised map

@@ -1055,12 +1055,89 @@ class PreparedWinograd(_Prepared):
         return self._publish(key, (U,))[0]
 
 
-def winograd_applies(x: torch.Tensor, cin: int, stride: int) -> bool:
-    """Is ``conv2d_winograd`` the faster route for a 3x3, pad-1 convolution of ``x``?  (stride 1, even maps, enough channels, and a tile count
-    between the point where 16 GEMMs fill the chip and the point where the direct kernel does; inference only.)"""
+class PreparedWinogradSplit(_Prepared):
+    """The same as bf16 hi / lo ``[16, cout, cin]`` (int16 storage) for ``e4s_gemm_pre``: split once, not in every GEMM."""
+
+    __slots__ = ()
+
+    def get(self, weight: torch.Tensor):
+        key = None if _volatile(weight) else ((weight.data_ptr(), weight._version), weight.device)
+        hit = self._lookup(key)
+        if hit is not None:
+            return hit
+        w = _c(weight.detach(), "weight")
+        cout, cin, kh, kw = w.shape
+        if (kh, kw) != (3, 3) or cin % 2:
+            raise ValueError("PreparedWinogradSplit: 3x3 kernels, an even number of input channels")
+        U = torch.empty((16, cout, cin), dtype=torch.float32, device=w.device)
+        lib().call("e4s_wino_weight", _p(U), _p(w), cout, cin, _stream())
+        hi, lo = torch.empty((16, cout, cin), dtype=torch.int16, device=w.device), torch.empty((16, cout, cin), dtype=torch.int16, device=w.device)
+        lib().call("e4s_split_bf16", _p(hi), _p(lo), _p(U), U.numel(), _stream())
+        return self._publish(key, (hi, lo))
+
+
+# 1: operands of the Winograd GEMMs split to bf16 by their producers (e4s_wino_input_pre + e4s_gemm_pre: 839 instead of 607 TFLOP/s, batch-8 full swap
+# 24.9 -> 23.8 ms).  OFF: with two such chains on two HIP streams at once the result of one of them is occasionally wrong (11 of 60 runs of
+# tools/probes/wino_race4.py; never on one stream, never with the fp32 input transform in front of the same GEMM) — e4s_wino_input_pre is involved,
+# the cause is not found, and the default swap runs the parser beside the encoder: not shippable until it is.
+WINOGRAD_PRE = os.environ.get("E4S_WINOGRAD_PRE", "0") != "0"
+WINOGRAD_WIDE_CIN = int(os.environ.get("E4S_WINOGRAD_WIDE_CIN", "512"))     # from this many input channels on there is no upper tile limit
+
+
+def winograd_route(x: torch.Tensor, cin: int, stride: int):
+    """Which route a 3x3, pad-1 convolution of ``x`` takes: ``"pre"`` (Winograd with operands split by their producers, ``cin % 32 == 0``),
+    ``"f32"`` (Winograd on the general split-bf16 GEMM) or ``None`` (the direct kernel).  Stride 1, even maps, inference only; at least
+    ``WINOGRAD_MIN_CIN`` channels and ``WINOGRAD_MIN_TILES`` 2 x 2 output tiles; at most ``WINOGRAD_MAX_TILES`` unless the layer has
+    ``WINOGRAD_WIDE_CIN`` channels and the pre-split route (below that the two transforms cost more than the GEMMs save once the direct kernel
+    fills the chip: 256 -> 256 @64^2 at 16 faces 0.31 against 0.28 ms; 512 -> 512 @32^2 0.21 against 0.26)."""
     bs, _, h, w = x.shape
-    return (WINOGRAD and stride == 1 and x.is_cuda and not torch.is_grad_enabled() and cin >= WINOGRAD_MIN_CIN and h % 2 == 0 and w % 2 == 0
-            and WINOGRAD_MIN_TILES <= bs * (h // 2) * (w // 2) <= WINOGRAD_MAX_TILES)
+    if not (WINOGRAD and stride == 1 and x.is_cuda and not torch.is_grad_enabled() and cin >= WINOGRAD_MIN_CIN and h % 2 == 0 and w % 2 == 0):
+        return None
+    tiles = bs * (h // 2) * (w // 2)
+    if tiles < WINOGRAD_MIN_TILES:
+        return None
+    pre = cin % 32 == 0 and WINOGRAD_PRE
+    if tiles > WINOGRAD_MAX_TILES and not (pre and cin >= WINOGRAD_WIDE_CIN):
+        return None
+    return "pre" if pre else "f32"
+
+
+def conv3x3_s1(x: torch.Tensor, weight: torch.Tensor, caches, *, in_norm=None, prelu: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """A stride-1, pad-1 3x3 convolution by whichever route ``winograd_route`` picks; ``caches = (PreparedConv, PreparedWinograd,
+    PreparedWinogradSplit)`` of the layer."""
+    route = winograd_route(x, x.shape[1], 1)
+    if route == "pre":
+        return conv2d_winograd_pre(x, caches[2].get(weight), in_norm=in_norm, prelu=prelu)
+    if route == "f32":
+        return conv2d_winograd(x, caches[1].get(weight), in_norm=in_norm, prelu=prelu)
+    return conv2d(x, caches[0].get(weight), 1, 1, in_norm=in_norm, prelu=prelu)
+
+
+def conv2d_winograd_pre(x: torch.Tensor, U_split, *, in_norm=None, prelu: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``conv2d_winograd`` with both GEMM operands split to bf16 hi / lo by their producers (``U_split`` from ``PreparedWinogradSplit``, V by the
+    input transform, eight channels per 16-byte piece): the GEMM stages copies — ``e4s_gemm_pre``.  ``cin % 32 == 0``."""
+    x = _c(x, "input")
+    bs, cin, h, w = x.shape
+    uh, ul = U_split
+    if uh.dim() != 3 or uh.shape[0] != 16 or uh.shape[2] != cin or cin % 32:
+        raise ValueError(f"conv2d_winograd_pre: U {tuple(uh.shape)} does not fit {cin} input channels (a multiple of 32)")
+    cout = uh.shape[1]
+    T = bs * (h // 2) * (w // 2)
+    mean = rstd = None
+    if in_norm is not None:
+        mean, rstd = _c(in_norm[0], "in_mean"), _c(in_norm[1], "in_rstd")
+    vh = torch.empty((16, cin // 8, T, 8), dtype=torch.int16, device=x.device)
+    vl = torch.empty_like(vh)
+    ev = _timed("conv2d_winograd_pre<3,1>")
+    lib().call("e4s_wino_input_pre", _p(vh), _p(vl), _p(x), _p(mean), _p(rstd), bs, cin, h, w, _stream())
+    M = torch.empty((16, cout, T), dtype=torch.float32, device=x.device)
+    lib().call("e4s_gemm_pre", _p(M), _p(uh), _p(ul), _p(vh), _p(vl), cout, T, cin, cout * cin, cin * T, cout * T, 16, _stream())
+    del vh, vl
+    out = torch.empty((bs, cout, h, w), dtype=torch.float32, device=x.device)
+    lib().call("e4s_wino_output", _p(out), _p(M), _p(_c(prelu.detach(), "prelu")) if prelu is not None else None, bs, cout, h, w, _stream())
+    if ev is not None:
+        ev.record()
+    return out
 
 
 def conv2d_winograd(x: torch.Tensor, U: torch.Tensor, *, in_norm=None, prelu: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -199,6 +199,13 @@ def test_winograd_route_of_the_stride1_3x3_convolutions(bs, cin, cout, h, w, nor
     U = _ops.PreparedWinograd().get(wt)
     out = _ops.conv2d_winograd(x, U, in_norm=stats, prelu=slope)
     again = _ops.conv2d_winograd(x, U, in_norm=stats, prelu=slope)
+    if cin % 32 == 0:               # the route with operands split by their producers (e4s_wino_input_pre + e4s_gemm_pre)
+        Us = _ops.PreparedWinogradSplit().get(wt)
+        pre = _ops.conv2d_winograd_pre(x, Us, in_norm=stats, prelu=slope)
+        assert torch.equal(pre, _ops.conv2d_winograd_pre(x, Us, in_norm=stats, prelu=slope))
+        if bs > 1:                  # a face's result does not depend on the batch it is in
+            st1 = (stats[0][:1].contiguous(), stats[1][:1].contiguous()) if norm else None
+            assert torch.equal(_ops.conv2d_winograd_pre(x[:1].contiguous(), Us, in_norm=st1, prelu=slope)[0], pre[0])
     direct = _ops.conv2d(x, _ops.PreparedConv().get(wt), 1, 1, in_norm=stats, prelu=slope)
     xn = x.double()
     if norm:
@@ -212,3 +219,7 @@ def test_winograd_route_of_the_stride1_3x3_convolutions(bs, cin, cout, h, w, nor
     e_w, e_d = (out.double() - ref).abs().max().item() / scale, (direct.double() - ref).abs().max().item() / scale
     record_parity(f"conv2d_winograd.{bs}x{cin}to{cout}_{h}x{w}.rel_vs_fp64", e_w, CONV_RTOL, f"direct kernel {e_d:.2e}")
     assert e_w <= CONV_RTOL and e_d <= CONV_RTOL, (e_w, e_d)
+    if cin % 32 == 0:
+        e_p = (pre.double() - ref).abs().max().item() / scale
+        record_parity(f"conv2d_winograd_pre.{bs}x{cin}to{cout}_{h}x{w}.rel_vs_fp64", e_p, CONV_RTOL)
+        assert e_p <= CONV_RTOL, e_p

@@ -29,4 +29,15 @@ with torch.no_grad():
         T = bs * h * h // 4
         V = torch.empty(16, cin, T, device=dev)
         g = t(lambda: ops.gemm_sb(pw, V, True, False))
-        print(f"bs {bs} {cin}->{cout} @{h}: direct {d:.3f} ms   winograd {wg:.3f} ms (its 16 GEMMs alone {g:.3f})", flush=True)
+        ps = ops.PreparedWinogradSplit().get(w)
+        wp = t(lambda: ops.conv2d_winograd_pre(x, ps, in_norm=st, prelu=slope))
+        vh = torch.empty(16, cin // 8, T, 8, dtype=torch.int16, device=dev); vl = torch.empty_like(vh); M = torch.empty(16, cout, T, device=dev)
+        from e4s2024_amd._lib import lib
+        from e4s2024_amd.ops import _p, _stream
+        gp = t(lambda: lib().call("e4s_gemm_pre", _p(M), _p(ps[0]), _p(ps[1]), _p(vh), _p(vl), cout, T, cin, cout * cin, cin * T, cout * T, 16, _stream()))
+        ti = t(lambda: lib().call("e4s_wino_input_pre", _p(vh), _p(vl), _p(x), _p(st[0]), _p(st[1]), bs, cin, h, h, _stream()))
+        y = torch.empty(bs, cout, h, h, device=dev)
+        to = t(lambda: lib().call("e4s_wino_output", _p(y), _p(M), _p(slope), bs, cout, h, h, _stream()))
+        err = (ops.conv2d_winograd_pre(x, ps, in_norm=st, prelu=slope) - ops.conv2d(x, pc, 1, 1, in_norm=st, prelu=slope)).abs().max().item()
+        print(f"bs {bs} {cin}->{cout} @{h}: direct {d:.3f} ms   winograd {wg:.3f} ms (its 16 GEMMs alone {g:.3f})   pre-split {wp:.3f} ms "
+              f"(input {ti:.3f} + GEMMs {gp:.3f} + output {to:.3f}; max |diff| vs direct {err:.1e})", flush=True)
