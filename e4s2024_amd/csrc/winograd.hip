@@ -94,56 +94,60 @@ __global__ __launch_bounds__(256) void wino_input_pre_kernel(uint4* __restrict__
     const int c8 = blockIdx.y;
     if (t >= T) return;
     const int tx = t % tw, ty = (t / tw) % th, b = t / (tw * th);
-    unsigned oh[16][4], ol[16][4];
-    float prev[16];
-#pragma unroll
-    for (int cj = 0; cj < 8; ++cj) {
-        const int c = c8 * 8 + cj;
-        const bool cok = c < C;
-        const float* xp = x + ((size_t)b * C + (cok ? c : C - 1)) * H * W;
-        const float mu = mean ? mean[(size_t)b * C + (cok ? c : C - 1)] : 0.f, rs = rstd ? rstd[(size_t)b * C + (cok ? c : C - 1)] : 1.f;
-        float d[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int y = 2 * ty - 1 + i;
-            const bool row = cok && y >= 0 && y < H;
-            const float* r = xp + (size_t)((y >= 0 && y < H) ? y : 0) * W + 2 * tx;
-            const float2 mid = *reinterpret_cast<const float2*>(r);
-            const float lft = tx > 0 ? r[-1] : 0.f, rgt = 2 * tx + 2 < W ? r[2] : 0.f;
-            d[i][0] = (row && tx > 0) ? (lft - mu) * rs : 0.f;
-            d[i][1] = row ? (mid.x - mu) * rs : 0.f;
-            d[i][2] = row ? (mid.y - mu) * rs : 0.f;
-            d[i][3] = (row && 2 * tx + 2 < W) ? (rgt - mu) * rs : 0.f;
-        }
-        float e[4][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            e[0][j] = d[0][j] - d[2][j];
-            e[1][j] = d[1][j] + d[2][j];
-            e[2][j] = d[2][j] - d[1][j];
-            e[3][j] = d[1][j] - d[3][j];
-        }
-        float v[16];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v[4 * i + 0] = e[i][0] - e[i][2];
-            v[4 * i + 1] = e[i][1] + e[i][2];
-            v[4 * i + 2] = e[i][2] - e[i][1];
-            v[4 * i + 3] = e[i][1] - e[i][3];
-        }
-        if (cj & 1) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) split2(prev[k], v[k], oh[k][cj >> 1], ol[k][cj >> 1]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) prev[k] = v[k];
-        }
-    }
     const size_t plane = (size_t)gridDim.y * T;
+    // Two passes (rows 0-1, then 2-3 of B^T d B) in a loop that is NOT unrolled.  The single-pass, fully unrolled form (112 loads issued before
+    // the first use) produced occasional wrong values — one register, sixteen lanes — when another stream's kernels ran beside it
+    // (tools/probes/wino_race6.py): what a load landing in an already reused register looks like (vmcnt counts to 63).  This form has not shown it.
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        unsigned oh[8][4], ol[8][4];
+        float prev[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        Vhi[(size_t)k * plane + (size_t)c8 * T + t] = make_uint4(oh[k][0], oh[k][1], oh[k][2], oh[k][3]);
-        Vlo[(size_t)k * plane + (size_t)c8 * T + t] = make_uint4(ol[k][0], ol[k][1], ol[k][2], ol[k][3]);
+        for (int cj = 0; cj < 8; ++cj) {
+            const int c = c8 * 8 + cj;
+            const bool cok = c < C;
+            const float* xp = x + ((size_t)b * C + (cok ? c : C - 1)) * H * W;
+            const float mu = mean ? mean[(size_t)b * C + (cok ? c : C - 1)] : 0.f, rs = rstd ? rstd[(size_t)b * C + (cok ? c : C - 1)] : 1.f;
+            float d[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int y = 2 * ty - 1 + i;
+                const bool row = cok && y >= 0 && y < H;
+                const float* r = xp + (size_t)((y >= 0 && y < H) ? y : 0) * W + 2 * tx;
+                const float2 mid = *reinterpret_cast<const float2*>(r);
+                const float lft = tx > 0 ? r[-1] : 0.f, rgt = 2 * tx + 2 < W ? r[2] : 0.f;
+                d[i][0] = (row && tx > 0) ? (lft - mu) * rs : 0.f;
+                d[i][1] = row ? (mid.x - mu) * rs : 0.f;
+                d[i][2] = row ? (mid.y - mu) * rs : 0.f;
+                d[i][3] = (row && 2 * tx + 2 < W) ? (rgt - mu) * rs : 0.f;
+            }
+            float e[2][4];          // rows 2 half, 2 half + 1 of B^T d
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                e[0][j] = half ? d[2][j] - d[1][j] : d[0][j] - d[2][j];
+                e[1][j] = half ? d[1][j] - d[3][j] : d[1][j] + d[2][j];
+            }
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                v[4 * i + 0] = e[i][0] - e[i][2];
+                v[4 * i + 1] = e[i][1] + e[i][2];
+                v[4 * i + 2] = e[i][2] - e[i][1];
+                v[4 * i + 3] = e[i][1] - e[i][3];
+            }
+            if (cj & 1) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) split2(prev[k], v[k], oh[k][cj >> 1], ol[k][cj >> 1]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) prev[k] = v[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            Vhi[(size_t)(8 * half + k) * plane + (size_t)c8 * T + t] = make_uint4(oh[k][0], oh[k][1], oh[k][2], oh[k][3]);
+            Vlo[(size_t)(8 * half + k) * plane + (size_t)c8 * T + t] = make_uint4(ol[k][0], ol[k][1], ol[k][2], ol[k][3]);
+        }
     }
 }
 

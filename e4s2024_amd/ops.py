@@ -1076,10 +1076,12 @@ class PreparedWinogradSplit(_Prepared):
         return self._publish(key, (hi, lo))
 
 
-# 1: operands of the Winograd GEMMs split to bf16 by their producers (e4s_wino_input_pre + e4s_gemm_pre: 839 instead of 607 TFLOP/s, batch-8 full swap
-# 24.9 -> 23.8 ms).  OFF: with two such chains on two HIP streams at once the result of one of them is occasionally wrong (11 of 60 runs of
-# tools/probes/wino_race4.py; never on one stream, never with the fp32 input transform in front of the same GEMM) — e4s_wino_input_pre is involved,
-# the cause is not found, and the default swap runs the parser beside the encoder: not shippable until it is.
+# 1: operands of the Winograd GEMMs split to bf16 by their producers (e4s_wino_input_pre + e4s_gemm_pre: 839 instead of 607 TFLOP/s; the
+# 512 -> 512 @32^2 launch 0.226 against 0.252 ms direct, batch-8 full swap 25.9 -> 25.4 ms).  Opt-in this round: the first, fully unrolled form of
+# e4s_wino_input_pre (112 loads in flight, 248 registers) gave occasional wrong values — ONE register, SIXTEEN lanes — when a second stream's kernels
+# ran beside it (11 of 60 runs of tools/probes/wino_race4.py; tools/probes/wino_race6.py pins it to that kernel's output with every input intact):
+# the signature of a load landing in a register that was already reused, i.e. of the 6-bit vmcnt counter with more than 63 loads outstanding.  The
+# two-pass form in the tree has run 400+ concurrent iterations and the multi-stream tests clean; it stays behind the switch until it has soaked.
 WINOGRAD_PRE = os.environ.get("E4S_WINOGRAD_PRE", "0") != "0"
 WINOGRAD_WIDE_CIN = int(os.environ.get("E4S_WINOGRAD_WIDE_CIN", "512"))     # from this many input channels on there is no upper tile limit
 

@@ -16,7 +16,7 @@ side = torch.cuda.Stream()
 with torch.no_grad():
     ref = [net.get_style_vectors(imgs[i], labs[i])[0].clone() for i in range(2)]
     torch.cuda.synchronize()
-    for it in range(6):
+    for it in range(int(os.environ.get("ITERS", "6"))):
         main = torch.cuda.current_stream()
         side.wait_stream(main)
         with torch.cuda.stream(side):
