@@ -1081,7 +1081,7 @@ class PreparedWinogradSplit(_Prepared):
 # e4s_wino_input_pre (112 loads in flight, 248 registers) gave occasional wrong values — ONE register, SIXTEEN lanes — when a second stream's kernels
 # ran beside it (11 of 60 runs of tools/probes/wino_race4.py; tools/probes/wino_race6.py pins it to that kernel's output with every input intact):
 # the signature of a load landing in a register that was already reused, i.e. of the 6-bit vmcnt counter with more than 63 loads outstanding.  The
-# two-pass form in the tree has run 400+ concurrent iterations and the multi-stream tests clean; it stays behind the switch until it has soaked.
+# two-pass form in the tree has run 1 400+ concurrent iterations and the multi-stream tests clean; it stays behind the switch (2 % is not worth a flaky frame).
 WINOGRAD_PRE = os.environ.get("E4S_WINOGRAD_PRE", "0") != "0"
 WINOGRAD_WIDE_CIN = int(os.environ.get("E4S_WINOGRAD_WIDE_CIN", "512"))     # from this many input channels on there is no upper tile limit
 
