@@ -490,7 +490,7 @@ class Generator(nn.Module):
             return (2 * jj + 1 >= rli and not cu.mask_op and not c2.mask_op and not tr.mask_op and tuple(tr.upsample.kernel.shape) == (4, 4)
                     and cu.conv.kernel_size == 3 and c2.conv.kernel_size == 3 and cu.conv._two_stage(False)
                     and ops.chain_supported(cu.conv.in_channel, cu.conv.out_channel, res // 2, res // 2, True)
-                    and ops.chain_supported(c2.conv.in_channel, c2.conv.out_channel, res, res, False)
+                    and ops.chain_supported(c2.conv.in_channel, c2.conv.out_channel, res, res, False, last=(jj == n_stage - 1))
                     and ops.can_fuse_rgb(c2.conv.out_channel, res, False, False))
         sp_from = n_stage
         if chain and ops.SP_CHAIN and lat is not None and not torch.is_grad_enabled():

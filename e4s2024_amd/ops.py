@@ -343,14 +343,21 @@ def invalidate_weight_caches(module: torch.nn.Module) -> int:
     after writing parameters behind autograd's back between two ``no_grad`` forwards — ``p.data.copy_(...)``, an EMA update, a replay of a
     captured optimiser step (``pti.GraphedPTIStep`` does it itself) — which leaves no trace the caches could key on; ``load_state_dict``,
     ordinary in-place ops and any training forward are tracked."""
-    n = 0
-    for m in module.modules():
-        for v in vars(m).values():
-            for c in (v if isinstance(v, (list, tuple)) else (v,)):
-                if isinstance(c, _Prepared):
-                    c.key = None
-                    n += 1
-    return n
+    seen = set()
+
+    def drop(v) -> int:
+        if isinstance(v, _Prepared):
+            first = id(v) not in seen
+            seen.add(id(v))
+            v.key = None
+            return int(first)
+        if isinstance(v, (list, tuple)):       # e.g. bottleneck_IR_SE_Ours._wino: a list of (PreparedConv, PreparedWinograd, PreparedWinogradSplit)
+            return sum(drop(c) for c in v)
+        if isinstance(v, dict):
+            return sum(drop(c) for c in v.values())
+        return 0
+
+    return sum(drop(v) for m in module.modules() for v in vars(m).values())
 
 
 class _Prepared:
@@ -797,13 +804,16 @@ def from_split_planes(sp: torch.Tensor) -> torch.Tensor:
     return v.permute(0, 1, 4, 2, 3).reshape(bs, cb * 8, h, w)
 
 
-def chain_supported(cin: int, cout: int, h: int, w: int, up: bool) -> bool:
-    """Is there a persistent split-plane kernel for this single-region layer?  (Generator(1024): 64 -> 64 @ 512, 32 -> 32 @ 1024)"""
+def chain_supported(cin: int, cout: int, h: int, w: int, up: bool, last: bool = False) -> bool:
+    """Is there a persistent split-plane kernel for this single-region layer?  (Generator(1024): 64 -> 64 @ 512, 32 -> 32 @ 1024.)
+    ``last``: the layer is the generator's final convolution (fused ToRGB, no split-plane output).  ``e4s_chain_conv3x3`` is built in exactly
+    two variants — 64 -> 64 with ToRGB AND a split-plane hand-over, 32 -> 32 with ToRGB and NO hand-over — so a 64-channel last layer
+    (``Generator(512)``) or a 32-channel one that is not the last has no chain kernel and stays on ``region_modconv3x3``."""
     if MODCONV_MODE != "sb":
         return False
     if up:
         return UP_FUSED and UP_TWO_STAGE and cin % 16 == 0 and cout % 32 == 0
-    return (cin, cout) in ((32, 32), (64, 64)) and h % 16 == 0 and w % 32 == 0
+    return (cin, cout) == ((32, 32) if last else (64, 64)) and h % 16 == 0 and w % 32 == 0
 
 
 def chain_upconv(x_sp: torch.Tensor, wt, d, blur, noise, noise_weight, act_bias, act: bool, cout: int, s_next) -> torch.Tensor:

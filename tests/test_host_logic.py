@@ -465,3 +465,26 @@ def test_stream_pipeline_with_one_stream_is_a_plain_call():
     with StreamPipeline(1) as sp:
         out = [sp.submit(lambda a, b=0: seen.append((a, b)) or a + b, i, b=10) for i in range(4)]
     assert out == [10, 11, 12, 13] and seen == [(0, 10), (1, 10), (2, 10), (3, 10)]
+
+
+def test_invalidate_weight_caches_reaches_nested_containers():
+    """``bottleneck_IR_SE_Ours._wino`` is a list of tuples (direct-conv cache, Winograd cache, pre-split Winograd cache); a write behind
+    autograd's back followed by ``invalidate_weight_caches`` must reset all of them, or the Winograd route keeps the old weights."""
+    from e4s2024_amd import ops
+    from e4s2024_amd.dropin.models.encoders.psp_encoders import bottleneck_IR_SE_Ours
+    unit = bottleneck_IR_SE_Ours(64, 64, 1)
+    caches = list(unit._w) + [c for tup in unit._wino for c in tup[1:]]
+    assert len({id(c) for c in caches}) == 7
+    for c in caches:
+        c._state = (("stale",), None, None, None, frozenset())
+        assert c.key == ("stale",)
+    assert ops.invalidate_weight_caches(unit) == 7          # every distinct cache once, however many containers name it
+    assert all(c.key is None for c in caches)
+
+
+def test_chain_supported_knows_the_last_layer():
+    """``e4s_chain_conv3x3`` exists as 64 -> 64 with a split-plane hand-over and as 32 -> 32 without one; a 64-channel LAST layer
+    (``Generator(512)``) must not be routed to the chain."""
+    from e4s2024_amd import ops
+    assert ops.chain_supported(64, 64, 512, 512, False) and not ops.chain_supported(64, 64, 512, 512, False, last=True)
+    assert ops.chain_supported(32, 32, 1024, 1024, False, last=True) and not ops.chain_supported(32, 32, 1024, 1024, False)
