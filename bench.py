@@ -43,6 +43,15 @@ SWAP_BATCH = 8                    # BASELINE configs[2]: full swap at batch 8
 SUSTAINED_BF16_TFLOPS_RANDOM_DATA = 1255.0
 
 
+def mfma_cost_per_product(kernel: str) -> float:
+    """Nominal matrix-pipe time per algorithmic multiply-add of a kernel's arithmetic, in units of one bf16 MFMA multiply-add:
+    split-bf16 = 3 bf16 MFMAs; the mx kernel's f16 + 2 x MX-fp6 = one f16 MFMA (bf16 rate) + two fp6 MFMAs at 4x the rate whose K = 64 holds the
+    24 products of a kernel row x 8 channels (8 slots idle): 1 + 2 * (1/4) * (32/24) = 1.667."""
+    if kernel.startswith("region_modconv_mx_kernel<1"):
+        return 1.0 + 2.0 * 0.25 * 32.0 / 24.0
+    return 3.0
+
+
 def conv3x3_flops_per_face(size=1024, want_executed=False, uniform_frac=None):
     """Algorithmic FLOPs of the 3x3 modulated convs per face, each counted once, keyed by the kernel that runs them
     (the transposed convs are counted per INPUT pixel).  Layers up to 256x256 are masked (12 regions).
@@ -62,7 +71,7 @@ def conv3x3_flops_per_face(size=1024, want_executed=False, uniform_frac=None):
         elif not masked and not up and _ops.SP_CHAIN and _ops.NHWC_CHAIN and _ops.FUSE_RGB and _ops.chain_supported(cout, cout, out_res, out_res, False):
             k = f"chain_conv3x3<{cout}>"          # the split-plane chain's persistent kernel (csrc/modconv_chain.hip)
         else:
-            k = modconv_kernel_name(cout, w_in, None, masked)
+            k = modconv_kernel_name(cout, w_in, None, masked, cin=None)
         f = 0.0
         if up and masked and uniform_frac and _ops.UP_BLOCKS and _ops.MODCONV_MODE == "sb" and w_in >= max(32, _ops.UP_BLOCKS_MIN_WIDTH) and cout >= 128:
             f1, f2 = uniform_frac.get(out_res, (0.0, 0.0))
@@ -108,7 +117,7 @@ def _by_layer(kt, kernel, bs, peak, uniform_frac):
     return rows
 
 
-TRAFFIC_FILE = "profiles/r02_traffic.json"
+TRAFFIC_FILE = "profiles/r03_traffic.json"
 
 
 def _pmc_traffic(kernel_key):
@@ -168,6 +177,7 @@ def main():
     ap.add_argument("--no-mask-sensitivity", action="store_true", help="skip the two short runs under coarse / i.i.d. region maps")
     ap.add_argument("--labels", choices=["blocky", "coarse", "portrait", "iid"], default="blocky",
                     help="region maps: 16 x 16 constant cells on the 512 x 512 map (default, BASELINE configs[1]), 4 x 4 cells (face-sized regions), or i.i.d. per pixel")
+    ap.add_argument("--soak-seconds", type=float, default=2.0, help="after the timed K steps: the same steps for at least this long (sustained rate, a side field); 0 skips it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-swap", action="store_true", help="skip the secondary full-swap p50 measurement")
     ap.add_argument("--no-pti", action="store_true", help="skip the secondary PTI step measurement (BASELINE configs[3])")
@@ -250,23 +260,50 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
     kt_overlap = kt if args.streams > 1 else None
+    # sustained rate: the same step on the same streams for >= --soak-seconds (the K = 20 steps of the contract last ~60 ms, shorter than the board's
+    # power / clock settling); reported beside `value`, never instead of it
+    soak = None
+    if args.soak_seconds > 0 and world == 1:
+        n_soak = 0
+        t_s0 = time.perf_counter()
+        with pipe:
+            while True:
+                for _ in range(2 * args.steps):
+                    img_s = pipe.submit(step)
+                n_soak += 2 * args.steps
+                torch.cuda.synchronize()
+                if time.perf_counter() - t_s0 >= args.soak_seconds:
+                    break
+        t_soak = time.perf_counter() - t_s0
+        soak = {"seconds": round(t_soak, 3), "steps": n_soak, "faces_per_s": round(n_soak * bs / t_soak, 1), "ms_per_step": round(t_soak / n_soak * 1e3, 3),
+                "streams": args.streams, "what": "the timed region's step repeated for at least --soak-seconds (synchronised every 2K steps)"}
+        del img_s
     one_stream = None
     if args.streams > 1:
-        # the same K steps on ONE stream with every launch timed: a kernel's duration between its own events is its rate only while it has the
-        # chip to itself (under the overlap two batches' kernels share it), so the roofline object is computed from this pass; its elapsed time is
-        # reported beside `value`
+        # the same K steps on ONE stream, twice: (a) with events on the dominant kernel's launches only, exactly the instrumentation of the timed region —
+        # the one-stream HEADLINE (comparable with `value` and with earlier rounds' one-stream figures); (b) with every launch bracketed by events (~4 % of
+        # a step): a kernel's duration between its own events is its rate only while it has the chip to itself (under the overlap two batches' kernels
+        # share it), so the roofline object is computed from pass (b)
         for _ in range(2):
             img1 = step()
         torch.cuda.synchronize()
+        t1s = time.perf_counter()
+        with ops.KernelTimer(only={dom0} if dom0 else None):
+            for _ in range(args.steps):
+                img1 = step()
+            torch.cuda.synchronize()
+            e1a = time.perf_counter() - t1s
         t1s = time.perf_counter()
         with ops.KernelTimer() as kt:
             for _ in range(args.steps):
                 img1 = step()
             torch.cuda.synchronize()
             e1 = time.perf_counter() - t1s
-        one_stream = {"faces_per_s": round(args.steps * bs / e1, 1), "ms_per_step": round(e1 / args.steps * 1e3, 3),
+        one_stream = {"faces_per_s": round(args.steps * bs / e1a, 1), "ms_per_step": round(e1a / args.steps * 1e3, 3),
+                      "faces_per_s_every_launch_timed": round(args.steps * bs / e1, 1),
                       "images_equal_overlapped": bool(torch.equal(img1, img)),
-                      "what": "the same K steps on one stream, every instrumented launch bracketed by HIP events (the pass `roofline` is computed from)"}
+                      "what": "the same K steps on one stream: `faces_per_s` with the timed region's instrumentation (events on the dominant kernel only), "
+                              "`faces_per_s_every_launch_timed` with every instrumented launch bracketed by HIP events (the pass `roofline` is computed from)"}
         del img1
     ksum = kt.summary()
     kt_for_layers = kt
@@ -547,12 +584,23 @@ def main():
             all_ms = sum(v[1] for v in ksum.values())
             all_fl = sum(fl.values()) * bs * args.steps
             sb = ops.MODCONV_MODE == "sb"
-            # split-bf16: every algorithmic multiply-add costs three bf16 MFMA multiply-adds, so the ceiling for ALGORITHMIC FLOPs
-            # is a third of the dense bf16 MFMA peak; exact mode is priced against the fp32 MFMA peak.
-            peak = BF16_MATRIX_PEAK_TFLOPS / 3.0 if sb else FP32_MATRIX_PEAK_TFLOPS
+            # split arithmetics: every algorithmic multiply-add costs `mfma_cost_per_product` bf16-MFMA multiply-adds of matrix-pipe time (3 for
+            # split-bf16, 1.667 for the mx kernel's f16 + 2 x MX fp6), so the ceiling for ALGORITHMIC FLOPs is the dense bf16 MFMA peak divided by
+            # it; exact mode is priced against the fp32 MFMA peak.
+            cost = mfma_cost_per_product(dom)
+            peak = BF16_MATRIX_PEAK_TFLOPS / cost if sb else FP32_MATRIX_PEAK_TFLOPS
+            # the whole job against ITS ceiling: every kernel's algorithmic FLOPs at its own arithmetic's cost (the 0.4 GFLOP of 1x1 ToRGB convs: fp32)
+            job_cost = sum(fl[k] * (mfma_cost_per_product(k) if sb else 16.0) for k in fl) / sum(fl.values())
+            job_peak = BF16_MATRIX_PEAK_TFLOPS / job_cost
+            job_ach = value * 148.52e9 / 1e12 / world
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": _pmc_traffic(dom)[0], "traffic_source": _pmc_traffic(dom)[1],
-                    "peak_basis": ("dense bf16 MFMA 2500 TFLOP/s / 3 MFMAs per fp32-accurate product (split-bf16)" if sb else "fp32 MFMA 157.3 TFLOP/s"),
+                    "peak_basis": ((f"dense bf16 MFMA 2500 TFLOP/s / {cost:.3f} bf16-MFMA multiply-adds of matrix-pipe time per fp32-accurate product ("
+                                    + ("f16 MFMA + 2 MX-fp6 MFMAs at 4x the rate, 24 of 32 K slots used" if cost < 3 else "split-bf16: 3 bf16 MFMAs") + ")") if sb else "fp32 MFMA 157.3 TFLOP/s"),
+                    "frac_on_split_bf16_basis": round(ach / (BF16_MATRIX_PEAK_TFLOPS / 3.0), 4) if sb else None,
+                    "whole_job_frac": round(job_ach / job_peak, 4), "whole_job_peak": round(job_peak, 1), "whole_job_achieved": round(job_ach, 2),
+                    "whole_job_basis": f"148.52 algorithmic GFLOP per face x `value` against 2500 TFLOP/s / {job_cost:.3f} (FLOP-weighted cost of the arithmetic each 3x3 layer runs in)",
+                    "whole_job_frac_on_split_bf16_basis": round(job_ach / (BF16_MATRIX_PEAK_TFLOPS / 3.0), 4) if sb else None,
                     "vs_fp32_mfma_peak": round(ach / FP32_MATRIX_PEAK_TFLOPS, 3),
                     "measured_over": ("the one-stream pass of the same K steps inside this run (`one_stream`): between its own HIP events a kernel shows its rate only "
                                       "while it has the chip to itself; `in_overlapped_region` = the same launches inside the timed region, where two batches share the chip")
@@ -564,7 +612,7 @@ def main():
                     # instruction mix sustains on this board with random operands
                     "executed_over_algorithmic": round(fl_exec[dom] / fl[dom], 3),
                     "executed_frac_of_nominal_peak": round(ach * fl_exec[dom] / fl[dom] / peak, 4) if sb else None,
-                    "executed_frac_of_measured_sustained": round(ach * fl_exec[dom] / fl[dom] / (SUSTAINED_BF16_TFLOPS_RANDOM_DATA / 3.0), 4) if sb else None,
+                    "executed_frac_of_measured_sustained": round(ach * fl_exec[dom] / fl[dom] / (SUSTAINED_BF16_TFLOPS_RANDOM_DATA / cost), 4) if sb else None,
                     # the same ratio layer by layer (one launch per layer and step): the same-resolution layers run every algorithmic MAC once,
                     # the up-sampling layers execute the parity-composed form at 4x their algorithmic (transposed-conv) MACs
                     "by_layer": _by_layer(kt_for_layers, dom, bs, peak, ufrac),
@@ -594,16 +642,19 @@ def main():
             "metric": "1024x1024 faces/sec (StyleGAN2 regional synthesis, gen_img)", "value": round(value, 3), "unit": "faces/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16x3" if ops.MODCONV_MODE == "sb" else "f32", "data": "synthetic",
+            "dtype": ("f32" if ops.MODCONV_MODE != "sb" else "f16+mxfp6x2 (masked 3x3 layers >= 32^2) / bf16x3 (all other layers)" if ops.mx_arith() == 1 else "bf16x3"),
+            "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: StyleGAN2 1024x1024 synthesis from random W+ (Net3.gen_img, randomize_noise=False), "
                                    f"12-region {args.labels} masks (a fresh one-hot mask tensor per step: the mask -> region-map conversion is timed), batch={bs}/GPU; arithmetic = "
-                                   + ("split-bf16: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate (max-abs pixel error "
-                                      "6e-5 vs the reference; plain bf16 would miss the 1e-3 bar)" if ops.MODCONV_MODE == "sb" else "exact fp32 MFMA"),
+                                   + (("split-bf16: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate (max-abs pixel error "
+                                       "6e-5 vs the reference; plain bf16 would miss the 1e-3 bar)"
+                                       + ("; the masked 3x3 layers of width >= 32: f16 MFMA for a1*w1 plus two block-scaled MX-fp6 MFMAs for the cross terms "
+                                          "(csrc/modconv_mx.hip; 2e-4 on the pixels)" if ops.mx_arith() == 1 else "")) if ops.MODCONV_MODE == "sb" else "exact fp32 MFMA"),
                        "batch_per_gpu": bs, "global_batch": bs * world, "resolution": 1024, "regions": 12, "parallelism": f"frames x{world}",
                        "streams_per_gpu": args.streams,
                        "step_overlap": (f"consecutive steps (independent batches) alternate over {args.streams} HIP streams: the latency-bound 4^2-32^2 layers of a "
                                         "batch run under the large layers of the one before; all K steps complete inside the timed region") if args.streams > 1 else "none"},
-            "one_stream": one_stream,
+            "one_stream": one_stream, "soak": soak,
             "roofline": roof, "cpu_baseline": cpu, "full_swap": full_swap, "pti": pti_info, "clip": clip_info, "mask_sensitivity": mask_sens,
             "algorithmic_gflop_per_face": 148.52,
             "job_algorithmic_tflops_per_gpu": round(value * 148.52e9 / 1e12 / world, 2),

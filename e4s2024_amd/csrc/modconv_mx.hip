@@ -1,0 +1,461 @@
+// a3/a4, round 3: the masked 3x3 modulated conv (128 co x 256 px workgroup tile, the seven 32^2 ... 256^2 launches of a synthesis step) with
+//   (1) a DMA-fed pipeline — the weights of a K chunk live in a ring of three ROW slots (the three taps of one kernel row, 24-25 KB) that
+//       global_load_lds refills as soon as every wave is done with a row, the activation patch is double-buffered, so the K loop has no store phase:
+//       three barriers per chunk with nothing but waits between them (modconv_sb.hip's kernel: stage-in-registers, two barriers around a 95 KB
+//       LDS store phase during which the matrix pipe idles: 42-49 % busy in its loop against 94 % for the same loop on registers alone);
+//   (2) a choice of split arithmetic (template ARITH):
+//       0  bf16 x 3 — a_hi w_hi + a_hi w_lo + a_lo w_hi, bit-identical to modconv_sb.hip (same products, same accumulation order);
+//       1  f16 + 2 x MX fp6 — a1 w1 on v_mfma_f32_32x32x16_f16 (a1 = f16(a), w1 = f16(w)), and the two cross terms fp6(a) * fp6(w - w1) and
+//          fp6(a - a1) * fp6(w1) on v_mfma_scale_f32_32x32x64_f8f6f4 (e2m3, one power-of-two scale per lane = per 24 values: the three taps of a
+//          kernel row x 8 channels; K slots 24..31 meet zero weights).  The residuals are ~2^-12 of their operands, so 4 significant bits of
+//          them leave ~2^-16 per product: measured end to end on the 1024^2 generator 1.9e-4 max-abs against the fp32 oracle (bf16 x 3: 8e-5;
+//          bar 1e-3; tests/experiments/emulate_split_variants.py — the two-term f16 forms (a1 + a2) w1 / a1 (w1 + w2) miss the bar at 2-5e-3).
+//          Matrix-pipe time per 16-deep K step of one kernel row, measured (tools/probes/mx_probe.hip, random operands, power-limited clocks):
+//          3 x 4 f16 (20.2 ns each) + 2 x 4 fp6 K=64 (23.8 ns each) = 433 ns against 36 bf16 (18.4 ns each) = 663 ns.
+//          f16 range: |x * s| must stay below 65504; the kernel raises flags[0] when a block maximum does not (ops falls back to ARITH 0).
+// Operand layouts, prepared by e4s_modconv_prep_weights_mx, one ROW SLOT = what a workgroup DMAs for (parity, chunk, co tile, kernel row):
+//   ARITH 0: [hi | lo][tap 3][k half 2][co 128] x 16 B (8 bf16 = channels 8 half .. 8 half + 7 of the chunk)                          24 576 B
+//   ARITH 1: w1 f16 [tap 3][half 2][co 128] x 16 B | fp6 codes, first 16 B [term 2][half 2][co 128] | last 8 B [term 2][half 2][co 128] |
+//            E8M0 scales [half 2][co 128] x 4 B (byte 0: term 0 = fp6(w1), byte 1: term 1 = fp6(w - w1))                              25 600 B
+//            a lane's 32 fp6 positions: tap t (of the row) channel e -> position 8 t + e, positions 24..31 zero.
+#include <stdlib.h>
+
+#include "common.h"
+#include "sb_common.h"
+#include "modconv_sb.h"
+
+using namespace e4s;
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
+typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+constexpr int MX_TN = 128;                                    // output channels per workgroup
+constexpr int MX_ROWB0 = 2 * 3 * 2 * MX_TN * 16;              // 24 576
+constexpr int MX_W1B = 3 * 2 * MX_TN * 16;                    // 12 288: the f16 part of an ARITH 1 row
+constexpr int MX_F6LO = 2 * 2 * MX_TN * 16;                   // 8 192
+constexpr int MX_F6HI = 2 * 2 * MX_TN * 8;                    // 4 096
+constexpr int MX_SCB = 2 * MX_TN * 4;                         // 1 024
+constexpr int MX_ROWB1 = MX_W1B + MX_F6LO + MX_F6HI + MX_SCB; // 25 600
+__host__ __device__ constexpr int mx_rowb(int arith) { return arith ? MX_ROWB1 : MX_ROWB0; }
+
+__device__ __forceinline__ unsigned pack_f16_rne(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, f16x2));      // v_cvt_pk_f16_f32
+}
+
+// LDS-DMA issued from inline asm: 16 bytes per lane from (scalar base + 32-bit lane offset) to LDS address `lds_dst` + 16 * lane.  Through the builtin
+// hipcc 7.2 treats the DMA as a store to LDS that every later ds_read may alias and puts `s_waitcnt vmcnt(0)` in front of the next LDS read — the row
+// just requested would have to land before the NEXT row's first operand read, i.e. the whole L2 latency exposed once per kernel row.  From asm the
+// compiler neither orders LDS reads behind it nor counts it: the kernel waits (E4S_WAIT_VM(0)) before each barrier itself, and hipcc's own counted
+// waits for the ordinary loads of the activation patch only become longer, never shorter, by uncounted requests (vmcnt retires in order).
+__device__ __forceinline__ void dma16_asm(const void* gbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(gbase), "s"(lds_dst)
+                 : "memory");
+}
+
+// ============================================================================ weight preparation
+// One thread per (par, chunk, co tile, row, half, co): the lane's 24 values of that kernel row.
+__global__ __launch_bounds__(256) void prep_weights_mx_kernel(unsigned char* __restrict__ dst, const float* __restrict__ weight, const float* __restrict__ blur,
+                                                              int cout, int cin, int up, int arith, float scale) {
+    const int npar = up ? 4 : 1;
+    const int nchunk = (cin + CKS - 1) / CKS;
+    const int ntile = (cout + MX_TN - 1) / MX_TN;
+    const int64_t total = (int64_t)npar * nchunk * ntile * 3 * 2 * MX_TN;
+    const int rowb = mx_rowb(arith);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t r = i;
+        const int n = (int)(r % MX_TN); r /= MX_TN;
+        const int half = (int)(r & 1); r >>= 1;
+        const int row = (int)(r % 3); r /= 3;
+        const int tile = (int)(r % ntile); r /= ntile;
+        const int chunk = (int)(r % nchunk);
+        const int par = (int)(r / nchunk);
+        const int co = tile * MX_TN + n;
+        unsigned char* slot = dst + ((((size_t)par * nchunk + chunk) * ntile + tile) * 3 + row) * rowb;
+        float v[24];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ci = chunk * CKS + half * 8 + e;
+                float x = 0.f;
+                if (ci < cin && co < cout) { x = sb_weff(weight, blur, cin, co, ci, row * 3 + t, par, up); x *= scale; }
+                v[t * 8 + e] = x;
+            }
+        if (arith == 0) {
+            uint4* hi = reinterpret_cast<uint4*>(slot);
+            uint4* lo = reinterpret_cast<uint4*>(slot + 3 * 2 * MX_TN * 16);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                unsigned h[4], l[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {          // exactly prep_weights_sb_kernel's split: per element, RNE both times
+                    const unsigned h0 = pack_bf16_rne(v[t * 8 + 2 * j], 0.f) & 0xffffu, h1 = pack_bf16_rne(v[t * 8 + 2 * j + 1], 0.f) & 0xffffu;
+                    const unsigned l0 = pack_bf16_rne(v[t * 8 + 2 * j] - __builtin_bit_cast(float, h0 << 16), 0.f) & 0xffffu;
+                    const unsigned l1 = pack_bf16_rne(v[t * 8 + 2 * j + 1] - __builtin_bit_cast(float, h1 << 16), 0.f) & 0xffffu;
+                    h[j] = h0 | (h1 << 16);
+                    l[j] = l0 | (l1 << 16);
+                }
+                hi[(t * 2 + half) * MX_TN + n] = make_uint4(h[0], h[1], h[2], h[3]);
+                lo[(t * 2 + half) * MX_TN + n] = make_uint4(l[0], l[1], l[2], l[3]);
+            }
+        } else {
+            uint4* w1p = reinterpret_cast<uint4*>(slot);
+            uint4* f6lo = reinterpret_cast<uint4*>(slot + MX_W1B);
+            uint2* f6hi = reinterpret_cast<uint2*>(slot + MX_W1B + MX_F6LO);
+            unsigned* scp = reinterpret_cast<unsigned*>(slot + MX_W1B + MX_F6LO + MX_F6HI);
+            // w1 = f16(w); the residual w - w1 is at most 2^-12 |w|: it goes through f16 scaled by 2^12 (so that it stays a normal f16 whatever
+            // the layer's weight scale) and the factor comes back out through its block scale
+            u32x16 q1, q2;
+            float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const float a = v[2 * j], b = v[2 * j + 1];
+                const f16x2 h = __builtin_convertvector((f32x2){a, b}, f16x2);
+                const float ra = (a - (float)h[0]) * 4096.f, rb = (b - (float)h[1]) * 4096.f;
+                q1[j] = __builtin_bit_cast(unsigned, h);
+                q2[j] = pack_f16_rne(ra, rb);
+                m1 = fmaxf(m1, fmaxf(fabsf((float)h[0]), fabsf((float)h[1])));
+                m2 = fmaxf(m2, fmaxf(fabsf(ra), fabsf(rb)));
+            }
+#pragma unroll
+            for (int j = 12; j < 16; ++j) { q1[j] = 0u; q2[j] = 0u; }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) w1p[(t * 2 + half) * MX_TN + n] = make_uint4(q1[4 * t], q1[4 * t + 1], q1[4 * t + 2], q1[4 * t + 3]);
+            // block scale 2^(E - 2) with 2^E <= max < 2^(E + 1): the largest value lands in [4, 8) of e2m3's [0, 7.5] (a maximum above 7.5 * 2^(E - 2)
+            // saturates: 6 % on that one element of a term that is 2^-12 of the product)
+            auto expo = [](float m) { const unsigned ex = (__builtin_bit_cast(unsigned, m) >> 23) & 0xffu; return ex > 3u ? ex - 2u : 1u; };
+            const unsigned e1 = expo(m1), e2 = expo(m2);
+            const u32x6 c1 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, q1), __builtin_bit_cast(float, e1 << 23));
+            const u32x6 c2 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, q2), __builtin_bit_cast(float, e2 << 23));
+            f6lo[(0 * 2 + half) * MX_TN + n] = make_uint4(c1[0], c1[1], c1[2], c1[3]);
+            f6hi[(0 * 2 + half) * MX_TN + n] = make_uint2(c1[4], c1[5]);
+            f6lo[(1 * 2 + half) * MX_TN + n] = make_uint4(c2[0], c2[1], c2[2], c2[3]);
+            f6hi[(1 * 2 + half) * MX_TN + n] = make_uint2(c2[4], c2[5]);
+            const unsigned e2s = e2 > 12u ? e2 - 12u : 0u;       // the 2^12 of the residual's f16 detour
+            scp[half * MX_TN + n] = e1 | (e2s << 8);
+        }
+    }
+}
+
+// ============================================================================ the conv kernel
+using C = SbCfg<4, 1, 1, 8, 5>;     // 128 co x (32 x 8) px, 512 threads; wave w = tile row w, its 32 pixels x all 128 output channels
+constexpr int MX_PATCHB = C::PATCH * CKS * 4;                 // 21 760: [pixel][16 ch] fp32, 16-B slots swizzled as in modconv_sb.hip
+constexpr int MX_SSB = E4S_MAX_REGIONS * CKS * 4;             // 1 024
+template <int ARITH>
+struct MxLds {
+    static constexpr int ROWB = ARITH ? MX_ROWB1 : MX_ROWB0;
+    static constexpr int RING = 3 * ROWB;
+    static constexpr int PATCH0 = RING;
+    static constexpr int SS0 = PATCH0 + 2 * MX_PATCHB;
+    static constexpr int BYTES = SS0 + 2 * MX_SSB;
+    static constexpr int NPIECE = ROWB / 1024;                // 1 KB per wave instruction
+    static_assert(ROWB % 1024 == 0 && BYTES <= 160 * 1024, "LDS plan");
+    static_assert((E4S_MAX_REGIONS + 5) * MX_TN * 4 + 64 <= RING, "the epilogue's tables overlay the weight ring");
+};
+
+template <int ARITH, bool RGB, bool OSP>
+__global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParams p) {
+    using L = MxLds<ARITH>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: DMA destinations (M0) and the piece loop stay in SGPRs
+    const int l5 = lane & 31, khalf = lane >> 5;
+
+    const int ntile = p.tiles_x * p.tiles_y;
+    const int npar = p.up ? 4 : 1;
+    unsigned bxp = p.perm_mul ? (unsigned)(((unsigned long long)blockIdx.x * p.perm_mul) % gridDim.x) : blockIdx.x;
+    if (p.perm_mul && (gridDim.x & 7u) == 0) bxp = (bxp & ~7u) | ((bxp + (bxp >> 3)) & 7u);       // (see modconv_sb.hip)
+    const int ks = bxp / (ntile * npar);
+    const int bx = bxp - ks * ntile * npar;
+    const int tile = bx % ntile;
+    const int par = bx / ntile;
+    const int pa = par >> 1, pb_ = par & 1;
+    const int y0 = (tile / p.tiles_x) * C::TH, x0 = (tile % p.tiles_x) * C::TW;
+    const int cotile = blockIdx.y;
+    const int co0 = cotile * MX_TN;
+    const int b = blockIdx.z;
+    const int hw = p.h * p.w;
+    const int ho = p.up ? 2 * p.h : p.h, wo = p.up ? 2 * p.w : p.w;
+    const int nchunk = (p.cin + CKS - 1) / CKS;
+    const int ncot = (p.cout + MX_TN - 1) / MX_TN;
+
+    unsigned ub_skip = 0;       // (masked up layer) bit j: 16 x 16 output block j of this tile belongs to the block kernel
+    if (p.up && p.uni_blocks && p.uni_ctrl[2] != 0) {
+        const int nbx = wo >> 4, nby = ho >> 4;
+        const int by = (2 * y0) >> 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int bxk = ((2 * x0) >> 4) + j;
+            const bool uni = by < nby && bxk < nbx && p.uni_blocks[((size_t)b * nby + by) * nbx + bxk] != 255;
+            const bool outside = by >= nby || bxk >= nbx;
+            if (uni || outside) ub_skip |= 1u << j;
+        }
+        if (ub_skip == 0xfu) return;
+    }
+
+    // this thread's patch pixel (threads 0..339) and its region / patch position as an output pixel (lane l5 of tile row `wave`)
+    const int ppy = tid / C::PW, ppx = tid - ppy * C::PW;
+    const int pgy = y0 - 1 + ppy, pgx = x0 - 1 + ppx;
+    const bool p_in = tid < C::PATCH && pgy >= 0 && pgy < p.h && pgx >= 0 && pgx < p.w;
+    const int goffs = p_in ? pgy * p.w + pgx : 0;
+    const float* xb = p.x + (size_t)b * p.cin * hw;
+    const float* sb = p.s + (size_t)b * p.nreg * p.cin;
+
+    int cls[1], xoff;
+    {
+        const int ty = wave, tx = l5;
+        xoff = ty * C::PW + tx;
+        const int y = y0 + ty, x = x0 + tx;
+        int c = E4S_LABEL_NONE;
+        if (y < p.h && x < p.w) {
+            const int oy = p.up ? 2 * y + pa : y, ox = p.up ? 2 * x + pb_ : x;
+            c = p.labels[((size_t)b * p.lh + nearest_src(oy, p.lscale_y, p.lh)) * p.lw + nearest_src(ox, p.lscale_x, p.lw)];
+        }
+        cls[0] = (c < p.nreg) ? c : -1;
+    }
+
+    f32x16 acc[4][1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+    // ---- staging
+    float xr[CKS];
+    float sr = 0.f;
+    // Unconditional, branch-free loads (as modconv_sb.hip learned): a load under a per-lane condition, or a register that is also written by a plain
+    // move (`sr = cond ? load : 0`), makes hipcc wait vmcnt(0) right behind the issue — the whole latency exposed once per chunk.  Out-of-range
+    // lanes read a clamped valid address and are zeroed when the chunk is written to LDS; waves 6 and 7 own no patch pixel (wave-uniform branch).
+    const int s_r = tid / CKS < p.nreg ? tid / CKS : p.nreg - 1, s_c = tid % CKS;
+    auto load_x = [&](int chunk) __attribute__((always_inline)) {       // next chunk's patch pixel (16 channels) and modulation table entry
+        const int ci0 = chunk * CKS;
+        const int cmax = p.cin - 1 - ci0;
+        if (wave < (C::PATCH + 63) / 64) {
+#pragma unroll
+            for (int c = 0; c < CKS; ++c) xr[c] = xb[(size_t)(ci0 + (c < cmax ? c : cmax)) * hw + goffs];
+        }
+        sr = sb[(size_t)s_r * p.cin + ci0 + (s_c < cmax ? s_c : cmax)];
+    };
+    auto store_x = [&](int buf, int chunk) __attribute__((always_inline)) {
+        float4* xf4 = reinterpret_cast<float4*>(lds_raw + L::PATCH0 + buf * MX_PATCHB);
+        if (tid < C::PATCH) {
+            const int g = (tid >> 2) & 3;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                xf4[tid * 4 + (k ^ g)] = p_in ? make_float4(xr[4 * k], xr[4 * k + 1], xr[4 * k + 2], xr[4 * k + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (tid < E4S_MAX_REGIONS * CKS)
+            reinterpret_cast<float*>(lds_raw + L::SS0 + buf * MX_SSB)[tid] = (tid / CKS < p.nreg && chunk * CKS + s_c < p.cin) ? sr : 0.f;
+    };
+    // row `row` of chunk `chunk` -> ring slot `row`: pieces wave, wave + 8, ... of NPIECE
+    const unsigned char* wbase = p.wmx + (size_t)par * nchunk * ncot * 3 * L::ROWB;
+    auto dma_row = [&](int chunk, int row) __attribute__((always_inline)) {
+        const unsigned char* src = wbase + ((size_t)(chunk * ncot + cotile) * 3 + row) * L::ROWB;
+#pragma unroll
+        for (int k = 0; k < (L::NPIECE + 7) / 8; ++k) {
+            const int piece = wave + 8 * k;
+            if (piece < L::NPIECE) dma16_asm(src, (unsigned)(piece * 1024 + lane * 16), (unsigned)(row * L::ROWB + piece * 1024));
+        }
+    };
+
+    const int ch_begin = ks * p.chunks_per;
+    const int ch_end = (ch_begin + p.chunks_per < nchunk) ? ch_begin + p.chunks_per : nchunk;
+    if (ch_begin < ch_end) {
+        dma_row(ch_begin, 0);
+        dma_row(ch_begin, 1);
+        dma_row(ch_begin, 2);
+        load_x(ch_begin);
+        store_x(0, ch_begin);
+    }
+    E4S_WAIT_VM(0);
+    E4S_LDS_BARRIER();
+
+#pragma unroll 1
+    for (int chunk = ch_begin; chunk < ch_end; ++chunk) {
+        const int cur = (chunk - ch_begin) & 1;
+        const bool more = chunk + 1 < ch_end;
+        if (more) load_x(chunk + 1);                       // lands during this chunk, written to the other patch buffer before its last barrier
+
+        const float4* xf4 = reinterpret_cast<const float4*>(lds_raw + L::PATCH0 + cur * MX_PATCHB);
+        const float* ss = reinterpret_cast<const float*>(lds_raw + L::SS0 + cur * MX_SSB);
+        float sv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sv[e] = cls[0] >= 0 ? ss[cls[0] * CKS + khalf * 8 + e] : 0.f;
+
+#pragma unroll
+        for (int row = 0; row < 3; ++row) {
+            const unsigned char* slot = lds_raw + row * L::ROWB;
+            if constexpr (ARITH == 0) {
+                const uint4* whalf = reinterpret_cast<const uint4*>(slot) + khalf * MX_TN + l5;      // + t * 2 * TN, + 6 * TN for the lo slab
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int e = xoff + row * C::PW + t;
+                    const int g = (e >> 2) & 3;
+                    const float4 x0v = xf4[e * 4 + ((2 * khalf) ^ g)], x1v = xf4[e * 4 + ((2 * khalf + 1) ^ g)];
+                    uint4 bh, bl;
+                    split2(x0v.x * sv[0], x0v.y * sv[1], bh.x, bl.x);
+                    split2(x0v.z * sv[2], x0v.w * sv[3], bh.y, bl.y);
+                    split2(x1v.x * sv[4], x1v.y * sv[5], bh.z, bl.z);
+                    split2(x1v.z * sv[6], x1v.w * sv[7], bh.w, bl.w);
+                    uint4 ah[4], al[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        ah[i] = whalf[t * 2 * MX_TN + i * 32];
+                        al[i] = whalf[6 * MX_TN + t * 2 * MX_TN + i * 32];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh), acc[i][0], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl), acc[i][0], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh), acc[i][0], 0, 0, 0);
+                }
+            } else {
+                const uint4* w1half = reinterpret_cast<const uint4*>(slot) + khalf * MX_TN + l5;
+                const uint4* f6lo = reinterpret_cast<const uint4*>(slot + MX_W1B) + khalf * MX_TN + l5;                    // + term * 2 * TN + i * 32
+                const uint2* f6hi = reinterpret_cast<const uint2*>(slot + MX_W1B + MX_F6LO) + khalf * MX_TN + l5;
+                const unsigned* wsc = reinterpret_cast<const unsigned*>(slot + MX_W1B + MX_F6LO + MX_F6HI) + khalf * MX_TN + l5;
+                u32x16 v1, v2;        // a1 = f16(a) and a - a1 of the row's 24 values, as the f16 pairs the conversions below take (registers 12..15: copies)
+                float amax = 0.f;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int e = xoff + row * C::PW + t;
+                    const int g = (e >> 2) & 3;
+                    const float4 x0v = xf4[e * 4 + ((2 * khalf) ^ g)], x1v = xf4[e * 4 + ((2 * khalf + 1) ^ g)];
+                    const float xv[8] = {x0v.x, x0v.y, x0v.z, x0v.w, x1v.x, x1v.y, x1v.z, x1v.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float a = xv[2 * j] * sv[2 * j], bq = xv[2 * j + 1] * sv[2 * j + 1];
+                        const f16x2 a1 = __builtin_convertvector((f32x2){a, bq}, f16x2);
+                        v1[t * 4 + j] = __builtin_bit_cast(unsigned, a1);
+                        v2[t * 4 + j] = pack_f16_rne(a - (float)a1[0], bq - (float)a1[1]);
+                        amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(bq)));
+                    }
+                    const uint4 b1 = make_uint4(v1[t * 4], v1[t * 4 + 1], v1[t * 4 + 2], v1[t * 4 + 3]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w1half[t * 2 * MX_TN + i * 32]), __builtin_bit_cast(f16x8, b1), acc[i][0], 0, 0, 0);
+                }
+                // block scales of this lane's 24 values: 2^(E - 2) for fp6(a1), 2^(E - 13) for fp6(a - a1)  (|a - a1| <= 2^(E - 11));  E >= 16 leaves f16
+                const unsigned ex = (__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu;
+                if (ex >= 143u && p.flags) atomicOr(p.flags, 1);
+                const unsigned e1 = ex > 3u ? ex - 2u : 1u, e2 = ex > 14u ? ex - 13u : 1u;
+#pragma unroll
+                for (int j = 12; j < 16; ++j) { v1[j] = v1[j - 12]; v2[j] = v2[j - 12]; }     // (positions 24..31 meet zero weights)
+                const u32x6 p1 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, v1), __builtin_bit_cast(float, e1 << 23));
+                const u32x6 p2 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, v2), __builtin_bit_cast(float, e2 << 23));
+                const i32x8 bx1 = {(int)p1[0], (int)p1[1], (int)p1[2], (int)p1[3], (int)p1[4], (int)p1[5], 0, 0};
+                const i32x8 bx2 = {(int)p2[0], (int)p2[1], (int)p2[2], (int)p2[3], (int)p2[4], (int)p2[5], 0, 0};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {       // fp6(w - w1) x fp6(a1)
+                    const uint4 lo = f6lo[2 * MX_TN + i * 32];
+                    const uint2 hi = f6hi[2 * MX_TN + i * 32];
+                    const i32x8 aw = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, 0, 0};
+                    acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aw, bx1, acc[i][0], 2, 2, 1, (int)wsc[i * 32], 0, (int)e1);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {       // fp6(w1) x fp6(a - a1)
+                    const uint4 lo = f6lo[i * 32];
+                    const uint2 hi = f6hi[i * 32];
+                    const i32x8 aw = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, 0, 0};
+                    acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aw, bx2, acc[i][0], 2, 2, 0, (int)wsc[i * 32], 0, (int)e2);
+                }
+            }
+            if (row == 2 && more) store_x(cur ^ 1, chunk + 1);         // (its last readers passed the previous chunk's last barrier)
+            // everything this wave issued so far has landed; then: every wave is done with this row's slot (and, after row 2, with the patch)
+            E4S_WAIT_VM(0);
+            E4S_LDS_BARRIER();
+            if (more) dma_row(chunk + 1, row);
+        }
+    }
+
+    if (p.ksplit > 1) {
+        float* part = p.partial + ((size_t)ks * p.bs + b) * p.cout * ho * wo;
+        const int y = y0 + wave, x = x0 + l5;
+        if (y < p.h && x < p.w) {
+            const size_t opix = (size_t)(p.up ? 2 * y + pa : y) * wo + (p.up ? 2 * x + pb_ : x);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    if (co < p.cout) part[(size_t)co * ho * wo + opix] = acc[i][0][r];
+                }
+        }
+        return;
+    }
+    sb_epilogue<C, 4, 1, 8, RGB, OSP>(p, lds_raw, acc, cls, co0, b, y0, x0, pa, pb_, ho, wo, ub_skip);
+}
+
+template <int ARITH, bool RGB, bool OSP>
+int launch_mx_variant(const SbParams& p, dim3 grid, hipStream_t st) {
+    using L = MxLds<ARITH>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&region_modconv_mx_kernel<ARITH, RGB, OSP>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES);
+    if (attr != hipSuccess) return fail((int)attr, "region_modconv3x3_mx: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+    hipLaunchKernelGGL((region_modconv_mx_kernel<ARITH, RGB, OSP>), grid, dim3(512), L::BYTES, st, p);
+    return check_launch("region_modconv3x3_mx");
+}
+
+}  // namespace
+
+extern "C" int e4s_modconv_mx_weight_bytes(int cout, int cin, int up, int arith, int64_t* bytes) {
+    E4S_REQUIRE(bytes && cout >= 1 && cin >= 1 && (arith == 0 || arith == 1), "modconv_mx_weight_bytes: bad arguments");
+    *bytes = (int64_t)(up ? 4 : 1) * cdiv(cin, CKS) * cdiv(cout, MX_TN) * 3 * mx_rowb(arith);
+    return 0;
+}
+
+extern "C" int e4s_modconv_prep_weights_mx(void* dst, const float* weight, const float* blur, int cout, int cin, int up, int arith, void* stream) {
+    E4S_REQUIRE(dst && weight, "modconv_prep_weights_mx: null tensor");
+    E4S_REQUIRE(cout >= 1 && cin >= 1 && (arith == 0 || arith == 1), "modconv_prep_weights_mx: bad arguments");
+    E4S_REQUIRE(!up || blur, "modconv_prep_weights_mx: up-conv needs the 4x4 blur kernel");
+    E4S_REQUIRE(((uintptr_t)dst & 15) == 0, "modconv_prep_weights_mx: the destination must be 16-byte aligned");
+    const float scale = 1.0f / sqrtf((float)cin * 9.f);
+    const int64_t total = (int64_t)(up ? 4 : 1) * cdiv(cin, CKS) * cdiv(cout, MX_TN) * 3 * 2 * MX_TN;
+    const int grid = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
+    hipLaunchKernelGGL(prep_weights_mx_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (unsigned char*)dst, weight, blur, cout, cin, up, arith, scale);
+    return check_launch("modconv_prep_weights_mx");
+}
+
+int e4s::launch_modconv_mx(SbParams& p, int arith, hipStream_t st, float* workspace, int64_t workspace_floats) {
+    p.tiles_x = cdiv(p.w, C::TW);
+    p.tiles_y = cdiv(p.h, C::TH);
+    const int npar = p.up ? 4 : 1;
+    const int64_t base = (int64_t)p.tiles_x * p.tiles_y * npar * cdiv(p.cout, MX_TN) * p.bs;
+    const int ho = p.up ? 2 * p.h : p.h, wo = p.up ? 2 * p.w : p.w;
+    const int64_t out_floats = (int64_t)p.bs * p.cout * ho * wo;
+    const int nchunk = cdiv(p.cin, CKS);
+    int ksplit = 1;
+    if (workspace && base < 384)         // one workgroup per CU: split K until one round of the chip is full (as modconv_sb.hip's 96 KB tile)
+        while (ksplit < 16 && base * ksplit * 2 <= 256 && ksplit * 2 <= nchunk && (int64_t)(ksplit * 2) * out_floats <= workspace_floats) ksplit *= 2;
+    if (p.rgb_out) {
+        if (p.cout > MX_TN || p.up) return fail(E4S_ERR_ARG, "region_modconv3x3_mx: fused ToRGB needs all %d output channels in one workgroup tile", p.cout);
+        ksplit = 1;
+    }
+    if (p.uni_blocks) ksplit = 1;
+    p.ksplit = ksplit;
+    p.chunks_per = cdiv(nchunk, ksplit);
+    p.partial = workspace;
+    dim3 grid(p.tiles_x * p.tiles_y * npar * ksplit, cdiv(p.cout, MX_TN), p.bs);
+    p.perm_mul = p.uni_blocks ? coprime_stride(grid.x) : 0u;
+    const bool rgb = p.rgb_out != nullptr, osp = p.s_next != nullptr;
+    if (osp && !rgb) return fail(E4S_ERR_ARG, "region_modconv3x3_mx: split-plane output is built for the masked fused-ToRGB layer");
+    int rc;
+    if (arith == 0) rc = osp ? launch_mx_variant<0, true, true>(p, grid, st) : rgb ? launch_mx_variant<0, true, false>(p, grid, st) : launch_mx_variant<0, false, false>(p, grid, st);
+    else            rc = osp ? launch_mx_variant<1, true, true>(p, grid, st) : rgb ? launch_mx_variant<1, true, false>(p, grid, st) : launch_mx_variant<1, false, false>(p, grid, st);
+    return rc;
+}

@@ -647,8 +647,6 @@ extern "C" int e4s_modconv_up_fused_sb(float* out, const float* x, const uint16_
     p.tiles_y = cdiv(2 * h, UF_OUT);
     { const char* e = getenv("E4S_UF_EXP"); p.exp = e ? atoi(e) : 0; }
     hipStream_t st = (hipStream_t)stream;
-    static const int cb2 = [] { const char* e = getenv("E4S_UPFUSED_CB2"); return e ? atoi(e) : 0; }();
-    if (cb2 && cout > 32) return launch_up_fused<2, 2>(p, st);   // 64 co per workgroup: x staged once, 1 workgroup per CU
     if (x_sp && out_sp) {
         static const int use_dma = [] { const char* e = getenv("E4S_UP_DMA"); return e ? atoi(e) : 1; }();
         if (use_dma && cout % 32 == 0 && cin % 16 == 0 && d) {
@@ -656,8 +654,7 @@ extern "C" int e4s_modconv_up_fused_sb(float* out, const float* x, const uint16_
                 void* ptr = nullptr;
                 return hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_uf_zero)) == hipSuccess ? static_cast<const float*>(ptr) : nullptr;
             }();
-            // tuning knob: E4S_UP_ONE_PER_CU=1 asks for 84 KB of LDS, so that one workgroup per CU stays (phase timings without a neighbour)
-            static const int lds_bytes = [] { const char* e = getenv("E4S_UP_ONE_PER_CU"); return (e && atoi(e)) ? 84 * 1024 : UD_LDS_BYTES; }();
+            constexpr int lds_bytes = UD_LDS_BYTES;
             static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&up_fused_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
             if (zeros && attr == hipSuccess) {
                 p.zeros = zeros;

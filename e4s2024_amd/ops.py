@@ -237,10 +237,10 @@ class _StreamCtx:
     model: ONE host thread per stream; the prepared weight copies, which ARE shared, publish themselves atomically and are ordered across
     streams by an event, see ``_Prepared``)."""
 
-    __slots__ = ("label_cache", "table_plan", "forward_stamp", "workspace", "up_ctrl")
+    __slots__ = ("label_cache", "table_plan", "forward_stamp", "workspace", "up_ctrl", "mx_flags")
 
     def __init__(self):
-        self.label_cache, self.table_plan, self.forward_stamp, self.workspace, self.up_ctrl = {}, {}, None, None, None
+        self.label_cache, self.table_plan, self.forward_stamp, self.workspace, self.up_ctrl, self.mx_flags = {}, {}, None, None, None, None
 
 
 _ctxs = {}
@@ -468,6 +468,67 @@ class PreparedWeights(_Prepared):
         return wt, wsq
 
 
+# The DMA-fed masked kernel (csrc/modconv_mx.hip) for the masked layers of width >= 32 and >= 128 output channels — the seven launches that dominate
+# a synthesis step.  E4S_MX: 0 = off (modconv_sb.hip's register-staged kernel), 1 = its pipeline with the split-bf16 arithmetic (bit-identical
+# results), 2 = with the f16 + 2 x MX-fp6 arithmetic (about half the matrix-pipe time; 2-3x the split-bf16 error, still 5x inside the 1e-3 bar).
+MX_MODE = int(os.environ.get("E4S_MX", "2"))
+
+
+def mx_arith() -> Optional[int]:
+    """Arithmetic selector of the mx kernel under the current settings, or None when it is off."""
+    if MX_MODE <= 0 or MODCONV_MODE != "sb":
+        return None
+    return 1 if MX_MODE >= 2 else 0
+
+
+def mx_eligible(cin: int, cout: int, w: int, masked: bool) -> bool:
+    return mx_arith() is not None and masked and w >= 32 and cout >= 128 and cin % 16 == 0 and not torch.is_grad_enabled()
+
+
+class PreparedMx(_Prepared):
+    """A ModulatedConv2d weight as the row slots ``e4s_region_modconv3x3_mx`` DMAs (``e4s_modconv_prep_weights_mx``); rebuilt when the parameter,
+    the blur buffer or the arithmetic changes.  Inference only (``mx_eligible``), so the copy is always cacheable."""
+
+    __slots__ = ()
+
+    def get(self, weight: torch.Tensor, blur: Optional[torch.Tensor], up: bool, arith: int) -> torch.Tensor:
+        key = (weight.data_ptr(), weight._version, weight.device, None if blur is None else (blur.data_ptr(), blur._version), up, arith)
+        hit = self._lookup(key)
+        if hit is not None:
+            return hit[0]
+        w = _c(weight.detach(), "weight")
+        _, cout, cin, k, _ = w.shape
+        if k != 3:
+            raise ValueError("the mx kernel is a 3x3 kernel")
+        bk = _c(blur, "blur kernel") if up else None
+        nbytes = ctypes.c_int64(0)
+        lib().call("e4s_modconv_mx_weight_bytes", cout, cin, 1 if up else 0, arith, ctypes.byref(nbytes))
+        wmx = torch.empty((nbytes.value,), dtype=torch.uint8, device=w.device)
+        lib().call("e4s_modconv_prep_weights_mx", _p(wmx), _p(w), _p(bk), cout, cin, 1 if up else 0, arith, _stream())
+        self._publish(key, (wmx,))          # (a tuple: the base class walks the payload's tensors when another stream first uses the copy)
+        return wmx
+
+
+def mx_flags(device) -> torch.Tensor:
+    """The device word the f16 arithmetic raises (bit 0) when a modulated activation leaves the f16 range; one per stream context."""
+    c = _ctx()
+    if c.mx_flags is None or c.mx_flags.device != torch.device(device):
+        c.mx_flags = torch.zeros((4,), dtype=torch.int32, device=device)
+    return c.mx_flags
+
+
+def mx_overflowed(reset: bool = True) -> bool:
+    """Did any mx launch on the current stream since the last reset see |x * s| >= 2^16?  (Synchronises the stream.)  The results of such a forward
+    are not to be trusted (f16 infinities); rerun with ``E4S_MX=1`` / ``ops.MX_MODE = 1``."""
+    c = _ctx()
+    if c.mx_flags is None:
+        return False
+    v = int(c.mx_flags[0].item())
+    if reset and v:
+        c.mx_flags.zero_()
+    return bool(v & 1)
+
+
 UP_FUSED = os.environ.get("E4S_UP_FUSED", "1") != "0"     # single-region up layers: one launch (blur in LDS) instead of tconv + blur epilogue
 UP_TWO_STAGE = os.environ.get("E4S_UP_TWO_STAGE", "1") != "0"
 
@@ -643,8 +704,7 @@ FUSE_RGB = os.environ.get("E4S_FUSE_RGB", "1") != "0"
 
 def can_fuse_rgb(cout: int, w: int, up: bool, masked: bool) -> bool:
     """Can the single-region ToRGB that follows a layer ride in its epilogue?  (the layer's Cout must fit one workgroup tile)"""
-    wide = os.environ.get("E4S_SB_WIDE", "1") != "0"
-    return FUSE_RGB and MODCONV_MODE == "sb" and not up and w >= 32 and (cout <= 64 or (masked and wide and cout == 128))
+    return FUSE_RGB and MODCONV_MODE == "sb" and not up and w >= 32 and (cout <= 64 or (masked and cout == 128))
 
 
 UP_BLOCKS = os.environ.get("E4S_UP_BLOCKS", "1") != "0"    # masked up layers: region-uniform 16 x 16 output blocks in the transposed-conv form
@@ -655,7 +715,7 @@ UP_BLOCK = 16
 # portrait-shaped maps 1086 / 1080 / 1082 / 1084 (a second box: 1044 / - / 1031 / -), 4 x 4-cell maps 1092 / 1229 / 1203 / 1139, the bench's
 # blocky maps 1084 / 1113 / 1126 / 1127 (tools/sweep_blocks_minw.sh).  E4S_UP_BLOCKS_MINW=64 / 32 for maps made of large cells.
 UP_BLOCKS_MIN_WIDTH = int(os.environ.get("E4S_UP_BLOCKS_MINW", "128"))
-UP_SUBBLOCKS = os.environ.get("E4S_UP_SUBBLOCKS", "0") != "0"   # also blocks made of four uniform 8 x 8 sub-blocks (slower than the composed form on the benchmark maps)
+UP_SUBBLOCKS = False   # (no environment switch: measured slower for two rounds; the GPU tests that pin the variant set this attribute)   also blocks made of four uniform 8 x 8 sub-blocks (slower than the composed form on the benchmark maps)
 
 
 UP_BLOCK_QUAD = 254      # block map value: four region-uniform 8 x 8 sub-blocks with different regions
@@ -687,8 +747,9 @@ def uniform_blocks(labels: torch.Tensor, ho: int, wo: int, nreg: int, with_ctrl:
 
 
 def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: bool, cout: int, up: bool, rgb=None, want_out: bool = True,
-                      x_nhwc: bool = False, out_nhwc: bool = False, s_next=None, up_blocks=None):
-    """``rgb = (wt_rgb [cout,3], s_rgb [bs,1,cout], bias [1,3,1,1], skip or None, up_kernel)`` fuses the following single-region
+                      x_nhwc: bool = False, out_nhwc: bool = False, s_next=None, up_blocks=None, mx=None):
+    """``mx = (wmx, arith)`` (``PreparedMx``, a layer ``mx_eligible`` accepts): run on the DMA-fed kernel of csrc/modconv_mx.hip.
+    ``rgb = (wt_rgb [cout,3], s_rgb [bs,1,cout], bias [1,3,1,1], skip or None, up_kernel)`` fuses the following single-region
     ToRGB; the call then returns ``(out, rgb_image)``.  ``want_out=False`` (with ``rgb``) skips writing the layer's own activation
     and returns ``(None, rgb_image)``.  ``x_nhwc`` / ``out_nhwc``: the activation is channel-blocked, ``[bs, c/8, h, w, 8]`` (split-bf16
     kernel, width >= 32; the 256x256-and-up layers can chain in this layout inside ``Generator.forward``).  ``s_next [bs, 1, cout]`` (masked
@@ -745,7 +806,7 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
                    nbs or 0, _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, int(UP_SUBBLOCKS), _stream())
         if evb is not None:
             evb.record()
-    ev = _timed(modconv_kernel_name(cout, w, sb, labels is not None), f"{cin}->{cout} @{h}{' up' if up else ''}")
+    ev = _timed(modconv_kernel_name(cout, w, sb, labels is not None, cin, mx[1] if (sb and mx is not None) else None), f"{cin}->{cout} @{h}{' up' if up else ''}")
     rgb_out = None
     if rgb is not None:
         if not sb:
@@ -758,7 +819,15 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
                     _p(_c(r_upk, "upsample.kernel")) if r_skip is not None else None)
     else:
         rgb_args = (None,) * 6
-    if sb:
+    if sb and mx is not None:
+        if labels is None or w < 32 or cout < 128 or cin % 16 or x_nhwc or out_nhwc:
+            raise ValueError("region_modconv3x3: the mx kernel is built for masked layers of width >= 32, cout >= 128, cin % 16 == 0, channels-first")
+        wmx, arith = mx
+        lib().call("e4s_region_modconv3x3_mx", _p(out), _p(x), _p(wmx), arith, _p(mx_flags(x.device)) if arith else None, _p(s), _p(d), _p(labels), lh, lw,
+                   _p(nz), nbs or 0, _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg,
+                   (1 if up else 0) | (16 if sn is not None else 0), _p(ws), wsn, *rgb_args, _p(sn),
+                   _p(blocks), _p(bctrl) if blocks is not None else None, _stream())
+    elif sb:
         lib().call("e4s_region_modconv3x3_sb", _p(out), _p(x), _p(wt[0]), _p(wt[1]), _p(s), _p(d), _p(labels), lh, lw, _p(nz), nbs or 0,
                    _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg,
                    (1 if up else 0) | (2 if x_nhwc else 0) | (4 if out_nhwc else 0) | (16 if sn is not None else 0), _p(ws), wsn, *rgb_args, _p(sn),
@@ -1398,6 +1467,10 @@ def erode_labels(labels: torch.Tensor, radius: int, bg_classes: Sequence[int] = 
 
 # ------------------------------------------------------------------------------------ f1: native gradients of the masked conv
 NATIVE_BWD = os.environ.get("E4S_NATIVE_BWD", "1") != "0"
+# The backward of the path runs on this library's kernels.  The two ways a vendor library can still enter it are both opt-in: E4S_NATIVE_BWD=0 (the
+# stock-PyTorch forms of torch_ref.py, kept as the comparison arm of the gradient tests) and E4S_ALLOW_MIOPEN_BWD=1 (aten.convolution_backward for the
+# single-region shapes the hand-written kernels do not cover: cout < 16 or a kernel size other than 1 / 3); without the latter such a shape raises.
+ALLOW_LIBRARY_BWD = os.environ.get("E4S_ALLOW_MIOPEN_BWD", "0") != "0"
 _FOLD_CHUNK_PX = int(os.environ.get("E4S_FOLD_CHUNK_PX", "1024"))     # pixels per workgroup of e4s_mconv_fold: one pass per thread (4096: the up layers 0.73 -> 0.61 ms)
 _SCALE_CHUNK_PX = 8192
 
@@ -1476,8 +1549,8 @@ def unfold2d(x, ks: int, stride: int, pad: int, ho: int, wo: int):
 
 # the data / style gradient of a masked 3x3 layer as one kernel instead of the GEMM that writes U + the fold that reads it twice.  Off by default:
 # measured slower on all but the two largest masked layers (csrc/mconv_dgrad.hip, STATUS)
-DGRAD_FUSED = os.environ.get("E4S_DGRAD_FUSED", "0") != "0"
-DGRAD_FUSED_MIN_WIDTH = int(os.environ.get("E4S_DGRAD_FUSED_MINW", "32"))
+DGRAD_FUSED = False           # e4s_mconv_dgrad (csrc/mconv_dgrad.hip): measured slower than GEMM + fold on all but the two largest masked layers; no environment
+DGRAD_FUSED_MIN_WIDTH = 32    # switch any more — the parity tests and tools/time_dgrad.py set the attribute
 
 
 def _mconv_input_grads(gz, wg, x, s, lab, up: int, need_x: bool, need_s: bool, need_w: bool):
@@ -1717,7 +1790,8 @@ class _SingleStyledConvGrad(torch.autograd.Function):
         out = leaky_relu(conv(x, wmod)  [or blur(conv_transpose(x, wmod, stride 2)) for the up-sampling layers]  + nw·noise + bias) · √2
 
     g' = dL/dout · act'(out), Σ g', Σ g'·noise come from ``e4s_mconv_scale``; the blur's transpose is the same FIR kernel
-    (``e4s_upfirdn2d``); the data / weight gradients of the convolution itself are MIOpen's (``aten.convolution_backward``)."""
+    (``e4s_upfirdn2d``); the data gradient runs on the three-way-split MFMA conv kernel, the weight gradient on ``e4s_mconv_wgrad`` /
+    ``e4s_unfold2d`` + ``e4s_gemm_sb``; shapes those do not cover raise unless ``E4S_ALLOW_MIOPEN_BWD=1`` admits ``aten.convolution_backward``."""
 
     @staticmethod
     def forward(ctx, x, wmod, noise_weight, act_bias, noise, act, blur, out):
@@ -1766,7 +1840,10 @@ class _SingleStyledConvGrad(torch.autograd.Function):
             else:
                 dw = _gemm_nt(x.reshape(bs, cin, h * w), unfold2d(g, k, 2, 0, h, w)).view(bs, cin, cout, k, k).transpose(1, 2)
         want_dx, want_dw = need_x and dx is None, need_w and dw is None
-        if want_dx or want_dw:                                  # shapes the kernels above do not cover: MIOpen
+        if want_dx or want_dw:                                  # shapes the kernels above do not cover
+            if not ALLOW_LIBRARY_BWD:
+                raise NotImplementedError(f"single-region conv backward: no native kernel for cout {cout}, kernel size {k}"
+                                          f"{' (up)' if blur is not None else ''}; set E4S_ALLOW_MIOPEN_BWD=1 to let MIOpen compute it")
             g1 = g.reshape(1, bs * cout, g.shape[2], g.shape[3])
             if blur is None:
                 dxm, dwm, _ = conv_bwd(g1, xin, wmod.reshape(bs * cout, cin, k, k), None, [1, 1], [k // 2, k // 2], [1, 1], False, [0, 0], bs,
@@ -2091,14 +2168,18 @@ def _timed(name: str, detail: Optional[str] = None):
     return b
 
 
-def modconv_kernel_name(cout: int, w: int, sb: Optional[bool] = None, masked: bool = True) -> str:
-    """Template instantiation the dispatch picks (mirrors the switches in csrc/modconv.hip and csrc/modconv_sb.hip)."""
+def modconv_kernel_name(cout: int, w: int, sb: Optional[bool] = None, masked: bool = True, cin: Optional[int] = None, mx: Optional[int] = -1) -> str:
+    """Template instantiation the dispatch picks (mirrors the switches in csrc/modconv.hip, csrc/modconv_sb.hip and csrc/modconv_mx.hip).
+    ``mx``: arithmetic of the DMA-fed masked kernel when the launch takes that route (None: it does not; -1: what an inference forward would do)."""
     if sb is None:
         sb = MODCONV_MODE == "sb"
+    if mx == -1:
+        mx = mx_arith() if (sb and masked and w >= 32 and cout >= 128 and (cin is None or cin % 16 == 0)) else None
+    if sb and mx is not None:
+        return f"region_modconv_mx_kernel<{mx}>"
     if sb:
         if w >= 32:
-            wide = os.environ.get("E4S_SB_WIDE", "1") != "0"
-            cfg = "4,1,1,8,5" if (wide and masked and cout >= 128) else ("2,2,1,4,5" if cout > 32 else "1,2,1,4,5")
+            cfg = "4,1,1,8,5" if (masked and cout >= 128) else ("2,2,1,4,5" if cout > 32 else "1,2,1,4,5")
         else:
             cfg = "1,2,2,2,4" if w >= 16 else ("1,1,2,2,3" if w >= 8 else "1,1,2,2,2")
         return f"region_modconv_sb_kernel<{cfg}>"

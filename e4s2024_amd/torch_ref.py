@@ -1,10 +1,12 @@
-"""Differentiable stock-PyTorch (ROCm ATen/MIOpen) forms of the fused synthesis layers, used ONLY for the backward pass.
+"""Differentiable PyTorch forms of the fused synthesis layers: the GLUE of the backward pass, not its arithmetic.
 
-SURVEY §8 row f1: the HIP kernels of rows a3-a7 are forward kernels.  Until their dgrad / wgrad kernels exist, a backward through
-the drop-in modules (PTI tuning, ``training/video_swap_ft_coach.py:242-299``; W-optimisation, ``optimization.py:321-349``) re-evaluates
-the layer with the functions below under autograd (``ops._attach(..., ref=...)``) and back-propagates through that — the forward that
-produced the activations is still the fused HIP kernel, the gradients are PyTorch's.  Each function states the reference lines it
-evaluates; none of this runs under ``torch.no_grad()`` inference.
+SURVEY §8 row f1.  A backward through the drop-in modules (PTI tuning, ``training/video_swap_ft_coach.py:242-299``; W-optimisation,
+``optimization.py:321-349``) differentiates each layer from the fused forward kernel's own output: the expressions below are evaluated under
+autograd on the saved inputs, and every contraction in them is one of this library's kernels (``ops.masked_conv_core``, ``ops.mconv_wgrad``,
+``ops.gemm_sb``, ``ops.small_map``, ``ops.local_mlps_grad``, ``ops.equal_linear_grad`` ...) — with the default ``E4S_NATIVE_BWD=1`` no rocBLAS /
+MIOpen kernel runs in a PTI step (asserted under torch.profiler by ``tests/test_gpu_backward.py``).  ``E4S_NATIVE_BWD=0`` selects the stock ATen
+forms kept next to them: the comparison arm of the gradient tests, never the default.  Each function states the reference lines it evaluates;
+none of this runs under ``torch.no_grad()`` inference.
 """
 from __future__ import annotations
 

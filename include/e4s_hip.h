@@ -136,6 +136,24 @@ E4S_API int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16_t*
                                      float* rgb_out, const float* rgb_wt, const float* rgb_s, const float* rgb_bias,
                                      const float* rgb_skip, const float* rgb_up_kernel, const float* s_next,
                                      const uint8_t* uniform_blocks, const int* uniform_ctrl, void* stream);
+
+/* Round 3: the same masked layer on a DMA-fed kernel (csrc/modconv_mx.hip; masked layers of width >= 32, cout >= 128, cin % 16 == 0, channels-first
+ * activations): the weights arrive as ready-to-DMA row slots (one kernel row of a 16-channel chunk for 128 output channels: 24-25 KB) from
+ * e4s_modconv_prep_weights_mx.  arith 0 = the split-bf16 arithmetic above, bit-identical results; arith 1 = a1*w1 on the f16 MFMA plus the two cross
+ * terms fp6(a)*fp6(w - w1) and fp6(a - a1)*fp6(w1) on the block-scaled MX fp6 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4): about half the matrix-pipe
+ * time, 2-3x the split-bf16 error (1.9e-4 max-abs on the 1024^2 generator against 8e-5; bar 1e-3).  flags (optional, arith 1): flags[0] |= 1 when a
+ * modulated activation reaches 2^16 and so leaves the f16 range — the result is then not to be trusted.
+ * e4s_modconv_mx_weight_bytes: size of the prepared copy.  All other arguments as e4s_region_modconv3x3_sb. */
+E4S_API int e4s_modconv_mx_weight_bytes(int cout, int cin, int up, int arith, int64_t* bytes);
+E4S_API int e4s_modconv_prep_weights_mx(void* dst, const float* weight, const float* blur, int cout, int cin, int up, int arith, void* stream);
+E4S_API int e4s_region_modconv3x3_mx(float* out, const float* x, const void* wmx, int arith, int* flags, const float* s, const float* d,
+                                     const uint8_t* labels, int lh, int lw,
+                                     const float* noise, int noise_bs, const float* noise_weight, const float* act_bias, int act,
+                                     int bs, int cin, int cout, int h, int w, int nreg, int up,
+                                     float* workspace, int64_t workspace_floats,
+                                     float* rgb_out, const float* rgb_wt, const float* rgb_s, const float* rgb_bias, const float* rgb_skip,
+                                     const float* rgb_up_kernel, const float* s_next, const uint8_t* uniform_blocks, const int* uniform_ctrl,
+                                     void* stream);
 /* Masked up-sampling layers, region-uniform output blocks (model.py:287-300 per region == one transposed conv + blur where a block of output
  * pixels has ONE region):
  *   e4s_uniform_blocks: sub[b][2by+sy][2bx+sx] = the region of an 8 x 8 output sub-block (labels uint8 [bs][lh][lw] sampled 'nearest' at

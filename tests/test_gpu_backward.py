@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from conftest import install_dropin, record_parity, template_from_manifest
-from e4s2024_amd import seeded
+from e4s2024_amd import ops, seeded
 from oracle import e4s_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -447,6 +447,36 @@ def test_pti_step_gradients_1024_vs_oracle_autograd(net3_sd):
             worst = (k, r)
         assert r <= TOL, (k, r)
     record_parity("pti1024.grad.worst_of_subset", worst[1], TOL, worst[0])
+
+
+def test_pti_step_1024_runs_no_library_gemm_or_convolution(net3_sd):
+    """one eager PTI step at 1024 x 1024 (BASELINE configs[3]'s unit) under torch.profiler — no rocBLAS / Tensile (``Cijk_``),
+    no MIOpen kernel and no ``aten::mm / bmm / addmm / convolution*`` op anywhere in forward, backward or optimiser step."""
+    from conftest import default_opts
+    from torch.profiler import profile, ProfilerActivity
+    from e4s2024_amd import pti
+    install_dropin()
+    from models.networks import Net3
+    assert ops.NATIVE_BWD and not ops.ALLOW_LIBRARY_BWD
+    net = Net3(default_opts(train_G=True))
+    net.load_state_dict(net3_sd)
+    net = net.to(DEV).train()
+    net.latent_avg = seeded.seeded_latent_avg(2, 18).to(DEV)
+    opt = torch.optim.Adam(pti.trainable_parameters(net), lr=1e-3, fused=True)
+    vec = T(seeded.seeded_array(41, "vec", (1, 12, 1280), dist="normal")).to(DEV)
+    lab = T(seeded.blocky_labels(3, 1, 12, 512, 16)).to(DEV).to(torch.uint8)
+    target = torch.tanh(T(seeded.seeded_array(5, "img", (1, 3, 1024, 1024), dist="normal"))).to(DEV)
+    pti.pti_step(net, opt, vec, lab, target)
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        pti.pti_step(net, opt, vec, lab, target)
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages()]
+    bad_ops = {"aten::mm", "aten::bmm", "aten::addmm", "aten::baddbmm", "aten::matmul", "aten::convolution", "aten::_convolution",
+               "aten::convolution_backward", "aten::miopen_convolution", "aten::conv2d", "aten::conv_transpose2d", "aten::linear"}
+    hit = [n for n in names if n in bad_ops or n.startswith("Cijk_") or "miopen" in n.lower() or "MIOpen" in n or "igemm" in n.lower()]
+    assert not hit, hit
+    assert any(n.startswith("e4s::") or "gemm_sb" in n or "mconv" in n for n in names), "the profile should show this library's kernels"
 
 
 def test_graphed_pti_replay_then_eval_uses_fresh_weights():

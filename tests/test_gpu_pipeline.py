@@ -137,6 +137,83 @@ def test_swap_batch_bs8_vs_oracle(gpu_net3, parser, faces, oracle_chain, net3_sd
         assert grey <= 1
 
 
+def test_swap_batch_with_mask_surgery_bs8_vs_oracle(gpu_net3, parser, faces, oracle_chain, net3_sd):
+    """The clip's unit of work (BASELINE configs[4], what ``bench.py --clip`` times): ``swap_batch(mask_surgery=True)`` at batch 8 — the synthesis is
+    driven by ``swap_head_mask_hole_first(driven map, target map)`` (face_swap_video_pipeline.py:420, 429-443) — against the oracle chain
+    parse x2 -> swap_head_mask_hole_first -> get_style_vectors x2 (on the faces' OWN maps, :332-354) -> mix -> cal_style_codes -> generator_forward
+    on the SWAPPED map, for one face of each half batch: region map exact, pixels <= 1e-3, frames <= 1 grey level; three runs bit-identical."""
+    drv, tgt = faces[0].to(DEV), faces[1].to(DEV)
+    runs = []
+    for _ in range(3):
+        img, lab, extra = pipeline.swap_batch(gpu_net3, parser, drv, tgt, to_uint8=False, mask_surgery=True)
+        runs.append((img.clone(), lab.clone(), extra["hole_mask"].clone()))
+    frames, lab_u8, _ = pipeline.swap_batch(gpu_net3, parser, drv, tgt, to_uint8=True, mask_surgery=True)
+    torch.cuda.synchronize()
+    for r in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(r, runs[0])), "swap_batch(mask_surgery=True) is not run-to-run bit-identical"
+    img, lab, hole = runs[0]
+    assert torch.equal(lab_u8, lab) and tuple(lab.shape) == (BS, 512, 512)
+    la = oracle_chain["latent_avg"]
+    with torch.no_grad():
+        both = parser.parse_batch((torch.cat([drv, tgt]) + 1) / 2, seg12=True).cpu().numpy()
+    lab_d_gpu, lab_t_gpu = both[:BS], both[BS:]
+    for b in CHECK_FACES:
+        ent = oracle_chain[b]
+        _check_labels(f"surgery.face{b}.target", lab_t_gpu[b], ent, "t")
+        _check_labels(f"surgery.face{b}.driven", lab_d_gpu[b], ent, "d")
+        res, hole_o, _, _, _ = O.swap_head_mask_hole_first(lab_d_gpu[b], lab_t_gpu[b])          # from the maps the device parsed (ties aside: the oracle's)
+        assert np.array_equal(lab[b].cpu().numpy(), res.astype(np.uint8)), f"face {b}: swapped region map differs from the oracle's"
+        assert np.array_equal(hole[b].cpu().numpy().astype(bool).reshape(res.shape), np.asarray(hole_o).astype(bool))
+        v_d, v_t, mixed, codes, _ = _oracle_rest(ent, lab_d_gpu[b], lab_t_gpu[b], net3_sd, la)   # style vectors from each face's own map
+        ref, _ = O.generator_forward(net3_sd, codes, O.label_map_to_onehot(T(res.astype(np.int64))[None, None], 12), None)
+        d = (img[b].cpu() - ref[0]).abs().max().item()
+        record_parity(f"swap_bs8.mask_surgery.face{b}.pixels_vs_oracle", d, PIXEL_TOL)
+        assert d <= PIXEL_TOL, f"face {b} of the batch is {d:.3e} from the oracle chain"
+        grey = np.abs(frames[b].cpu().numpy().astype(np.int16) - O.tensor2im_array(ref[0]).astype(np.int16)).max()
+        record_parity(f"swap_bs8.mask_surgery.face{b}.frame_grey_levels_vs_oracle", int(grey), 1)
+        assert grey <= 1
+
+
+def test_two_stream_stress_of_the_default_routes_is_bit_stable(gpu_net3, parser, faces):
+    """Concurrency canary (bounded, ~15 s): the DEFAULT encoder route (direct + Winograd convolutions, as ``ops.winograd_route`` picks them) and the
+    masked synthesis kernel, each hammered on one stream while the other stream runs the other — every result of every round must equal the
+    single-stream result bit for bit.  A kernel that loses a wait under concurrency (round 2's first pre-split Winograd transform did, with a
+    second stream beside it and never alone) shows up here as a changing value."""
+    import time
+    drv, tgt = faces[0].to(DEV), faces[1].to(DEV)
+    net = gpu_net3
+    la = net.latent_avg.cpu()
+    codes = seeded.seeded_codes(91, 4, 12, 18, la).to(DEV)
+    lab_g = torch.from_numpy(seeded.iid_labels(92, 4, 12, 512)).to(DEV).to(torch.uint8)
+    small = [drv[:1].contiguous(), drv[:2].contiguous(), tgt[:4].contiguous()]        # batches 1, 2, 4: the Winograd route's range
+    with torch.no_grad():
+        labs = [parser.parse_batch((x + 1) / 2, seg12=True) for x in small]
+        ref_vec = [net.get_style_vectors(x, l)[0].clone() for x, l in zip(small, labs)]
+        ref_img = net.gen_img(None, codes, lab_g, randomize_noise=False)[0].clone()
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        t0, rounds, bad = time.time(), 0, []
+        while time.time() - t0 < 12.0 and rounds < 40:
+            outs_v, outs_i = [], []
+            with torch.cuda.stream(s1):
+                for x, l in zip(small, labs):
+                    outs_v.append(net.get_style_vectors(x, l)[0])
+            with torch.cuda.stream(s2):
+                for _ in range(2):
+                    outs_i.append(net.gen_img(None, codes, lab_g, randomize_noise=False)[0])
+            torch.cuda.synchronize()
+            for k, (o, r) in enumerate(zip(outs_v, ref_vec)):
+                if not torch.equal(o, r):
+                    bad.append(("style_vectors", rounds, k, (o - r).abs().max().item()))
+            for k, o in enumerate(outs_i):
+                if not torch.equal(o, ref_img):
+                    bad.append(("gen_img", rounds, k, (o - ref_img).abs().max().item()))
+            rounds += 1
+    record_parity("two_stream_stress.rounds", rounds, None, "encoder (batches 1, 2, 4) on one stream beside masked synthesis (i.i.d. maps, batch 4) on another")
+    record_parity("two_stream_stress.mismatches", len(bad), 0)
+    assert rounds >= 5 and not bad, bad[:5]
+
+
 def test_swap_batch_stages_vs_oracle(gpu_net3, parser, faces, oracle_chain, net3_sd):
     """The intermediate tensors of the same chain on one checked face: style vectors of both faces, the mix, the codes."""
     drv, tgt = faces[0].to(DEV), faces[1].to(DEV)

@@ -143,9 +143,15 @@ def test_gen_img_batch4_properties(gpu_net3):
         img4, _, f4 = gpu_net3.gen_img(None, codes, mask, randomize_noise=False)
         img4b, _, _ = gpu_net3.gen_img(None, codes, mask, randomize_noise=False)
         assert torch.equal(img4, img4b)
+        # With the f16 + MX-fp6 arithmetic of the masked layers (E4S_MX=2) a last-bit difference upstream — the 4^2-32^2 layers' split-K slice count
+        # depends on the launch size — can move a value across an f16 rounding boundary or a block's power-of-two scale, i.e. two evaluations differ
+        # by up to the arithmetic's own error (2e-4 on the pixels), not by the perturbation: the bound follows the arithmetic, not 1e-4.
+        tol = 5e-4 if _ops.mx_arith() == 1 else 1e-4
         for b in (0, 3):
             img1, _, f1 = gpu_net3.gen_img(None, codes[b:b + 1], mask[b:b + 1].contiguous(), randomize_noise=False)
-            assert (img1[0] - img4[b]).abs().max().item() <= 1e-4 and (f1[0] - f4[b]).abs().max().item() <= 1e-4
+            d_img, d_f = (img1[0] - img4[b]).abs().max().item(), (f1[0] - f4[b]).abs().max().item()
+            record_parity(f"gen1024.batch4_face{b}_vs_alone.pixels", d_img, tol)
+            assert d_img <= tol and d_f <= 1e-4, (d_img, d_f)
         noise = [getattr(gpu_net3.G.noises, f"noise_{i}") for i in range(17)]
         img_n, _, _ = gpu_net3.gen_img(None, codes, mask, noise=noise)
         assert torch.equal(img_n, img4)

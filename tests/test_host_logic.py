@@ -39,7 +39,7 @@ def test_abi_signatures_carry_no_torch_types():
         for arg in decl[decl.index("(") + 1: decl.rindex(")")].split(","):
             ty = " ".join(arg.split()[:-1])
             assert ty in ("", "void", "int", "float", "int64_t", "void*", "float*", "const float*", "uint8_t*", "const uint8_t*", "int*", "const int*", "int32_t*", "const int32_t*",
-                          "const float* const*", "uint16_t*", "const uint16_t*", "const E4sStyleJob*", "const E4sChainLayer*", "unsigned"), (decl.split("(")[0], arg)
+                          "const float* const*", "uint16_t*", "const uint16_t*", "int64_t*", "const void*", "const E4sStyleJob*", "const E4sChainLayer*", "unsigned"), (decl.split("(")[0], arg)
 
 
 def test_argument_validation_without_gpu():

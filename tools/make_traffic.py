@@ -28,6 +28,11 @@ KEYS = {
                                             "7 launches per step (6 plain + 1 with fused ToRGB and split-plane output; on the benchmark maps the 128->256 up "
                                             "layer's launch leaves at once: its blocks are all region-uniform and run in masked_up_block_kernel); dword activation "
                                             "loads: no FETCH correction", (823900000 - 4 * (256 * 128 * 128 * 4 + 128 * 256 * 256 * 4)) // 7),
+    "region_modconv_mx_kernel<1>": (["region_modconv_mx_kernel<1"], 1.0,
+                                    "7 launches per step (the DMA-fed masked kernel, f16 + 2 x MX fp6; on the benchmark maps the 128->256 up layer's launch leaves at "
+                                    "once); dword activation loads, 16-byte weight DMA: FETCH uncorrected (a lower bound on the weight share)",
+                                    (823900000 - 4 * (256 * 128 * 128 * 4 + 128 * 256 * 256 * 4)) // 7),
+    "region_modconv_mx_kernel<0>": (["region_modconv_mx_kernel<0"], 1.0, "as <1> with the split-bf16 arithmetic", (823900000 - 4 * (256 * 128 * 128 * 4 + 128 * 256 * 256 * 4)) // 7),
     "masked_upconv_blocks": (["masked_up_block_kernel"], 1.0, "3 launches per step (the masked up layers of width >= 32); on the benchmark maps only the 128->256 "
                              "layer has region-uniform blocks, the other two launches leave at once: averages over all three; dword loads",
                              4 * (256 * 128 * 128 * 4 + 128 * 256 * 256 * 4) // 3),
