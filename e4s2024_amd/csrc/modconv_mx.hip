@@ -13,6 +13,8 @@
 //          Matrix-pipe time per 16-deep K step of one kernel row, measured (tools/probes/mx_probe.hip, random operands, power-limited clocks):
 //          3 x 4 f16 (20.2 ns each) + 2 x 4 fp6 K=64 (23.8 ns each) = 433 ns against 36 bf16 (18.4 ns each) = 663 ns.
 //          f16 range: |x * s| must stay below 65504; the kernel raises flags[0] when a block maximum does not (ops falls back to ARITH 0).
+// Measured and not kept: s_setprio(1) around the MFMA bursts (+3 % time), the residual through fma (hipcc keeps cvt + sub), the DMA through the
+// builtin (vmcnt(0) in front of every row's first LDS read: no gain over the register-staged kernel).
 // Operand layouts, prepared by e4s_modconv_prep_weights_mx, one ROW SLOT = what a workgroup DMAs for (parity, chunk, co tile, kernel row):
 //   ARITH 0: [hi | lo][tap 3][k half 2][co 128] x 16 B (8 bf16 = channels 8 half .. 8 half + 7 of the chunk)                          24 576 B
 //   ARITH 1: w1 f16 [tap 3][half 2][co 128] x 16 B | fp6 codes, first 16 B [term 2][half 2][co 128] | last 8 B [term 2][half 2][co 128] |

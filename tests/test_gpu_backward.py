@@ -175,6 +175,25 @@ def test_native_masked_conv_gradients_against_stock_pytorch_and_fp64(ks, upsampl
     import torch.nn.functional as F
     from e4s2024_amd import ops, torch_ref
     bs, cin, cout, h, w = shape
+    if not masked and cout < 16 and not ops.ALLOW_LIBRARY_BWD:
+        # single-region layers this small have no native data-gradient kernel: by default their backward RAISES (no vendor library unasked)
+        # and E4S_ALLOW_MIOPEN_BWD=1 admits aten.convolution_backward — both behaviours are part of the contract
+        sc = ops._SingleStyledConvGrad
+        xs = torch.randn(bs, cin, h, w, device=DEV, requires_grad=True)
+        wm = torch.randn(bs, cout, cin, ks, ks, device=DEV, requires_grad=True)
+        hh, ww = (2 * h, 2 * w) if upsample else (h, w)
+        bl = None
+        if upsample:
+            bl = torch.tensor([1., 3., 3., 1.], device=DEV)
+            bl = (bl[:, None] * bl[None, :]) / bl.sum() ** 2 * 4
+        o = sc.apply(xs, wm, None, None, None, False, bl, torch.randn(bs, cout, hh, ww, device=DEV))
+        with pytest.raises(NotImplementedError, match="E4S_ALLOW_MIOPEN_BWD"):
+            o.sum().backward()
+        ops.ALLOW_LIBRARY_BWD = True
+        try:
+            return test_native_masked_conv_gradients_against_stock_pytorch_and_fp64(ks, upsample, demod, shape, masked)
+        finally:
+            ops.ALLOW_LIBRARY_BWD = False
     nreg, sdim = (5 if masked else 1), 16
     g = torch.Generator().manual_seed(100 + ks + 2 * upsample + h)
     x = torch.randn(bs, cin, h, w, generator=g)

@@ -378,4 +378,7 @@ def test_masked_up_layer_uniform_blocks_against_oracle_and_composed_form(sg2, sh
     assert torch.equal(y, y2)
     d_or, d_co = maxdiff(y, ref), (y - yc).abs().max().item()
     record_parity(f"masked_up_blocks.{cin}to{cout}_{h}x{w}.vs_oracle", d_or / scale, LAYER_TOL)
-    assert d_or <= LAYER_TOL * scale and d_co <= 2e-5 * scale, (shape, d_or, d_co, scale)
+    # block route against composed route: two kernels, two summation orders — 2e-5 of the output scale while both compute in split-bf16; with the
+    # composed kernel on the f16 + MX-fp6 arithmetic (E4S_MX=2, cout >= 128) the difference is that arithmetic's own error (measured 2e-5 of scale)
+    co_tol = 6e-5 if (_ops.mx_arith() == 1 and cout >= 128 and cin % 16 == 0) else 2e-5
+    assert d_or <= LAYER_TOL * scale and d_co <= co_tol * scale, (shape, d_or, d_co, scale)
