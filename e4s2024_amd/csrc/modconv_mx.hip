@@ -164,8 +164,11 @@ struct MxLds {
     static_assert((E4S_MAX_REGIONS + 5) * MX_TN * 4 + 64 <= RING, "the epilogue's tables overlay the weight ring");
 };
 
-template <int ARITH, bool RGB, bool OSP>
+// ENC = plain-convolution mode (the regional-style encoder's stride-1 3x3 convolutions, helpers.py:122-144): no region map and no modulation;
+// instance-norm statistics are applied to the input while it is staged ((x - mean) * rstd, padding stays exactly 0), the epilogue is an optional PReLU.
+template <int ARITH, bool RGB, bool OSP, bool ENC = false>
 __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParams p) {
+    static_assert(!ENC || (!RGB && !OSP), "plain-convolution mode has its own epilogue");
     using L = MxLds<ARITH>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
     const int ncot = (p.cout + MX_TN - 1) / MX_TN;
 
     unsigned ub_skip = 0;       // (masked up layer) bit j: 16 x 16 output block j of this tile belongs to the block kernel
-    if (p.up && p.uni_blocks && p.uni_ctrl[2] != 0) {
+    if (!ENC && p.up && p.uni_blocks && p.uni_ctrl[2] != 0) {
         const int nbx = wo >> 4, nby = ho >> 4;
         const int by = (2 * y0) >> 4;
 #pragma unroll
@@ -219,8 +222,8 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
         const int ty = wave, tx = l5;
         xoff = ty * C::PW + tx;
         const int y = y0 + ty, x = x0 + tx;
-        int c = E4S_LABEL_NONE;
-        if (y < p.h && x < p.w) {
+        int c = ENC ? 0 : E4S_LABEL_NONE;
+        if (!ENC && y < p.h && x < p.w) {
             const int oy = p.up ? 2 * y + pa : y, ox = p.up ? 2 * x + pb_ : x;
             c = p.labels[((size_t)b * p.lh + nearest_src(oy, p.lscale_y, p.lh)) * p.lw + nearest_src(ox, p.lscale_x, p.lw)];
         }
@@ -247,18 +250,50 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
 #pragma unroll
             for (int c = 0; c < CKS; ++c) xr[c] = xb[(size_t)(ci0 + (c < cmax ? c : cmax)) * hw + goffs];
         }
-        sr = sb[(size_t)s_r * p.cin + ci0 + (s_c < cmax ? s_c : cmax)];
+        if constexpr (!ENC) sr = sb[(size_t)s_r * p.cin + ci0 + (s_c < cmax ? s_c : cmax)];
     };
     auto store_x = [&](int buf, int chunk) __attribute__((always_inline)) {
         float4* xf4 = reinterpret_cast<float4*>(lds_raw + L::PATCH0 + buf * MX_PATCHB);
-        if (tid < C::PATCH) {
+        if constexpr (ENC) {      // instance norm on load: wave-uniform statistics of this sample's 16 channels (scalar loads)
+            if (p.in_mean && tid < C::PATCH) {
+#pragma unroll
+                for (int c = 0; c < CKS; ++c) {
+                    const int ci = chunk * CKS + c < p.cin ? chunk * CKS + c : p.cin - 1;
+                    xr[c] = (xr[c] - p.in_mean[(size_t)b * p.cin + ci]) * p.in_rstd[(size_t)b * p.cin + ci];
+                }
+            }
+        }
+        if constexpr (ENC && ARITH == 1) {
+            // The operand does not depend on the output pixel here, so a1 = f16(a) and a - a1 are made ONCE per staged value (each feeds nine taps):
+            // the pixel's 64 bytes hold [a1 of channels 0-7 | a - a1 of 0-7 | a1 of 8-15 | a - a1 of 8-15] as f16, in the fp32 patch's swizzled slots —
+            // the K loop then reads its two fragments per tap and does no floating-point VALU work at all.
+            if (tid < C::PATCH) {
+                uint4* xq = reinterpret_cast<uint4*>(xf4);
+                const int g = (tid >> 2) & 3;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    unsigned q1[4], q2[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float a = p_in ? xr[hh * 8 + 2 * j] : 0.f, bq = p_in ? xr[hh * 8 + 2 * j + 1] : 0.f;
+                        const f16x2 a1 = __builtin_convertvector((f32x2){a, bq}, f16x2);
+                        q1[j] = __builtin_bit_cast(unsigned, a1);
+                        q2[j] = pack_f16_rne(a - (float)a1[0], bq - (float)a1[1]);
+                    }
+                    xq[tid * 4 + ((2 * hh) ^ g)] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+                    xq[tid * 4 + ((2 * hh + 1) ^ g)] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+                }
+            }
+        } else if (tid < C::PATCH) {
             const int g = (tid >> 2) & 3;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 xf4[tid * 4 + (k ^ g)] = p_in ? make_float4(xr[4 * k], xr[4 * k + 1], xr[4 * k + 2], xr[4 * k + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (tid < E4S_MAX_REGIONS * CKS)
-            reinterpret_cast<float*>(lds_raw + L::SS0 + buf * MX_SSB)[tid] = (tid / CKS < p.nreg && chunk * CKS + s_c < p.cin) ? sr : 0.f;
+        if constexpr (!ENC) {
+            if (tid < E4S_MAX_REGIONS * CKS)
+                reinterpret_cast<float*>(lds_raw + L::SS0 + buf * MX_SSB)[tid] = (tid / CKS < p.nreg && chunk * CKS + s_c < p.cin) ? sr : 0.f;
+        }
     };
     // row `row` of chunk `chunk` -> ring slot `row`: pieces wave, wave + 8, ... of NPIECE
     const unsigned char* wbase = p.wmx + (size_t)par * nchunk * ncot * 3 * L::ROWB;
@@ -293,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
         const float* ss = reinterpret_cast<const float*>(lds_raw + L::SS0 + cur * MX_SSB);
         float sv[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sv[e] = cls[0] >= 0 ? ss[cls[0] * CKS + khalf * 8 + e] : 0.f;
+        for (int e = 0; e < 8; ++e) sv[e] = ENC ? 1.f : (cls[0] >= 0 ? ss[cls[0] * CKS + khalf * 8 + e] : 0.f);
 
 #pragma unroll
         for (int row = 0; row < 3; ++row) {
@@ -332,6 +367,32 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
                 const uint2* f6hi = reinterpret_cast<const uint2*>(slot + MX_W1B + MX_F6LO) + khalf * MX_TN + l5;
                 const unsigned* wsc = reinterpret_cast<const unsigned*>(slot + MX_W1B + MX_F6LO + MX_F6HI) + khalf * MX_TN + l5;
                 u32x16 v1, v2;        // a1 = f16(a) and a - a1 of the row's 24 values, as the f16 pairs the conversions below take (registers 12..15: copies)
+                unsigned ex;          // biased fp32 exponent of the largest |a| among them
+                if constexpr (ENC) {
+                    const uint4* xq = reinterpret_cast<const uint4*>(xf4);
+                    unsigned m = 0u;  // running maximum of |a1| as f16 BITS (non-negative halves order like unsigned integers), two lanes of 16 bits
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const int e = xoff + row * C::PW + t;
+                        const int g = (e >> 2) & 3;
+                        const uint4 b1 = xq[e * 4 + ((2 * khalf) ^ g)], b2 = xq[e * 4 + ((2 * khalf + 1) ^ g)];
+                        v1[t * 4] = b1.x; v1[t * 4 + 1] = b1.y; v1[t * 4 + 2] = b1.z; v1[t * 4 + 3] = b1.w;
+                        v2[t * 4] = b2.x; v2[t * 4 + 1] = b2.y; v2[t * 4 + 2] = b2.z; v2[t * 4 + 3] = b2.w;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                            const u16x2 mm = __builtin_elementwise_max(__builtin_bit_cast(u16x2, m), __builtin_bit_cast(u16x2, v1[t * 4 + j] & 0x7fff7fffu));   // v_pk_max_u16
+                            m = __builtin_bit_cast(unsigned, mm);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w1half[t * 2 * MX_TN + i * 32]), __builtin_bit_cast(f16x8, b1), acc[i][0], 0, 0, 0);
+                    }
+                    const unsigned mh = (m & 0xffffu) > (m >> 16) ? (m & 0xffffu) : (m >> 16);
+                    const unsigned e16 = mh >> 10;                    // f16 exponent field: 31 = the value left the f16 range (inf)
+                    if (e16 >= 31u && p.flags) atomicOr(p.flags, 1);
+                    ex = (e16 ? e16 : 1u) + 112u;                     // f16 bias 15 -> fp32 bias 127
+                } else {
                 float amax = 0.f;
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
@@ -353,8 +414,9 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
                         acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w1half[t * 2 * MX_TN + i * 32]), __builtin_bit_cast(f16x8, b1), acc[i][0], 0, 0, 0);
                 }
                 // block scales of this lane's 24 values: 2^(E - 2) for fp6(a1), 2^(E - 13) for fp6(a - a1)  (|a - a1| <= 2^(E - 11));  E >= 16 leaves f16
-                const unsigned ex = (__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu;
+                ex = (__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu;
                 if (ex >= 143u && p.flags) atomicOr(p.flags, 1);
+                }
                 const unsigned e1 = ex > 3u ? ex - 2u : 1u, e2 = ex > 14u ? ex - 13u : 1u;
 #pragma unroll
                 for (int j = 12; j < 16; ++j) { v1[j] = v1[j - 12]; v2[j] = v2[j - 12]; }     // (positions 24..31 meet zero weights)
@@ -385,6 +447,26 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
         }
     }
 
+    if constexpr (ENC) {
+        __syncthreads();
+        float* sl = reinterpret_cast<float*>(lds_raw);
+        if (tid < MX_TN) sl[tid] = (p.slope && co0 + tid < p.cout) ? p.slope[co0 + tid] : 1.f;      // PReLU slope (1 = identity)
+        __syncthreads();
+        const int y = y0 + wave, x = x0 + l5;
+        if (y < p.h && x < p.w) {
+            float* op = p.out + (size_t)b * p.cout * hw + (size_t)y * p.w + x;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    float v = acc[i][0][r];
+                    v = v > 0.f ? v : v * sl[n];
+                    if (co0 + n < p.cout) op[(size_t)(co0 + n) * hw] = v;
+                }
+        }
+        return;
+    }
     if (p.ksplit > 1) {
         float* part = p.partial + ((size_t)ks * p.bs + b) * p.cout * ho * wo;
         const int y = y0 + wave, x = x0 + l5;
@@ -403,14 +485,14 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
     sb_epilogue<C, 4, 1, 8, RGB, OSP>(p, lds_raw, acc, cls, co0, b, y0, x0, pa, pb_, ho, wo, ub_skip);
 }
 
-template <int ARITH, bool RGB, bool OSP>
+template <int ARITH, bool RGB, bool OSP, bool ENC = false>
 int launch_mx_variant(const SbParams& p, dim3 grid, hipStream_t st) {
     using L = MxLds<ARITH>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&region_modconv_mx_kernel<ARITH, RGB, OSP>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&region_modconv_mx_kernel<ARITH, RGB, OSP, ENC>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES);
     if (attr != hipSuccess) return fail((int)attr, "region_modconv3x3_mx: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
-    hipLaunchKernelGGL((region_modconv_mx_kernel<ARITH, RGB, OSP>), grid, dim3(512), L::BYTES, st, p);
-    return check_launch("region_modconv3x3_mx");
+    hipLaunchKernelGGL((region_modconv_mx_kernel<ARITH, RGB, OSP, ENC>), grid, dim3(512), L::BYTES, st, p);
+    return check_launch(ENC ? "conv3x3_mx" : "region_modconv3x3_mx");
 }
 
 }  // namespace
@@ -421,19 +503,46 @@ extern "C" int e4s_modconv_mx_weight_bytes(int cout, int cin, int up, int arith,
     return 0;
 }
 
+static int prep_weights_mx(void* dst, const float* weight, const float* blur, int cout, int cin, int up, int arith, float scale, void* stream);
+
 extern "C" int e4s_modconv_prep_weights_mx(void* dst, const float* weight, const float* blur, int cout, int cin, int up, int arith, void* stream) {
+    return prep_weights_mx(dst, weight, blur, cout, cin, up, arith, 1.0f / sqrtf((float)cin * 9.f), stream);      // the equalised-lr scale of ModulatedConv2d
+}
+
+// A plain convolution weight [cout, cin, 3, 3] (no scale) in the same row-slot layout, for e4s_conv3x3_mx.
+extern "C" int e4s_conv_prep_weights_mx(void* dst, const float* weight, int cout, int cin, int arith, void* stream) {
+    return prep_weights_mx(dst, weight, nullptr, cout, cin, 0, arith, 1.0f, stream);
+}
+
+static int prep_weights_mx(void* dst, const float* weight, const float* blur, int cout, int cin, int up, int arith, float scale, void* stream) {
     E4S_REQUIRE(dst && weight, "modconv_prep_weights_mx: null tensor");
     E4S_REQUIRE(cout >= 1 && cin >= 1 && (arith == 0 || arith == 1), "modconv_prep_weights_mx: bad arguments");
     E4S_REQUIRE(!up || blur, "modconv_prep_weights_mx: up-conv needs the 4x4 blur kernel");
     E4S_REQUIRE(((uintptr_t)dst & 15) == 0, "modconv_prep_weights_mx: the destination must be 16-byte aligned");
-    const float scale = 1.0f / sqrtf((float)cin * 9.f);
     const int64_t total = (int64_t)(up ? 4 : 1) * cdiv(cin, CKS) * cdiv(cout, MX_TN) * 3 * 2 * MX_TN;
     const int grid = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
     hipLaunchKernelGGL(prep_weights_mx_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (unsigned char*)dst, weight, blur, cout, cin, up, arith, scale);
     return check_launch("modconv_prep_weights_mx");
 }
 
-int e4s::launch_modconv_mx(SbParams& p, int arith, hipStream_t st, float* workspace, int64_t workspace_floats) {
+// out = PReLU(conv3x3(norm(x), W)), stride 1, pad 1: the regional-style encoder's stride-1 3x3 convolutions (models/encoders/helpers.py:128-139) on the
+// DMA-fed kernel.  in_mean / in_rstd [bs][cin] (optional, together): instance norm of the input on load; prelu_slope [cout] optional.
+extern "C" int e4s_conv3x3_mx(float* out, const float* x, const void* wmx, int arith, int* flags, const float* in_mean, const float* in_rstd,
+                              const float* prelu_slope, int bs, int cin, int cout, int h, int w, void* stream) {
+    E4S_REQUIRE(out && x && wmx, "conv3x3_mx: null tensor");
+    E4S_REQUIRE((in_mean == nullptr) == (in_rstd == nullptr), "conv3x3_mx: in_mean and in_rstd go together");
+    E4S_REQUIRE(bs >= 0 && bs <= 65535 && cin >= 16 && cin % CKS == 0 && cout >= 1 && h >= 1 && w >= 1 && (arith == 0 || arith == 1), "conv3x3_mx: bad size (cin %% 16 == 0)");
+    E4S_REQUIRE(((uintptr_t)wmx & 15) == 0, "conv3x3_mx: the weights must be 16-byte aligned");
+    if (bs == 0) return 0;
+    SbParams p;
+    memset(&p, 0, sizeof(p));
+    p.out = out; p.x = x; p.wmx = reinterpret_cast<const unsigned char*>(wmx); p.flags = flags;
+    p.in_mean = in_mean; p.in_rstd = in_rstd; p.slope = prelu_slope;
+    p.bs = bs; p.cin = cin; p.cout = cout; p.h = h; p.w = w; p.nreg = 1;
+    return launch_modconv_mx(p, arith, (hipStream_t)stream, nullptr, 0, true);
+}
+
+int e4s::launch_modconv_mx(SbParams& p, int arith, hipStream_t st, float* workspace, int64_t workspace_floats, bool plain_conv) {
     p.tiles_x = cdiv(p.w, C::TW);
     p.tiles_y = cdiv(p.h, C::TH);
     const int npar = p.up ? 4 : 1;
@@ -454,6 +563,12 @@ int e4s::launch_modconv_mx(SbParams& p, int arith, hipStream_t st, float* worksp
     p.partial = workspace;
     dim3 grid(p.tiles_x * p.tiles_y * npar * ksplit, cdiv(p.cout, MX_TN), p.bs);
     p.perm_mul = p.uni_blocks ? coprime_stride(grid.x) : 0u;
+    if (plain_conv) {
+        p.ksplit = 1;
+        p.chunks_per = nchunk;
+        grid = dim3(p.tiles_x * p.tiles_y, cdiv(p.cout, MX_TN), p.bs);
+        return arith == 0 ? launch_mx_variant<0, false, false, true>(p, grid, st) : launch_mx_variant<1, false, false, true>(p, grid, st);
+    }
     const bool rgb = p.rgb_out != nullptr, osp = p.s_next != nullptr;
     if (osp && !rgb) return fail(E4S_ERR_ARG, "region_modconv3x3_mx: split-plane output is built for the masked fused-ToRGB layer");
     int rc;

@@ -42,6 +42,9 @@ struct SbParams {
     const uint8_t* uni_blocks;
     const int* uni_ctrl;     // uni_ctrl[2] == 0: the map is not in use for this layer (too few blocks qualify)
     const unsigned char* wmx;  // (modconv_mx.hip) the weights as DMA-ready row slots: e4s_modconv_prep_weights_mx
+    const float* in_mean;      // (modconv_mx.hip, plain-convolution mode) [bs][cin] instance-norm statistics applied to the input on load, or NULL
+    const float* in_rstd;
+    const float* slope;        // (plain-convolution mode) PReLU slopes [cout] or NULL
     int* flags;                // (modconv_mx.hip, f16 arithmetic) flags[0] |= 1 when a modulated activation leaves the f16 range
     unsigned perm_mul;       // (with uni_blocks) workgroup i works on tile slot (i * perm_mul) % gridDim.x: consecutive workgroups go to the 8 XCDs
                              // round-robin, so a skip pattern with a period of 2 / 4 / 8 tiles would idle whole XCDs; a golden-ratio stride
@@ -237,6 +240,6 @@ __device__ __forceinline__ void sb_epilogue(const SbParams& p, unsigned char* ld
 }
 
 // modconv_mx.hip: the DMA-fed 128 co x 256 px masked kernel (p.wmx set).  Returns E4S_OK or an error code.
-int launch_modconv_mx(SbParams& p, int arith, hipStream_t st, float* workspace, int64_t workspace_floats);
+int launch_modconv_mx(SbParams& p, int arith, hipStream_t st, float* workspace, int64_t workspace_floats, bool plain_conv = false);
 
 }  // namespace e4s

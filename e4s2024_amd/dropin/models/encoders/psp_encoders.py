@@ -72,7 +72,7 @@ class bottleneck_IR_SE_Ours(Module):
         )
         self._w = [ops.PreparedConv() for _ in range(3)]
         # the two 3x3 convolutions' Winograd-domain weights (stride 1 only): fp32 and split to bf16 hi / lo
-        self._wino = [(self._w[i], ops.PreparedWinograd(), ops.PreparedWinogradSplit()) for i in range(2)]
+        self._wino = [(self._w[i], ops.PreparedWinograd(), ops.PreparedWinogradSplit(), ops.PreparedMx()) for i in range(2)]
 
     def forward(self, x):
         rl = self.res_layer

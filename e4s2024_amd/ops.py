@@ -492,19 +492,25 @@ class PreparedMx(_Prepared):
     __slots__ = ()
 
     def get(self, weight: torch.Tensor, blur: Optional[torch.Tensor], up: bool, arith: int) -> torch.Tensor:
+        """``weight``: a ModulatedConv2d weight ``[1, cout, cin, 3, 3]`` (equalised-lr scale folded in, up layers composed with ``blur``) or a plain
+        convolution weight ``[cout, cin, 3, 3]`` (as it is: the encoder's convolutions)."""
         key = (weight.data_ptr(), weight._version, weight.device, None if blur is None else (blur.data_ptr(), blur._version), up, arith)
         hit = self._lookup(key)
         if hit is not None:
             return hit[0]
         w = _c(weight.detach(), "weight")
-        _, cout, cin, k, _ = w.shape
-        if k != 3:
+        plain = w.dim() == 4
+        cout, cin, k = w.shape[-4], w.shape[-3], w.shape[-1]
+        if k != 3 or w.shape[-2] != 3 or (plain and up):
             raise ValueError("the mx kernel is a 3x3 kernel")
         bk = _c(blur, "blur kernel") if up else None
         nbytes = ctypes.c_int64(0)
         lib().call("e4s_modconv_mx_weight_bytes", cout, cin, 1 if up else 0, arith, ctypes.byref(nbytes))
         wmx = torch.empty((nbytes.value,), dtype=torch.uint8, device=w.device)
-        lib().call("e4s_modconv_prep_weights_mx", _p(wmx), _p(w), _p(bk), cout, cin, 1 if up else 0, arith, _stream())
+        if plain:
+            lib().call("e4s_conv_prep_weights_mx", _p(wmx), _p(w), cout, cin, arith, _stream())
+        else:
+            lib().call("e4s_modconv_prep_weights_mx", _p(wmx), _p(w), _p(bk), cout, cin, 1 if up else 0, arith, _stream())
         self._publish(key, (wmx,))          # (a tuple: the base class walks the payload's tensors when another stream first uses the copy)
         return wmx
 
@@ -1183,14 +1189,46 @@ def winograd_route(x: torch.Tensor, cin: int, stride: int):
     return "pre" if pre else "f32"
 
 
+MX_CONV_MIN_WORKGROUPS = 128       # below half a round of the chip the direct kernel's smaller tiles (or Winograd) serve a launch better
+
+
+def mx_conv_eligible(x: torch.Tensor, cout: int) -> bool:
+    """Does a stride-1 3x3 convolution of ``x`` run on the DMA-fed kernel's plain-convolution mode?  (inference, the split arithmetic in force,
+    16-channel chunks, >= 128 output channels, maps at least 32 wide, enough 128 co x (32 x 8) px tiles to fill half the chip)"""
+    bs, cin, h, w = x.shape
+    if mx_arith() is None or CONV_MODE != "sb" or torch.is_grad_enabled() or not x.is_cuda:
+        return False
+    return cin % 16 == 0 and cout >= 128 and w >= 32 and bs * (-(-w // 32)) * (-(-h // 8)) * (-(-cout // 128)) >= MX_CONV_MIN_WORKGROUPS
+
+
+def conv3x3_mx(x: torch.Tensor, wmx: torch.Tensor, arith: int, cout: int, *, in_norm=None, prelu: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``PReLU(conv3x3(norm(x), W))``, stride 1, pad 1, on ``e4s_conv3x3_mx`` (``wmx`` from ``PreparedMx.get`` of the plain weight)."""
+    x = _c(x, "input")
+    bs, cin, h, w = x.shape
+    out = torch.empty((bs, cout, h, w), dtype=torch.float32, device=x.device)
+    mean = rstd = None
+    if in_norm is not None:
+        mean, rstd = _c(in_norm[0], "in_mean"), _c(in_norm[1], "in_rstd")
+    ev = _timed(f"conv3x3_mx<{arith}>", f"{cin}->{cout} @{h}")
+    lib().call("e4s_conv3x3_mx", _p(out), _p(x), _p(wmx), arith, _p(mx_flags(x.device)) if arith else None, _p(mean), _p(rstd),
+               _p(_c(prelu.detach(), "prelu")) if prelu is not None else None, bs, cin, cout, h, w, _stream())
+    if ev is not None:
+        ev.record()
+    return out
+
+
 def conv3x3_s1(x: torch.Tensor, weight: torch.Tensor, caches, *, in_norm=None, prelu: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """A stride-1, pad-1 3x3 convolution by whichever route ``winograd_route`` picks; ``caches = (PreparedConv, PreparedWinograd,
-    PreparedWinogradSplit)`` of the layer."""
+    """A stride-1, pad-1 3x3 convolution by whichever route fits the launch: Winograd (``winograd_route``: small batches), the DMA-fed kernel
+    (``mx_conv_eligible``: launches that fill the chip) or the direct kernel; ``caches = (PreparedConv, PreparedWinograd, PreparedWinogradSplit
+    [, PreparedMx])`` of the layer."""
     route = winograd_route(x, x.shape[1], 1)
     if route == "pre":
         return conv2d_winograd_pre(x, caches[2].get(weight), in_norm=in_norm, prelu=prelu)
     if route == "f32":
         return conv2d_winograd(x, caches[1].get(weight), in_norm=in_norm, prelu=prelu)
+    if len(caches) > 3 and mx_conv_eligible(x, weight.shape[0]):
+        arith = mx_arith()
+        return conv3x3_mx(x, caches[3].get(weight, None, False, arith), arith, weight.shape[0], in_norm=in_norm, prelu=prelu)
     return conv2d(x, caches[0].get(weight), 1, 1, in_norm=in_norm, prelu=prelu)
 
 

@@ -154,6 +154,13 @@ E4S_API int e4s_region_modconv3x3_mx(float* out, const float* x, const void* wmx
                                      float* rgb_out, const float* rgb_wt, const float* rgb_s, const float* rgb_bias, const float* rgb_skip,
                                      const float* rgb_up_kernel, const float* s_next, const uint8_t* uniform_blocks, const int* uniform_ctrl,
                                      void* stream);
+/* The regional-style encoder's stride-1, pad-1 3x3 convolutions (models/encoders/helpers.py:128-139) on the same kernel in its plain-convolution mode:
+ *   out[bs,cout,h,w] = PReLU( conv3x3( (x - in_mean[b,ci]) * in_rstd[b,ci], W ) )          in_mean / in_rstd (together) and prelu_slope optional
+ * cin % 16 == 0; padding is exactly 0 (the normalisation applies to in-image pixels only).  wmx from e4s_conv_prep_weights_mx (weight [cout,cin,3,3],
+ * no scale; size: e4s_modconv_mx_weight_bytes(cout, cin, 0, arith)).  arith and flags as above. */
+E4S_API int e4s_conv_prep_weights_mx(void* dst, const float* weight, int cout, int cin, int arith, void* stream);
+E4S_API int e4s_conv3x3_mx(float* out, const float* x, const void* wmx, int arith, int* flags, const float* in_mean, const float* in_rstd,
+                           const float* prelu_slope, int bs, int cin, int cout, int h, int w, void* stream);
 /* Masked up-sampling layers, region-uniform output blocks (model.py:287-300 per region == one transposed conv + blur where a block of output
  * pixels has ONE region):
  *   e4s_uniform_blocks: sub[b][2by+sy][2bx+sx] = the region of an 8 x 8 output sub-block (labels uint8 [bs][lh][lw] sampled 'nearest' at

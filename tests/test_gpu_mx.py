@@ -109,3 +109,71 @@ def test_mx_fused_torgb_and_split_plane_handover_equal_the_register_staged_kerne
     d = float((imgs[2] - imgs[0]).abs().max())
     record_parity("mx_generator256_vs_split_bf16", d, 5e-4, note="f16 + 2 x MX fp6 against the split-bf16 arithmetic, pixels")
     assert d <= 5e-4
+
+
+# ---------------------------------------------------------------------------------------------- plain-convolution mode (the encoder's 3x3 convs)
+#             bs cin cout  h   w
+CONV_SHAPES = [(16, 64, 128, 32, 32), (2, 48, 136, 40, 36), (4, 128, 256, 64, 64)]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+@pytest.mark.parametrize("norm_prelu", [True, False])
+def test_conv3x3_mx_against_fp64_and_the_direct_kernel(shape, norm_prelu):
+    """``e4s_conv3x3_mx`` (instance norm on load, PReLU epilogue — the two convolutions of ``bottleneck_IR_SE_Ours``, helpers.py:128-139) against a float64
+    convolution on the host and against the direct split-bf16 kernel: ragged sizes, an output-channel tail, padding that must stay exactly zero."""
+    bs, cin, cout, h, w = shape
+    g = torch.Generator().manual_seed(7 * cin + h)
+    x = torch.randn(bs, cin, h, w, generator=g) * 2.0 + 0.5
+    wgt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9.0)
+    slope = torch.rand(cout, generator=g) * 0.5
+    xd, wd = x.to(DEV), wgt.to(DEV)
+    mean = rstd = None
+    xn = x.double()
+    if norm_prelu:
+        mean = x.mean((2, 3))
+        rstd = 1.0 / torch.sqrt(x.var((2, 3), unbiased=False) + 1e-5)
+        xn = (x.double() - mean.double()[:, :, None, None]) * rstd.double()[:, :, None, None]
+    ref = torch.nn.functional.conv2d(xn, wgt.double(), padding=1)
+    if norm_prelu:
+        ref = torch.where(ref > 0, ref, ref * slope.double()[None, :, None, None])
+    scale = float(ref.abs().max())
+    in_norm = (mean.to(DEV), rstd.to(DEV)) if norm_prelu else None
+    pr = slope.to(DEV) if norm_prelu else None
+    with torch.no_grad():
+        y_dir = ops.conv2d(xd, ops.PreparedConv().get(wd), 1, 1, in_norm=in_norm, prelu=pr).cpu()
+        ys = {a: ops.conv3x3_mx(xd, ops.PreparedMx().get(wd, None, False, a), a, cout, in_norm=in_norm, prelu=pr).cpu() for a in (0, 1)}
+    e_dir = float((y_dir.double() - ref).abs().max()) / scale
+    e0 = float((ys[0].double() - ref).abs().max()) / scale
+    e1 = float((ys[1].double() - ref).abs().max()) / scale
+    record_parity(f"conv3x3_mx_{cin}to{cout}_{h}x{w}_{'norm_prelu' if norm_prelu else 'plain'}", e1, MX_LAYER_TOL,
+                  note=f"f16 + 2 x MX fp6 against float64, relative to the output scale; split-bf16 in the same kernel {e0:.2e}, direct kernel {e_dir:.2e}")
+    assert e0 <= 2e-5 and e1 <= MX_LAYER_TOL, (shape, e0, e1, e_dir)
+    assert float((ys[0] - y_dir).abs().max()) / scale <= 2e-5
+    assert not ops.mx_overflowed()
+
+
+def test_encoder_at_batch_16_takes_the_mx_route_and_matches_the_direct_route(mx_mode):
+    """``FSEncoder_PSP`` on 16 images (what a batch-8 swap feeds it): its stride-1 3x3 convolutions with >= 128 output channels run on
+    ``e4s_conv3x3_mx``; the style vectors must equal the all-direct route's (E4S_MX=0) within the encoder's parity bar."""
+    from conftest import default_opts
+    install_dropin()
+    from models.networks import Net3
+    from e4s2024_amd import seeded
+    net = Net3(default_opts())
+    seeded.apply_seeded(net.encoder, 4, "net3", prefix="encoder.")
+    net = net.to(DEV).eval()
+    img = seeded.seeded_image(5, 16, 1024).to(DEV)
+    lab = torch.from_numpy(seeded.blocky_labels(3, 16, 12, 512, 16)).to(DEV).to(torch.uint8)
+    out = {}
+    with torch.no_grad():
+        for mode in (0, 2):
+            mx_mode(mode)
+            with ops.KernelTimer() as kt:
+                out[mode] = net.get_style_vectors(img, lab)[0].cpu()
+            names = set(kt.summary())
+            assert any(n.startswith("conv3x3_mx") for n in names) == (mode == 2), names
+    scale = float(out[0].abs().max())
+    d = float((out[2] - out[0]).abs().max()) / scale
+    record_parity("encoder_bs16_mx_vs_direct_route.style_vectors", d, 1e-3, note=f"relative to the largest style vector entry {scale:.2f}")
+    assert d <= 1e-3
+    assert not ops.mx_overflowed()
