@@ -346,12 +346,23 @@ __device__ __forceinline__ void c2_split2(float t0, float t1, unsigned& hi, unsi
     hi = c2_pack_bf16(t0, t1);
     lo = c2_pack_bf16(t0 - __builtin_bit_cast(float, hi << 16), t1 - __builtin_bit_cast(float, hi & 0xffff0000u));
 }
+typedef _Float16 f16x8c __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2c __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned c2_pack_f16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, f16x2c));      // v_cvt_pk_f16_f32 (RNE)
+}
+// the f16 two-term split: a = a1 + a2 with a1 = f16(a), a2 = f16(a - a1): 22 significand bits (while a2 stays a normal f16: |a| >= 2^-3)
+__device__ __forceinline__ void c2_split2_f16(float t0, float t1, unsigned& hi, unsigned& lo) {
+    const f16x2c h = __builtin_convertvector((f32x2){t0, t1}, f16x2c);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = c2_pack_f16(t0 - (float)h[0], t1 - (float)h[1]);
+}
 
 __global__ __launch_bounds__(256) void conv_prep_sb_kernel(uint16_t* __restrict__ whi, uint16_t* __restrict__ wlo, uint16_t* __restrict__ wlo2, float* __restrict__ bias_out,
                                                            const float* __restrict__ weight, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ mean,
                                                            const float* __restrict__ var, float eps, const float* __restrict__ conv_bias,
-                                                           int cout, int cin, int kk) {
+                                                           int cout, int cin, int kk, int f16 = 0, float wscale = 1.f) {
     const int nchunk = (cin + CKS2 - 1) / CKS2;
     const int64_t total = (int64_t)nchunk * kk * 2 * cout * 8;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -366,6 +377,13 @@ __global__ __launch_bounds__(256) void conv_prep_sb_kernel(uint16_t* __restrict_
         if (ci < cin) {
             const float g = var ? gamma[co] / sqrtf(var[co] + eps) : 1.f;
             v = weight[((size_t)co * cin + ci) * kk + tap] * g;
+        }
+        if (f16) {      // w * 2^k = w1 + w2 in f16 (the power of two keeps w2 a normal f16; the kernel's epilogue takes it out again)
+            unsigned h, l;
+            c2_split2_f16(v * wscale, 0.f, h, l);
+            whi[i] = (uint16_t)(h & 0xffffu);
+            wlo[i] = (uint16_t)(l & 0xffffu);
+            continue;
         }
         const unsigned hp = c2_pack_bf16(v, 0.f) & 0xffffu;
         whi[i] = (uint16_t)hp;
@@ -428,13 +446,18 @@ struct Conv2dSbParams {
     int act;
     int bs, cin, cin0, cout, h, w, ho, wo, pad;
     int tiles_x, tiles_y;
+    float out_scale;       // (NS = 4) 2^-k of the weights' power-of-two pre-scale; 1 otherwise
 };
 
 // NS = number of bf16 terms per operand.  NS = 2: a*b ~ a0*b0 + a0*b1 + a1*b0 (3 MFMAs per 16-deep step, ~2^-17 per product).
 // NS = 3: a0*b0 + a0*b1 + a1*b0 + a0*b2 + a2*b0 + a1*b1 (6 MFMAs, ~2^-24: fp32-class, for the face parser whose argmax must not move)
 // — still 2.7x less matrix-pipe time than the 8 fp32 MFMAs of the exact kernel.
+// NS = 4 (round 3): TWO f16 terms per operand, a1*b1 + a1*b2 + a2*b1 on v_mfma_f32_32x32x16_f16 — 22 significand bits per operand, ~2^-23 per product:
+// the fp32-class error of NS = 3 at HALF its MFMAs (f16 carries 11 bits per term where bf16 carries 8).  Weights are pre-scaled by a power of two so
+// that their second term stays a normal f16 (e4s_conv_prep_weights_f16x3); the activations of the networks on this path are O(1) after their norms.
 template <int KS, int S, int CB, int PB, int WC, int WP, int LOG_TW, int NS = 2>
 struct C2SbCfg {
+    static constexpr int NP = NS == 4 ? 2 : NS;      // operand planes / weight slabs
     static constexpr int KK = KS * KS;
     static constexpr int TN = WC * CB * 32;
     static constexpr int NPB = WP * PB;
@@ -445,9 +468,9 @@ struct C2SbCfg {
     static constexpr int PATCH = PH * PW;
     static constexpr int NT = 64 * WC * WP;          // threads per workgroup (256 or 512)
     static constexpr int EPT = (PATCH + NT - 1) / NT;
-    static constexpr int W4 = NS * KK * 2 * TN;      // uint4: [term][tap][half][TN]
+    static constexpr int W4 = NP * KK * 2 * TN;      // uint4: [term][tap][half][TN]
     static constexpr int WPT = (W4 + NT - 1) / NT;
-    static constexpr int LDS_BYTES = W4 * 16 + PATCH * 32 * NS;
+    static constexpr int LDS_BYTES = W4 * 16 + PATCH * 32 * NP;
     static_assert(WC * WP == 4 || WC * WP == 8, "256- or 512-thread workgroups");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS per CU");
 };
@@ -581,7 +604,7 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void conv2d_sb_kernel(const Conv2d
                     // padding stays exactly 0: the normalisation applies to in-bounds pixels only
                     const float t0 = ginb[j] ? (xs[2 * c][j] - m[2 * c]) * r[2 * c] : 0.f;
                     const float t1 = ginb[j] ? (xs[2 * c + 1][j] - m[2 * c + 1]) * r[2 * c + 1] : 0.f;
-                    c2_split2(t0, t1, h[c], l[c]);
+                    if constexpr (NS == 4) c2_split2_f16(t0, t1, h[c], l[c]); else c2_split2(t0, t1, h[c], l[c]);
                     if (NS == 3) {   // third term: what the first two leave over
                         const float q0 = (t0 - __builtin_bit_cast(float, h[c] << 16)) - __builtin_bit_cast(float, l[c] << 16);
                         const float q1 = (t1 - __builtin_bit_cast(float, h[c] & 0xffff0000u)) - __builtin_bit_cast(float, l[c] & 0xffff0000u);
@@ -611,17 +634,17 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void conv2d_sb_kernel(const Conv2d
 #pragma unroll
         for (int tap = 0; tap < C::KK; ++tap) {
             const int toff = (tap / KS) * C::PW + (tap % KS);
-            uint4 bt[NS][PB];
+            uint4 bt[C::NP][PB];
 #pragma unroll
             for (int q = 0; q < PB; ++q) {
                 const int e = xoff[q] + toff;
                 const int slot = e * 2 + (khalf ^ ((e >> 3) & 1));
 #pragma unroll
-                for (int t = 0; t < NS; ++t) bt[t][q] = xpl[t * 2 * C::PATCH + slot];
+                for (int t = 0; t < C::NP; ++t) bt[t][q] = xpl[t * 2 * C::PATCH + slot];
             }
-            uint4 at[NS][CB];
+            uint4 at[C::NP][CB];
 #pragma unroll
-            for (int t = 0; t < NS; ++t)
+            for (int t = 0; t < C::NP; ++t)
 #pragma unroll
                 for (int i = 0; i < CB; ++i) at[t][i] = whalf[t * C::KK * 2 * C::TN + tap * 2 * C::TN + i * 32];
             // products in order of magnitude: (0,0) (0,1) (1,0) [ (0,2) (2,0) (1,1) ]
@@ -633,8 +656,12 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void conv2d_sb_kernel(const Conv2d
 #pragma unroll
                 for (int i = 0; i < CB; ++i)
 #pragma unroll
-                    for (int q = 0; q < PB; ++q)
-                        acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, at[TA[pr]][i]), __builtin_bit_cast(bf16x8, bt[TB[pr]][q]), acc[i][q], 0, 0, 0);
+                    for (int q = 0; q < PB; ++q) {
+                        if constexpr (NS == 4)
+                            acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8c, at[TA[pr]][i]), __builtin_bit_cast(f16x8c, bt[TB[pr]][q]), acc[i][q], 0, 0, 0);
+                        else
+                            acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, at[TA[pr]][i]), __builtin_bit_cast(bf16x8, bt[TB[pr]][q]), acc[i][q], 0, 0, 0);
+                    }
         }
     };
 
@@ -685,6 +712,7 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void conv2d_sb_kernel(const Conv2d
                 const int co = co0 + (wc * CB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                 if (pix_ok && co < p.cout) {
                     float v = acc[i][q][r];
+                    if constexpr (NS == 4) v *= p.out_scale;
                     if (p.bias) v += p.bias[co];
                     if (p.residual) v += p.residual[((size_t)b * p.cout + co) * ohw + opix];
                     if (p.act == 1) v = fmaxf(v, 0.f);
@@ -717,7 +745,7 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void conv2d_sb_kernel(const Conv2d
 template <int KS, int S, int CB, int PB, int WC, int WP, int LOG_TW, int NS = 2>
 static int launch2d_sb(Conv2dSbParams& p, hipStream_t st) {
     // two chunks of register prefetch wherever both stages fit in 256 registers without spilling (measured with hipcc 7.2)
-    constexpr int PF = (NS == 2 && CB * PB <= 2 && (S == 1 || KS == 1)) ? 2 : 1;
+    constexpr int PF = ((NS == 2 || NS == 4) && CB * PB <= 2 && (S == 1 || KS == 1)) ? 2 : 1;
     using C = C2SbCfg<KS, S, CB, PB, WC, WP, LOG_TW, NS>;
     p.tiles_x = cdiv(p.wo, C::TW);
     p.tiles_y = cdiv(p.ho, C::TH);
@@ -747,6 +775,18 @@ static int dispatch2d_sb(Conv2dSbParams& p, hipStream_t st) {
     return launch2d_sb<KS, S, 1, 1, 2, 2, 4>(p, st);                                                                      // 64 co x 64 px (16 x 4)
 }
 
+// f16 two-term split: two planes and two slabs like split-bf16, so its tiles
+template <int KS, int S>
+static int dispatch2d_f16x3(Conv2dSbParams& p, hipStream_t st) {
+    constexpr int64_t FILL = 512;
+    if (p.wo >= 32) {
+        if (S == 1 && p.cout > 32 && nblocks_sb(p, 64, 8, 32) >= FILL) return launch2d_sb<KS, S, 2, 2, 1, 4, 5, 4>(p, st);   // 64 co x 256 px
+        if (p.cout > 32 && nblocks_sb(p, 64, 4, 32) >= FILL) return launch2d_sb<KS, S, 2, 1, 1, 4, 5, 4>(p, st);             // 64 co x 128 px
+        return launch2d_sb<KS, S, 1, 1, 2, 2, 5, 4>(p, st);                                                                  // 64 co x  64 px
+    }
+    return launch2d_sb<KS, S, 1, 1, 2, 2, 4, 4>(p, st);                                                                      // 64 co x 64 px (16 x 4)
+}
+
 // three-way split: the 64 co x 128 px tile is the largest whose three planes + three slabs leave room for two workgroups per CU
 template <int KS, int S>
 static int dispatch2d_sb3(Conv2dSbParams& p, hipStream_t st) {
@@ -759,8 +799,8 @@ static int dispatch2d_sb3(Conv2dSbParams& p, hipStream_t st) {
 
 static int conv2d_sb_common(int nterms, float* out, const float* x0, const float* x1, int cin0, const uint16_t* w0, const uint16_t* w1, const uint16_t* w2,
                             const float* bias, const float* in_mean, const float* in_rstd, const float* prelu_slope, const float* residual, int act,
-                            int bs, int cin, int cout, int h, int w, int ks, int stride, int pad, void* stream) {
-    E4S_REQUIRE(out && x0 && w0 && w1 && (nterms == 2 || w2), "conv2d_sb: null tensor");
+                            int bs, int cin, int cout, int h, int w, int ks, int stride, int pad, void* stream, float out_scale = 1.f) {
+    E4S_REQUIRE(out && x0 && w0 && w1 && (nterms != 3 || w2), "conv2d_sb: null tensor");
     E4S_REQUIRE(bs >= 0 && bs <= 65535 && cin >= 1 && cout >= 1 && h >= 1 && w >= 1, "conv2d_sb: bad size");
     E4S_REQUIRE(stride == 1 || stride == 2, "conv2d_sb: stride %d not supported (1 or 2)", stride);
     E4S_REQUIRE(pad >= 0 && pad <= ks, "conv2d_sb: bad padding");
@@ -776,9 +816,15 @@ static int conv2d_sb_common(int nterms, float* out, const float* x0, const float
     p.bs = bs; p.cin = cin; p.cin0 = x1 ? cin0 : cin; p.cout = cout; p.h = h; p.w = w; p.pad = pad;
     p.ho = (h + 2 * pad - ks) / stride + 1;
     p.wo = (w + 2 * pad - ks) / stride + 1;
+    p.out_scale = out_scale;
     E4S_REQUIRE(p.ho >= 1 && p.wo >= 1, "conv2d_sb: empty output");
     hipStream_t st = (hipStream_t)stream;
-    if (nterms == 3) {
+    if (nterms == 4) {
+        if (ks == 3 && stride == 1) return dispatch2d_f16x3<3, 1>(p, st);
+        if (ks == 3 && stride == 2) return dispatch2d_f16x3<3, 2>(p, st);
+        if (ks == 1 && stride == 1) return dispatch2d_f16x3<1, 1>(p, st);
+        if (ks == 1 && stride == 2) return dispatch2d_f16x3<1, 2>(p, st);
+    } else if (nterms == 3) {
         if (ks == 3 && stride == 1) return dispatch2d_sb3<3, 1>(p, st);
         if (ks == 3 && stride == 2) return dispatch2d_sb3<3, 2>(p, st);
         if (ks == 1 && stride == 1) return dispatch2d_sb3<1, 1>(p, st);
@@ -804,4 +850,28 @@ extern "C" int e4s_conv2d_sb3(float* out, const float* x0, const float* x1, int 
                               int bs, int cin, int cout, int h, int w, int ks, int stride, int pad, void* stream) {
     return conv2d_sb_common(3, out, x0, x1, cin0, w0, w1, w2, bias, in_mean, in_rstd, prelu_slope, residual, act, bs, cin, cout, h, w, ks, stride, pad,
                             stream);
+}
+
+// The f16 two-term split (NS = 4 above): fp32-class error at three f16 MFMAs per 16-deep step.  w1 / w2: f16 (as uint16) slabs of weight * 2^wscale_log2 in
+// e4s_conv_prep_weights_sb's layout (choose wscale_log2 so that the largest folded weight lands near 2^10); e4s_conv2d_f16x3 takes the same power back out.
+extern "C" int e4s_conv_prep_weights_f16x3(uint16_t* w1, uint16_t* w2, float* bias_out, const float* weight, const float* bn_gamma, const float* bn_beta,
+                                           const float* bn_mean, const float* bn_var, float bn_eps, const float* conv_bias, int cout, int cin, int kh, int kw,
+                                           int wscale_log2, void* stream) {
+    E4S_REQUIRE(w1 && w2 && weight, "conv_prep_weights_f16x3: null tensor");
+    E4S_REQUIRE(cout >= 1 && cin >= 1 && kh >= 1 && kw >= 1 && wscale_log2 >= -40 && wscale_log2 <= 40, "conv_prep_weights_f16x3: bad arguments");
+    const bool bn = bn_var != nullptr;
+    E4S_REQUIRE(!bn || (bn_gamma && bn_beta && bn_mean && bias_out), "conv_prep_weights_f16x3: BatchNorm fold needs gamma, beta, mean, var and bias_out");
+    E4S_REQUIRE(!conv_bias || bias_out, "conv_prep_weights_f16x3: conv bias needs bias_out");
+    const int64_t total = (int64_t)cdiv(cin, CKS2) * kh * kw * 2 * cout * 8;
+    const int grid = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
+    hipLaunchKernelGGL(conv_prep_sb_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w1, w2, (uint16_t*)nullptr, bias_out, weight, bn_gamma, bn_beta,
+                       bn_mean, bn_var, bn_eps, conv_bias, cout, cin, kh * kw, 1, ldexpf(1.f, wscale_log2));
+    return check_launch("conv_prep_weights_f16x3");
+}
+
+extern "C" int e4s_conv2d_f16x3(float* out, const float* x0, const float* x1, int cin0, const uint16_t* w1, const uint16_t* w2, const float* bias,
+                                const float* in_mean, const float* in_rstd, const float* prelu_slope, const float* residual, int act, int bs, int cin,
+                                int cout, int h, int w, int ks, int stride, int pad, int wscale_log2, void* stream) {
+    return conv2d_sb_common(4, out, x0, x1, cin0, w1, w2, nullptr, bias, in_mean, in_rstd, prelu_slope, residual, act, bs, cin, cout, h, w, ks, stride, pad,
+                            stream, ldexpf(1.f, -wscale_log2));
 }

@@ -313,7 +313,7 @@ CONV_MODE = os.environ.get("E4S_CONV", "sb")      # same switch for the plain co
 # than fp32 MFMA; measured against the CPU oracle it differs on exactly the same kind of pixel as the exact kernel does — true ties,
 # top-2 gap 4e-8 of the logit scale: tests/test_gpu_parser.py), "f32" = exact fp32 MFMA, "sb" = the two-way split of the other
 # convolutions (flips a handful of near-tie pixels)
-PARSER_EXACT = {"f32": True, "sb3": "sb3", "sb": False}[os.environ.get("E4S_PARSER_CONV", "sb3")]
+PARSER_EXACT = {"f32": True, "sb3": "sb3", "sb": False, "f16x3": "f16x3"}[os.environ.get("E4S_PARSER_CONV", "f16x3")]
 
 
 def _volatile(t: torch.Tensor) -> bool:
@@ -1010,11 +1010,14 @@ class PreparedConv(_Prepared):
         wt = property(lambda self: self[0])
         bias = property(lambda self: self[1])
         shape = property(lambda self: self[2])
+        kexp = property(lambda self: self[3] if len(self) > 3 else None)       # (f16x3) log2 of the weights' pre-scale
 
     def __init__(self, exact=False):
         """``exact=True`` pins this convolution to the exact-fp32 MFMA kernel whatever ``CONV_MODE`` says (the face parser:
         its argmax must match the reference pixel for pixel, and split-bf16's ~2e-5 relative logit error flips near-ties);
-        ``exact="sb3"`` asks for the three-way bf16 split (fp32-class error) where a split kernel exists, fp32 elsewhere."""
+        ``exact="sb3"`` asks for the three-way bf16 split (fp32-class error) where a split kernel exists, fp32 elsewhere; ``exact="f16x3"`` for the
+        two-term f16 split (the same error class at half the MFMAs; its preparation reads the largest folded weight back to pick a power-of-two
+        scale — one host sync per weight version, so not for weights prepared inside a graph capture)."""
         super().__init__()
         self.exact = exact
 
@@ -1028,6 +1031,8 @@ class PreparedConv(_Prepared):
             return 0
         if self.exact == "sb3":
             return 3
+        if self.exact == "f16x3":
+            return 4
         return 2 if (CONV_MODE == "sb" and not self.exact) else 0
 
     def get(self, weight: torch.Tensor, bn=None, conv_bias: Optional[torch.Tensor] = None):
@@ -1043,7 +1048,7 @@ class PreparedConv(_Prepared):
         sb = self.use_sb(cin, kh, kw)
         if sb:
             shape = ((cin + 15) // 16, kh * kw, 2, cout, 8)
-            wt = tuple(torch.empty(shape, dtype=torch.int16, device=w.device) for _ in range(sb))
+            wt = tuple(torch.empty(shape, dtype=torch.int16, device=w.device) for _ in range(2 if sb == 4 else sb))
         else:
             wt = torch.empty((cin, kh * kw, cout), dtype=torch.float32, device=w.device)
         bias = torch.empty((cout,), dtype=torch.float32, device=w.device) if (bn is not None or conv_bias is not None) else None
@@ -1056,7 +1061,19 @@ class PreparedConv(_Prepared):
             g = be = mu = var = None
             eps = 0.0
         cb = _c(conv_bias.detach(), "conv bias") if conv_bias is not None else None
-        if sb == 3:
+        kexp = 0
+        if sb == 4:
+            # power-of-two pre-scale: the largest folded weight lands in (2^9, 2^10], so that every weight's second f16 term stays normal
+            with torch.no_grad():
+                wmax = w.abs().flatten(1).amax(1)
+                if bn is not None:
+                    wmax = wmax * (g / torch.sqrt(var + eps)).abs()
+                m = float(wmax.max().item())
+            kexp = 10 - int(math.ceil(math.log2(m))) if m > 0 and math.isfinite(m) else 0
+            kexp = max(-30, min(30, kexp))
+            lib().call("e4s_conv_prep_weights_f16x3", _p(wt[0]), _p(wt[1]), _p(bias), _p(w), _p(g), _p(be), _p(mu), _p(var), eps, _p(cb), cout, cin, kh, kw,
+                       kexp, _stream())
+        elif sb == 3:
             lib().call("e4s_conv_prep_weights_sb3", _p(wt[0]), _p(wt[1]), _p(wt[2]), _p(bias), _p(w), _p(g), _p(be), _p(mu), _p(var), eps, _p(cb),
                        cout, cin, kh, kw, _stream())
         elif sb:
@@ -1065,7 +1082,11 @@ class PreparedConv(_Prepared):
         else:
             lib().call("e4s_conv_prep_weights", _p(wt), _p(bias), _p(w), _p(g), _p(be), _p(mu), _p(var), eps, _p(cb), cout, cin, kh, kw,
                        _stream())
-        return self._publish(key, PreparedConv.Copy((wt, bias, (cout, cin, kh, kw))))
+        return self._publish(key, PreparedConv.Copy((wt, bias, (cout, cin, kh, kw), kexp, "f16x3" if sb == 4 else "")))
+
+
+def _is_f16x3(prepared) -> bool:
+    return len(prepared) > 4 and prepared[4] == "f16x3"
 
 
 def conv2d(x: torch.Tensor, prepared: PreparedConv, stride: int = 1, pad: int = 0, *, x1: Optional[torch.Tensor] = None, in_norm=None,
@@ -1096,7 +1117,10 @@ def conv2d(x: torch.Tensor, prepared: PreparedConv, stride: int = 1, pad: int = 
     sb = isinstance(prepared.wt, tuple)
     ev = _timed(f"conv2d_{'sb_' if sb else ''}kernel<{kh},{stride}>")
     pr = _p(_c(prelu.detach(), "prelu")) if prelu is not None else None
-    if sb and len(prepared.wt) == 3:
+    if sb and _is_f16x3(prepared):
+        lib().call("e4s_conv2d_f16x3", _p(out), _p(x), _p(x1), c0, _p(prepared.wt[0]), _p(prepared.wt[1]), _p(prepared.bias), _p(mean), _p(rstd),
+                   pr, _p(res), act, bs, cin, cout, h, w, kh, stride, pad, prepared.kexp, _stream())
+    elif sb and len(prepared.wt) == 3:
         lib().call("e4s_conv2d_sb3", _p(out), _p(x), _p(x1), c0, _p(prepared.wt[0]), _p(prepared.wt[1]), _p(prepared.wt[2]), _p(prepared.bias),
                    _p(mean), _p(rstd), pr, _p(res), act, bs, cin, cout, h, w, kh, stride, pad, _stream())
     elif sb:

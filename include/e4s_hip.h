@@ -317,6 +317,17 @@ E4S_API int e4s_conv2d_sb3(float* out, const float* x0, const float* x1, int cin
                            const uint16_t* w2, const float* bias, const float* in_mean, const float* in_rstd,
                            const float* prelu_slope, const float* residual, int act, int bs, int cin, int cout, int h, int w,
                            int ks, int stride, int pad, void* stream);
+/* Round 3: the fp32-class convolution at half the MFMAs of the three-way bf16 split — TWO f16 terms per operand (11 significand bits each where bf16 has 8),
+ * a1*b1 + a1*b2 + a2*b1 on v_mfma_f32_32x32x16_f16, ~2^-23 per product.  w1 / w2: f16 (as uint16) slabs of weight * 2^wscale_log2 in the layout of
+ * e4s_conv_prep_weights_sb — the power of two keeps the second term a normal f16; pick it so that the largest (BatchNorm-folded) weight lands near 2^10 and
+ * pass the same value to e4s_conv2d_f16x3, which takes it out again.  Activations are used as they are (|x| < 65504; their second term loses bits below
+ * |x| ~ 2^-3, harmless next to the O(1) activations of the networks on this path).  Same fusions as e4s_conv2d. */
+E4S_API int e4s_conv_prep_weights_f16x3(uint16_t* w1, uint16_t* w2, float* bias_out, const float* weight,
+                                        const float* bn_gamma, const float* bn_beta, const float* bn_mean, const float* bn_var, float bn_eps,
+                                        const float* conv_bias, int cout, int cin, int kh, int kw, int wscale_log2, void* stream);
+E4S_API int e4s_conv2d_f16x3(float* out, const float* x0, const float* x1, int cin0, const uint16_t* w1, const uint16_t* w2, const float* bias,
+                             const float* in_mean, const float* in_rstd, const float* prelu_slope, const float* residual, int act,
+                             int bs, int cin, int cout, int h, int w, int ks, int stride, int pad, int wscale_log2, void* stream);
 
 /* Per-plane statistics of x [planes = bs*C, hw]: mean, rstd = 1/sqrt(biased var + eps) (InstanceNorm2d without affine / running
  * stats, helpers.py:133,138), nmean = mean of the normalised plane (what SEModule's avg_pool sees, helpers.py:66).  rstd and nmean

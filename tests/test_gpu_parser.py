@@ -128,17 +128,17 @@ def test_training_mode_is_refused(parser):
 
 
 def test_three_way_split_parser_against_exact_fp32_and_oracle(bisenet_sd):
-    """The parser's convolutions in the three-way bf16 split (6 MFMAs per product, E4S_PARSER_CONV=sb3) next to the exact-fp32 MFMA
-    kernel (the default) on seeded images with random weights — a near-tie generator far harsher than real faces.  Logits agree to
-    fp32 rounding; every pixel on which the two argmaxes differ is a near-tie of the CPU oracle (top-2 gap below 1e-5 of the logit
-    scale), and each variant disagrees with the oracle on such pixels only."""
+    """The parser's convolutions in the two-term f16 split (3 f16 MFMAs per product, E4S_PARSER_CONV=f16x3: the default since round 3) and in the
+    three-way bf16 split (6 bf16 MFMAs, ``sb3``) next to the exact-fp32 MFMA kernel (``f32``) on seeded images with random weights — a near-tie
+    generator far harsher than real faces.  Logits agree to fp32 rounding; every pixel on which two argmaxes differ is a near-tie of the CPU
+    oracle (top-2 gap below 1e-5 of the logit scale), and each variant disagrees with the oracle on such pixels only."""
     from e4s2024_amd import ops
     install_dropin()
     from swap_face_fine.face_parsing.face_parsing_demo import FaceParser
     old = ops.PARSER_EXACT
     parsers = {}
     try:
-        for mode in (True, "sb3"):
+        for mode in (True, "sb3", "f16x3"):
             ops.PARSER_EXACT = mode
             p = FaceParser(seg_ckpt=None, device=DEV)
             p.seg.load_state_dict(bisenet_sd)
@@ -156,18 +156,23 @@ def test_three_way_split_parser_against_exact_fp32_and_oracle(bisenet_sd):
         x = parsers[True].preprocess_tensor(batch.to(DEV))
         la = parsers[True].seg(x)[0].cpu()
         lb = parsers["sb3"].seg(x)[0].cpu()
+        lc = parsers["f16x3"].seg(x)[0].cpu()
         ref = O.bisenet_forward(bisenet_sd, O.parser_preprocess(batch))
         ref = ref[0] if isinstance(ref, (tuple, list)) else ref
     scale = ref.abs().max().item()
     assert (la - lb).abs().max().item() <= 2e-5 * scale
+    record_parity("parser.random_inputs.f16x3_logits_vs_exact_fp32", (la - lc).abs().max().item() / scale, 2e-5, "of the logit scale; three-way bf16: "
+                  f"{(la - lb).abs().max().item() / scale:.2e}")
+    assert (la - lc).abs().max().item() <= 2e-5 * scale
     top2 = ref.topk(2, dim=1).values
     gap = (top2[:, 0] - top2[:, 1]) / scale
-    am_ref, am_a, am_b = ref.argmax(1), la.argmax(1), lb.argmax(1)
-    for name, am in (("exact fp32 MFMA", am_a), ("three-way split", am_b)):
+    am_ref, am_a, am_b, am_c = ref.argmax(1), la.argmax(1), lb.argmax(1), lc.argmax(1)
+    for name, am in (("exact fp32 MFMA", am_a), ("three-way split", am_b), ("two-term f16 split", am_c)):
         bad = am != am_ref
         n = int(bad.sum())
         record_parity(f"parser.random_inputs.argmax_flips_vs_oracle[{name}]", n, 64,
                       f"of {am.numel()} px; largest oracle top-2 gap among them {gap[bad].max().item() if n else 0.0:.2e} of the logit scale")
         assert n <= 64 and (n == 0 or gap[bad].max().item() < 1e-5)
-    diff = am_a != am_b
-    assert int(diff.sum()) <= 16 and (int(diff.sum()) == 0 or gap[diff].max().item() < 1e-5)
+    for am in (am_b, am_c):
+        diff = am_a != am
+        assert int(diff.sum()) <= 16 and (int(diff.sum()) == 0 or gap[diff].max().item() < 1e-5)
