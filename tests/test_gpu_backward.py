@@ -138,6 +138,59 @@ def test_pti_step_eager_and_graph_agree():
     assert np.allclose(losses_b, losses_c, rtol=2e-3), (losses_b, losses_c)
 
 
+def test_style_vector_optimisation_steps_follow_the_oracle_with_a_second_target():
+    """W-space optimisation as a CHECKED loop (optimization.py:321-349, 422-454): four gradient steps on the per-region style vectors of a 64 x 64 Net3 —
+    L2 against the target plus an ``extra_loss`` term (the hook the reference's recolouring second target enters through, video_swap_ft_coach.py:283-284:
+    here the mean colour of the reconstruction against a given colour) — beside the same four steps through autograd on the CPU oracle
+    (cal_style_codes + the faithful twelve-pass generator_forward): the loss at every step and the tuned vectors must agree.  Plain SGD on both sides
+    so that the comparison is well conditioned (Adam's first steps move every entry by +-lr whatever its gradient's size: the sign of a near-zero
+    gradient entry would decide a 2 lr difference; the Adam loop itself is the property test below)."""
+    import types
+    install_dropin()
+    from models.networks import Net3
+    from e4s2024_amd import pti
+    opts = types.SimpleNamespace(fsencoder_type="psp", remaining_layer_idx=5, num_seg_cls=12, out_size=64, train_G=False,
+                                 start_from_latent_avg=True, learn_in_w=False)
+    net = Net3(opts)
+    seeded.apply_seeded(net, 4, "net3")
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    la = seeded.seeded_latent_avg(2, 10)
+    net = net.to(DEV).eval()
+    net.latent_avg = la.to(DEV)
+    vec0 = T(seeded.seeded_array(41, "vec", (1, 12, 1280), dist="normal"))
+    lab = seeded.blocky_labels(3, 1, 12, 64, 8)
+    mask = seeded.labels_to_onehot(lab, 12)
+    target = torch.tanh(T(seeded.seeded_array(5, "img", (1, 3, 64, 64), dist="normal")))
+    colour = torch.tensor([0.3, -0.2, 0.1])
+
+    def extra(dev):
+        c = colour.to(dev).view(1, 3)
+        return lambda recon, tgt: 0.5 * (recon.mean((2, 3)) - c).pow(2).mean()
+    # device
+    latent = vec0.clone().to(DEV).requires_grad_(True)
+    opt = torch.optim.SGD([latent], lr=2.0)
+    losses = [pti.style_vector_step(net, opt, latent, T(lab).to(DEV), target.to(DEV), extra_loss=extra(DEV), randomize_noise=False)[0].item()
+              for _ in range(4)]
+    # oracle
+    lat_o = vec0.clone().requires_grad_(True)
+    opt_o = torch.optim.SGD([lat_o], lr=2.0)
+    losses_o = []
+    for _ in range(4):
+        opt_o.zero_grad()
+        codes = O.cal_style_codes(sd, lat_o, la, 5)
+        img, _ = O.generator_forward(sd, codes, mask, None, size=64, remaining_layer_idx=5)
+        l = torch.nn.functional.mse_loss(img, target) + extra("cpu")(img, target)
+        l.backward()
+        opt_o.step()
+        losses_o.append(l.item())
+    rel = max(abs(a - b) / abs(b) for a, b in zip(losses, losses_o))
+    dv = (latent.detach().cpu() - lat_o.detach()).abs().max().item()
+    moved = (lat_o.detach() - vec0).abs().max().item()
+    record_parity("w_optimisation.4_sgd_steps.loss_rel_vs_oracle", rel, 2e-3)
+    record_parity("w_optimisation.4_sgd_steps.style_vectors_vs_oracle", dv / max(moved, 1e-12), 3e-2, note=f"relative to the largest move of an entry ({moved:.2e})")
+    assert rel <= 2e-3 and dv <= 3e-2 * moved and moved > 0, (losses, losses_o, dv, moved)
+
+
 def test_style_vector_optimisation_reduces_the_loss():
     """W-optimisation (optimization.py:321-349): gradient steps on the style vectors alone, network frozen."""
     import types
