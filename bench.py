@@ -553,7 +553,7 @@ def main():
             # the loop of configs[3] itself on a short clip: passes over the frames, one optimiser step per frame, eroded maps, foreground-weighted
             # L2 (pti.tune_clip: training/video_swap_ft_coach.py:242-317); the first two steps run eagerly, the rest replays one captured step
             del step
-            nf, passes = 8, 2
+            nf, passes = 32, 5                   # BASELINE configs[3]'s clip length (its 200 passes are 40 of these)
             vecs = torch.from_numpy(seeded.seeded_array(42, "vecs", (nf, 12, 1280), dist="normal")).to(dev)
             labs = torch.from_numpy(seeded.blocky_labels(43, nf, 12, 512, 16)).to(dev).to(torch.uint8)
             imgs = torch.tanh(torch.from_numpy(seeded.seeded_array(44, "imgs", (nf, 3, 1024, 1024), dist="normal"))).to(dev)
@@ -563,8 +563,10 @@ def main():
             torch.cuda.synchronize()
             pti_info["clip_loop"] = {"frames": nf, "passes": passes, "optimizer_steps": nf * passes, "seconds": round(time.perf_counter() - t2, 4),
                                      "mean_loss_per_pass": [round(h, 4) for h in hist],
-                                     "what": "pti.tune_clip: erode_mask radius 3 + foreground-weighted L2, the first 2 steps eagerly on the capture stream, then one captured step replayed per frame "
-                                             "(includes the capture); BASELINE configs[3] is 200 passes x 32 frames, sharded over 4 GPUs with averaged gradients"}
+                                     "seconds_per_pass": round((time.perf_counter() - t2) / passes, 4),
+                                     "what": "pti.tune_clip on configs[3]'s 32-frame clip at 1024 x 1024: erode_mask radius 3 + foreground-weighted L2, the first 2 steps eagerly on the "
+                                             "capture stream, then one captured step replayed per frame (includes the capture); BASELINE configs[3] is 200 such passes, sharded over 4 GPUs "
+                                             "with averaged gradients"}
             del topt, tnet, params, vecs, labs, imgs
             torch.cuda.empty_cache()
         except Exception as e:      # noqa: BLE001 - secondary measurement

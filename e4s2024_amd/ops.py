@@ -258,6 +258,16 @@ def _ctx(stream=None) -> _StreamCtx:
     return c
 
 
+def release_stream_context(stream) -> bool:
+    """Drop ``stream``'s host context — its 128 MB split-K workspace, control words, region-map cache (a long-running process that keeps
+    creating streams — ``StreamPipeline``, ``run_clip_streamed``, graph captures — would otherwise pin one workspace per stream id it ever used).  The
+    caller vouches that no launch of this library is still queued on the stream (``StreamPipeline.close()`` synchronises first) and that no live
+    hipGraph was captured on it.  Returns whether a context existed."""
+    key = (stream.device.index, stream.cuda_stream)
+    with _ctx_lock:
+        return _ctxs.pop(key, None) is not None
+
+
 def prepare_stream_context(stream) -> None:
     """Create ``stream``'s context and its split-K workspace NOW (eagerly, outside any capture), so that a hipGraph captured on that stream
     later bakes in a pointer that outlives the graph's private memory pool."""

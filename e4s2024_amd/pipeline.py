@@ -70,7 +70,7 @@ def mix_style_vectors(target_vec: torch.Tensor, driven_vec: torch.Tensor, comp_i
 @torch.no_grad()
 def swap_batch(net, parser, driven: torch.Tensor, target: torch.Tensor, comp_indices: Sequence[int] = DEFAULT_COMP_INDICES,
                randomize_noise: bool = False, to_uint8: bool = True, timings: Optional[dict] = None, mask_surgery: bool = False,
-               paste_radius: int = 5, two_streams: bool = TWO_STREAMS, batched: Optional[bool] = None):
+               paste_radius: int = 5, two_streams: Optional[bool] = None, batched: Optional[bool] = None):
     """``driven`` / ``target``: ``[bs, 3, 1024, 1024]`` in [-1, 1] on the device.  Returns uint8 ``[bs, 1024, 1024, 3]`` frames
     (or the float image) and the 12-class region maps the synthesis used; with ``mask_surgery`` a third value
     ``{"hole_mask", "hole_map", "lines", "content", "border", "full"}`` (the reference's paste-back inputs, :456-463)."""
@@ -81,7 +81,9 @@ def swap_batch(net, parser, driven: torch.Tensor, target: torch.Tensor, comp_ind
             timings.setdefault("_events", []).append((name, ev))
     mark("start")
     if batched is None:
-        batched = SWAP_BATCHED and two_streams is TWO_STREAMS          # an explicit two_streams= argument selects the unbatched routes
+        batched = SWAP_BATCHED and two_streams is None                 # an explicit two_streams= argument (True or False) selects the unbatched routes
+    if two_streams is None:
+        two_streams = TWO_STREAMS
     if batched:
         bs = driven.shape[0]
         both = torch.cat([driven, target])

@@ -165,13 +165,15 @@ class FrameShardRunner:
             return work, send, bufs, k, ev
 
         on_gpu = torch.device(self.device).type == "cuda"
-        with StreamPipeline(streams if on_gpu else 1, device=self.device if on_gpu else None) as pipe:
+        pipe = StreamPipeline(streams if on_gpu else 1, device=self.device if on_gpu else None)
+        with pipe:
             for k in range(rounds):
                 pending.append(pipe.submit(one_round, k))
                 if len(pending) > 2:
                     finish(pending.pop(0))
         while pending:                          # (after the pipeline's exit the current stream has waited for every round's stream)
             finish(pending.pop(0))
+        pipe.close()                            # the clip's side streams give their host contexts (128 MB of split-K workspace each) back
         return out if self.rank == dst else None
 
     def run_clip(self, n_frames: int, shared: torch.Tensor, frame_inputs: Callable[[int, int], object],
@@ -249,6 +251,15 @@ class StreamPipeline:
             for st in self.streams:
                 main.wait_stream(st)
         return False
+
+    def close(self):
+        """Give back what the side streams hold on the host side (each stream's context pins a 128 MB split-K workspace): waits for them, then drops
+        their contexts.  For long-running processes that create pipelines repeatedly; a pipeline can be re-entered after ``close`` (contexts are
+        re-created on demand).  Do not call while a hipGraph captured on one of these streams is still in use."""
+        from . import ops
+        for st in self.streams:
+            st.synchronize()
+            ops.release_stream_context(st)
 
 
 def gen_img_frames(net, codes: torch.Tensor, labels: torch.Tensor, randomize_noise: bool = False) -> torch.Tensor:
