@@ -1223,16 +1223,25 @@ def winograd_route(x: torch.Tensor, cin: int, stride: int):
     return "pre" if pre else "f32"
 
 
-MX_CONV_MIN_WORKGROUPS = 128       # below half a round of the chip the direct kernel's smaller tiles (or Winograd) serve a launch better
+MX_CONV_MIN_WORKGROUPS = 128       # (layers that can also take the Winograd route) below half a round of the chip Winograd / the direct kernel serve a launch better
+MX_CONV_MIN_WORKGROUPS_PER_IMAGE = 64
 
 
 def mx_conv_eligible(x: torch.Tensor, cout: int) -> bool:
     """Does a stride-1 3x3 convolution of ``x`` run on the DMA-fed kernel's plain-convolution mode?  (inference, the split arithmetic in force,
-    16-channel chunks, >= 128 output channels, maps at least 32 wide, enough 128 co x (32 x 8) px tiles to fill half the chip)"""
+    16-channel chunks, >= 128 output channels, maps at least 32 wide.)  Layers below ``WINOGRAD_MIN_CIN`` input channels decide from the image alone
+    — at least ``MX_CONV_MIN_WORKGROUPS_PER_IMAGE`` 128 co x (32 x 8) px tiles per image — so that a face's style vectors do not depend on how many
+    faces share the batch; the 256- / 512-channel layers, whose Winograd route already depends on the launch size, take it when the whole launch
+    has ``MX_CONV_MIN_WORKGROUPS`` tiles (the full swap's 16 images; smaller batches keep Winograd / the direct kernel)."""
     bs, cin, h, w = x.shape
     if mx_arith() is None or CONV_MODE != "sb" or torch.is_grad_enabled() or not x.is_cuda:
         return False
-    return cin % 16 == 0 and cout >= 128 and w >= 32 and bs * (-(-w // 32)) * (-(-h // 8)) * (-(-cout // 128)) >= MX_CONV_MIN_WORKGROUPS
+    if cin % 16 or cout < 128 or w < 32:
+        return False
+    per_image = (-(-w // 32)) * (-(-h // 8)) * (-(-cout // 128))
+    if cin < WINOGRAD_MIN_CIN:
+        return per_image >= MX_CONV_MIN_WORKGROUPS_PER_IMAGE
+    return bs * per_image >= MX_CONV_MIN_WORKGROUPS
 
 
 def conv3x3_mx(x: torch.Tensor, wmx: torch.Tensor, arith: int, cout: int, *, in_norm=None, prelu: Optional[torch.Tensor] = None) -> torch.Tensor:
