@@ -28,6 +28,12 @@
 
 using namespace e4s;
 
+// Tuning builds only (-DMX_ABL=bits, never the product library; results are then meaningless): 1 = the plain-convolution f16 + fp6 K loop without its MFMAs,
+// 2 = without its LDS operand reads (operands from registers), 4 = without barriers / waits / DMA.  What is left tells which part bounds the loop.
+#ifndef MX_ABL
+#define MX_ABL 0
+#endif
+
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -61,6 +67,21 @@ __device__ __forceinline__ void dma16_asm(const void* gbase, unsigned voff, unsi
                  : "=&s"(keep)
                  : "v"(voff), "s"(gbase), "s"(lds_dst)
                  : "memory");
+}
+
+// fp6 operands of the MX MFMA: six registers of codes in an eight-register tuple whose last two are never read (left undefined: shufflevector index -1)
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+typedef int i32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ i32x8 mx_op6(u32x6 c) {
+    typedef unsigned u32x8v __attribute__((ext_vector_type(8)));
+    const u32x8v w = __builtin_shufflevector(c, c, 0, 1, 2, 3, 4, 5, -1, -1);
+    return __builtin_bit_cast(i32x8, w);
+}
+__device__ __forceinline__ i32x8 mx_op6(uint4 lo, uint2 hi) {
+    const i32x4v a = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w};
+    const i32x2v b2 = {(int)hi.x, (int)hi.y};
+    const i32x4v b = __builtin_shufflevector(b2, b2, 0, 1, -1, -1);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, -1, -1);
 }
 
 // ============================================================================ weight preparation
@@ -179,7 +200,22 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
 
     const int ntile = p.tiles_x * p.tiles_y;
     const int npar = p.up ? 4 : 1;
-    unsigned bxp = p.perm_mul ? (unsigned)(((unsigned long long)blockIdx.x * p.perm_mul) % gridDim.x) : blockIdx.x;
+    // XCD affinity (p.xcd_remap, set by the launcher when the grid allows it): workgroup `lin` runs on XCD lin % 8 (observed dispatch order; a different
+    // placement would only cost speed), and each XCD has its own 4 MB L2.  A co tile's weights for all chunks are 1.2-2.5 MB and every workgroup of that co
+    // tile streams them once — so the XCDs are divided among the co tiles (8 / ncot XCDs each) and an XCD's L2 holds ONE co tile's weights instead of all of
+    // them (9.8 MB for a 512 -> 512 layer: each launch re-fetched its weights from beyond the L2 at the LDS-DMA path's limit, tools: -DMX_ABL).
+    unsigned bx_g = blockIdx.x, cot_g = blockIdx.y, b_g = blockIdx.z;
+    if (p.xcd_remap) {
+        const unsigned nx = gridDim.x, ncg = gridDim.y;
+        const unsigned lin = blockIdx.x + nx * (blockIdx.y + ncg * blockIdx.z);
+        const unsigned per = 8u / ncg;                       // XCDs per co tile (ncg in {1, 2, 4, 8})
+        const unsigned xcd = lin & 7u, q = lin >> 3;
+        cot_g = xcd / per;
+        const unsigned r = q * per + (xcd % per);            // 0 .. nx * nb - 1
+        bx_g = r % nx;
+        b_g = r / nx;
+    }
+    unsigned bxp = p.perm_mul ? (unsigned)(((unsigned long long)bx_g * p.perm_mul) % gridDim.x) : bx_g;
     if (p.perm_mul && (gridDim.x & 7u) == 0) bxp = (bxp & ~7u) | ((bxp + (bxp >> 3)) & 7u);       // (see modconv_sb.hip)
     const int ks = bxp / (ntile * npar);
     const int bx = bxp - ks * ntile * npar;
@@ -187,9 +223,9 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
     const int par = bx / ntile;
     const int pa = par >> 1, pb_ = par & 1;
     const int y0 = (tile / p.tiles_x) * C::TH, x0 = (tile % p.tiles_x) * C::TW;
-    const int cotile = blockIdx.y;
+    const int cotile = (int)cot_g;
     const int co0 = cotile * MX_TN;
-    const int b = blockIdx.z;
+    const int b = (int)b_g;
     const int hw = p.h * p.w;
     const int ho = p.up ? 2 * p.h : p.h, wo = p.up ? 2 * p.w : p.w;
     const int nchunk = (p.cin + CKS - 1) / CKS;
@@ -369,15 +405,33 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
                 u32x16 v1, v2;        // a1 = f16(a) and a - a1 of the row's 24 values, as the f16 pairs the conversions below take (registers 12..15: copies)
                 unsigned ex;          // biased fp32 exponent of the largest |a| among them
                 if constexpr (ENC) {
-                    const uint4* xq = reinterpret_cast<const uint4*>(xf4);
+                    // The row's 36 LDS reads are ISSUED TOGETHER, ahead of its first MFMA (sched_barrier below): with two in-order waves per SIMD the loop
+                    // was bound by LDS latency — a dozen load -> wait -> use hops per row (-DMX_ABL=1: the reads alone took 78 % of the kernel's time, at a
+                    // third of the LDS bandwidth); one hop per row (0.198 -> 0.184 ms on the 512 -> 512 @32^2 launch).  Requesting the next row's fragments under this row's
+                    // fp6 MFMAs as well was tried: all three taps spill (the activation prefetch holds 17 registers through the chunk), one tap changes nothing.
+                    uint4 xb1[3], wv[3][4], flo[2][4];
+                    uint2 fhi[2][4];
+                    int fsc[4];
+                    {
+                        const uint4* xq = reinterpret_cast<const uint4*>(xf4);
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) {
+                            const int e = xoff + row * C::PW + t;
+                            const int g = (e >> 2) & 3;
+                            xb1[t] = xq[e * 4 + ((2 * khalf) ^ g)];
+                            const uint4 b2 = xq[e * 4 + ((2 * khalf + 1) ^ g)];
+                            v2[t * 4] = b2.x; v2[t * 4 + 1] = b2.y; v2[t * 4 + 2] = b2.z; v2[t * 4 + 3] = b2.w;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) wv[t][i] = w1half[t * 2 * MX_TN + i * 32];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_sched_barrier(0);
                     unsigned m = 0u;  // running maximum of |a1| as f16 BITS (non-negative halves order like unsigned integers), two lanes of 16 bits
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
-                        const int e = xoff + row * C::PW + t;
-                        const int g = (e >> 2) & 3;
-                        const uint4 b1 = xq[e * 4 + ((2 * khalf) ^ g)], b2 = xq[e * 4 + ((2 * khalf + 1) ^ g)];
+                        const uint4 b1 = xb1[t];
                         v1[t * 4] = b1.x; v1[t * 4 + 1] = b1.y; v1[t * 4 + 2] = b1.z; v1[t * 4 + 3] = b1.w;
-                        v2[t * 4] = b2.x; v2[t * 4 + 1] = b2.y; v2[t * 4 + 2] = b2.z; v2[t * 4 + 3] = b2.w;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -386,20 +440,52 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
                         }
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w1half[t * 2 * MX_TN + i * 32]), __builtin_bit_cast(f16x8, b1), acc[i][0], 0, 0, 0);
+                            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wv[t][i]), __builtin_bit_cast(f16x8, b1), acc[i][0], 0, 0, 0);
+                        // the fp6 operands of this row are requested under the f16 MFMAs, into the registers the taps' weight fragments leave behind
+                        if (t == 0) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { flo[1][i] = f6lo[2 * MX_TN + i * 32]; fhi[1][i] = f6hi[2 * MX_TN + i * 32]; fsc[i] = (int)wsc[i * 32]; }
+                        }
+                        if (t == 1) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { flo[0][i] = f6lo[i * 32]; fhi[0][i] = f6hi[i * 32]; }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     const unsigned mh = (m & 0xffffu) > (m >> 16) ? (m & 0xffffu) : (m >> 16);
                     const unsigned e16 = mh >> 10;                    // f16 exponent field: 31 = the value left the f16 range (inf)
                     if (e16 >= 31u && p.flags) atomicOr(p.flags, 1);
                     ex = (e16 ? e16 : 1u) + 112u;                     // f16 bias 15 -> fp32 bias 127
+                    const unsigned e1 = ex > 3u ? ex - 2u : 1u, e2 = ex > 14u ? ex - 13u : 1u;
+                    const u32x6 p1 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, v1), __builtin_bit_cast(float, e1 << 23));
+                    const u32x6 p2 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, v2), __builtin_bit_cast(float, e2 << 23));
+                    const i32x8 bx1 = mx_op6(p1), bx2 = mx_op6(p2);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)       // fp6(w - w1) x fp6(a1)
+                        acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(mx_op6(flo[1][i], fhi[1][i]), bx1, acc[i][0], 2, 2, 1, fsc[i], 0, (int)e1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)       // fp6(w1) x fp6(a - a1)
+                        acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(mx_op6(flo[0][i], fhi[0][i]), bx2, acc[i][0], 2, 2, 0, fsc[i], 0, (int)e2);
                 } else {
+                // as in the plain-convolution mode: the row's activation and f16 weight fragments are requested together, ahead of the first conversion
                 float amax = 0.f;
+                float4 xa[3], xb[3];
+                uint4 wv[3][4];
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     const int e = xoff + row * C::PW + t;
                     const int g = (e >> 2) & 3;
-                    const float4 x0v = xf4[e * 4 + ((2 * khalf) ^ g)], x1v = xf4[e * 4 + ((2 * khalf + 1) ^ g)];
-                    const float xv[8] = {x0v.x, x0v.y, x0v.z, x0v.w, x1v.x, x1v.y, x1v.z, x1v.w};
+                    xa[t] = xf4[e * 4 + ((2 * khalf) ^ g)];
+                    xb[t] = xf4[e * 4 + ((2 * khalf + 1) ^ g)];
+                }
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) wv[t][i] = w1half[t * 2 * MX_TN + i * 32];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const float xv[8] = {xa[t].x, xa[t].y, xa[t].z, xa[t].w, xb[t].x, xb[t].y, xb[t].z, xb[t].w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float a = xv[2 * j] * sv[2 * j], bq = xv[2 * j + 1] * sv[2 * j + 1];
@@ -411,39 +497,47 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
                     const uint4 b1 = make_uint4(v1[t * 4], v1[t * 4 + 1], v1[t * 4 + 2], v1[t * 4 + 3]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w1half[t * 2 * MX_TN + i * 32]), __builtin_bit_cast(f16x8, b1), acc[i][0], 0, 0, 0);
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wv[t][i]), __builtin_bit_cast(f16x8, b1), acc[i][0], 0, 0, 0);
                 }
                 // block scales of this lane's 24 values: 2^(E - 2) for fp6(a1), 2^(E - 13) for fp6(a - a1)  (|a - a1| <= 2^(E - 11));  E >= 16 leaves f16
                 ex = (__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu;
                 if (ex >= 143u && p.flags) atomicOr(p.flags, 1);
                 }
+                if constexpr (!ENC) {
                 const unsigned e1 = ex > 3u ? ex - 2u : 1u, e2 = ex > 14u ? ex - 13u : 1u;
-#pragma unroll
-                for (int j = 12; j < 16; ++j) { v1[j] = v1[j - 12]; v2[j] = v2[j - 12]; }     // (positions 24..31 meet zero weights)
+                // (positions 24..31 meet zero weights and every fp6 code is finite: registers 12..15 of the tuples are left undefined — no moves)
                 const u32x6 p1 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, v1), __builtin_bit_cast(float, e1 << 23));
                 const u32x6 p2 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, v2), __builtin_bit_cast(float, e2 << 23));
-                const i32x8 bx1 = {(int)p1[0], (int)p1[1], (int)p1[2], (int)p1[3], (int)p1[4], (int)p1[5], 0, 0};
-                const i32x8 bx2 = {(int)p2[0], (int)p2[1], (int)p2[2], (int)p2[3], (int)p2[4], (int)p2[5], 0, 0};
+                // the MX MFMA reads 6 of its operands' 8 registers for fp6: the last two stay undefined (zero-filling them cost 2 moves per operand)
+                const i32x8 bx1 = mx_op6(p1), bx2 = mx_op6(p2);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {       // fp6(w - w1) x fp6(a1)
-                    const uint4 lo = f6lo[2 * MX_TN + i * 32];
-                    const uint2 hi = f6hi[2 * MX_TN + i * 32];
-                    const i32x8 aw = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, 0, 0};
-                    acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aw, bx1, acc[i][0], 2, 2, 1, (int)wsc[i * 32], 0, (int)e1);
+                    uint4 lo; uint2 hi; int sc;
+                    if constexpr (ENC && (MX_ABL & 2)) { lo = make_uint4(tid, i, row, 1); hi = make_uint2(tid, i); sc = 127 << 8; }
+                    else { lo = f6lo[2 * MX_TN + i * 32]; hi = f6hi[2 * MX_TN + i * 32]; sc = (int)wsc[i * 32]; }
+                    const i32x8 aw = mx_op6(lo, hi);
+                    if constexpr (ENC && (MX_ABL & 1)) { asm volatile("" :: "v"(lo.x), "v"(hi.x), "v"(sc), "v"(bx1[0])); }
+                    else acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aw, bx1, acc[i][0], 2, 2, 1, sc, 0, (int)e1);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {       // fp6(w1) x fp6(a - a1)
-                    const uint4 lo = f6lo[i * 32];
-                    const uint2 hi = f6hi[i * 32];
-                    const i32x8 aw = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, 0, 0};
-                    acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aw, bx2, acc[i][0], 2, 2, 0, (int)wsc[i * 32], 0, (int)e2);
+                    uint4 lo; uint2 hi; int sc;
+                    if constexpr (ENC && (MX_ABL & 2)) { lo = make_uint4(tid, i, row, 2); hi = make_uint2(i, tid); sc = 127; }
+                    else { lo = f6lo[i * 32]; hi = f6hi[i * 32]; sc = (int)wsc[i * 32]; }
+                    const i32x8 aw = mx_op6(lo, hi);
+                    if constexpr (ENC && (MX_ABL & 1)) { asm volatile("" :: "v"(lo.x), "v"(hi.x), "v"(sc), "v"(bx2[0])); }
+                    else acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aw, bx2, acc[i][0], 2, 2, 0, sc, 0, (int)e2);
+                }
                 }
             }
             if (row == 2 && more) store_x(cur ^ 1, chunk + 1);         // (its last readers passed the previous chunk's last barrier)
             // everything this wave issued so far has landed; then: every wave is done with this row's slot (and, after row 2, with the patch)
-            E4S_WAIT_VM(0);
-            E4S_LDS_BARRIER();
-            if (more) dma_row(chunk + 1, row);
+            if constexpr (!(ENC && (MX_ABL & 4))) {
+                E4S_WAIT_VM(0);
+                E4S_LDS_BARRIER();
+                if (more) dma_row(chunk + 1, row);
+            }
+
         }
     }
 
@@ -563,10 +657,14 @@ int e4s::launch_modconv_mx(SbParams& p, int arith, hipStream_t st, float* worksp
     p.partial = workspace;
     dim3 grid(p.tiles_x * p.tiles_y * npar * ksplit, cdiv(p.cout, MX_TN), p.bs);
     p.perm_mul = p.uni_blocks ? coprime_stride(grid.x) : 0u;
+    static const int xcd_on = [] { const char* e = getenv("E4S_MX_XCD"); return e ? atoi(e) : 1; }();
+    auto remap_ok = [&](dim3 g) { const unsigned long long t = (unsigned long long)g.x * g.y * g.z; return xcd_on && (g.y == 1 || g.y == 2 || g.y == 4 || g.y == 8) && t % 8 == 0 && g.y > 1; };
+    p.xcd_remap = remap_ok(grid) ? 1 : 0;
     if (plain_conv) {
         p.ksplit = 1;
         p.chunks_per = nchunk;
         grid = dim3(p.tiles_x * p.tiles_y, cdiv(p.cout, MX_TN), p.bs);
+        p.xcd_remap = remap_ok(grid) ? 1 : 0;
         return arith == 0 ? launch_mx_variant<0, false, false, true>(p, grid, st) : launch_mx_variant<1, false, false, true>(p, grid, st);
     }
     const bool rgb = p.rgb_out != nullptr, osp = p.s_next != nullptr;
