@@ -28,9 +28,8 @@
 
 using namespace e4s;
 
-// Tuning builds only (-DMX_ABL=bits, never the product library; results are then meaningless; tools/build_abl.sh): 1 = the f16 + fp6 K loop without its MFMAs,
-// 2 = without its LDS operand reads (operands from registers), 4 = without barriers / waits / DMA (one-phase loop), 8 = two-phase loop without the row refills and
-// their waits, 16 = two-phase loop without its barriers.  What is left tells which part bounds the loop.
+// Tuning builds only (-DMX_ABL=bits, never the product library; results are then meaningless; tools/build_abl.sh): 1 = the plain-convolution f16 + fp6 K loop without
+// its MFMAs, 2 = without its LDS operand reads (operands from registers), 4 = without barriers / waits / DMA.  What is left tells which part bounds the loop.
 #ifndef MX_ABL
 #define MX_ABL 0
 #endif
@@ -65,15 +64,6 @@ __device__ __forceinline__ unsigned pack_f16_rne(float a, float b) {
 __device__ __forceinline__ void dma16_asm(const void* gbase, unsigned voff, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(gbase), "s"(lds_dst)
-                 : "memory");
-}
-
-// the 4-byte form: lane l's dword from (scalar base + its 32-bit offset) to LDS address `lds_dst` + 4 * l
-__device__ __forceinline__ void dma4_asm(const void* gbase, unsigned voff, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(gbase), "s"(lds_dst)
                  : "memory");
@@ -186,20 +176,17 @@ __global__ __launch_bounds__(256) void prep_weights_mx_kernel(unsigned char* __r
 
 // ============================================================================ the conv kernel
 using C = SbCfg<4, 1, 1, 8, 5>;     // 128 co x (32 x 8) px, 512 threads; wave w = tile row w, its 32 pixels x all 128 output channels
-constexpr int MX_PATCHB = C::PATCH * CKS * 4;                 // 21 760: [16-B slot 4][pixel 340] (a slot = 4 fp32 channels, or 8 f16: plain mode) — slot-major, so that
+constexpr int MX_PSTRIDE = 352;                               // pixels per slot row (the 340 of the patch, padded)
+constexpr int MX_PATCHB = 4 * MX_PSTRIDE * 16;                // 22 528: [16-B slot 4][pixel 352] (a slot = 4 fp32 channels, or 8 f16: plain mode) — slot-major, so that
                                                               // every fragment read of a lane is ONE base register + an immediate and 16 consecutive lanes read 256 consecutive bytes
 constexpr int MX_SSB = E4S_MAX_REGIONS * CKS * 4;             // 1 024
-constexpr int MX_RAWPX = 384;                                 // six wave requests of 64 pixels per channel
-constexpr int MX_RAWB = CKS * MX_RAWPX * 4;                   // 24 576
 template <int ARITH>
 struct MxLds {
     static constexpr int ROWB = ARITH ? MX_ROWB1 : MX_ROWB0;
     static constexpr int RING = 3 * ROWB;
     static constexpr int PATCH0 = RING;
     static constexpr int SS0 = PATCH0 + 2 * MX_PATCHB;
-    static constexpr int RAW0 = SS0 + 2 * MX_SSB;             // the next chunk's patch as it arrives from global memory: fp32 [16 ch][384 px] (340 used)
-    static constexpr int DUMMY0 = RAW0 + MX_RAWB;             // 256 B that waves without a table piece aim their (counted) request at
-    static constexpr int BYTES = DUMMY0 + 256;
+    static constexpr int BYTES = SS0 + 2 * MX_SSB;
     static constexpr int NPIECE = ROWB / 1024;                // 1 KB per wave instruction
     static_assert(ROWB % 1024 == 0 && BYTES <= 160 * 1024, "LDS plan");
     static_assert((E4S_MAX_REGIONS + 5) * MX_TN * 4 + 64 <= RING, "the epilogue's tables overlay the weight ring");
@@ -211,11 +198,9 @@ static_assert(MxLds<0>::BYTES + MX_NORM_BYTES <= 160 * 1024 && MxLds<1>::BYTES +
 
 // ENC = plain-convolution mode (the regional-style encoder's stride-1 3x3 convolutions, helpers.py:122-144): no region map and no modulation;
 // instance-norm statistics are applied to the input while it is staged ((x - mean) * rstd, padding stays exactly 0), the epilogue is an optional PReLU.
-// PP = the two-phase ("ping-pong") K loop of ARITH 1, see the loop.
-template <int ARITH, bool RGB, bool OSP, bool ENC = false, bool PP = (ARITH == 1)>
+template <int ARITH, bool RGB, bool OSP, bool ENC = false>
 __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParams p) {
     static_assert(!ENC || (!RGB && !OSP), "plain-convolution mode has its own epilogue");
-    static_assert(!PP || ARITH == 1, "the two-phase loop is built for the f16 + fp6 arithmetic");
     using L = MxLds<ARITH>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
@@ -294,48 +279,36 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
 
-    // ---- staging
-    // The next chunk's patch and modulation table travel global -> LDS by DMA as well (round 3, with the two-phase loop): no destination registers live through
-    // the chunk (they were the first to be spilled), and EVERY vector-memory request of the K loop is then one of this kernel's own — hipcc counts none of
-    // them, so the loop's counted vmcnt waits are exact.  Every wave issues the same number: 12 requests of 64 pixels (channels 2 wave, 2 wave + 1 of the chunk;
-    // out-of-map pixels read a clamped address and are zeroed when the patch is written) and, masked mode, one of the 12 x 16 table (waves 3-7: a dummy).
-    // (per-lane offsets are recomputed per chunk from a pinned copy of the lane number: as loop invariants they would sit in eight registers through the K loop,
-    // whose two-phase form has none to spare)
-    auto load_x = [&](int buf, int chunk) __attribute__((always_inline)) {       // chunk's patch -> RAW0, its modulation table -> SS buffer `buf`
+    // ---- staging: each patch thread loads its pixel's 16 channels at the chunk's start (registers through the chunk) and writes them to the other patch buffer in
+    // row 2.  Round 3 measured two LDS-DMA alternatives (sum of the seven masked launches of a step / the plain 512 -> 512 @32^2 x 16 launch; registers: 1.63 / 0.172 ms):
+    //   12 global_load_lds_dword requests per wave (64 pixels of one channel) into a raw fp32 buffer, converted from there in row 2:      1.71 / 0.174 ms
+    //   masked: 11 requests per wave of 16 pixels x 4 channels, per-lane addresses, straight into the fp32 patch (no conversion pass):    1.89 ms
+    // — 4-byte DMA requests are no cheaper than 4-byte loads, and the conversion pass or the scattered lanes cost more than the 17 registers.
+    float xr[CKS];
+    float sr = 0.f;
+    // this thread's patch pixel (threads 0..339)
+    const int ppy = tid / C::PW, ppx = tid - ppy * C::PW;
+    const int pgy = y0 - 1 + ppy, pgx = x0 - 1 + ppx;
+    const bool p_in = tid < C::PATCH && pgy >= 0 && pgy < p.h && pgx >= 0 && pgx < p.w;
+    const int goffs = p_in ? pgy * p.w + pgx : 0;
+    const int s_r = tid / CKS < p.nreg ? tid / CKS : p.nreg - 1, s_c = tid % CKS;
+    auto load_x = [&](int chunk) __attribute__((always_inline)) {       // next chunk's patch pixel (16 channels) and modulation table entry
+        // Unconditional, branch-free loads (as modconv_sb.hip learned): a load under a per-lane condition, or a register that is also written by a plain
+        // move (`sr = cond ? load : 0`), makes hipcc wait vmcnt(0) right behind the issue — the whole latency exposed once per chunk.  Out-of-range
+        // lanes read a clamped valid address and are zeroed when the chunk is written to LDS; waves 6 and 7 own no patch pixel (wave-uniform branch).
         const int ci0 = chunk * CKS;
-        int ln = lane;
-        pin_here(ln);
+        const int cmax = p.cin - 1 - ci0;
+        if (wave < (C::PATCH + 63) / 64) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int e = j * 64 + ln;
-            const int ey = e / C::PW, ex = e - ey * C::PW;
-            const int gy = y0 - 1 + ey, gx = x0 - 1 + ex;
-            const unsigned goff = (e < C::PATCH && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) ? (unsigned)(gy * p.w + gx) * 4u : 0u;
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                const int c = 2 * wave + cc;
-                const int ci = ci0 + c < p.cin ? ci0 + c : p.cin - 1;
-                dma4_asm(xb + (size_t)ci * hw, goff, (unsigned)(L::RAW0 + (c * MX_RAWPX + j * 64) * 4));
-            }
+            for (int c = 0; c < CKS; ++c) xr[c] = xb[(size_t)(ci0 + (c < cmax ? c : cmax)) * hw + goffs];
         }
-        if constexpr (!ENC) {
-            const int l = (wave < 3 ? wave : 0) * 64 + ln;       // (region, channel) of the table
-            const int r = l / CKS < p.nreg ? l / CKS : p.nreg - 1;
-            dma4_asm(sb + ci0, (unsigned)(r * p.cin + (l % CKS)) * 4u, wave < 3 ? (unsigned)(L::SS0 + buf * MX_SSB + wave * 256) : (unsigned)L::DUMMY0);
-        }
+        if constexpr (!ENC) sr = sb[(size_t)s_r * p.cin + ci0 + (s_c < cmax ? s_c : cmax)];
     };
-    auto store_x = [&](int buf, int chunk) __attribute__((always_inline)) {     // RAW0 -> patch buffer `buf` in the K loop's operand form
+    auto store_x = [&](int buf, int chunk) __attribute__((always_inline)) {     // the staged chunk -> patch buffer `buf` in the K loop's operand form
         float4* xf4 = reinterpret_cast<float4*>(lds_raw + L::PATCH0 + buf * MX_PATCHB);
-        int tid = threadIdx.x;      // (pinned copy: the addresses below are recomputed per call instead of living in registers through the K loop)
-        pin_here(tid);
-        const int ppy = tid / C::PW, ppx = tid - ppy * C::PW;
-        const int pgy = y0 - 1 + ppy, pgx = x0 - 1 + ppx;
-        const bool p_in = tid < C::PATCH && pgy >= 0 && pgy < p.h && pgx >= 0 && pgx < p.w;
         if (tid < C::PATCH) {
-            const float* raw = reinterpret_cast<const float*>(lds_raw + L::RAW0) + tid;
-            float xr[CKS];
 #pragma unroll
-            for (int c = 0; c < CKS; ++c) xr[c] = p_in ? raw[c * MX_RAWPX] : 0.f;
+            for (int c = 0; c < CKS; ++c) xr[c] = p_in ? xr[c] : 0.f;
             if constexpr (ENC) {  // instance norm on load: this sample's statistics from the table staged in LDS at kernel start (mean 0 / rstd 1 without),
                                   // read as wave-uniform float4s — as global loads they were 32 vector-memory requests per chunk inside the K loop
                 const float4* nm = reinterpret_cast<const float4*>(lds_raw + L::BYTES) + chunk * (CKS / 4);
@@ -364,13 +337,17 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
                         q1[j] = __builtin_bit_cast(unsigned, a1);
                         q2[j] = pack_f16_rne(a - (float)a1[0], bq - (float)a1[1]);
                     }
-                    xq[(2 * hh) * C::PATCH + tid] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
-                    xq[(2 * hh + 1) * C::PATCH + tid] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+                    xq[(2 * hh) * MX_PSTRIDE + tid] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+                    xq[(2 * hh + 1) * MX_PSTRIDE + tid] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) xf4[k * C::PATCH + tid] = make_float4(xr[4 * k], xr[4 * k + 1], xr[4 * k + 2], xr[4 * k + 3]);
+                for (int k = 0; k < 4; ++k) xf4[k * MX_PSTRIDE + tid] = make_float4(xr[4 * k], xr[4 * k + 1], xr[4 * k + 2], xr[4 * k + 3]);
             }
+        }
+        if constexpr (!ENC) {
+            if (tid < E4S_MAX_REGIONS * CKS)
+                reinterpret_cast<float*>(lds_raw + L::SS0 + buf * MX_SSB)[tid] = (tid / CKS < p.nreg && chunk * CKS + s_c < p.cin) ? sr : 0.f;
         }
     };
     // row `row` of chunk `chunk` -> ring slot `row`: pieces wave, wave + 8, ... of NPIECE
@@ -400,197 +377,23 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
         dma_row(ch_begin, 0);
         dma_row(ch_begin, 1);
         dma_row(ch_begin, 2);
-        load_x(0, ch_begin);
+        load_x(ch_begin);
+        store_x(0, ch_begin);
     }
     E4S_WAIT_VM(0);
     E4S_LDS_BARRIER();
-    if (ch_begin < ch_end) store_x(0, ch_begin);
-    E4S_LDS_BARRIER();
 
-
-    if constexpr (PP) {
-    // ---- the two-phase K loop.  With one barrier per kernel row all eight waves run in lock-step: after the barrier BOTH waves of a SIMD request their operands,
-    // wait out the LDS latency and convert, and only then issue MFMAs — the matrix pipe idles through every read / convert phase (the loop ran 1.7-2.1 us per row
-    // against 0.87 us of matrix work for the SIMD's two waves).  Here a row is split into an R phase (all LDS reads of the row, modulate / split / fp6 conversion:
-    // everything the MFMAs take is in registers at its end) and an M phase (the row's 20 MFMAs, nothing else), a barrier after each, and waves 4-7 run HALF A ROW
-    // behind waves 0-3 (one extra barrier up front, one for waves 0-3 at the end; s_barrier counts arrivals, not program counters): every SIMD holds one wave of
-    // each group, so at any time one of its waves feeds the matrix pipe while the other reads and converts.
-    //   barrier index (global):  waves 0-3  R(r) | 2r+1 | M(r) | 2r+2     waves 4-7  R(r) | 2r+2 | M(r) | 2r+3
-    // Hazards: ring slot of row r is last read in phase 2r+1 (waves 4-7), so its refill is requested right after barrier 2r+2 by both groups and must have landed
-    // before barrier 2r+6 (row r+3's first reader): counted vmcnt waits that leave only the most recent request (and, in row 0, the patch prefetch) in flight.
-    // The patch of chunk c+1 is requested in phases 6c / 6c+1 into the raw buffer (last read in phase 6c-1), every wave has waited for its part before barrier
-    // 6c+4, it is converted into the other patch buffer in phases 6c+4 / 6c+5 (last reader of that buffer: phase 6c-1; first reader of the new data: 6c+6).
-    const int grp = (wave >> p.pp_shift) & 1;
-    unsigned ovf = 0u;
-#if MX_ABL & 32
-    unsigned long long tR = 0, tWR = 0, tM = 0, tWM = 0, tS, tLoop = __builtin_readcyclecounter();
-#define MX_STAMP(accum) { const unsigned long long tn = __builtin_readcyclecounter(); accum += tn - tS; tS = tn; }
-#else
-#define MX_STAMP(accum)
-#endif
-    constexpr int LX = 12 + (ENC ? 0 : 1);       // requests of load_x, every wave
-    auto wait_rows = [&](int row, bool more) __attribute__((always_inline)) {
-        // the row refill requested two barriers ago has landed; this wave's latest refill (wave 0: 4 pieces, others 3) stays in flight, and so does the next
-        // chunk's patch in row 0 (requested at the chunk's start, read — by store_x, two barriers after row 1's wait — from row 1's end on)
-        if (!more) { if (row == 0) { if (wave == 0) E4S_WAIT_VM(4); else E4S_WAIT_VM(3); } else E4S_WAIT_VM(0); }
-        else if (row == 0) { if (wave == 0) E4S_WAIT_VM(4 + LX); else E4S_WAIT_VM(3 + LX); }
-        else { if (wave == 0) E4S_WAIT_VM(4); else E4S_WAIT_VM(3); }
-    };
-    if constexpr (!(MX_ABL & 16)) { if (grp) E4S_LDS_BARRIER(); }
-#if MX_ABL & 32
-    tS = __builtin_readcyclecounter();
-#endif
+    // A two-phase ("ping-pong") form of this loop was built and measured in round 3 (commit 75c84a8): waves 4-7 half a row behind waves 0-3, each row split into a
+    // read / convert phase and an MFMA-only phase with a barrier after each, so that every SIMD always has one wave feeding the matrix pipe.  Correct, but slower
+    // (plain mode 512 -> 512 @32^2 x 16: 0.220 against 0.178 ms): cycle stamps put the read phase at 1 550 - 2 450 cycles per row against 810 for the row's 20
+    // MFMAs — the row's 38 LDS reads (144 LDS-array cycles per wave, 576 per phase for the four waves of a group, in two dependent rounds) and the patch
+    // conversion, not the matrix pipe, set the pace, and the MFMA waves waited at the barrier.  What carried over: the DMA staging, the slot-major patch, and pinning
+    // the accumulators (LLVM sinks a row's last MFMAs behind the next barrier otherwise — 60 registers).
 #pragma unroll 1
     for (int chunk = ch_begin; chunk < ch_end; ++chunk) {
         const int cur = (chunk - ch_begin) & 1;
         const bool more = chunk + 1 < ch_end;
-        if (more) load_x(cur ^ 1, chunk + 1);
-        const float4* xf4 = reinterpret_cast<const float4*>(lds_raw + L::PATCH0 + cur * MX_PATCHB);
-        const float* ss = reinterpret_cast<const float*>(lds_raw + L::SS0 + cur * MX_SSB);
-        float sv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sv[e] = ENC ? 1.f : (cls[0] >= 0 ? ss[cls[0] * CKS + khalf * 8 + e] : 0.f);
-#pragma unroll
-        for (int row = 0; row < 3; ++row) {
-            const unsigned char* slot = lds_raw + row * L::ROWB;
-            const uint4* w1half = reinterpret_cast<const uint4*>(slot) + khalf * MX_TN + l5;
-            const uint4* f6lo = reinterpret_cast<const uint4*>(slot + MX_W1B) + khalf * MX_TN + l5;                    // + term * 2 * TN + i * 32
-            const uint2* f6hi = reinterpret_cast<const uint2*>(slot + MX_W1B + MX_F6LO) + khalf * MX_TN + l5;
-            const unsigned* wsc = reinterpret_cast<const unsigned*>(slot + MX_W1B + MX_F6LO + MX_F6HI) + khalf * MX_TN + l5;
-            // ---------------- R phase
-            // (the next chunk's patch is converted first, while no operand of the row is live yet: phase 6c+4 for waves 0-3, 6c+5 for waves 4-7)
-            if (row == 2 && more) store_x(cur ^ 1, chunk + 1);
-            u32x16 v1, v2;        // a1 = f16(a) and a - a1 of the row's 24 values as f16 pairs (registers 12..15 undefined: they meet zero weights and every fp6 code is finite)
-            uint4 wv[3][4], flo[2][4];
-            uint2 fhi[2][4];
-            int fsc[4];
-            unsigned ex;          // biased fp32 exponent of the largest |a| among the lane's 24 values
-            if constexpr (ENC) {
-                const uint4* xq = reinterpret_cast<const uint4*>(xf4);
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const int e = xoff + row * C::PW + t;
-                    const uint4 b1 = xq[(2 * khalf) * C::PATCH + e], b2 = xq[(2 * khalf + 1) * C::PATCH + e];
-                    v1[t * 4] = b1.x; v1[t * 4 + 1] = b1.y; v1[t * 4 + 2] = b1.z; v1[t * 4 + 3] = b1.w;
-                    v2[t * 4] = b2.x; v2[t * 4 + 1] = b2.y; v2[t * 4 + 2] = b2.z; v2[t * 4 + 3] = b2.w;
-                }
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) wv[t][i] = w1half[t * 2 * MX_TN + i * 32];
-                __builtin_amdgcn_sched_barrier(0);
-                unsigned m = 0u;  // running maximum of |a1| as f16 BITS (non-negative halves order like unsigned integers), two lanes of 16 bits
-#pragma unroll
-                for (int j = 0; j < 12; ++j) {
-                    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-                    const u16x2 mm = __builtin_elementwise_max(__builtin_bit_cast(u16x2, m), __builtin_bit_cast(u16x2, v1[j] & 0x7fff7fffu));   // v_pk_max_u16
-                    m = __builtin_bit_cast(unsigned, mm);
-                }
-                const unsigned mh = (m & 0xffffu) > (m >> 16) ? (m & 0xffffu) : (m >> 16);
-                const unsigned e16 = mh >> 10;                    // f16 exponent field: 31 = the value left the f16 range (inf)
-                ovf |= e16 >= 31u ? 1u : 0u;
-                ex = (e16 ? e16 : 1u) + 112u;                     // f16 bias 15 -> fp32 bias 127
-            } else {
-                float4 xa[3], xb[3];
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const int e = xoff + row * C::PW + t;
-                    xa[t] = xf4[(2 * khalf) * C::PATCH + e];
-                    xb[t] = xf4[(2 * khalf + 1) * C::PATCH + e];
-                }
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) wv[t][i] = w1half[t * 2 * MX_TN + i * 32];
-                __builtin_amdgcn_sched_barrier(0);
-                float amax = 0.f;
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const float xv[8] = {xa[t].x, xa[t].y, xa[t].z, xa[t].w, xb[t].x, xb[t].y, xb[t].z, xb[t].w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float a = xv[2 * j] * sv[2 * j], bq = xv[2 * j + 1] * sv[2 * j + 1];
-                        const f16x2 a1 = __builtin_convertvector((f32x2){a, bq}, f16x2);
-                        v1[t * 4 + j] = __builtin_bit_cast(unsigned, a1);
-                        v2[t * 4 + j] = pack_f16_rne(a - (float)a1[0], bq - (float)a1[1]);
-                        amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(bq)));
-                    }
-                }
-                // block scales of this lane's 24 values: 2^(E - 2) for fp6(a1), 2^(E - 13) for fp6(a - a1)  (|a - a1| <= 2^(E - 11));  E >= 16 leaves f16
-                ex = (__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu;
-                ovf |= ex >= 143u ? 1u : 0u;
-            }
-            const unsigned e1 = ex > 3u ? ex - 2u : 1u, e2 = ex > 14u ? ex - 13u : 1u;
-            u32x6 p1 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, v1), __builtin_bit_cast(float, e1 << 23));
-            u32x6 p2 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, v2), __builtin_bit_cast(float, e2 << 23));
-            uint4 b1r[3];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) b1r[t] = make_uint4(v1[t * 4], v1[t * 4 + 1], v1[t * 4 + 2], v1[t * 4 + 3]);
-            pin_here(p1); pin_here(p2);
-#pragma unroll
-            for (int t = 0; t < 3; ++t) { pin_here(b1r[t].x); pin_here(b1r[t].y); pin_here(b1r[t].z); pin_here(b1r[t].w); }
-            // the MX MFMA reads 6 of its operands' 8 registers for fp6: the last two stay undefined (zero-filling them cost 2 moves per operand)
-            const i32x8 bx1 = mx_op6(p1), bx2 = mx_op6(p2);
-            // (register budget: 256 per wave; the activation fragments and the conversion's temporaries are gone before the fp6 weight codes are requested)
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                flo[1][i] = f6lo[2 * MX_TN + i * 32]; fhi[1][i] = f6hi[2 * MX_TN + i * 32];
-                flo[0][i] = f6lo[i * 32]; fhi[0][i] = f6hi[i * 32];
-                fsc[i] = (int)wsc[i * 32];
-            }
-            if constexpr (!(MX_ABL & 8)) { if (grp) wait_rows(row, more); }
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            MX_STAMP(tR)
-            if constexpr (MX_ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else E4S_LDS_BARRIER();
-            MX_STAMP(tWR)
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(MX_ABL & 8)) { if (grp && more) dma_row(chunk + 1, row); }
-            // ---------------- M phase: operands in registers, nothing but the matrix pipe
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if constexpr (MX_ABL & 1) asm volatile("" :: "v"(wv[t][i].x), "v"(wv[t][i].y), "v"(wv[t][i].z), "v"(wv[t][i].w), "v"(b1r[t].x), "v"(b1r[t].w));
-                    else acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wv[t][i]), __builtin_bit_cast(f16x8, b1r[t]), acc[i][0], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {     // fp6(w - w1) x fp6(a1)
-                if constexpr (MX_ABL & 1) asm volatile("" :: "v"(flo[1][i].x), "v"(flo[1][i].w), "v"(fhi[1][i].x), "v"(fhi[1][i].y), "v"(fsc[i]), "v"(bx1[0]), "v"(bx1[5]));
-                else acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(mx_op6(flo[1][i], fhi[1][i]), bx1, acc[i][0], 2, 2, 1, fsc[i], 0, (int)e1);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {     // fp6(w1) x fp6(a - a1)
-                if constexpr (MX_ABL & 1) asm volatile("" :: "v"(flo[0][i].x), "v"(flo[0][i].w), "v"(fhi[0][i].x), "v"(fhi[0][i].y), "v"(bx2[0]), "v"(bx2[5]));
-                else acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(mx_op6(flo[0][i], fhi[0][i]), bx2, acc[i][0], 2, 2, 0, fsc[i], 0, (int)e2);
-            }
-            // (without this LLVM sinks the row's last MFMAs to their first use — behind the NEXT row's barrier, their 56 operand registers with them)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) pin_here(acc[i][0]);
-            if constexpr (!(MX_ABL & 8)) { if (!grp) wait_rows(row, more); }
-            __builtin_amdgcn_sched_barrier(0);
-            MX_STAMP(tM)
-            if constexpr (MX_ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else E4S_LDS_BARRIER();
-            MX_STAMP(tWM)
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(MX_ABL & 8)) { if (!grp && more) dma_row(chunk + 1, row); }
-        }
-    }
-    if constexpr (!(MX_ABL & 16)) { if (!grp) E4S_LDS_BARRIER(); }
-    E4S_WAIT_VM(0);
-#if MX_ABL & 32
-    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0)
-        printf("wave %d grp %d: loop %llu cyc, R %llu, wait after R %llu, M %llu, wait after M %llu  (rows %d)\n", wave, grp, __builtin_readcyclecounter() - tLoop, tR, tWR, tM, tWM, 3 * (ch_end - ch_begin));
-#endif
-    if (ovf && p.flags) atomicOr(p.flags, 1);
-    } else {
-#pragma unroll 1
-    for (int chunk = ch_begin; chunk < ch_end; ++chunk) {
-        const int cur = (chunk - ch_begin) & 1;
-        const bool more = chunk + 1 < ch_end;
-        if (more) load_x(cur ^ 1, chunk + 1);              // lands during this chunk (row 0's wait), written to the other patch buffer before its last barrier
+        if (more) load_x(chunk + 1);                       // lands during this chunk (row 0's wait), written to the other patch buffer before its last barrier
 
         const float4* xf4 = reinterpret_cast<const float4*>(lds_raw + L::PATCH0 + cur * MX_PATCHB);
         const float* ss = reinterpret_cast<const float*>(lds_raw + L::SS0 + cur * MX_SSB);
@@ -606,7 +409,7 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     const int e = xoff + row * C::PW + t;
-                    const float4 x0v = xf4[(2 * khalf) * C::PATCH + e], x1v = xf4[(2 * khalf + 1) * C::PATCH + e];
+                    const float4 x0v = xf4[(2 * khalf) * MX_PSTRIDE + e], x1v = xf4[(2 * khalf + 1) * MX_PSTRIDE + e];
                     uint4 bh, bl;
                     split2(x0v.x * sv[0], x0v.y * sv[1], bh.x, bl.x);
                     split2(x0v.z * sv[2], x0v.w * sv[3], bh.y, bl.y);
@@ -648,8 +451,8 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
 #pragma unroll
                         for (int t = 0; t < 3; ++t) {
                             const int e = xoff + row * C::PW + t;
-                            xb1[t] = xq[(2 * khalf) * C::PATCH + e];
-                            const uint4 b2 = xq[(2 * khalf + 1) * C::PATCH + e];
+                            xb1[t] = xq[(2 * khalf) * MX_PSTRIDE + e];
+                            const uint4 b2 = xq[(2 * khalf + 1) * MX_PSTRIDE + e];
                             v2[t * 4] = b2.x; v2[t * 4 + 1] = b2.y; v2[t * 4 + 2] = b2.z; v2[t * 4 + 3] = b2.w;
 #pragma unroll
                             for (int i = 0; i < 4; ++i) wv[t][i] = w1half[t * 2 * MX_TN + i * 32];
@@ -710,8 +513,8 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     const int e = xoff + row * C::PW + t;
-                    xa[t] = xf4[(2 * khalf) * C::PATCH + e];
-                    xb[t] = xf4[(2 * khalf + 1) * C::PATCH + e];
+                    xa[t] = xf4[(2 * khalf) * MX_PSTRIDE + e];
+                    xb[t] = xf4[(2 * khalf + 1) * MX_PSTRIDE + e];
                 }
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
@@ -774,7 +577,6 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
             }
 
         }
-    }
     }
 
     if constexpr (ENC) {
@@ -1067,23 +869,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mx2_kernel(const SbParams p) {
     }
 }
 
-template <int ARITH, bool RGB, bool OSP, bool ENC, bool PP>
-int launch_mx_variant_pp(const SbParams& p, dim3 grid, hipStream_t st) {
-    constexpr int lds = MxLds<ARITH>::BYTES + (ENC ? MX_NORM_BYTES : 0);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&region_modconv_mx_kernel<ARITH, RGB, OSP, ENC, PP>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (attr != hipSuccess) return fail((int)attr, "region_modconv3x3_mx: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
-    hipLaunchKernelGGL((region_modconv_mx_kernel<ARITH, RGB, OSP, ENC, PP>), grid, dim3(512), lds, st, p);
-    return check_launch(ENC ? "conv3x3_mx" : "region_modconv3x3_mx");
-}
 template <int ARITH, bool RGB, bool OSP, bool ENC = false>
 int launch_mx_variant(const SbParams& p, dim3 grid, hipStream_t st) {
-    if constexpr (ARITH == 1) {
-        static const int pp = [] { const char* e = getenv("E4S_MX_PP"); return e ? atoi(e) : 0; }();      // (measurement switch: the two-phase loop is slower, see its header)
-        return pp ? launch_mx_variant_pp<ARITH, RGB, OSP, ENC, true>(p, grid, st) : launch_mx_variant_pp<ARITH, RGB, OSP, ENC, false>(p, grid, st);
-    } else {
-        return launch_mx_variant_pp<ARITH, RGB, OSP, ENC, false>(p, grid, st);
-    }
+    constexpr int lds = MxLds<ARITH>::BYTES + (ENC ? MX_NORM_BYTES : 0);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&region_modconv_mx_kernel<ARITH, RGB, OSP, ENC>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr != hipSuccess) return fail((int)attr, "region_modconv3x3_mx: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+    hipLaunchKernelGGL((region_modconv_mx_kernel<ARITH, RGB, OSP, ENC>), grid, dim3(512), lds, st, p);
+    return check_launch(ENC ? "conv3x3_mx" : "region_modconv3x3_mx");
 }
 
 }  // namespace
@@ -1157,8 +950,6 @@ int e4s::launch_modconv_mx(SbParams& p, int arith, hipStream_t st, float* worksp
     static const int xcd_on = [] { const char* e = getenv("E4S_MX_XCD"); return e ? atoi(e) : 1; }();
     auto remap_ok = [&](dim3 g) { const unsigned long long t = (unsigned long long)g.x * g.y * g.z; return xcd_on && (g.y == 1 || g.y == 2 || g.y == 4 || g.y == 8) && t % 8 == 0 && g.y > 1; };
     p.xcd_remap = remap_ok(grid) ? 1 : 0;
-    static const int pp_shift = [] { const char* e = getenv("E4S_MX_PP_SHIFT"); return e ? atoi(e) : 2; }();
-    p.pp_shift = pp_shift;
     if (plain_conv) {
         p.ksplit = 1;
         p.chunks_per = nchunk;

@@ -46,7 +46,6 @@ struct SbParams {
     const float* in_rstd;
     const float* slope;        // (plain-convolution mode) PReLU slopes [cout] or NULL
     int xcd_remap;             // (modconv_mx.hip) 1: workgroups are re-indexed so that each XCD (own L2) works on one co tile's weights
-    int pp_shift;      // (measurement) two-phase loop: group of wave w = (w >> pp_shift) & 1
     int* flags;                // (modconv_mx.hip, f16 arithmetic) flags[0] |= 1 when a modulated activation leaves the f16 range
     unsigned perm_mul;       // (with uni_blocks) workgroup i works on tile slot (i * perm_mul) % gridDim.x: consecutive workgroups go to the 8 XCDs
                              // round-robin, so a skip pattern with a period of 2 / 4 / 8 tiles would idle whole XCDs; a golden-ratio stride
