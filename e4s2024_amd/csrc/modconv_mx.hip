@@ -69,6 +69,16 @@ __device__ __forceinline__ void dma16_asm(const void* gbase, unsigned voff, unsi
                  : "memory");
 }
 
+// f16 pair of the split's residuals: lo = f16(xa * sa - a1.lo), hi = f16(xb * sb - a1.hi), each ONE v_fma_mix instruction (fp32 operands and an f16 addend, the
+// product not rounded before the subtraction).  Written out through the compiler the same pair is two conversions back to fp32, a packed subtraction and a packed
+// conversion — 6 instructions per two values where this is 4 with the product and a1 (hipcc 7.2 does not form the mix instructions from fma(fpext) here).
+__device__ __forceinline__ unsigned resid_pair_f16(float xa, float sa, float xb, float sb, unsigned a1) {
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(xa), "v"(sa), "v"(a1));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(r) : "v"(xb), "v"(sb), "v"(a1));
+    return r;
+}
+
 // "This value exists HERE": an empty asm that claims to rewrite the register(s).  The two-phase loop needs it — LLVM sinks pure conversions to their first
 // use, i.e. across the barrier into the phase that must hold nothing but MFMAs (and keeps their 32 source registers alive across it).
 template <typename T>
@@ -529,7 +539,7 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
                         const float a = xv[2 * j] * sv[2 * j], bq = xv[2 * j + 1] * sv[2 * j + 1];
                         const f16x2 a1 = __builtin_convertvector((f32x2){a, bq}, f16x2);
                         v1[t * 4 + j] = __builtin_bit_cast(unsigned, a1);
-                        v2[t * 4 + j] = pack_f16_rne(a - (float)a1[0], bq - (float)a1[1]);
+                        v2[t * 4 + j] = resid_pair_f16(xv[2 * j], sv[2 * j], xv[2 * j + 1], sv[2 * j + 1], v1[t * 4 + j]);
                         amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(bq)));
                     }
                     const uint4 b1 = make_uint4(v1[t * 4], v1[t * 4 + 1], v1[t * 4 + 2], v1[t * 4 + 3]);
