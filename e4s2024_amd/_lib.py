@@ -32,6 +32,9 @@ _PROTOS = {
     "e4s_region_modconv3x3_mx": [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr, c_int] + [c_int] * 7 + [c_ptr, c_i64] + [c_ptr] * 10,
     "e4s_conv_prep_weights_mx": [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
     "e4s_conv3x3_mx": [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr],
+    "e4s_conv3x3_mx3_weight_bytes": [c_int, c_int, c_ptr],
+    "e4s_conv_prep_weights_mx3": [c_ptr, c_ptr, c_int, c_int, c_ptr],
+    "e4s_conv3x3_mx3": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_uniform_blocks": [c_ptr, c_ptr, c_ptr, c_ptr] + [c_int] * 8 + [c_ptr],
     "e4s_masked_upconv_blocks": [c_ptr] * 11 + [c_int, c_ptr, c_ptr] + [c_int] * 8 + [c_ptr],
     "e4s_modconv_tconv_sb": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr],

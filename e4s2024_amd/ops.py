@@ -515,6 +515,14 @@ class PreparedMx(_Prepared):
             raise ValueError("the mx kernel is a 3x3 kernel")
         bk = _c(blur, "blur kernel") if up else None
         nbytes = ctypes.c_int64(0)
+        if arith == 3:            # the two-phase plain-convolution kernel's unit slots (csrc/conv_mx3.hip)
+            if not plain:
+                raise ValueError("arith 3 (conv_mx3) is a plain-convolution layout")
+            lib().call("e4s_conv3x3_mx3_weight_bytes", cout, cin, ctypes.byref(nbytes))
+            wmx = torch.empty((nbytes.value,), dtype=torch.uint8, device=w.device)
+            lib().call("e4s_conv_prep_weights_mx3", _p(wmx), _p(w), cout, cin, _stream())
+            self._publish(key, (wmx,))
+            return wmx
         lib().call("e4s_modconv_mx_weight_bytes", cout, cin, 1 if up else 0, arith, ctypes.byref(nbytes))
         wmx = torch.empty((nbytes.value,), dtype=torch.uint8, device=w.device)
         if plain:
@@ -1223,6 +1231,7 @@ def winograd_route(x: torch.Tensor, cin: int, stride: int):
     return "pre" if pre else "f32"
 
 
+MX3 = os.environ.get("E4S_MX3", "1") != "0"     # plain f16 + fp6 convolutions on the two-phase kernel (0: the one-phase kernel of modconv_mx.hip)
 MX_CONV_MIN_WORKGROUPS = 128       # (layers that can also take the Winograd route) below half a round of the chip Winograd / the direct kernel serve a launch better
 MX_CONV_MIN_WORKGROUPS_PER_IMAGE = 64
 
@@ -1245,7 +1254,8 @@ def mx_conv_eligible(x: torch.Tensor, cout: int) -> bool:
 
 
 def conv3x3_mx(x: torch.Tensor, wmx: torch.Tensor, arith: int, cout: int, *, in_norm=None, prelu: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``PReLU(conv3x3(norm(x), W))``, stride 1, pad 1, on ``e4s_conv3x3_mx`` (``wmx`` from ``PreparedMx.get`` of the plain weight)."""
+    """``PReLU(conv3x3(norm(x), W))``, stride 1, pad 1, on ``e4s_conv3x3_mx`` / ``e4s_conv3x3_mx3`` (``arith`` 3) (``wmx`` from ``PreparedMx.get`` of the
+    plain weight with the same ``arith``)."""
     x = _c(x, "input")
     bs, cin, h, w = x.shape
     out = torch.empty((bs, cout, h, w), dtype=torch.float32, device=x.device)
@@ -1253,8 +1263,11 @@ def conv3x3_mx(x: torch.Tensor, wmx: torch.Tensor, arith: int, cout: int, *, in_
     if in_norm is not None:
         mean, rstd = _c(in_norm[0], "in_mean"), _c(in_norm[1], "in_rstd")
     ev = _timed(f"conv3x3_mx<{arith}>", f"{cin}->{cout} @{h}")
-    lib().call("e4s_conv3x3_mx", _p(out), _p(x), _p(wmx), arith, _p(mx_flags(x.device)) if arith else None, _p(mean), _p(rstd),
-               _p(_c(prelu.detach(), "prelu")) if prelu is not None else None, bs, cin, cout, h, w, _stream())
+    pr = _p(_c(prelu.detach(), "prelu")) if prelu is not None else None
+    if arith == 3:
+        lib().call("e4s_conv3x3_mx3", _p(out), _p(x), _p(wmx), _p(mx_flags(x.device)), _p(mean), _p(rstd), pr, bs, cin, cout, h, w, _stream())
+    else:
+        lib().call("e4s_conv3x3_mx", _p(out), _p(x), _p(wmx), arith, _p(mx_flags(x.device)) if arith else None, _p(mean), _p(rstd), pr, bs, cin, cout, h, w, _stream())
     if ev is not None:
         ev.record()
     return out
@@ -1271,6 +1284,8 @@ def conv3x3_s1(x: torch.Tensor, weight: torch.Tensor, caches, *, in_norm=None, p
         return conv2d_winograd(x, caches[1].get(weight), in_norm=in_norm, prelu=prelu)
     if len(caches) > 3 and mx_conv_eligible(x, weight.shape[0]):
         arith = mx_arith()
+        if arith == 1 and MX3 and x.shape[1] % 32 == 0 and x.shape[1] <= 512:
+            arith = 3             # same arithmetic, the two-phase kernel (csrc/conv_mx3.hip)
         return conv3x3_mx(x, caches[3].get(weight, None, False, arith), arith, weight.shape[0], in_norm=in_norm, prelu=prelu)
     return conv2d(x, caches[0].get(weight), 1, 1, in_norm=in_norm, prelu=prelu)
 

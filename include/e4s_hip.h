@@ -161,6 +161,15 @@ E4S_API int e4s_region_modconv3x3_mx(float* out, const float* x, const void* wmx
 E4S_API int e4s_conv_prep_weights_mx(void* dst, const float* weight, int cout, int cin, int arith, void* stream);
 E4S_API int e4s_conv3x3_mx(float* out, const float* x, const void* wmx, int arith, int* flags, const float* in_mean, const float* in_rstd,
                            const float* prelu_slope, int bs, int cin, int cout, int h, int w, void* stream);
+
+/* The same operator (f16 + 2 x MX fp6 only) on the two-phase kernel of csrc/conv_mx3.hip: 32-channel chunks (cin % 32 == 0, cin <= 512), activations converted
+ * to fp6 once per staged value, waves 4-7 half a unit behind waves 0-3 so that every SIMD always has a wave on the matrix pipe.  Replaces the same reference
+ * statements (models/encoders/helpers.py:128-139).  wmx3 from e4s_conv_prep_weights_mx3 (weight [cout,cin,3,3]; size: e4s_conv3x3_mx3_weight_bytes);
+ * flags[0] bit 0 is raised when a normalised activation leaves the f16 range. */
+E4S_API int e4s_conv3x3_mx3_weight_bytes(int cout, int cin, int64_t* bytes);
+E4S_API int e4s_conv_prep_weights_mx3(void* dst, const float* weight, int cout, int cin, void* stream);
+E4S_API int e4s_conv3x3_mx3(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
+                            int bs, int cin, int cout, int h, int w, void* stream);
 /* Masked up-sampling layers, region-uniform output blocks (model.py:287-300 per region == one transposed conv + blur where a block of output
  * pixels has ONE region):
  *   e4s_uniform_blocks: sub[b][2by+sy][2bx+sx] = the region of an 8 x 8 output sub-block (labels uint8 [bs][lh][lw] sampled 'nearest' at

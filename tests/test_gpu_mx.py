@@ -152,6 +152,57 @@ def test_conv3x3_mx_against_fp64_and_the_direct_kernel(shape, norm_prelu):
     assert not ops.mx_overflowed()
 
 
+#              bs cin cout  h   w        (cin % 32 == 0; ragged maps, an output-channel tail, one chunk / several, a map smaller than a tile)
+CONV3_SHAPES = [(16, 64, 128, 32, 32), (2, 32, 136, 40, 36), (4, 128, 256, 64, 64), (1, 96, 128, 7, 45), (3, 512, 512, 32, 32)]
+
+
+@pytest.mark.parametrize("shape", CONV3_SHAPES)
+@pytest.mark.parametrize("norm_prelu", [True, False])
+def test_conv3x3_mx3_against_fp64_and_the_direct_kernel(shape, norm_prelu):
+    """``e4s_conv3x3_mx3`` — the same operator and arithmetic as ``e4s_conv3x3_mx`` (f16 + 2 x MX fp6; helpers.py:128-139) on the two-phase kernel with
+    32-channel chunks and activations converted once per staged value — against float64 and against the direct split-bf16 kernel."""
+    bs, cin, cout, h, w = shape
+    g = torch.Generator().manual_seed(11 * cin + h)
+    x = torch.randn(bs, cin, h, w, generator=g) * 2.0 + 0.5
+    wgt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9.0)
+    slope = torch.rand(cout, generator=g) * 0.5
+    xd, wd = x.to(DEV), wgt.to(DEV)
+    mean = rstd = None
+    xn = x.double()
+    if norm_prelu:
+        mean = x.mean((2, 3))
+        rstd = 1.0 / torch.sqrt(x.var((2, 3), unbiased=False) + 1e-5)
+        xn = (x.double() - mean.double()[:, :, None, None]) * rstd.double()[:, :, None, None]
+    ref = torch.nn.functional.conv2d(xn, wgt.double(), padding=1)
+    if norm_prelu:
+        ref = torch.where(ref > 0, ref, ref * slope.double()[None, :, None, None])
+    scale = float(ref.abs().max())
+    in_norm = (mean.to(DEV), rstd.to(DEV)) if norm_prelu else None
+    pr = slope.to(DEV) if norm_prelu else None
+    with torch.no_grad():
+        y_dir = ops.conv2d(xd, ops.PreparedConv().get(wd), 1, 1, in_norm=in_norm, prelu=pr).cpu()
+        w3 = ops.PreparedMx().get(wd, None, False, 3)
+        y3 = ops.conv3x3_mx(xd, w3, 3, cout, in_norm=in_norm, prelu=pr).cpu()
+        y3b = ops.conv3x3_mx(xd, w3, 3, cout, in_norm=in_norm, prelu=pr).cpu()
+    e3 = float((y3.double() - ref).abs().max()) / scale
+    record_parity(f"conv3x3_mx3_{cin}to{cout}_{h}x{w}_{'norm_prelu' if norm_prelu else 'plain'}", e3, MX_LAYER_TOL,
+                  note=f"two-phase kernel, f16 + 2 x MX fp6 against float64, relative to the output scale; direct kernel {float((y_dir.double() - ref).abs().max()) / scale:.2e}")
+    assert e3 <= MX_LAYER_TOL, (shape, e3)
+    assert torch.equal(y3, y3b)                        # run-to-run identical (no race between the wave groups, the DMA ring and the single patch buffer)
+    assert not ops.mx_overflowed()
+
+
+def test_conv3x3_mx3_raises_the_overflow_flag():
+    """A normalised activation beyond the f16 range raises ``flags[0]`` (the result is then not to be used), as in the one-phase kernel."""
+    x = torch.randn(1, 32, 16, 32, device=DEV)
+    x[0, 3, 5, 7] = 1.0e5
+    wgt = torch.randn(128, 32, 3, 3, device=DEV) * 0.05
+    with torch.no_grad():
+        ops.conv3x3_mx(x, ops.PreparedMx().get(wgt, None, False, 3), 3, 128)
+    assert ops.mx_overflowed()
+    assert not ops.mx_overflowed()
+
+
 def test_encoder_at_batch_16_takes_the_mx_route_and_matches_the_direct_route(mx_mode):
     """``FSEncoder_PSP`` on 16 images (what a batch-8 swap feeds it): its stride-1 3x3 convolutions with >= 128 output channels run on
     ``e4s_conv3x3_mx``; the style vectors must equal the all-direct route's (E4S_MX=0) within the encoder's parity bar."""
