@@ -182,12 +182,14 @@ __global__ __launch_bounds__(256) void se_gate_kernel(float* __restrict__ gate, 
         float a[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) a[q] = 0.f;
+#pragma unroll 4
         for (int i = lane; i < C; i += 64) {
             const float xv = xr[i];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int j = j0 + 4 * q;
-                if (j < H) a[q] += W1[(size_t)j * C + i] * xv;
+                const float wv = W1[(size_t)(j < H ? j : H - 1) * C + i];      // (unconditional load: no branch between the requests)
+                if (j < H) a[q] += wv * xv;
             }
         }
 #pragma unroll
