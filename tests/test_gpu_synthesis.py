@@ -100,6 +100,27 @@ def test_g5_small_generators(sg2, manifest, tag, man):
     assert maxdiff(f[:: max(1, f.numel() // 4096)], g[tag + ".feats_sample"]) <= 5e-4
 
 
+def test_generator512_default_settings_vs_oracle(sg2):
+    """A size-512 generator (its last stage is 64 -> 64 @512 AND the last layer: the split-plane chain must stop one stage earlier there — the round-2
+    advisor's crash) under the default settings against the oracle's twelve-pass forward (models/stylegan2/model.py:607-698)."""
+    size, rli, ncls, bs = 512, 13, 12, 1
+    gen = sg2.Generator(size, 512, 8, split_layer_idx=5, remaining_layer_idx=rli)
+    seeded.apply_seeded(gen, 21, "net3", prefix="G.")
+    sd = {"G." + k: v.clone() for k, v in gen.state_dict().items()}
+    n_latent = int(np.log2(size)) * 2 - 2
+    lab = seeded.blocky_labels(31, bs, ncls, 512, cells=16)
+    codes = seeded.seeded_codes(23, bs, ncls, n_latent, seeded.seeded_latent_avg(2, n_latent))
+    mask = seeded.labels_to_onehot(lab, ncls)
+    ref, _ = O.generator_forward(sd, codes, mask, None, size=size, remaining_layer_idx=rli, split_layer_idx=5)
+    gen = gen.to(DEV).eval()
+    with torch.no_grad():
+        img, _, _ = gen([codes.to(DEV)], None, mask.to(DEV), input_is_latent=True, randomize_noise=False)
+    assert tuple(img.shape) == (bs, 3, size, size)
+    d = maxdiff(img, ref)
+    record_parity(f"generator512.pixels_vs_oracle[{_ops.MODCONV_MODE}]", d, 1e-3)
+    assert d <= 1e-3
+
+
 def _config2_inputs(bs, seed_labels=3, iid=False):
     la = seeded.seeded_latent_avg(2, 18)
     codes = seeded.seeded_codes(1, bs, 12, 18, la)
