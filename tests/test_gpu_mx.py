@@ -192,6 +192,40 @@ def test_conv3x3_mx3_against_fp64_and_the_direct_kernel(shape, norm_prelu):
     assert not ops.mx_overflowed()
 
 
+def test_conv3x3_mx3_is_bit_stable_beside_another_stream():
+    """The two-phase kernel counts its own vector-memory requests (weight DMA and activation prefetch are issued from asm, its ``vmcnt`` waits leave the younger
+    ones in flight): a miscount would show as a changing value when memory gets slower — with another stream's kernels beside it.  Bounded (~8 s): the
+    512 -> 512 @32^2 x 16 launch on one stream, a stream of 256 -> 256 @64^2 launches of the same kernel and of the direct kernel on the other."""
+    import time
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(16, 512, 32, 32, device=DEV, generator=g)
+    w = torch.randn(512, 512, 3, 3, device=DEV, generator=g) * 0.02
+    x2 = torch.randn(8, 256, 64, 64, device=DEV, generator=g)
+    w2 = torch.randn(256, 256, 3, 3, device=DEV, generator=g) * 0.03
+    mean, rstd = x.mean((2, 3)), 1.0 / torch.sqrt(x.var((2, 3), unbiased=False) + 1e-5)
+    with torch.no_grad():
+        w3, w23, pc2 = ops.PreparedMx().get(w, None, False, 3), ops.PreparedMx().get(w2, None, False, 3), ops.PreparedConv().get(w2)
+        ref = ops.conv3x3_mx(x, w3, 3, 512, in_norm=(mean, rstd)).clone()
+        ref2 = ops.conv3x3_mx(x2, w23, 3, 256).clone()
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        t0, rounds, bad = time.time(), 0, 0
+        while time.time() - t0 < 6.0 and rounds < 400:
+            with torch.cuda.stream(s1):
+                outs = [ops.conv3x3_mx(x, w3, 3, 512, in_norm=(mean, rstd)) for _ in range(6)]
+            with torch.cuda.stream(s2):
+                outs2 = []
+                for _ in range(4):
+                    outs2.append(ops.conv3x3_mx(x2, w23, 3, 256))
+                    ops.conv2d(x2, pc2, 1, 1)
+            torch.cuda.synchronize()
+            bad += sum(not torch.equal(o, ref) for o in outs) + sum(not torch.equal(o, ref2) for o in outs2)
+            rounds += 1
+    record_parity("conv3x3_mx3.two_stream_mismatches", bad, 0, note=f"{rounds} rounds of 6 + 4 launches")
+    assert rounds >= 5 and bad == 0
+    assert not ops.mx_overflowed()
+
+
 def test_conv3x3_mx3_raises_the_overflow_flag():
     """A normalised activation beyond the f16 range raises ``flags[0]`` (the result is then not to be used), as in the one-phase kernel."""
     x = torch.randn(1, 32, 16, 32, device=DEV)
