@@ -388,7 +388,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
             }
             // vector-memory requests behind the LDS reads (they issue while the LDS data returns): the refill of the slot the previous unit left — both groups
             // have read it: waves 0-3 are two barriers past their read of it, waves 4-7 one barrier past theirs, which was the later one — then the prefetch
+#ifndef MX3_NODMA     // (tuning builds: -DMX3_NODMA leaves the in-loop refills out — results are then meaningless; measured: their issue costs 7 % of the kernel)
             if (g >= 1 && g + 2 < nunits) dma_unit(g + 2, slot == 0 ? 2 : slot - 1);
+#endif
             // which requests are younger than the refill that must have landed (the one of the previous read phase): this phase's refill and, in a chunk's first
             // unit, the prefetch requested in the store phase between the two
             const bool d_younger = g + 2 < nunits;
