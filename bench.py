@@ -49,6 +49,8 @@ def mfma_cost_per_product(kernel: str) -> float:
     24 products of a kernel row x 8 channels (8 slots idle): 1 + 2 * (1/4) * (32/24) = 1.667."""
     if kernel.startswith("region_modconv_mx_kernel<1"):
         return 1.0 + 2.0 * 0.25 * 32.0 / 24.0
+    if kernel.startswith("conv3x3_mx3"):      # csrc/conv_mx3.hip: the fp6 MFMAs' K = 64 holds two taps x 32 channels, nine of a chunk's ten tap slots are used
+        return 1.0 + 2.0 * 0.25 * 10.0 / 9.0
     return 3.0
 
 
@@ -402,10 +404,11 @@ def main():
         total_gf = sum(gf.values())
         # bf16-MFMA multiply-adds of matrix-pipe time per algorithmic multiply-add, part by part: the parser's fp32-class convolutions 3 (two-term
         # f16 split; 6 with the three-way bf16 split, 16 exact), the encoder 3 (split-bf16) or — its stride-1 3x3 convolutions with >= 128 output channels, 90 %
-        # of its FLOPs, on the mx kernel at this batch — 1.667, the synthesis as in the headline's whole-job figure
+        # of its FLOPs, on the mx kernels at this batch — 1.556 (two-phase kernel) / 1.667, the synthesis as in the headline's whole-job figure
         mx = ops.mx_arith() == 1
         parser_cost = {"f16x3": 3.0, "sb3": 6.0, True: 16.0, False: 3.0}.get(ops.PARSER_EXACT, 3.0)
-        enc_cost = (0.9 * mfma_cost_per_product("region_modconv_mx_kernel<1>") + 0.1 * 3.0) if (mx and ops.CONV_MODE == "sb") else 3.0
+        enc_mx = "conv3x3_mx3_kernel" if getattr(ops, "MX3", False) else "region_modconv_mx_kernel<1>"     # (all of these layers have cin % 32 == 0)
+        enc_cost = (0.9 * mfma_cost_per_product(enc_mx) + 0.1 * 3.0) if (mx and ops.CONV_MODE == "sb") else 3.0
         fl_s = conv3x3_flops_per_face()
         syn_cost = sum(fl_s[k] * mfma_cost_per_product(k) for k in fl_s) / sum(fl_s.values())
         mfma_per_product = (gf["parser"] * parser_cost + gf["encoder"] * enc_cost + gf["mlps"] * 3.0 + gf["synthesis"] * syn_cost) / total_gf
