@@ -404,6 +404,16 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
         const int cur = (chunk - ch_begin) & 1;
         const bool more = chunk + 1 < ch_end;
         if (more) load_x(chunk + 1);                       // lands during this chunk (row 0's wait), written to the other patch buffer before its last barrier
+        // (masked f16 + fp6 loop) the refill of the ring slot the previous row left is requested behind the row's first MFMAs instead of right behind the barrier:
+        // a request stalls the issuing in-order wave on the CU's address unit (~30 cycles per 1 KB request: conv_mx3.hip's stamps), and in front of the row's
+        // LDS reads that stall delayed the operands of all of its MFMAs
+        auto deferred_refill = [&](int row) __attribute__((always_inline)) {
+            if (row == 0) {
+                if (chunk > ch_begin) dma_row(chunk, 2);
+            } else if (more) {
+                dma_row(chunk + 1, row - 1);
+            }
+        };
 
         const float4* xf4 = reinterpret_cast<const float4*>(lds_raw + L::PATCH0 + cur * MX_PATCHB);
         const float* ss = reinterpret_cast<const float*>(lds_raw + L::SS0 + cur * MX_SSB);
@@ -546,6 +556,7 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wv[t][i]), __builtin_bit_cast(f16x8, b1), acc[i][0], 0, 0, 0);
+                    if (t == 0) deferred_refill(row);
                 }
                 // block scales of this lane's 24 values: 2^(E - 2) for fp6(a1), 2^(E - 13) for fp6(a - a1)  (|a - a1| <= 2^(E - 11));  E >= 16 leaves f16
                 ex = (__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu;
@@ -583,7 +594,7 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
             if constexpr (!(ENC && (MX_ABL & 4))) {
                 E4S_WAIT_VM(0);
                 E4S_LDS_BARRIER();
-                if (more) dma_row(chunk + 1, row);
+                if constexpr (ARITH == 0 || ENC) { if (more) dma_row(chunk + 1, row); }
             }
 
         }
