@@ -9,13 +9,18 @@
 //     phase is 36 LDS reads in a single round.  (The one-phase kernel converted per wave and tap row: 1 550 - 2 450 cycles of reads + conversions per 810 of MFMA.)
 // K structure: chunk = 32 input channels; unit u = 0..4 of a chunk = taps 2u, 2u + 1 (tap 9 does not exist: zero weights): 16 f16 MFMAs (2 taps x 2 K-steps x
 // 2 x 2 blocks) + 8 fp6 MFMAs (K = 64 = the two taps' 32 channels, x 2 terms x 2 x 2 blocks) per wave and unit.
-// LDS (134 016 B, one workgroup per CU): ring of three UNIT slots refilled by LDS-DMA from inline asm (29 696 B each), ONE patch buffer (40 832 B: a store phase
-// between chunks costs a barrier pair; two buffers do not fit beside a three-slot ring, and a two-slot ring leaves the DMA one unit of cover), norm table.
+// LDS (134 016 B, one workgroup per CU): ONE patch buffer (40 832 B: between two chunks nobody reads while both wave groups convert the next chunk's patch —
+// ~4 000 of a chunk's ~17 000 cycles; two buffers do not fit beside a three-slot ring, and a two-slot ring leaves the DMA one unit of cover), the instance-norm
+// table as (rstd, -mean rstd), a ring of three UNIT slots refilled by LDS-DMA from inline asm (29 696 B each).
 //   unit slot: f16 w1 [tap 2][K-step 2][k half 2][co 128] x 16 B | fp6 codes, first 16 B [term 2][k half 2][co 128] | last 8 B [term][half][co] |
 //              E8M0 scales [half 2][co 128] x 4 B (byte 0: fp6(w1), byte 1: fp6(w - w1); k half = tap 2u / 2u + 1, its 32 channels in order)
 //   patch:     a1 f16 [16-B slot 4][pixel 352] (slot s = channels 8 s .. 8 s + 7) | codes first 16 B [term 2][pixel] | last 8 B [term][pixel] | scales [pixel] x 4 B
 // Every vector-memory request inside the loop is issued from inline asm (weight DMA and the next chunk's activation loads), so hipcc counts none of them and
-// the counted vmcnt waits below are exact; the activation loads' destination registers are first read in the store phase, behind such a wait.
+// the counted vmcnt waits below are exact; the activation loads' destination registers are first read in the store phase, behind such a wait, and the loads
+// have ONE call site (their results are asm outputs: a merge of two call sites' registers would copy them before the data has landed).
+// Measured (16 images, in-run against e4s_conv3x3_mx): 512 -> 512 @32^2 0.1776 -> 0.1498 ms (516 algorithmic TFLOP/s), 256 -> 256 @64^2 0.184 -> 0.163;
+// cycle stamps (-DMX3_PROF): read phase 1 000 - 1 150 cycles (550 of LDS reads + the wave's share of the refill requests: the CU's address unit takes ~30
+// cycles per 1 KB request and stalls the issuing wave), MFMA phase 870; without the in-loop refills (-DMX3_NODMA) the kernel takes 0.134 ms.
 #include <stdlib.h>
 
 #include "common.h"
