@@ -34,6 +34,7 @@ OVERRIDES = {
     "models.stylegan2.op": "models/stylegan2/op/__init__.py",
     "models.stylegan2.op.fused_act": "models/stylegan2/op/fused_act.py",
     "models.stylegan2.op.upfirdn2d": "models/stylegan2/op/upfirdn2d.py",
+    "models.stylegan2.op.conv2d_gradfix": "models/stylegan2/op/conv2d_gradfix.py",
     "models.encoders.psp_encoders": "models/encoders/psp_encoders.py",
     "swap_face_fine.face_parsing.model": "swap_face_fine/face_parsing/model.py",
     "swap_face_fine.face_parsing.resnet": "swap_face_fine/face_parsing/resnet.py",

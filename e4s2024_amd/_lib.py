@@ -87,6 +87,8 @@ _PROTOS = {
     "e4s_to_split_planes": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_chain_conv3x3": [c_ptr, c_ptr],
     "e4s_chain_upconv": [c_ptr, c_ptr, c_ptr],
+    "e4s_modconv_prep_weights_hc": [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr],
+    "e4s_modconv_up_hc": [c_ptr] * 7 + [c_int, c_ptr, c_ptr, c_int] + [c_int] * 5 + [c_ptr, c_ptr],
     "e4s_small_map": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_i64, c_int, c_int, c_ptr],
     "e4s_grouped_linear_bwd": [c_ptr] * 8 + [c_f32, c_f32, c_f32] + [c_int] * 5 + [c_ptr],
     "e4s_grouped_linear": [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_int, c_f32] + [c_int] * 4 + [c_ptr],

@@ -56,18 +56,9 @@ __device__ __forceinline__ unsigned pack_f16_rne(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, f16x2));      // v_cvt_pk_f16_f32
 }
 
-// LDS-DMA issued from inline asm: 16 bytes per lane from (scalar base + 32-bit lane offset) to LDS address `lds_dst` + 16 * lane.  Through the builtin
-// hipcc 7.2 treats the DMA as a store to LDS that every later ds_read may alias and puts `s_waitcnt vmcnt(0)` in front of the next LDS read — the row
-// just requested would have to land before the NEXT row's first operand read, i.e. the whole L2 latency exposed once per kernel row.  From asm the
-// compiler neither orders LDS reads behind it nor counts it: the kernel waits (E4S_WAIT_VM(0)) before each barrier itself, and hipcc's own counted
-// waits for the ordinary loads of the activation patch only become longer, never shorter, by uncounted requests (vmcnt retires in order).
-__device__ __forceinline__ void dma16_asm(const void* gbase, unsigned voff, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(gbase), "s"(lds_dst)
-                 : "memory");
-}
+// (LDS-DMA is issued from inline asm — dma16_asm, sb_common.h: through the builtin hipcc puts `s_waitcnt vmcnt(0)` in front of the next LDS read, i.e. the row just
+// requested would have to land before the NEXT row's first operand read; hipcc's own counted waits for the ordinary loads of the activation patch only become longer,
+// never shorter, by uncounted requests: vmcnt retires in order.)
 
 // f16 pair of the split's residuals: lo = f16(xa * sa - a1.lo), hi = f16(xb * sb - a1.hi), each ONE v_fma_mix instruction (fp32 operands and an f16 addend, the
 // product not rounded before the subtraction).  Written out through the compiler the same pair is two conversions back to fp32, a packed subtraction and a packed

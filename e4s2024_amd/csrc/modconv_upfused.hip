@@ -366,7 +366,6 @@ __global__ __launch_bounds__(UF_NT, 4) void up_fused_dma_kernel(const UpFusedPar
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint4* lds4 = reinterpret_cast<uint4*>(lds_raw);
     float* epw = reinterpret_cast<float*>(lds_raw + UD_BODY);
-    lds_byte* const lds_b = (lds_byte*)lds_raw;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -397,12 +396,15 @@ __global__ __launch_bounds__(UF_NT, 4) void up_fused_dma_kernel(const UpFusedPar
         xoffs[k] = (unsigned)((combo >> 1) * p.plane_in) + (unsigned)((b * cb8 + (combo & 1)) * hw + gy * p.w + gx);
         xdst[k] = (unsigned)((combo * UF_PATCH + j * 64) * 16);
     }
+    // Every request goes out from inline asm (dma16_asm / dma4_asm, sb_common.h): issued through the builtin, hipcc put `s_waitcnt vmcnt(0)` in front of the
+    // loop's first LDS read — chunk c + 1 had to land before chunk c's MFMAs could start, one exposed memory round trip per chunk (rounds 2-3: K loop
+    // 10 us per workgroup for ~3 us of MFMA).  The kernel's own counted wait (E4S_WAIT_VM(UD_G)) is now the only one.
     auto issue = [&](int c) __attribute__((always_inline)) {
         const unsigned st = (unsigned)(c & 1) * (unsigned)(UD_STAGE4 * 16);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int e = ((wave + 8 * k < 20 ? wave + 8 * k : 19) % 5) * 64 + lane;
-            if (e < UF_PATCH) dma16(p.x, xin[k] ? (xoffs[k] + (unsigned)(2 * c * hw)) * 16u : zero_off, lds_b + st + xdst[k]);
+            if (e < UF_PATCH) dma16_asm(p.x, xin[k] ? (xoffs[k] + (unsigned)(2 * c * hw)) * 16u : zero_off, st + xdst[k]);
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(UF_NT, 4) void up_fused_dma_kernel(const UpFusedPar
             piece = piece < 18 ? piece : 17;
             const int hl = piece / 9;                                            // 18 x 32 uint4 = 9 pieces per slab
             const int rem = piece * 64 - hl * 576 + lane;                        // [tap][half][32] index
-            dma16(hl ? p.wlo : p.whi, (unsigned)((((c * 18 + (rem >> 5)) * p.cout) + co0 + (rem & 31)) * 16), lds_b + st + (UD_XS4 + piece * 64) * 16);
+            dma16_asm(hl ? p.wlo : p.whi, (unsigned)((((c * 18 + (rem >> 5)) * p.cout) + co0 + (rem & 31)) * 16), st + (unsigned)((UD_XS4 + piece * 64) * 16));
         }
     };
     // ---- epilogue operands by DMA as well: noise tile (13 pieces: 2 per wave), d / s_next / bias of the 32 channels (every wave, same bytes)
@@ -423,13 +425,15 @@ __global__ __launch_bounds__(UF_NT, 4) void up_fused_dma_kernel(const UpFusedPar
             const int ry = e / UF_OUT, rx = e - ry * UF_OUT;
             const int ny = tyt * UF_OUT + ry, nx = txt * UF_OUT + rx;
             const bool ok = p.noise && e < UF_OUT * UF_OUT && ny < ho && nx < wo;
-            if (ok) dma4(p.noise, (unsigned)((b * p.noise_bstride + ny * wo + nx) * 4), lds_b + UD_BODY + (UD_EP_N + piece * 64) * 4);
-            else dma4(p.zeros, 0u, lds_b + UD_BODY + (UD_EP_N + piece * 64) * 4);
+            // (two exec-masked requests, together they fill the piece; a wave may skip one entirely — that only lowers the number of OLDER requests in flight,
+            //  which a counted vmcnt wait tolerates)
+            if (ok) dma4_asm(p.noise, (unsigned)((b * p.noise_bstride + ny * wo + nx) * 4), (unsigned)(UD_BODY + (UD_EP_N + piece * 64) * 4));
+            else dma4_asm(p.zeros, 0u, (unsigned)(UD_BODY + (UD_EP_N + piece * 64) * 4));
         }
         const unsigned co4 = (unsigned)((co0 + l5) * 4);
-        dma4(p.d, (unsigned)(b * p.cout * 4) + co4, lds_b + UD_BODY + UD_EP_D * 4);
-        dma4(p.s_next, (unsigned)(b * p.cout * 4) + co4, lds_b + UD_BODY + UD_EP_S * 4);
-        dma4(p.act_bias ? p.act_bias : p.zeros, p.act_bias ? co4 : 0u, lds_b + UD_BODY + UD_EP_B * 4);
+        dma4_asm(p.d, (unsigned)(b * p.cout * 4) + co4, (unsigned)(UD_BODY + UD_EP_D * 4));
+        dma4_asm(p.s_next, (unsigned)(b * p.cout * 4) + co4, (unsigned)(UD_BODY + UD_EP_S * 4));
+        dma4_asm(p.act_bias ? p.act_bias : p.zeros, p.act_bias ? co4 : 0u, (unsigned)(UD_BODY + UD_EP_B * 4));
     }
     issue(0);
     if (nchunk > 1) issue(1);

@@ -34,6 +34,24 @@ __device__ __forceinline__ void dma16(const void* gbase, unsigned voff, lds_byte
 __device__ __forceinline__ void dma4(const void* gbase, unsigned voff, lds_byte* dst) {
     __builtin_amdgcn_global_load_lds((gl_byte*)gbase + voff, dst, 4, 0, 0);
 }
+// The same requests issued from inline asm.  Through the builtin hipcc 7.2 treats an LDS-DMA as a store every later ds_read may alias and puts
+// `s_waitcnt vmcnt(0)` in front of the next LDS read: a ring of stages then degenerates (the chunk just requested has to land before the CURRENT
+// chunk's operands are read — up_fused_dma_kernel's K loop ran that way through round 3).  From asm the compiler neither orders LDS reads behind
+// the request nor counts it; the kernel waits by itself (E4S_WAIT_VM + E4S_LDS_BARRIER).  `lds_dst` must be wave-uniform (it goes to M0).
+__device__ __forceinline__ void dma16_asm(const void* gbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(gbase), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ void dma4_asm(const void* gbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(gbase), "s"(lds_dst)
+                 : "memory");
+}
 // s_waitcnt vmcnt(n) with a literal n, and a workgroup barrier that leaves LDS-DMA in flight (a __syncthreads() would drain it: its fence waits
 // vmcnt(0) while a DMA is pending)
 #define E4S_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")

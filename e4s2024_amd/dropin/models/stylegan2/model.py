@@ -135,6 +135,7 @@ class ModulatedConv2d(nn.Module):
         self._prepared = ops.PreparedWeights()
         self._prepared_tconv = ops.PreparedWeights()
         self._prepared_mx = ops.PreparedMx()
+        self._prepared_hc = ops.PreparedHc()
 
     def __repr__(self):
         return (f"{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, "
@@ -182,7 +183,8 @@ class ModulatedConv2d(nn.Module):
                 raise ValueError("split-plane input is built for the single-region 3x3 layers")
             wt, s, d = self.tables(styles, masked=False)
             if self.upsample:
-                return ops.modconv_up_single(input, wt, s, d, self.blur.kernel, noise, noise_weight, act_bias, act, self.out_channel, s_next=s_next)
+                hc = self._prepared_hc.get(self.weight, self.blur.kernel) if d is not None else None      # half-composed form (csrc/modconv_uphc.hip)
+                return ops.modconv_up_single(input, wt, s, d, self.blur.kernel, noise, noise_weight, act_bias, act, self.out_channel, s_next=s_next, hc=hc)
             out_sp, rgb_img = ops.chain_conv3x3(input, wt, d, noise, noise_weight, act_bias, act, self.out_channel, s_next=s_next, rgb=rgb)
             return out_sp if rgb is None else (out_sp, rgb_img)
         if self._two_stage(labels is not None):

@@ -553,16 +553,67 @@ def mx_overflowed(reset: bool = True) -> bool:
     return bool(v & 1)
 
 
+# The chain's up layers in the half-composed form (csrc/modconv_uphc.hip): vertical blur factor composed into the weights, horizontal factor applied to the
+# MFMA accumulators in registers.  Needs a rank-1 blur kernel (the reference's always is: outer([1,3,3,1]), model.py:23-31); anything else keeps the fused kernel.
+UP_HC = os.environ.get("E4S_UP_HC", "1") != "0"
+_blur_rank1 = {}
+
+
+def blur_is_rank1(blur: torch.Tensor) -> bool:
+    """Is the 4 x 4 blur kernel an outer product (to fp32 rounding)?  One device -> host copy per kernel tensor version, then cached."""
+    key = (blur.data_ptr(), blur._version, blur.device)
+    hit = _blur_rank1.get(key)
+    if hit is None:
+        k = blur.detach().double().cpu()
+        tot = float(k.sum())
+        ok = tuple(k.shape) == (4, 4) and tot > 0
+        if ok:
+            outer = k.sum(1, keepdim=True) * k.sum(0, keepdim=True) / tot
+            ok = bool((outer - k).abs().max() <= 1e-6 * k.abs().max())
+        if len(_blur_rank1) > 64:
+            _blur_rank1.clear()
+        hit = _blur_rank1[key] = ok
+    return hit
+
+
+class PreparedHc(_Prepared):
+    """Half-composed weight slabs of a single-region up layer (``e4s_modconv_prep_weights_hc``): ``(whi, wlo)`` int16
+    ``[2, cin/16, 9, 2, cout, 8]``, or None when the route does not apply (switch off, exact-fp32 mode, blur kernel not rank 1, channel counts)."""
+
+    __slots__ = ()
+
+    def get(self, weight: torch.Tensor, blur: torch.Tensor):
+        if not (UP_HC and MODCONV_MODE == "sb"):         # (the only caller is the split-plane chain, an inference route: the copy is always cacheable)
+            return None
+        _, cout, cin, k, _ = weight.shape
+        if k != 3 or cin % 16 or cout % 32 or torch.cuda.is_current_stream_capturing() and (blur.data_ptr(), blur._version, blur.device) not in _blur_rank1:
+            return None
+        if not blur_is_rank1(blur):
+            return None
+        key = (weight.data_ptr(), weight._version, weight.device, blur.data_ptr(), blur._version)
+        hit = self._lookup(key)
+        if hit is not None:
+            return hit[0]
+        w = _c(weight.detach(), "weight")
+        shape = (2, cin // 16, 9, 2, cout, 8)
+        whi = torch.empty(shape, dtype=torch.int16, device=w.device)
+        wlo = torch.empty(shape, dtype=torch.int16, device=w.device)
+        lib().call("e4s_modconv_prep_weights_hc", _p(whi), _p(wlo), _p(w), _p(_c(blur, "blur kernel")), cout, cin, _stream())
+        self._publish(key, ((whi, wlo),))
+        return (whi, wlo)
+
+
 UP_FUSED = os.environ.get("E4S_UP_FUSED", "1") != "0"     # single-region up layers: one launch (blur in LDS) instead of tconv + blur epilogue
 UP_TWO_STAGE = os.environ.get("E4S_UP_TWO_STAGE", "1") != "0"
 
 
 def modconv_up_single(x, wt, s, d, blur, noise, noise_weight, act_bias, act: bool, cout: int, x_nhwc: bool = False, out_nhwc: bool = False,
-                      s_next=None) -> torch.Tensor:
+                      s_next=None, hc=None) -> torch.Tensor:
     """Single-region up layer: transposed conv (1x MACs) into a pre-blur buffer, then blur + demod + noise + bias + act.
     ``x_nhwc`` / ``out_nhwc``: channel-blocked activations ``[bs, c/8, h, w, 8]`` (fused kernel only).
     ``s_next [bs, 1, cout]``: the chain form — ``x`` is split planes ``[2, bs, cin/8, h, w, 8]`` (already carrying this layer's modulation)
-    and the result is written as split planes modulated for the next layer (csrc/modconv_chain.hip)."""
+    and the result is written as split planes modulated for the next layer (csrc/modconv_chain.hip); ``hc`` = ``PreparedHc.get(...)``: the
+    half-composed slabs — the layer then runs on csrc/modconv_uphc.hip (``d`` must be given)."""
     if s_next is not None:
         _req(x, "x_sp", torch.int16)
         if x.dim() != 6 or x.shape[0] != 2 or x.shape[-1] != 8 or not x.is_contiguous() or not UP_FUSED:
@@ -577,9 +628,14 @@ def modconv_up_single(x, wt, s, d, blur, noise, noise_weight, act_bias, act: boo
             nbs = nz.shape[0]
             if nz.numel() != nbs * 4 * h * w:
                 raise ValueError(f"noise shape {tuple(nz.shape)} does not match output {2 * h}x{2 * w}")
-        ev = _timed("modconv_up_fused_sb")
-        lib().call("e4s_modconv_up_fused_sb", _p(out), _p(x), _p(wt[0]), _p(wt[1]), _p(s), _p(d), _p(_c(blur, "blur kernel")), _p(nz), nbs or 0,
-                   _p(noise_weight) if nz is not None else None, _p(act_bias), (1 if act else 0) | 8 | 16, bs, cin, cout, h, w, _p(sn), _stream())
+        if hc is not None:
+            ev = _timed("modconv_up_hc")
+            lib().call("e4s_modconv_up_hc", _p(out), _p(x), _p(hc[0]), _p(hc[1]), _p(_c(d, "d").reshape(bs, cout)), _p(_c(blur, "blur kernel")), _p(nz), nbs or 0,
+                       _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, _p(sn), _stream())
+        else:
+            ev = _timed("modconv_up_fused_sb")
+            lib().call("e4s_modconv_up_fused_sb", _p(out), _p(x), _p(wt[0]), _p(wt[1]), _p(s), _p(d), _p(_c(blur, "blur kernel")), _p(nz), nbs or 0,
+                       _p(noise_weight) if nz is not None else None, _p(act_bias), (1 if act else 0) | 8 | 16, bs, cin, cout, h, w, _p(sn), _stream())
         if ev is not None:
             ev.record()
         return out

@@ -246,6 +246,22 @@ E4S_API int e4s_to_split_planes(uint16_t* out_sp, const float* x, const float* s
 E4S_API int e4s_chain_conv3x3(const E4sChainLayer* L, void* stream);
 E4S_API int e4s_chain_upconv(const E4sChainLayer* L, const float* blur, void* stream);
 
+/* The chain's up layer in the HALF-COMPOSED form (csrc/modconv_uphc.hip; model.py:287-301 + 417-421, single-region case).  The 4 x 4 blur of the
+ * reference is an outer product kv x kh (model.py:23-31 make_kernel of a 1-D list): its VERTICAL factor is composed into the weights — two output-row
+ * parities x 9 taps over the input rows m-1, m, m+1 (2x the MACs of the bare transposed conv, no vertical tile overlap) — and its HORIZONTAL factor is
+ * applied to the MFMA accumulators in registers (three DPP row shifts per register), so the epilogue needs no LDS round trip and no barrier; outputs leave
+ * as 16-byte stores of split planes.
+ *   e4s_modconv_prep_weights_hc : whi / wlo, bf16 (as uint16) [2 row parities][cin/16][9 = (dy+1)*3 + kx][2][cout][8] from the layer's 3x3 weight
+ *                                 [1,cout,cin,3,3] (equalised-lr scale folded in) and the blur kernel [4,4]
+ *   e4s_modconv_up_hc           : x_sp [2][bs][cin/8][h][w][8] split planes carrying this layer's modulation -> out_sp [2][bs][cout/8][2h][2w][8]
+ *                                 (+ 16 zero bytes) modulated by s_next[bs][cout]; d [bs][cout]; cin % 16 == 0, cout % 32 == 0.
+ * `blur` MUST be rank 1 (blur[r][c] == rowsum[r] * colsum[c] / sum): the caller checks that on the host (e4s2024_amd/ops.py PreparedHc) and keeps
+ * e4s_modconv_up_fused_sb for any other kernel. */
+E4S_API int e4s_modconv_prep_weights_hc(uint16_t* whi, uint16_t* wlo, const float* weight, const float* blur, int cout, int cin, void* stream);
+E4S_API int e4s_modconv_up_hc(uint16_t* out_sp, const uint16_t* x_sp, const uint16_t* whi, const uint16_t* wlo, const float* d, const float* blur,
+                              const float* noise, int noise_bs, const float* noise_weight, const float* act_bias, int act,
+                              int bs, int cin, int cout, int h, int w, const float* s_next, void* stream);
+
 /* ToRGB forward in one pass (model.py:439-479): 1x1 modulated conv without demodulation, + bias, + upsampled skip.
  *   x : [bs, cin, h, w]   wt : [cin, 3] from e4s_modconv_prep_weights(k=1)   s : [bs, nreg, cin]   bias : [3]
  *   skip : previous RGB [bs, 3, h/2, w/2] or NULL; up_kernel : [4,4] FIR of Upsample (model.py:34-53; up=2, pad=(2,1))

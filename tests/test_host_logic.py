@@ -141,11 +141,25 @@ def test_install_only_overrides_hot_path_modules():
     import importlib
     assert importlib.util.find_spec("models.encoders.model_irse") is None       # not ours: resolves from the reference tree when present
     assert set(e4s2024_amd.OVERRIDES) == {"models.networks", "models.stylegan2.model", "models.stylegan2.op", "models.stylegan2.op.fused_act",
-                                          "models.stylegan2.op.upfirdn2d", "models.encoders.psp_encoders",
+                                          "models.stylegan2.op.upfirdn2d", "models.stylegan2.op.conv2d_gradfix", "models.encoders.psp_encoders",
                                           "swap_face_fine.face_parsing.model", "swap_face_fine.face_parsing.resnet",
                                           "swap_face_fine.face_parsing.face_parsing_demo"}
     import models.networks
     assert models.networks.__file__.startswith(e4s2024_amd.DROPIN_DIR)
+
+
+def test_conv2d_gradfix_resolves_under_the_redirected_op_package():
+    """SURVEY §1 lists conv2d_gradfix.{conv2d, conv_transpose2d} in the L1 interface (reference op/conv2d_gradfix.py:22-75; caller criteria/adv_loss.py:4)."""
+    install_dropin()
+    from models.stylegan2.op import conv2d_gradfix
+    import torch.nn.functional as F
+    x, w = torch.randn(2, 6, 5, 5), torch.randn(4, 3, 3, 3)
+    assert torch.equal(conv2d_gradfix.conv2d(x, w, padding=1, groups=2), F.conv2d(x, w, padding=1, groups=2))
+    wt = torch.randn(6, 2, 3, 3)
+    assert torch.equal(conv2d_gradfix.conv_transpose2d(x, wt, stride=2, padding=0, groups=2), F.conv_transpose2d(x, wt, stride=2, groups=2))
+    with conv2d_gradfix.no_weight_gradients():
+        assert conv2d_gradfix.weight_gradients_disabled
+    assert not conv2d_gradfix.weight_gradients_disabled
 
 
 def test_remap_lut_matches_oracle():
