@@ -66,7 +66,7 @@ _PROTOS = {
     "e4s_region_torgb": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr] + [c_int] * 5 + [c_ptr],
     "e4s_conv_prep_weights": [c_ptr] * 7 + [c_f32, c_ptr, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_conv_prep_weights_f16x3": [c_ptr] * 8 + [c_f32, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr],
-    "e4s_conv2d_f16x3": [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int] + [c_int] * 9 + [c_ptr],
+    "e4s_conv2d_f16x3": [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int] + [c_int] * 9 + [c_ptr, c_ptr],
     "e4s_conv2d": [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int] + [c_int] * 8 + [c_ptr],
     "e4s_conv_prep_weights_sb": [c_ptr] * 8 + [c_f32, c_ptr, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_conv_prep_weights_sb3": [c_ptr] * 9 + [c_f32, c_ptr, c_int, c_int, c_int, c_int, c_ptr],

@@ -447,6 +447,7 @@ struct Conv2dSbParams {
     int bs, cin, cin0, cout, h, w, ho, wo, pad;
     int tiles_x, tiles_y;
     float out_scale;       // (NS = 4) 2^-k of the weights' power-of-two pre-scale; 1 otherwise
+    int* flags;            // (NS = 4) flags[0] |= 1, flags[1] += 1 when an activation leaves the f16 range (ops.MxGuard re-runs the pass on the bf16 x 3 kernels); or NULL
 };
 
 // NS = number of bf16 terms per operand.  NS = 2: a*b ~ a0*b0 + a0*b1 + a1*b0 (3 MFMAs per 16-deep step, ~2^-17 per product).
@@ -593,6 +594,7 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void conv2d_sb_kernel(const Conv2d
             r[c] = on ? p.in_rstd[(size_t)b * p.cin + ci0 + c] : 1.f;
         }
     };
+    bool ovf = false;      // (NS = 4) a staged activation left the f16 range
     auto store_chunk = [&](const float (&xs)[CKS2][C::EPT], const unsigned (&ws)[C::WPT][4], const float (&m)[CKS2], const float (&r)[CKS2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < C::EPT; ++j) {
@@ -604,7 +606,11 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void conv2d_sb_kernel(const Conv2d
                     // padding stays exactly 0: the normalisation applies to in-bounds pixels only
                     const float t0 = ginb[j] ? (xs[2 * c][j] - m[2 * c]) * r[2 * c] : 0.f;
                     const float t1 = ginb[j] ? (xs[2 * c + 1][j] - m[2 * c + 1]) * r[2 * c + 1] : 0.f;
-                    if constexpr (NS == 4) c2_split2_f16(t0, t1, h[c], l[c]); else c2_split2(t0, t1, h[c], l[c]);
+                    if constexpr (NS == 4) {
+                        c2_split2_f16(t0, t1, h[c], l[c]);
+                        const unsigned em = h[c] & 0x7c007c00u;            // an f16 exponent field of 31: the value rounded to infinity
+                        ovf |= (em & 0xffffu) == 0x7c00u || (em >> 16) == 0x7c00u;
+                    } else c2_split2(t0, t1, h[c], l[c]);
                     if (NS == 3) {   // third term: what the first two leave over
                         const float q0 = (t0 - __builtin_bit_cast(float, h[c] << 16)) - __builtin_bit_cast(float, l[c] << 16);
                         const float q1 = (t1 - __builtin_bit_cast(float, h[c] & 0xffff0000u)) - __builtin_bit_cast(float, l[c] & 0xffff0000u);
@@ -695,6 +701,9 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void conv2d_sb_kernel(const Conv2d
     }
 
     E4S_PROF_MARK(g_prof_conv, 2);
+    if constexpr (NS == 4) {
+        if (p.flags && __builtin_amdgcn_ballot_w64(ovf) != 0 && lane == 0) { atomicOr(p.flags, 1); atomicAdd(p.flags + 1, 1); }   // one report per wave
+    }
     E4S_PROF_MARK(g_prof_conv, 3);
     // Epilogue in two passes: every global load (bias, residual, slope) first, then the stores.  gfx9 tracks loads and stores with
     // one in-order counter (vmcnt), so a load issued after a store cannot complete its wait before that store has reached memory.
@@ -799,7 +808,7 @@ static int dispatch2d_sb3(Conv2dSbParams& p, hipStream_t st) {
 
 static int conv2d_sb_common(int nterms, float* out, const float* x0, const float* x1, int cin0, const uint16_t* w0, const uint16_t* w1, const uint16_t* w2,
                             const float* bias, const float* in_mean, const float* in_rstd, const float* prelu_slope, const float* residual, int act,
-                            int bs, int cin, int cout, int h, int w, int ks, int stride, int pad, void* stream, float out_scale = 1.f) {
+                            int bs, int cin, int cout, int h, int w, int ks, int stride, int pad, void* stream, float out_scale = 1.f, int* flags = nullptr) {
     E4S_REQUIRE(out && x0 && w0 && w1 && (nterms != 3 || w2), "conv2d_sb: null tensor");
     E4S_REQUIRE(bs >= 0 && bs <= 65535 && cin >= 1 && cout >= 1 && h >= 1 && w >= 1, "conv2d_sb: bad size");
     E4S_REQUIRE(stride == 1 || stride == 2, "conv2d_sb: stride %d not supported (1 or 2)", stride);
@@ -817,6 +826,7 @@ static int conv2d_sb_common(int nterms, float* out, const float* x0, const float
     p.ho = (h + 2 * pad - ks) / stride + 1;
     p.wo = (w + 2 * pad - ks) / stride + 1;
     p.out_scale = out_scale;
+    p.flags = flags;
     E4S_REQUIRE(p.ho >= 1 && p.wo >= 1, "conv2d_sb: empty output");
     hipStream_t st = (hipStream_t)stream;
     if (nterms == 4) {
@@ -871,7 +881,7 @@ extern "C" int e4s_conv_prep_weights_f16x3(uint16_t* w1, uint16_t* w2, float* bi
 
 extern "C" int e4s_conv2d_f16x3(float* out, const float* x0, const float* x1, int cin0, const uint16_t* w1, const uint16_t* w2, const float* bias,
                                 const float* in_mean, const float* in_rstd, const float* prelu_slope, const float* residual, int act, int bs, int cin,
-                                int cout, int h, int w, int ks, int stride, int pad, int wscale_log2, void* stream) {
+                                int cout, int h, int w, int ks, int stride, int pad, int wscale_log2, int* flags, void* stream) {
     return conv2d_sb_common(4, out, x0, x1, cin0, w1, w2, nullptr, bias, in_mean, in_rstd, prelu_slope, residual, act, bs, cin, cout, h, w, ks, stride, pad,
-                            stream, ldexpf(1.f, -wscale_log2));
+                            stream, ldexpf(1.f, -wscale_log2), flags);
 }

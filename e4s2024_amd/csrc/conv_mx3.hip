@@ -465,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0)
         printf("wave %d: loop %llu cyc | R %llu  wait after R %llu  M %llu  wait after M %llu | store: vm wait %llu  store_x %llu  barrier 1 %llu  barrier 2 %llu  (units %d)\n", wave, __builtin_readcyclecounter() - tLoop, tR, tWR, tM, tWM, tS1, tS2, tS3, tST, nunits);
 #endif
-    if (ovf && p.flags) atomicOr(p.flags, 1);
+    if (p.flags && __builtin_amdgcn_ballot_w64(ovf != 0u) != 0 && (threadIdx.x & 63) == 0) { atomicOr(p.flags, 1); atomicAdd(p.flags + 1, 1); }   // one report per wave: sticky bit + moving counter (ops.MxGuard)
 
     // ---- epilogue: PReLU, stores (lane = pixel column: consecutive lanes write consecutive floats of one channel plane)
     __syncthreads();
@@ -510,7 +510,7 @@ extern "C" int e4s_conv_prep_weights_mx3(void* dst, const float* weight, int cou
 }
 
 // out = PReLU(conv3x3(norm(x), W)), stride 1, pad 1.  in_mean / in_rstd [bs][cin] (optional, together), prelu_slope [cout] optional; flags[0] bit 0 is raised
-// when a normalised activation leaves the f16 range (the result is then invalid: callers fall back to the split-bf16 kernels).
+// when a normalised activation leaves the f16 range (the result is then invalid; the kernel does not fall back by itself — ops.MxGuard notices the counter flags[1] moving and the entry points re-run the pass on the split-bf16 kernels).
 extern "C" int e4s_conv3x3_mx3(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
                                int bs, int cin, int cout, int h, int w, void* stream) {
     E4S_REQUIRE(out && x && wmx3, "conv3x3_mx3: null tensor");

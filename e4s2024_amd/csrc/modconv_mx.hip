@@ -12,7 +12,9 @@
 //          bar 1e-3; tests/experiments/emulate_split_variants.py — the two-term f16 forms (a1 + a2) w1 / a1 (w1 + w2) miss the bar at 2-5e-3).
 //          Matrix-pipe time per 16-deep K step of one kernel row, measured (tools/probes/mx_probe.hip, random operands, power-limited clocks):
 //          3 x 4 f16 (20.2 ns each) + 2 x 4 fp6 K=64 (23.8 ns each) = 433 ns against 36 bf16 (18.4 ns each) = 663 ns.
-//          f16 range: |x * s| must stay below 65504; the kernel raises flags[0] when a block maximum does not (ops falls back to ARITH 0).
+//          f16 range: |x * s| must stay below 65520; a wave that sees a larger value raises flags[0] bit 0 and bumps the counter flags[1].  The kernel itself does NOT
+//          fall back: ops.MxGuard (e4s2024_amd/ops.py) snapshots the counter around a forward pass and the entry points (Generator.forward, FSEncoder_PSP.forward,
+//          pipeline.swap_batch, runner) re-run a pass that moved it with ARITH 0.
 // Measured and not kept: s_setprio(1) around the MFMA bursts (+3 % time), the residual through fma (hipcc keeps cvt + sub), the DMA through the
 // builtin (vmcnt(0) in front of every row's first LDS read: no gain over the register-staged kernel).
 // Operand layouts, prepared by e4s_modconv_prep_weights_mx, one ROW SLOT = what a workgroup DMAs for (parity, chunk, co tile, kernel row):
@@ -390,6 +392,7 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
     // MFMAs — the row's 38 LDS reads (144 LDS-array cycles per wave, 576 per phase for the four waves of a group, in two dependent rounds) and the patch
     // conversion, not the matrix pipe, set the pace, and the MFMA waves waited at the barrier.  What carried over: the DMA staging, the slot-major patch, and pinning
     // the accumulators (LLVM sinks a row's last MFMAs behind the next barrier otherwise — 60 registers).
+    bool ovf = false;       // (f16 arithmetic) a modulated activation of this lane left the f16 range
 #pragma unroll 1
     for (int chunk = ch_begin; chunk < ch_end; ++chunk) {
         const int cur = (chunk - ch_begin) & 1;
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
                     }
                     const unsigned mh = (m & 0xffffu) > (m >> 16) ? (m & 0xffffu) : (m >> 16);
                     const unsigned e16 = mh >> 10;                    // f16 exponent field: 31 = the value left the f16 range (inf)
-                    if (e16 >= 31u && p.flags) atomicOr(p.flags, 1);
+                    ovf |= e16 >= 31u;
                     ex = (e16 ? e16 : 1u) + 112u;                     // f16 bias 15 -> fp32 bias 127
                     const unsigned e1 = ex > 3u ? ex - 2u : 1u, e2 = ex > 14u ? ex - 13u : 1u;
                     const u32x6 p1 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, v1), __builtin_bit_cast(float, e1 << 23));
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
                 }
                 // block scales of this lane's 24 values: 2^(E - 2) for fp6(a1), 2^(E - 13) for fp6(a - a1)  (|a - a1| <= 2^(E - 11));  E >= 16 leaves f16
                 ex = (__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu;
-                if (ex >= 143u && p.flags) atomicOr(p.flags, 1);
+                ovf |= amax >= 65520.f;            // exactly the values f16 rounds to infinity (65520 is the tie between 65504 and 2^16)
                 }
                 if constexpr (!ENC) {
                 const unsigned e1 = ex > 3u ? ex - 2u : 1u, e2 = ex > 14u ? ex - 13u : 1u;
@@ -592,6 +595,11 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
         }
     }
 
+    if constexpr (ARITH == 1) {
+        // one report per wave: flags[0] bit 0 = "some launch overflowed" (sticky), flags[1] = a counter that moves whenever one does — the host compares
+        // snapshots of it taken before and after a forward pass (ops.MxGuard) and re-runs that pass with the split-bf16 arithmetic
+        if (p.flags && __builtin_amdgcn_ballot_w64(ovf) != 0 && lane == 0) { atomicOr(p.flags, 1); atomicAdd(p.flags + 1, 1); }
+    }
     if constexpr (ENC) {
         __syncthreads();
         float* sl = reinterpret_cast<float*>(lds_raw);
@@ -628,258 +636,6 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
         return;
     }
     sb_epilogue<C, 4, 1, 8, RGB, OSP>(p, lds_raw, acc, cls, co0, b, y0, x0, pa, pb_, ho, wo, ub_skip);
-}
-
-// ============================================================================ plain convolution, one wave per SIMD
-// The same pipeline (row-slot ring fed by LDS-DMA, pre-split f16 patch, f16 + 2 x MX fp6) with FOUR waves per workgroup, each owning two tile rows (64 pixels)
-// x all 128 output channels: a weight fragment read from LDS feeds two MFMAs instead of one, so the LDS operand traffic per MFMA drops by 40 % (the 8-wave
-// kernel's K loop is bound by its LDS reads: -DMX_ABL ablations), and the wave has the SIMD's 512 registers to itself — enough to request the NEXT row's
-// fragments under the current row's MFMAs, which is how a single in-order wave hides LDS latency.
-constexpr int MX2_MAX_CIN = MX_NORM_MAX_CIN;
-constexpr int MX2_NORM_BYTES = MX_NORM_BYTES;
-__global__ __launch_bounds__(256, 1) void conv3x3_mx2_kernel(const SbParams p) {
-    using L = MxLds<1>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l5 = lane & 31, khalf = lane >> 5;
-
-    unsigned bx_g = blockIdx.x, cot_g = blockIdx.y, b_g = blockIdx.z;
-    if (p.xcd_remap) {
-        const unsigned nx = gridDim.x, ncg = gridDim.y;
-        const unsigned lin = blockIdx.x + nx * (blockIdx.y + ncg * blockIdx.z);
-        const unsigned per = 8u / ncg;
-        const unsigned xcd = lin & 7u, q = lin >> 3;
-        cot_g = xcd / per;
-        const unsigned r = q * per + (xcd % per);
-        bx_g = r % nx;
-        b_g = r / nx;
-    }
-    const int tile = (int)bx_g;
-    const int y0 = (tile / p.tiles_x) * C::TH, x0 = (tile % p.tiles_x) * C::TW;
-    const int cotile = (int)cot_g, co0 = cotile * MX_TN, b = (int)b_g;
-    const int hw = p.h * p.w;
-    const int nchunk = p.cin / CKS;
-    const int ncot = (p.cout + MX_TN - 1) / MX_TN;
-
-    // staging: 340 patch pixels over 256 threads (threads 0..83 take a second one)
-    int goffs[2];
-    bool p_in[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int e = tid + 256 * j;
-        const int ppy = e / C::PW, ppx = e - ppy * C::PW;
-        const int pgy = y0 - 1 + ppy, pgx = x0 - 1 + ppx;
-        p_in[j] = e < C::PATCH && pgy >= 0 && pgy < p.h && pgx >= 0 && pgx < p.w;
-        goffs[j] = p_in[j] ? pgy * p.w + pgx : 0;
-    }
-    const float* xb = p.x + (size_t)b * p.cin * hw;
-    float xr[2][CKS];
-    const float2* nrm_m = reinterpret_cast<const float2*>(lds_raw + L::BYTES);
-    const float2* nrm_r = reinterpret_cast<const float2*>(lds_raw + L::BYTES + MX2_NORM_BYTES / 2);
-    auto load_x = [&](int chunk) __attribute__((always_inline)) {
-        const int ci0 = chunk * CKS;
-#pragma unroll
-        for (int c = 0; c < CKS; ++c) xr[0][c] = xb[(size_t)(ci0 + c) * hw + goffs[0]];
-        if (wave < 2) {                      // (wave-uniform: pixels 256..339 belong to threads 0..83)
-#pragma unroll
-            for (int c = 0; c < CKS; ++c) xr[1][c] = xb[(size_t)(ci0 + c) * hw + goffs[1]];
-        }
-    };
-    auto store_x = [&](int buf, int chunk) __attribute__((always_inline)) {
-        uint4* xq = reinterpret_cast<uint4*>(lds_raw + L::PATCH0 + buf * MX_PATCHB);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int e = tid + 256 * j;
-            if (e < C::PATCH) {
-                const int g = (e >> 2) & 3;
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    unsigned q1[4], q2[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        float a = xr[j][hh * 8 + 2 * k], bq = xr[j][hh * 8 + 2 * k + 1];
-                        {   // instance norm on load, statistics from the table staged in LDS at kernel start (mean 0 / rstd 1 without)
-                            const float2 m2 = nrm_m[(chunk * CKS + hh * 8 + 2 * k) >> 1], r2 = nrm_r[(chunk * CKS + hh * 8 + 2 * k) >> 1];
-                            a = (a - m2.x) * r2.x;
-                            bq = (bq - m2.y) * r2.y;
-                        }
-                        a = p_in[j] ? a : 0.f;
-                        bq = p_in[j] ? bq : 0.f;
-                        const f16x2 a1 = __builtin_convertvector((f32x2){a, bq}, f16x2);
-                        q1[k] = __builtin_bit_cast(unsigned, a1);
-                        q2[k] = pack_f16_rne(a - (float)a1[0], bq - (float)a1[1]);
-                    }
-                    xq[e * 4 + ((2 * hh) ^ g)] = make_uint4(q1[0], q1[1], q1[2], q1[3]);
-                    xq[e * 4 + ((2 * hh + 1) ^ g)] = make_uint4(q2[0], q2[1], q2[2], q2[3]);
-                }
-            }
-        }
-    };
-    const unsigned char* wbase = p.wmx;
-    auto dma_row = [&](int chunk, int row) __attribute__((always_inline)) {
-        const unsigned char* src = wbase + ((size_t)(chunk * ncot + cotile) * 3 + row) * L::ROWB;
-#pragma unroll
-        for (int k = 0; k < (L::NPIECE + 3) / 4; ++k) {
-            const int piece = wave + 4 * k;
-            if (piece < L::NPIECE) dma16_asm(src, (unsigned)(piece * 1024 + lane * 16), (unsigned)(row * L::ROWB + piece * 1024));
-        }
-    };
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.f;
-    int xoff[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) xoff[q] = (2 * wave + q) * C::PW + l5;
-
-    // this sample's instance-norm statistics, all channels, behind the regular LDS plan (read as wave-uniform pairs while a chunk is staged)
-    for (int c = tid; c < p.cin; c += 256) {
-        reinterpret_cast<float*>(lds_raw + L::BYTES)[c] = p.in_mean ? p.in_mean[(size_t)b * p.cin + c] : 0.f;
-        reinterpret_cast<float*>(lds_raw + L::BYTES + MX2_NORM_BYTES / 2)[c] = p.in_mean ? p.in_rstd[(size_t)b * p.cin + c] : 1.f;
-    }
-    __syncthreads();
-    dma_row(0, 0);
-    dma_row(0, 1);
-    dma_row(0, 2);
-    load_x(0);
-    store_x(0, 0);
-    E4S_WAIT_VM(0);
-    E4S_LDS_BARRIER();
-
-    // the NEXT row's f16 fragments (activations a1 | a - a1 of both pixel blocks, weights of the three taps), requested under the current row's MFMAs
-    uint4 na1[2][3], na2[2][3], nwv[3][4];
-    auto fetch_w = [&](int slot_row) __attribute__((always_inline)) {
-        const uint4* wh = reinterpret_cast<const uint4*>(lds_raw + slot_row * L::ROWB) + khalf * MX_TN + l5;
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) nwv[t][i] = wh[t * 2 * MX_TN + i * 32];
-    };
-    auto fetch_x = [&](int buf, int prow) __attribute__((always_inline)) {
-        const uint4* xq = reinterpret_cast<const uint4*>(lds_raw + L::PATCH0 + buf * MX_PATCHB);
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const int e = xoff[q] + prow * C::PW + t;
-                const int g = (e >> 2) & 3;
-                na1[q][t] = xq[e * 4 + ((2 * khalf) ^ g)];
-                na2[q][t] = xq[e * 4 + ((2 * khalf + 1) ^ g)];
-            }
-    };
-    fetch_w(0);
-    fetch_x(0, 0);
-
-#pragma unroll 1
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-        const int cur = chunk & 1;
-        const bool more = chunk + 1 < nchunk;
-        if (more) load_x(chunk + 1);
-#pragma unroll
-        for (int row = 0; row < 3; ++row) {
-            const unsigned char* slot = lds_raw + row * L::ROWB;
-            const uint4* f6lo = reinterpret_cast<const uint4*>(slot + MX_W1B) + khalf * MX_TN + l5;
-            const uint2* f6hi = reinterpret_cast<const uint2*>(slot + MX_W1B + MX_F6LO) + khalf * MX_TN + l5;
-            const unsigned* wsc = reinterpret_cast<const unsigned*>(slot + MX_W1B + MX_F6LO + MX_F6HI) + khalf * MX_TN + l5;
-            // this row's fragments: what the previous row requested
-            uint4 a1[2][3], wv[3][4];
-            u32x16 v1[2], v2[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    a1[q][t] = na1[q][t];
-                    v1[q][t * 4] = na1[q][t].x; v1[q][t * 4 + 1] = na1[q][t].y; v1[q][t * 4 + 2] = na1[q][t].z; v1[q][t * 4 + 3] = na1[q][t].w;
-                    v2[q][t * 4] = na2[q][t].x; v2[q][t * 4 + 1] = na2[q][t].y; v2[q][t * 4 + 2] = na2[q][t].z; v2[q][t * 4 + 3] = na2[q][t].w;
-                }
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) wv[t][i] = nwv[t][i];
-            // fp6 operands of this row (its slot landed two barriers ago)
-            uint4 flo[2][4];
-            uint2 fhi[2][4];
-            int fsc[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                flo[1][i] = f6lo[2 * MX_TN + i * 32]; fhi[1][i] = f6hi[2 * MX_TN + i * 32];
-                flo[0][i] = f6lo[i * 32];             fhi[0][i] = f6hi[i * 32];
-                fsc[i] = (int)wsc[i * 32];
-            }
-            unsigned m[2] = {0u, 0u};
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-                        acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wv[t][i]), __builtin_bit_cast(f16x8, a1[q][t]), acc[i][q], 0, 0, 0);
-            // next row's fragments: the same chunk's next slot and patch rows; after the last row the next chunk's first slot (landed since the barrier before
-            // last) and ITS patch buffer, which was written before this chunk's second barrier
-            if (row < 2) { fetch_w(row + 1); fetch_x(cur, row + 1); }
-            else if (more) { fetch_w(0); fetch_x(cur ^ 1, 0); }
-            i32x8 bx1[2], bx2[2];
-            unsigned e1[2], e2[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-#pragma unroll
-                for (int j = 0; j < 12; ++j) {
-                    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-                    const u16x2 mm = __builtin_elementwise_max(__builtin_bit_cast(u16x2, m[q]), __builtin_bit_cast(u16x2, v1[q][j] & 0x7fff7fffu));
-                    m[q] = __builtin_bit_cast(unsigned, mm);
-                }
-                const unsigned mh = (m[q] & 0xffffu) > (m[q] >> 16) ? (m[q] & 0xffffu) : (m[q] >> 16);
-                const unsigned e16 = mh >> 10;
-                if (e16 >= 31u && p.flags) atomicOr(p.flags, 1);
-                const unsigned ex = (e16 ? e16 : 1u) + 112u;
-                e1[q] = ex > 3u ? ex - 2u : 1u;
-                e2[q] = ex > 14u ? ex - 13u : 1u;
-                bx1[q] = mx_op6(__builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, v1[q]), __builtin_bit_cast(float, e1[q] << 23)));
-                bx2[q] = mx_op6(__builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, v2[q]), __builtin_bit_cast(float, e2[q] << 23)));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    acc[i][q] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(mx_op6(flo[1][i], fhi[1][i]), bx1[q], acc[i][q], 2, 2, 1, fsc[i], 0, (int)e1[q]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    acc[i][q] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(mx_op6(flo[0][i], fhi[0][i]), bx2[q], acc[i][q], 2, 2, 0, fsc[i], 0, (int)e2[q]);
-            if (row == 1 && more) store_x(cur ^ 1, chunk + 1);        // (the other patch buffer's last readers passed the previous chunk's last barrier)
-            E4S_WAIT_VM(0);
-            E4S_LDS_BARRIER();
-            if (more) dma_row(chunk + 1, row);
-        }
-    }
-
-    __syncthreads();
-    float* sl = reinterpret_cast<float*>(lds_raw);
-    if (tid < MX_TN) sl[tid] = (p.slope && co0 + tid < p.cout) ? p.slope[co0 + tid] : 1.f;
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int y = y0 + 2 * wave + q, x = x0 + l5;
-        if (y < p.h && x < p.w) {
-            float* op = p.out + (size_t)b * p.cout * hw + (size_t)y * p.w + x;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                    float v = acc[i][q][r];
-                    v = v > 0.f ? v : v * sl[n];
-                    if (co0 + n < p.cout) op[(size_t)(co0 + n) * hw] = v;
-                }
-        }
-    }
 }
 
 template <int ARITH, bool RGB, bool OSP, bool ENC = false>
@@ -968,14 +724,6 @@ int e4s::launch_modconv_mx(SbParams& p, int arith, hipStream_t st, float* worksp
         p.chunks_per = nchunk;
         grid = dim3(p.tiles_x * p.tiles_y, cdiv(p.cout, MX_TN), p.bs);
         p.xcd_remap = remap_ok(grid) ? 1 : 0;
-        static const int mx2 = [] { const char* e = getenv("E4S_MX2"); return e ? atoi(e) : 0; }();
-        if (arith == 1 && mx2 && p.cin % CKS == 0 && p.cin <= MX2_MAX_CIN) {       // one wave per SIMD, two pixel blocks per wave
-            constexpr int lds2 = MxLds<1>::BYTES + MX2_NORM_BYTES;
-            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mx2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-            if (attr != hipSuccess) return fail((int)attr, "conv3x3_mx: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
-            hipLaunchKernelGGL(conv3x3_mx2_kernel, grid, dim3(256), lds2, st, p);
-            return check_launch("conv3x3_mx");
-        }
         return arith == 0 ? launch_mx_variant<0, false, false, true>(p, grid, st) : launch_mx_variant<1, false, false, true>(p, grid, st);
     }
     const bool rgb = p.rgb_out != nullptr, osp = p.s_next != nullptr;

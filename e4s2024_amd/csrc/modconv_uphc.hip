@@ -45,6 +45,7 @@ struct UpHcParams {
     int noise_bstride, act;
     int bs, cin, cout, h, w;
     int tiles_x, tiles_y;
+    int ntile, ncot;                 // (persistent form) tiles_x * tiles_y * bs, cout / 32
     int64_t plane_in, plane_out;     // uint4 per plane
 };
 
@@ -70,6 +71,85 @@ constexpr int DPP_ROW_SHL1 = 0x101;              // lane i <- lane i + 1
 constexpr int DPP_ROW_SHR1 = 0x111;              // lane i <- lane i - 1
 
 E4S_PROF_DECL(g_prof_hc)
+
+// The register epilogue shared by both kernels: horizontal four-tap filter across the lanes of a DPP row, demodulation, noise, bias, leaky ReLU, the next
+// layer's modulation, bf16 hi / lo split, half exchange, 16-byte stores.  `accs[2 a + pb]` = V[2 pm + a][2 pbx + pb] of this lane's position for the 16 channels
+// 8 g + 4 khalf + j of its registers 4 g + j; the d / bias / s_next tables of the workgroup's 32 channels sit at LDS byte `ep_off` (64 floats apart).
+__device__ __forceinline__ void hc_epilogue(const UpHcParams& p, const f32x16 (&accs)[4], const unsigned char* lds_raw, int ep_off, const float2 (&nz)[2], bool lane_ok,
+                                            int b, int co0, int pm, int pbx, int khalf) {
+    const int ho = 2 * p.h, wo = 2 * p.w;
+    // kh'[u] = flipped horizontal factor: out[ox] = sum_u kh'[u] V[ox - 1 + u]
+    float khf[4];
+    {
+        float cs[4], S = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) { cs[cc] = p.blur[cc] + p.blur[4 + cc] + p.blur[8 + cc] + p.blur[12 + cc]; S += cs[cc]; }
+        const float rs = 1.f / sqrtf(S);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) khf[u] = cs[3 - u] * rs;
+    }
+    const float nw = p.noise ? p.noise_weight[0] : 0.f;
+    const float neg = p.act ? 0.2f : 1.f, gain = p.act ? 1.41421356237309515f : 1.f;
+    const size_t opl = (size_t)ho * wo;
+    // uint4 index of this lane's pixel after the half exchange (lower half-wave: column 2b, upper: 2b + 1) in 8-channel block 0 of this workgroup, row parity 0
+    const size_t o_base = ((size_t)b * (p.cout >> 3) + (size_t)(co0 >> 3)) * opl + (size_t)(2 * pm) * wo + (size_t)(2 * pbx + khalf);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        // registers 4g .. 4g + 3 = channels 8g + 4 khalf + (0..3)
+        unsigned ep_i = (unsigned)(ep_off / 4 + 8 * g + 4 * khalf);
+        asm volatile("" : "+v"(ep_i));
+        const float* ep = reinterpret_cast<const float*>(lds_raw) + ep_i;
+        const float4 d4 = *reinterpret_cast<const float4*>(ep + HC_EP_D);
+        const float4 b4 = *reinterpret_cast<const float4*>(ep + HC_EP_B);
+        const float4 s4 = *reinterpret_cast<const float4*>(ep + HC_EP_S);
+        const float dd[4] = {d4.x, d4.y, d4.z, d4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w}, sn[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa) {
+            const float nze = __fmul_rn(nw, nz[pa].x), nzo = __fmul_rn(nw, nz[pa].y);
+            float ue[4], uo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z0 = accs[2 * pa][4 * g + j], z1 = accs[2 * pa + 1][4 * g + j];
+                const float l1 = dpp_row<DPP_ROW_SHR1>(z1);                // column 2b - 1
+                const float r0 = dpp_row<DPP_ROW_SHL1>(z0);                // column 2b + 2
+                const float r1 = dpp_row<DPP_ROW_SHL1>(z1);                // column 2b + 3
+                float oe = __fmul_rn(khf[0], l1);
+                oe = __builtin_fmaf(khf[1], z0, oe);
+                oe = __builtin_fmaf(khf[2], z1, oe);
+                oe = __builtin_fmaf(khf[3], r0, oe);
+                float oo = __fmul_rn(khf[0], z0);
+                oo = __builtin_fmaf(khf[1], z1, oo);
+                oo = __builtin_fmaf(khf[2], r0, oo);
+                oo = __builtin_fmaf(khf[3], r1, oo);
+                float ve = __builtin_fmaf(oe, dd[j], bb[j]) + nze, vo = __builtin_fmaf(oo, dd[j], bb[j]) + nzo;
+                ve = fmaxf(ve, ve * neg) * gain;     // leaky relu 0.2 (max picks v for v >= 0, 0.2 v otherwise)
+                vo = fmaxf(vo, vo * neg) * gain;
+                ue[j] = __fmul_rn(ve, sn[j]);
+                uo[j] = __fmul_rn(vo, sn[j]);
+            }
+            unsigned he[2], le[2], ho_[2], lo_[2];
+            split2(ue[0], ue[1], he[0], le[0]);
+            split2(ue[2], ue[3], he[1], le[1]);
+            split2(uo[0], uo[1], ho_[0], lo_[0]);
+            split2(uo[2], uo[3], ho_[1], lo_[1]);
+            // Half exchange (guide T21): the lower half-wave keeps its column-2b values and receives the upper half-wave's (channels + 4 .. + 7 of the same pixel);
+            // the upper half-wave receives the lower one's column-(2b + 1) values and keeps its own: every lane then holds the 8 channels = 16 bytes of ONE pixel.
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                auto r = __builtin_amdgcn_permlane32_swap(he[q], ho_[q], false, false);
+                he[q] = r[0]; ho_[q] = r[1];
+                auto r2 = __builtin_amdgcn_permlane32_swap(le[q], lo_[q], false, false);
+                le[q] = r2[0]; lo_[q] = r2[1];
+            }
+            if (lane_ok) {
+                const size_t o4 = o_base + (size_t)g * opl + (size_t)pa * wo;
+                p.out[o4] = make_uint4(he[0], he[1], ho_[0], ho_[1]);
+                p.out[(size_t)p.plane_out + o4] = make_uint4(le[0], le[1], lo_[0], lo_[1]);
+            }
+        }
+    }
+}
+
 
 __global__ __launch_bounds__(HC_NT, 4) void up_hc_kernel(const UpHcParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -199,81 +279,177 @@ __global__ __launch_bounds__(HC_NT, 4) void up_hc_kernel(const UpHcParams p) {
     }
     E4S_PROF_MARK(g_prof_hc, 2);
 
-    // ---- epilogue, all in registers.  kh'[u] = flipped horizontal factor: out[ox] = sum_u kh'[u] V[ox - 1 + u]
-    float khf[4];
-    {
-        float cs[4], S = 0.f;
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) { cs[cc] = p.blur[cc] + p.blur[4 + cc] + p.blur[8 + cc] + p.blur[12 + cc]; S += cs[cc]; }
-        const float rs = 1.f / sqrtf(S);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) khf[u] = cs[3 - u] * rs;
-    }
-    const float nw = p.noise ? p.noise_weight[0] : 0.f;
-    const float neg = p.act ? 0.2f : 1.f, gain = p.act ? 1.41421356237309515f : 1.f;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid < 1) p.out[(size_t)p.plane_out * 2] = make_uint4(0u, 0u, 0u, 0u);   // zero tail
-    const size_t opl = (size_t)ho * wo;
-    // uint4 index of this lane's pixel after the half exchange (lower half-wave: column 2b, upper: 2b + 1) in 8-channel block 0 of this workgroup, row parity 0
-    const size_t o_base = ((size_t)b * (p.cout >> 3) + (size_t)(co0 >> 3)) * opl + (size_t)(2 * pm) * wo + (size_t)(2 * pbx + khalf);
     E4S_PROF_MARK(g_prof_hc, 3);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        // registers 4g .. 4g + 3 = channels 8g + 4 khalf + (0..3)
-        unsigned ep_i = (unsigned)(HC_BODY / 4 + 8 * g + 4 * khalf);
-        asm volatile("" : "+v"(ep_i));
-        const float* ep = reinterpret_cast<const float*>(lds_raw) + ep_i;
-        const float4 d4 = *reinterpret_cast<const float4*>(ep + HC_EP_D);
-        const float4 b4 = *reinterpret_cast<const float4*>(ep + HC_EP_B);
-        const float4 s4 = *reinterpret_cast<const float4*>(ep + HC_EP_S);
-        const float dd[4] = {d4.x, d4.y, d4.z, d4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w}, sn[4] = {s4.x, s4.y, s4.z, s4.w};
-#pragma unroll
-        for (int pa = 0; pa < 2; ++pa) {
-            const float nze = __fmul_rn(nw, nz[pa].x), nzo = __fmul_rn(nw, nz[pa].y);
-            float ue[4], uo[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float z0 = accs[2 * pa][4 * g + j], z1 = accs[2 * pa + 1][4 * g + j];
-                const float l1 = dpp_row<DPP_ROW_SHR1>(z1);                // column 2b - 1
-                const float r0 = dpp_row<DPP_ROW_SHL1>(z0);                // column 2b + 2
-                const float r1 = dpp_row<DPP_ROW_SHL1>(z1);                // column 2b + 3
-                float oe = __fmul_rn(khf[0], l1);
-                oe = __builtin_fmaf(khf[1], z0, oe);
-                oe = __builtin_fmaf(khf[2], z1, oe);
-                oe = __builtin_fmaf(khf[3], r0, oe);
-                float oo = __fmul_rn(khf[0], z0);
-                oo = __builtin_fmaf(khf[1], z1, oo);
-                oo = __builtin_fmaf(khf[2], r0, oo);
-                oo = __builtin_fmaf(khf[3], r1, oo);
-                float ve = __builtin_fmaf(oe, dd[j], bb[j]) + nze, vo = __builtin_fmaf(oo, dd[j], bb[j]) + nzo;
-                ve = fmaxf(ve, ve * neg) * gain;     // leaky relu 0.2 (max picks v for v >= 0, 0.2 v otherwise)
-                vo = fmaxf(vo, vo * neg) * gain;
-                ue[j] = __fmul_rn(ve, sn[j]);
-                uo[j] = __fmul_rn(vo, sn[j]);
-            }
-            unsigned he[2], le[2], ho_[2], lo_[2];
-            split2(ue[0], ue[1], he[0], le[0]);
-            split2(ue[2], ue[3], he[1], le[1]);
-            split2(uo[0], uo[1], ho_[0], lo_[0]);
-            split2(uo[2], uo[3], ho_[1], lo_[1]);
-            // Half exchange (guide T21): the lower half-wave keeps its column-2b values and receives the upper half-wave's (channels + 4 .. + 7 of the same pixel);
-            // the upper half-wave receives the lower one's column-(2b + 1) values and keeps its own: every lane then holds the 8 channels = 16 bytes of ONE pixel.
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                auto r = __builtin_amdgcn_permlane32_swap(he[q], ho_[q], false, false);
-                he[q] = r[0]; ho_[q] = r[1];
-                auto r2 = __builtin_amdgcn_permlane32_swap(le[q], lo_[q], false, false);
-                le[q] = r2[0]; lo_[q] = r2[1];
-            }
-            if (lane_ok) {
-                const size_t o4 = o_base + (size_t)g * opl + (size_t)pa * wo;
-                p.out[o4] = make_uint4(he[0], he[1], ho_[0], ho_[1]);
-                p.out[(size_t)p.plane_out + o4] = make_uint4(le[0], le[1], lo_[0], lo_[1]);
-            }
-        }
-    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid < 1) p.out[(size_t)p.plane_out * 2] = make_uint4(0u, 0u, 0u, 0u);   // zero tail
+    hc_epilogue(p, accs, lds_raw, HC_BODY, nz, lane_ok, b, co0, pm, pbx, khalf);
     E4S_PROF_MARK(g_prof_hc, 4);
     E4S_PROF_DRAIN();
     E4S_PROF_MARK(g_prof_hc, 5);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The persistent form (default).  Measured on the kernel above: 0.315 ms for the 64 -> 32 layer at batch 4 where its MFMAs need 0.12 — a workgroup lives
+// 35 us for 3.4 us of matrix work because its ring is ONE unit deep (two workgroups of 76 KB per CU leave no room for more): every unit waits a memory round
+// trip for a request issued 0.4 us earlier, and every workgroup pays the launch + first-chunk latency again.  Here ONE workgroup per CU walks over its
+// tiles (modconv_chain.hip's roles): eight compute waves + one loader wave that issues every LDS-DMA three units ahead (ring: three activation chunks + four
+// weight units = 129 KB), across tile boundaries — the next tile's first chunks land under this tile's epilogue.  Compute waves never touch vmcnt except
+// for their own noise loads; the loader's counted wait (56 = the two youngest groups: 38 + 18 requests) keeps the 6-bit vmcnt counter in range.
+// A tile's co tiles (cout / 32) are consecutive items of the SAME workgroup, so the second one's activation patch comes out of this XCD's L2.
+constexpr int HP_NCW = 8;                                   // compute waves; wave HP_NCW is the loader
+constexpr int HP_NT = 64 * (HP_NCW + 1);                    // 576 threads
+constexpr int HP_NX = 3, HP_NW = 4, HP_D = 3;               // activation buffers, weight slots, units requested ahead
+constexpr int HP_W0 = HP_NX * HC_XB4;                       // uint4 offset of the weight ring
+constexpr int HP_BODY = (HP_NX * HC_XB4 + HP_NW * HC_W4) * 16;     // 132 480
+constexpr int HP_LDS = HP_BODY + HC_EP_FLOATS * 4;          // 133 248
+constexpr int HP_GX = 20, HP_GW = 18;                       // requests of one activation chunk / one weight unit
+static_assert(HP_LDS <= 160 * 1024 && (HP_D - 1) * ((HP_GX + 2 * HP_GW + 1) / 2 + 1) <= 63 && HP_GX + 2 * HP_GW <= 63, "LDS per CU; vmcnt is a 6-bit counter");
+#define HP_WAIT_YOUNGEST_TWO() asm volatile("s_waitcnt vmcnt(56)" ::: "memory")        // HP_GX + 2 * HP_GW: one group with and one without an activation chunk
+
+__global__ __launch_bounds__(HP_NT) void up_hcp_kernel(const UpHcParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const uint4* lds4 = reinterpret_cast<const uint4*>(lds_raw);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hw = p.h * p.w, wo = 2 * p.w;
+    const int nchunk = p.cin >> 4, NU = 2 * nchunk;
+    const int first = blockIdx.x, stride = gridDim.x;
+    const int my_tiles = (p.ntile - first + stride - 1) / stride;
+    const int my_items = my_tiles * p.ncot;
+    const int per_img = p.tiles_x * p.tiles_y;
+    // item i of this workgroup: tile first + (i / ncot) * stride, co tile i % ncot
+    auto item_coords = [&](int i, int& b, int& cot, int& tyt, int& txt) __attribute__((always_inline)) {
+        i = i < my_items ? i : my_items - 1;                               // (ghost items past the end repeat the last one)
+        const int t = first + (i / p.ncot) * stride;
+        cot = i % p.ncot;
+        b = t / per_img;
+        const int r = t - b * per_img;
+        tyt = r / p.tiles_x;
+        txt = r - tyt * p.tiles_x;
+    };
+
+    if (wave == HP_NCW) {
+        // =================================================================================== loader
+        const int cb8 = p.cin >> 3;
+        lds_byte* const lds_b = (lds_byte*)lds_raw;
+        const unsigned zero_off = (unsigned)(2 * p.plane_in * 16);
+        auto issue_group = [&](int k) __attribute__((always_inline)) {       // unit k of this workgroup's walk: item k / NU, chunk (k % NU) / 2, row parity k & 1
+            const int u = k % NU, c = u >> 1, par = u & 1;
+            int b, cot, tyt, txt;
+            item_coords(k / NU, b, cot, tyt, txt);
+            if (par == 0) {
+                const unsigned xst = (unsigned)(((k >> 1) % HP_NX) * (HC_XB4 * 16));
+                const int m0 = tyt * HC_T, p0x = txt * HC_STEP - 1;
+                const unsigned cb0 = (unsigned)((b * cb8 + 2 * c) * hw);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {                                 // this lane's patch pixel of piece j: the same for the 4 (plane, half)
+                    const int e = j * 64 + lane;
+                    const int py = e / HC_PW, px = e - py * HC_PW;
+                    const int gy = m0 - 1 + py, gx = p0x - 1 + px;
+                    const bool inb = gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+                    const unsigned pix = (unsigned)(gy * p.w + gx);
+                    if (e < HC_PATCH) {
+#pragma unroll
+                        for (int combo = 0; combo < 4; ++combo) {
+                            const unsigned cbase = (unsigned)((combo >> 1) * p.plane_in) + cb0 + (unsigned)((combo & 1) * hw);
+                            dma16(p.x, inb ? (cbase + pix) * 16u : zero_off, lds_b + xst + (combo * HC_PATCH + j * 64) * 16);
+                        }
+                    }
+                }
+            }
+            const unsigned wst = (unsigned)((HP_W0 + (k % HP_NW) * HC_W4) * 16);
+#pragma unroll
+            for (int piece = 0; piece < HP_GW; ++piece) {
+                const int hl = piece / 9;                                     // 18 x 32 uint4 = 9 pieces per slab
+                const int rem = piece * 64 - hl * 576 + lane;                 // [tap][half][32] index
+                dma16(hl ? p.wlo : p.whi, (unsigned)(((((par * nchunk + c) * 18 + (rem >> 5)) * p.cout) + cot * 32 + (rem & 31)) * 16), lds_b + wst + piece * 1024);
+            }
+        };
+        auto item_setup = [&](int i) __attribute__((always_inline)) {         // d / s_next / bias of the item's 32 channels: read in its epilogue, NU - 1 >= 3 groups later
+            int b, cot, tyt, txt;
+            item_coords(i, b, cot, tyt, txt);
+            const unsigned co4 = (unsigned)((cot * 32 + (lane & 31)) * 4);
+            dma4(p.d, (unsigned)(b * p.cout * 4) + co4, lds_b + HP_BODY + HC_EP_D * 4);
+            dma4(p.s_next, (unsigned)(b * p.cout * 4) + co4, lds_b + HP_BODY + HC_EP_S * 4);
+            dma4(p.act_bias ? p.act_bias : p.zeros, p.act_bias ? co4 : 0u, lds_b + HP_BODY + HC_EP_B * 4);
+        };
+        item_setup(0);
+#pragma unroll
+        for (int k = 0; k < HP_D; ++k) issue_group(k);
+        const int total = my_items * NU;
+#pragma unroll 1
+        for (int k = 0; k < total; ++k) {
+            // unit k has landed: everything this wave requested except (at most) the two youngest groups — one of them carries an activation chunk, one does
+            // not, 56 requests; an item's three table requests in between only make the wait a little earlier than necessary
+            HP_WAIT_YOUNGEST_TWO();
+            E4S_LDS_BARRIER();
+            if (k > 0 && k % NU == 0) item_setup(k / NU);
+            issue_group(k + HP_D);
+        }
+        E4S_WAIT_VM(0);   // ghost groups must land before the workgroup's LDS is released
+        return;
+    }
+
+    // ======================================================================================= compute waves
+    const int l5 = lane & 31, khalf = lane >> 5;
+    const int pty = 2 * wave + (l5 >> 4), ptx = l5 & 15;
+    const int xoff = pty * HC_PW + ptx;
+    if (blockIdx.x == 0 && tid < 1) p.out[(size_t)p.plane_out * 2] = make_uint4(0u, 0u, 0u, 0u);   // the zero element behind the output planes
+    int xbuf = 0;                                        // (k >> 1) % HP_NX, carried along
+#pragma unroll 1
+    for (int ti = 0; ti < my_items; ++ti) {
+        int b, cot, tyt, txt;
+        item_coords(ti, b, cot, tyt, txt);
+        const int pm = tyt * HC_T + pty, pbx = txt * HC_STEP - 1 + ptx;
+        const bool lane_ok = ptx >= 1 && ptx <= HC_STEP && pbx < p.w && pm < p.h;
+        float2 nz[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+        if (p.noise && lane_ok) {                        // requested now, used after the K loop
+            const float* np = p.noise + (size_t)b * p.noise_bstride + (size_t)(2 * pm) * wo + 2 * pbx;
+            nz[0] = *reinterpret_cast<const float2*>(np);
+            nz[1] = *reinterpret_cast<const float2*>(np + wo);
+        }
+        f32x16 accs[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accs[a][r] = 0.f;
+#pragma unroll 1
+        for (int c = 0; c < nchunk; ++c) {
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                const int k = ti * NU + 2 * c + par;
+                E4S_LDS_BARRIER();
+                unsigned xb_i = (unsigned)(xbuf * HC_XB4 + khalf * HC_PATCH + xoff);
+                unsigned wb_i = (unsigned)(HP_W0 + (k % HP_NW) * HC_W4 + khalf * 32 + l5);
+                asm volatile("" : "+v"(xb_i), "+v"(wb_i));
+                const uint4* xs = lds4 + xb_i;
+                const uint4* whalf = lds4 + wb_i;
+                uint4 bh[2], bl[2], ah[2], al[2];
+                auto fetch = [&](int tap, int slot) __attribute__((always_inline)) {
+                    const int dyi = tap / 3, kx = tap % 3;
+                    const int eo = dyi * HC_PW + (1 - (kx >> 1));
+                    bh[slot] = xs[eo];
+                    bl[slot] = xs[2 * HC_PATCH + eo];
+                    ah[slot] = whalf[tap * 64];
+                    al[slot] = whalf[18 * 32 + tap * 64];
+                };
+                fetch(0, 0);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int cs = tap & 1;
+                    if (tap + 1 < 9) fetch(tap + 1, cs ^ 1);
+                    const int ai = 2 * par + ((tap % 3) & 1);
+                    accs[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[cs]), __builtin_bit_cast(bf16x8, bh[cs]), accs[ai], 0, 0, 0);
+                    accs[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[cs]), __builtin_bit_cast(bf16x8, bl[cs]), accs[ai], 0, 0, 0);
+                    accs[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[cs]), __builtin_bit_cast(bf16x8, bh[cs]), accs[ai], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            xbuf = xbuf + 1 < HP_NX ? xbuf + 1 : 0;
+        }
+        hc_epilogue(p, accs, lds_raw, HP_BODY, nz, lane_ok, b, cot * 32, pm, pbx, khalf);
+    }
 }
 
 // Half-composed weights: out[par][chunk][tap = (dy + 1) * 3 + kx][half][co][e] = scale * sum_ky kv'[ky + 2 dy + 1 - par] * W[co][ci][ky][kx], split into bf16 hi / lo;
@@ -358,7 +534,8 @@ extern "C" int e4s_modconv_up_hc(uint16_t* out_sp, const uint16_t* x_sp, const u
         return hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_hc_zero)) == hipSuccess ? static_cast<const float*>(ptr) : nullptr;
     }();
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&up_hc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, HC_LDS);
-    if (!zeros || attr != hipSuccess) return fail(E4S_ERR_ARG, "modconv_up_hc: cannot set up the kernel (zero block / dynamic LDS limit)");
+    static const hipError_t attr_p = hipFuncSetAttribute(reinterpret_cast<const void*>(&up_hcp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, HP_LDS);
+    if (!zeros || attr != hipSuccess || attr_p != hipSuccess) return fail(E4S_ERR_ARG, "modconv_up_hc: cannot set up the kernel (zero block / dynamic LDS limit)");
     UpHcParams p;
     p.out = reinterpret_cast<uint4*>(out_sp); p.x = reinterpret_cast<const uint4*>(x_sp);
     p.whi = reinterpret_cast<const uint4*>(whi); p.wlo = reinterpret_cast<const uint4*>(wlo);
@@ -366,8 +543,21 @@ extern "C" int e4s_modconv_up_hc(uint16_t* out_sp, const uint16_t* x_sp, const u
     p.noise_bstride = (noise && noise_bs > 1) ? 4 * h * w : 0;
     p.act = act & 1; p.bs = bs; p.cin = cin; p.cout = cout; p.h = h; p.w = w;
     p.tiles_x = cdiv(2 * w, 2 * HC_STEP); p.tiles_y = cdiv(h, HC_T);
+    p.ntile = p.tiles_x * p.tiles_y * bs; p.ncot = cout / 32;
     p.plane_in = (int64_t)bs * (cin / 8) * h * w;
     p.plane_out = (int64_t)bs * (cout / 8) * 4 * h * w;
+    // E4S_UP_HC_PERSIST=0: the two-workgroups-per-CU form (kept as the comparison arm of tools/time_uphc.py); cin = 16 has too few units per item for the
+    // persistent loader's table hand-over
+    static const int persist = [] { const char* e = getenv("E4S_UP_HC_PERSIST"); return e ? atoi(e) : 1; }();
+    if (persist && cin >= 32) {
+        static const int ncu = [] {
+            int dev = 0, n = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            return n > 0 ? n : 256;
+        }();
+        hipLaunchKernelGGL(up_hcp_kernel, dim3(p.ntile < ncu ? p.ntile : ncu), dim3(HP_NT), HP_LDS, (hipStream_t)stream, p);
+        return check_launch("modconv_up_hc");
+    }
     hipLaunchKernelGGL(up_hc_kernel, dim3(p.tiles_x * p.tiles_y, cout / 32, bs), dim3(HC_NT), HC_LDS, (hipStream_t)stream, p);
     return check_launch("modconv_up_hc");
 }

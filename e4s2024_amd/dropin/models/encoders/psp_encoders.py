@@ -132,7 +132,8 @@ class FSEncoder_PSP(Module):
         return ops.masked_avg_pool(style_feats, ops.mask_to_labels(segmap), nreg)
 
     def forward(self, x, segmap):
-        return self.codes(self.features(x), segmap)
+        # (ops.guarded: the stride-1 3x3 convolutions may run in f16 + fp6 arithmetic; a pass that left the f16 range is re-run in split-bf16)
+        return ops.guarded(lambda: self.codes(self.features(x), segmap))
 
     def features(self, x):
         """The feature maps the style codes are pooled from (after units 6, 20 and 23) — everything of ``forward`` that does not depend on the

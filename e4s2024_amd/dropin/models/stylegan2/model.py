@@ -437,9 +437,11 @@ class Generator(nn.Module):
 
     def forward(self, styles, structure_feats, mask, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
                 input_is_latent=False, noise=None, randomize_noise=True, use_structure_code=False):
+        # ops.guarded: the masked 3x3 layers run in f16 (+ fp6) arithmetic at inference; a pass that left the f16 range is re-run once in split-bf16
+        # (one host synchronisation per call, which the reference's callers do right behind gen_img anyway; pipelines own the guard themselves)
         with ops.one_forward():        # parameters do not change inside one pass: a trained layer's weights are re-laid out once per pass
-            return self._forward(styles, structure_feats, mask, return_latents, inject_index, truncation, truncation_latent, input_is_latent,
-                                 noise, randomize_noise, use_structure_code)
+            return ops.guarded(lambda: self._forward(styles, structure_feats, mask, return_latents, inject_index, truncation, truncation_latent,
+                                                     input_is_latent, noise, randomize_noise, use_structure_code))
 
     def _forward(self, styles, structure_feats, mask, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
                  input_is_latent=False, noise=None, randomize_noise=True, use_structure_code=False):

@@ -52,8 +52,22 @@ class GraphedCall:
                 raise ValueError(f"graphed call was captured for {tuple(dst.shape)} {dst.dtype}, got {tuple(src.shape)} {src.dtype}")
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
+        # f16 range guard around the replay (the two snapshots are ordinary stream-ordered copies, outside the graph): ``self.guard.tripped()`` tells
+        # the caller — where it synchronises anyway — whether this replay's frames can be trusted; ``checked()`` does that and heals by itself
+        self.guard = ops.MxGuard()
         self.graph.replay()
+        self.guard.arm()
         return self.static_out
+
+    def checked(self, *inputs: torch.Tensor):
+        """``__call__`` + the f16 range check (one host synchronisation): a replay whose arithmetic left the f16 range is repeated EAGERLY in the
+        split-bf16 arithmetic (``ops.mx_exact``) and those results are returned instead of the static outputs."""
+        out = self(*inputs)
+        if self.guard.tripped():
+            ops.mx_fallbacks += 1
+            with torch.no_grad(), ops.mx_exact(), ops.mx_guard_scope():
+                out = self.fn(*self.static_in)
+        return out
 
 
 def graphed_gen_img(net, codes: torch.Tensor, labels: torch.Tensor, randomize_noise: bool = False) -> GraphedCall:

@@ -237,10 +237,10 @@ class _StreamCtx:
     model: ONE host thread per stream; the prepared weight copies, which ARE shared, publish themselves atomically and are ordered across
     streams by an event, see ``_Prepared``)."""
 
-    __slots__ = ("label_cache", "table_plan", "forward_stamp", "workspace", "up_ctrl", "mx_flags")
+    __slots__ = ("label_cache", "table_plan", "forward_stamp", "workspace", "up_ctrl", "pinned")
 
     def __init__(self):
-        self.label_cache, self.table_plan, self.forward_stamp, self.workspace, self.up_ctrl, self.mx_flags = {}, {}, None, None, None, None
+        self.label_cache, self.table_plan, self.forward_stamp, self.workspace, self.up_ctrl, self.pinned = {}, {}, None, None, None, False
 
 
 _ctxs = {}
@@ -259,20 +259,29 @@ def _ctx(stream=None) -> _StreamCtx:
 
 
 def release_stream_context(stream) -> bool:
-    """Drop ``stream``'s host context — its 128 MB split-K workspace, control words, region-map cache (ADVICE r2: a long-running process that keeps
-    creating streams — ``StreamPipeline``, ``run_clip_streamed``, graph captures — would otherwise pin one workspace per stream id it ever used).  The
-    caller vouches that no launch of this library is still queued on the stream (``StreamPipeline.close()`` synchronises first) and that no live
-    hipGraph was captured on it.  Returns whether a context existed."""
+    """Drop ``stream``'s host context — its 128 MB split-K workspace, control words, region-map cache (a long-running process that keeps
+    creating streams — ``StreamPipeline``, ``run_clip_streamed`` — would otherwise pin one workspace per stream id it ever used).  The caller vouches
+    that no launch of this library is still queued on the stream (``StreamPipeline.close()`` synchronises first).  A context that was prepared for a
+    hipGraph capture (``prepare_stream_context``) is PINNED and stays: the graph baked its workspace / control-word pointers in, and torch hands stream
+    handles out of a pool of 32 per device, so another stream object can carry the same handle as a live graph's (round-3 advisor finding).
+    Returns whether a context was dropped."""
     key = (stream.device.index, stream.cuda_stream)
     with _ctx_lock:
-        return _ctxs.pop(key, None) is not None
+        c = _ctxs.get(key)
+        if c is None or c.pinned:
+            return False
+        del _ctxs[key]
+        return True
 
 
 def prepare_stream_context(stream) -> None:
-    """Create ``stream``'s context and its split-K workspace NOW (eagerly, outside any capture), so that a hipGraph captured on that stream
-    later bakes in a pointer that outlives the graph's private memory pool."""
+    """Create ``stream``'s context, its split-K workspace and the device's f16 range words NOW (eagerly, outside any capture), so that a hipGraph
+    captured on that stream later bakes in pointers that outlive the graph's private memory pool; the context is pinned (``release_stream_context``
+    leaves it alone)."""
     with torch.cuda.stream(stream):
         _workspace(stream.device, 1)
+        mx_flags(stream.device)
+        _ctx().pinned = True
 
 
 # ------------------------------------------------------------------------------ region map
@@ -488,7 +497,7 @@ def mx_arith() -> Optional[int]:
     """Arithmetic selector of the mx kernel under the current settings, or None when it is off."""
     if MX_MODE <= 0 or MODCONV_MODE != "sb":
         return None
-    return 1 if MX_MODE >= 2 else 0
+    return 1 if (MX_MODE >= 2 and not mx_exact_active()) else 0
 
 
 def mx_eligible(cin: int, cout: int, w: int, masked: bool) -> bool:
@@ -533,24 +542,143 @@ class PreparedMx(_Prepared):
         return wmx
 
 
+_mx_words = {}            # device index -> int32[4]: [0] sticky "some launch left the f16 range" bit, [1] a counter that moves whenever one does
+_mx_tls = threading.local()
+mx_fallbacks = 0          # passes re-run with the exact arithmetic since import (host counter; ``bench.py`` reports it)
+
+
 def mx_flags(device) -> torch.Tensor:
-    """The device word the f16 arithmetic raises (bit 0) when a modulated activation leaves the f16 range; one per stream context."""
-    c = _ctx()
-    if c.mx_flags is None or c.mx_flags.device != torch.device(device):
-        c.mx_flags = torch.zeros((4,), dtype=torch.int32, device=device)
-    return c.mx_flags
+    """The device words the f16 arithmetic reports to (``include/e4s_hip.h``: flags[0] |= 1, flags[1] += 1 per reporting wave).  ONE tensor per device,
+    shared by every stream, never reset by the guard — ``MxGuard`` compares two snapshots of the counter, so concurrent streams cannot hide each other's
+    reports (a report on another stream can at worst cause a spurious re-run)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    t = _mx_words.get(idx)
+    if t is None:
+        with _ctx_lock:
+            t = _mx_words.get(idx)
+            if t is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("the f16 range words must exist before a hipGraph capture: call ops.prepare_stream_context(stream) first")
+                t = _mx_words[idx] = torch.zeros((4,), dtype=torch.int32, device=dev)
+    return t
 
 
 def mx_overflowed(reset: bool = True) -> bool:
-    """Did any mx launch on the current stream since the last reset see |x * s| >= 2^16?  (Synchronises the stream.)  The results of such a forward
-    are not to be trusted (f16 infinities); rerun with ``E4S_MX=1`` / ``ops.MX_MODE = 1``."""
-    c = _ctx()
-    if c.mx_flags is None:
+    """Did any f16-arithmetic launch on this device since the last reset see a value outside the f16 range?  (Synchronises the device word; tests / tools.
+    The product path does not poll this: see ``MxGuard``.)"""
+    idx = torch.cuda.current_device()
+    t = _mx_words.get(idx)
+    if t is None:
         return False
-    v = int(c.mx_flags[0].item())
+    v = int(t[0].item())
     if reset and v:
-        c.mx_flags.zero_()
+        t[0:1].zero_()
     return bool(v & 1)
+
+
+def mx_exact_active() -> bool:
+    """Inside ``with ops.mx_exact():`` — every route that would use the f16 (+ fp6) arithmetic takes its split-bf16 form instead."""
+    return getattr(_mx_tls, "exact", 0) > 0
+
+
+class mx_exact:
+    """``with ops.mx_exact():`` re-runs of a pass whose f16 arithmetic overflowed: the masked 3x3 layers on the mx kernel's split-bf16 arithmetic
+    (bit-identical to modconv_sb.hip), the encoder's convolutions on the Winograd / direct split-bf16 kernels, the parser on the three-way bf16 split.
+    Thread-local (one host thread per stream is the supported concurrency model)."""
+
+    def __enter__(self):
+        _mx_tls.exact = getattr(_mx_tls, "exact", 0) + 1
+        return self
+
+    def __exit__(self, *exc):
+        _mx_tls.exact -= 1
+
+
+class MxGuard:
+    """Self-healing of the f16 arithmetic (default since round 3 for the masked 3x3 layers, the encoder's stride-1 3x3 convolutions and the parser).
+    A modulated activation >= 65520 becomes an f16 infinity and the frame carries inf / NaN; StyleGAN2 with trained weights is the textbook network for
+    that, the reference computes everything in fp32 (models/stylegan2/model.py:276-320) and the seeded networks of the tests peak at |x s| ~ 10.  The kernels
+    report an overflow by bumping a device counter; a guard snapshots that counter (4-byte asynchronous copies into pinned memory, ordered on the
+    current stream) before and after a pass, and whoever owns the pass re-runs it under ``mx_exact()`` when the two differ:
+
+        g = ops.MxGuard()            # snapshot "before" (a no-op object when the f16 arithmetic is off)
+        out = forward(...)
+        if g.tripped():              # snapshot "after" + wait for it (a host synchronisation with this stream)
+            with ops.mx_exact(): out = forward(...)
+
+    ``Generator.forward`` / ``FSEncoder_PSP.forward`` / ``FaceParser`` do exactly that by themselves — unless a caller up the stack owns a guard already
+    (``with ops.mx_guard_scope() as g:``): pipelines that must not synchronise per pass (``pipeline.swap_batch``, ``runner``, ``bench.py``) take the two
+    snapshots around their whole unit of work, call ``g.arm()`` when it is queued, and look at ``g.tripped()`` where they synchronise anyway.
+    Graph replays: take the guard around ``graph.replay()`` (the snapshots are ordinary stream-ordered copies)."""
+
+    __slots__ = ("_before", "_after", "_ev", "_live")
+
+    def __init__(self):
+        self._before = self._after = self._ev = None
+        # (inside a hipGraph capture a guard is a no-op: no pinned allocation, no event wait — bracket graph.replay() instead)
+        self._live = torch.cuda.is_available() and (MX_MODE >= 2 or PARSER_EXACT == "f16x3") and not mx_exact_active() \
+            and not torch.cuda.is_current_stream_capturing()
+        if self._live:
+            self._before = self._snap()
+
+    @staticmethod
+    def _snap():
+        words = mx_flags(torch.cuda.current_device())
+        host = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+        host.copy_(words[1:2], non_blocking=True)
+        return host
+
+    def arm(self) -> "MxGuard":
+        """Queue the "after" snapshot behind everything issued on the current stream so far."""
+        if self._live and self._after is None:
+            self._after = self._snap()
+            self._ev = torch.cuda.Event()
+            self._ev.record()
+        return self
+
+    def tripped(self) -> bool:
+        """Did the counter move between the two snapshots?  Arms the guard if the caller has not, then waits for the "after" copy."""
+        if not self._live:
+            return False
+        self.arm()
+        self._ev.synchronize()
+        return int(self._after[0]) != int(self._before[0])
+
+
+class mx_guard_scope:
+    """``with ops.mx_guard_scope() as g:`` — the caller owns the guard of everything inside: the modules' own per-pass guards (and their host
+    synchronisation) are switched off for this thread; the caller arms ``g`` when its unit of work is queued and checks ``g.tripped()`` where it
+    synchronises anyway, re-running the unit under ``ops.mx_exact()``."""
+
+    def __enter__(self) -> MxGuard:
+        self.guard = MxGuard()
+        _mx_tls.owned = getattr(_mx_tls, "owned", 0) + 1
+        return self.guard
+
+    def __exit__(self, *exc):
+        _mx_tls.owned -= 1
+
+
+def mx_guard_owned() -> bool:
+    """Is this thread inside somebody's ``mx_guard_scope`` (who will check and re-run), or already in the exact arithmetic?"""
+    return getattr(_mx_tls, "owned", 0) > 0 or mx_exact_active()
+
+
+def guarded(fn):
+    """Run ``fn()`` under its own guard unless the caller owns one (or the exact arithmetic is already on): one re-run under ``mx_exact()`` if the f16
+    arithmetic overflowed.  What the drop-in modules wrap their forward passes in."""
+    global mx_fallbacks
+    if getattr(_mx_tls, "owned", 0) > 0 or mx_exact_active() or torch.is_grad_enabled() or not torch.cuda.is_available() \
+            or torch.cuda.is_current_stream_capturing():
+        return fn()          # (under autograd the f16 routes are not taken at all: mx_eligible / mx_conv_eligible)
+    g = MxGuard()
+    out = fn()
+    if g.tripped():
+        mx_fallbacks += 1
+        with mx_exact():
+            out = fn()
+    return out
 
 
 # The chain's up layers in the half-composed form (csrc/modconv_uphc.hip): vertical blur factor composed into the weights, horizontal factor applied to the
@@ -1106,12 +1234,12 @@ class PreparedConv(_Prepared):
         if self.exact == "sb3":
             return 3
         if self.exact == "f16x3":
-            return 4
+            return 3 if mx_exact_active() else 4          # (the re-run of a pass whose f16 arithmetic overflowed: three-way bf16 split)
         return 2 if (CONV_MODE == "sb" and not self.exact) else 0
 
     def get(self, weight: torch.Tensor, bn=None, conv_bias: Optional[torch.Tensor] = None):
         ts = [weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else []) + ([conv_bias] if conv_bias is not None else [])
-        key = tuple((t.data_ptr(), t._version) for t in ts) + (weight.device, CONV_MODE)
+        key = tuple((t.data_ptr(), t._version) for t in ts) + (weight.device, CONV_MODE, self.exact == "f16x3" and mx_exact_active())
         if any(_volatile(t) for t in ts):
             key = None
         hit = self._lookup(key)
@@ -1193,7 +1321,7 @@ def conv2d(x: torch.Tensor, prepared: PreparedConv, stride: int = 1, pad: int = 
     pr = _p(_c(prelu.detach(), "prelu")) if prelu is not None else None
     if sb and _is_f16x3(prepared):
         lib().call("e4s_conv2d_f16x3", _p(out), _p(x), _p(x1), c0, _p(prepared.wt[0]), _p(prepared.wt[1]), _p(prepared.bias), _p(mean), _p(rstd),
-                   pr, _p(res), act, bs, cin, cout, h, w, kh, stride, pad, prepared.kexp, _stream())
+                   pr, _p(res), act, bs, cin, cout, h, w, kh, stride, pad, prepared.kexp, _p(mx_flags(x.device)), _stream())
     elif sb and len(prepared.wt) == 3:
         lib().call("e4s_conv2d_sb3", _p(out), _p(x), _p(x1), c0, _p(prepared.wt[0]), _p(prepared.wt[1]), _p(prepared.wt[2]), _p(prepared.bias),
                    _p(mean), _p(rstd), pr, _p(res), act, bs, cin, cout, h, w, kh, stride, pad, _stream())

@@ -70,10 +70,32 @@ def mix_style_vectors(target_vec: torch.Tensor, driven_vec: torch.Tensor, comp_i
 @torch.no_grad()
 def swap_batch(net, parser, driven: torch.Tensor, target: torch.Tensor, comp_indices: Sequence[int] = DEFAULT_COMP_INDICES,
                randomize_noise: bool = False, to_uint8: bool = True, timings: Optional[dict] = None, mask_surgery: bool = False,
-               paste_radius: int = 5, two_streams: Optional[bool] = None, batched: Optional[bool] = None):
+               paste_radius: int = 5, two_streams: Optional[bool] = None, batched: Optional[bool] = None, guard: Optional[list] = None):
     """``driven`` / ``target``: ``[bs, 3, 1024, 1024]`` in [-1, 1] on the device.  Returns uint8 ``[bs, 1024, 1024, 3]`` frames
     (or the float image) and the 12-class region maps the synthesis used; with ``mask_surgery`` a third value
-    ``{"hole_mask", "hole_map", "lines", "content", "border", "full"}`` (the reference's paste-back inputs, :456-463)."""
+    ``{"hole_mask", "hole_map", "lines", "content", "border", "full"}`` (the reference's paste-back inputs, :456-463).
+
+    f16 range (``ops.MxGuard``): parser, encoder and the masked synthesis layers run in f16-based split arithmetic.  The batch is bracketed by ONE
+    guard; by default the call waits for it at its end and re-runs the whole batch in the split-bf16 arithmetic if a value left the f16 range
+    (``ops.mx_fallbacks`` counts those).  Callers that keep several batches in flight pass ``guard=[]``: the armed guard is appended instead of
+    awaited, and the caller checks ``guard[-1].tripped()`` where it synchronises anyway, repeating the call under ``with ops.mx_exact():``."""
+    args = (net, parser, driven, target, comp_indices, randomize_noise, to_uint8, timings, mask_surgery, paste_radius, two_streams, batched)
+    if guard is None and ops.mx_guard_owned():        # a caller up the stack brackets this batch with its own guard (runner.run_clip_streamed, bench.py)
+        return _swap_batch_once(*args)
+    with ops.mx_guard_scope() as g:
+        out = _swap_batch_once(*args)
+        g.arm()
+    if guard is not None:
+        guard.append(g)
+        return out
+    if g.tripped():
+        ops.mx_fallbacks += 1
+        with ops.mx_exact():
+            out = _swap_batch_once(*args)
+    return out
+
+
+def _swap_batch_once(net, parser, driven, target, comp_indices, randomize_noise, to_uint8, timings, mask_surgery, paste_radius, two_streams, batched):
     def mark(name):
         if timings is not None:
             ev = torch.cuda.Event(enable_timing=True)

@@ -115,7 +115,7 @@ class FrameShardRunner:
 
         def finish(item):
             nonlocal out
-            work, send, bufs, k, ev = item
+            work, snd0, bufs, k, ev = item
             if ev is not None:
                 torch.cuda.current_stream().wait_event(ev)     # the round ran on its own stream
             if work is not None:
@@ -126,7 +126,7 @@ class FrameShardRunner:
                 lo = s + k * batch
                 hi = min(lo + batch, e)
                 if hi > lo:
-                    src = bufs[r] if bufs is not None else send
+                    src = bufs[r] if bufs is not None else snd0
                     if out is None:
                         out = torch.empty((n_frames,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
                     out[lo:hi].copy_(src[: hi - lo])
@@ -134,46 +134,80 @@ class FrameShardRunner:
                         src.record_stream(torch.cuda.current_stream())     # (allocated on the round's stream, read here)
 
         shape = None
+        on_gpu = torch.device(self.device).type == "cuda"
+        if on_gpu:
+            from . import ops
+        # A round is computed (``compute``) one loop turn before its frames are sent (``send``): the host looks at the round's f16 range guard
+        # (``ops.MxGuard``; a wait for that round) while the NEXT round is already queued on the other stream, so the wait costs no GPU time, and a
+        # round whose arithmetic overflowed is recomputed in split-bf16 before its frames leave.  Every rank issues the same sequence of gathers.
 
-        def one_round(k):
+        def compute(k, exact=False):
             nonlocal shape
             lo = start + k * batch
             hi = min(lo + batch, stop)
-            frames = None
+            frames = guard = None
+
+            def synth(a, b):
+                if not on_gpu:
+                    return synth_fn(shared, frame_inputs(a, b)), None
+                with ops.mx_guard_scope() as g:
+                    if exact:
+                        with ops.mx_exact():
+                            f = synth_fn(shared, frame_inputs(a, b))
+                    else:
+                        f = synth_fn(shared, frame_inputs(a, b))
+                    g.arm()
+                return f, g
             if hi > lo:
-                frames = synth_fn(shared, frame_inputs(lo, hi))
+                frames, guard = synth(lo, hi)
                 if frames.dtype != torch.uint8 or frames.shape[0] != hi - lo:
                     raise ValueError("synth_fn must return uint8 frames [n, H, W, 3] for the requested block")
                 shape = tuple(frames.shape[1:])
             elif shape is None:     # this rank has no frames at all: learn the frame shape from a probe, send padding
-                shape = tuple(synth_fn(shared, frame_inputs(0, min(1, n_frames))).shape[1:])
-            if frames is not None and frames.shape[0] == batch:
-                send = frames.contiguous()
-            else:
-                send = torch.zeros((batch,) + shape, dtype=torch.uint8, device=self.device)
-                if frames is not None:
-                    send[: frames.shape[0]] = frames
-            if self.distributed and self.world > 1:
-                bufs = [torch.empty_like(send) for _ in range(self.world)] if self.rank == dst else None
-                work = dist.gather(send, bufs, dst=dst, group=self.group, async_op=True)       # (ordered after this round's stream)
-            else:
-                bufs, work = None, None
-            ev = None
-            if send.is_cuda:
-                ev = torch.cuda.Event()
-                ev.record()
-            return work, send, bufs, k, ev
+                shape = tuple(synth(0, min(1, n_frames))[0].shape[1:])
+            return frames, guard, k, (torch.cuda.current_stream() if on_gpu else None)
 
-        on_gpu = torch.device(self.device).type == "cuda"
+        def send(item):
+            frames, guard, k, st = item
+            ctx = torch.cuda.stream(st) if st is not None else _null_context()
+            with ctx:
+                if guard is not None and guard.tripped():
+                    ops.mx_fallbacks += 1
+                    frames = compute(k, exact=True)[0]
+                if frames is not None and frames.shape[0] == batch:
+                    snd = frames.contiguous()
+                else:
+                    snd = torch.zeros((batch,) + shape, dtype=torch.uint8, device=self.device)
+                    if frames is not None:
+                        snd[: frames.shape[0]] = frames
+                if self.distributed and self.world > 1:
+                    bufs = [torch.empty_like(snd) for _ in range(self.world)] if self.rank == dst else None
+                    work = dist.gather(snd, bufs, dst=dst, group=self.group, async_op=True)       # (ordered after this round's stream)
+                else:
+                    bufs, work = None, None
+                ev = None
+                if snd.is_cuda:
+                    ev = torch.cuda.Event()
+                    ev.record()
+            return work, snd, bufs, k, ev
+
         pipe = StreamPipeline(streams if on_gpu else 1, device=self.device if on_gpu else None)
-        with pipe:
-            for k in range(rounds):
-                pending.append(pipe.submit(one_round, k))
-                if len(pending) > 2:
-                    finish(pending.pop(0))
-        while pending:                          # (after the pipeline's exit the current stream has waited for every round's stream)
-            finish(pending.pop(0))
-        pipe.close()                            # the clip's side streams give their host contexts (128 MB of split-K workspace each) back
+        try:
+            with pipe:
+                computed = None
+                for k in range(rounds):
+                    nxt = pipe.submit(compute, k)
+                    if computed is not None:
+                        pending.append(send(computed))
+                        if len(pending) > 2:
+                            finish(pending.pop(0))
+                    computed = nxt
+                if computed is not None:
+                    pending.append(send(computed))
+            while pending:                          # (after the pipeline's exit the current stream has waited for every round's stream)
+                finish(pending.pop(0))
+        finally:
+            pipe.close()                            # the clip's side streams give their host contexts (128 MB of split-K workspace each) back
         return out if self.rank == dst else None
 
     def run_clip(self, n_frames: int, shared: torch.Tensor, frame_inputs: Callable[[int, int], object],
@@ -194,6 +228,14 @@ class FrameShardRunner:
             probe = synth_fn(shared, frame_inputs(0, min(1, n_frames)))
             local = probe[:0]
         return self.gather_frames(local, n_frames, dst=dst)
+
+
+class _null_context:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
 
 
 class StreamPipeline:

@@ -141,8 +141,10 @@ E4S_API int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16_t*
  * activations): the weights arrive as ready-to-DMA row slots (one kernel row of a 16-channel chunk for 128 output channels: 24-25 KB) from
  * e4s_modconv_prep_weights_mx.  arith 0 = the split-bf16 arithmetic above, bit-identical results; arith 1 = a1*w1 on the f16 MFMA plus the two cross
  * terms fp6(a)*fp6(w - w1) and fp6(a - a1)*fp6(w1) on the block-scaled MX fp6 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4): about half the matrix-pipe
- * time, 2-3x the split-bf16 error (1.9e-4 max-abs on the 1024^2 generator against 8e-5; bar 1e-3).  flags (optional, arith 1): flags[0] |= 1 when a
- * modulated activation reaches 2^16 and so leaves the f16 range — the result is then not to be trusted.
+ * time, 2-3x the split-bf16 error (1.9e-4 max-abs on the 1024^2 generator against 8e-5; bar 1e-3).  flags (optional, arith 1; int[2]): a wave that sees a
+ * modulated activation >= 65520 (what f16 rounds to infinity) does flags[0] |= 1 and flags[1] += 1 — the result is then not to be trusted.  The library does not
+ * fall back by itself (no host synchronisation in the ABI): the host layer snapshots flags[1] before and after a forward pass and re-runs a pass that moved
+ * it with arith 0 (e4s2024_amd/ops.py MxGuard; the reference computes these layers in fp32, models/stylegan2/model.py:276-320).
  * e4s_modconv_mx_weight_bytes: size of the prepared copy.  All other arguments as e4s_region_modconv3x3_sb. */
 E4S_API int e4s_modconv_mx_weight_bytes(int cout, int cin, int up, int arith, int64_t* bytes);
 E4S_API int e4s_modconv_prep_weights_mx(void* dst, const float* weight, const float* blur, int cout, int cin, int up, int arith, void* stream);
@@ -165,7 +167,7 @@ E4S_API int e4s_conv3x3_mx(float* out, const float* x, const void* wmx, int arit
 /* The same operator (f16 + 2 x MX fp6 only) on the two-phase kernel of csrc/conv_mx3.hip: 32-channel chunks (cin % 32 == 0, cin <= 512), activations converted
  * to fp6 once per staged value, waves 4-7 half a unit behind waves 0-3 so that every SIMD always has a wave on the matrix pipe.  Replaces the same reference
  * statements (models/encoders/helpers.py:128-139).  wmx3 from e4s_conv_prep_weights_mx3 (weight [cout,cin,3,3]; size: e4s_conv3x3_mx3_weight_bytes);
- * flags[0] bit 0 is raised when a normalised activation leaves the f16 range. */
+ * flags as for e4s_region_modconv3x3_mx (flags[0] |= 1, flags[1] += 1 when a normalised activation leaves the f16 range). */
 E4S_API int e4s_conv3x3_mx3_weight_bytes(int cout, int cin, int64_t* bytes);
 E4S_API int e4s_conv_prep_weights_mx3(void* dst, const float* weight, int cout, int cin, void* stream);
 E4S_API int e4s_conv3x3_mx3(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
@@ -345,14 +347,15 @@ E4S_API int e4s_conv2d_sb3(float* out, const float* x0, const float* x1, int cin
 /* Round 3: the fp32-class convolution at half the MFMAs of the three-way bf16 split — TWO f16 terms per operand (11 significand bits each where bf16 has 8),
  * a1*b1 + a1*b2 + a2*b1 on v_mfma_f32_32x32x16_f16, ~2^-23 per product.  w1 / w2: f16 (as uint16) slabs of weight * 2^wscale_log2 in the layout of
  * e4s_conv_prep_weights_sb — the power of two keeps the second term a normal f16; pick it so that the largest (BatchNorm-folded) weight lands near 2^10 and
- * pass the same value to e4s_conv2d_f16x3, which takes it out again.  Activations are used as they are (|x| < 65504; their second term loses bits below
+ * pass the same value to e4s_conv2d_f16x3, which takes it out again.  Activations are used as they are (|x| < 65520 — a wave that stages a larger one raises
+ * flags[0] bit 0 and bumps the counter flags[1] (flags may be NULL), the result is then invalid and the caller re-runs the pass on e4s_conv2d_sb3; their second term loses bits below
  * |x| ~ 2^-3, harmless next to the O(1) activations of the networks on this path).  Same fusions as e4s_conv2d. */
 E4S_API int e4s_conv_prep_weights_f16x3(uint16_t* w1, uint16_t* w2, float* bias_out, const float* weight,
                                         const float* bn_gamma, const float* bn_beta, const float* bn_mean, const float* bn_var, float bn_eps,
                                         const float* conv_bias, int cout, int cin, int kh, int kw, int wscale_log2, void* stream);
 E4S_API int e4s_conv2d_f16x3(float* out, const float* x0, const float* x1, int cin0, const uint16_t* w1, const uint16_t* w2, const float* bias,
                              const float* in_mean, const float* in_rstd, const float* prelu_slope, const float* residual, int act,
-                             int bs, int cin, int cout, int h, int w, int ks, int stride, int pad, int wscale_log2, void* stream);
+                             int bs, int cin, int cout, int h, int w, int ks, int stride, int pad, int wscale_log2, int* flags, void* stream);
 
 /* Per-plane statistics of x [planes = bs*C, hw]: mean, rstd = 1/sqrt(biased var + eps) (InstanceNorm2d without affine / running
  * stats, helpers.py:133,138), nmean = mean of the normalised plane (what SEModule's avg_pool sees, helpers.py:66).  rstd and nmean

@@ -1,0 +1,166 @@
+"""The f16 range guard (ops.MxGuard): the masked 3x3 layers, the encoder's stride-1 3x3 convolutions and the parser run in f16-based split arithmetic;
+the reference computes them in fp32 (models/stylegan2/model.py:276-320, models/encoders/helpers.py:128-139, swap_face_fine/face_parsing/model.py).
+A network whose modulated activations leave the f16 range must (i) be noticed, (ii) come out right anyway — the pass is re-run in split-bf16 —
+and (iii) be counted.  The "hostile" networks here are seeded networks with one layer's modulation (or the input) scaled past 65 504; the
+"trained-like" fixture grows the activations layer by layer (gain 10^2 .. 10^5) to show where the default path trips."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import record_parity, install_dropin
+from e4s2024_amd import ops, seeded
+from oracle import e4s_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _generator(size, rli, hostile_layer=None, gain=3e4):
+    install_dropin()
+    from models.stylegan2.model import Generator
+    gen = Generator(size, 512, 8, split_layer_idx=5, remaining_layer_idx=rli)
+    seeded.apply_seeded(gen, 21, "net3", prefix="G.")
+    if hostile_layer is not None:
+        with torch.no_grad():
+            gen.convs[hostile_layer].conv.modulation.bias.fill_(gain)      # s = W_mod w / sqrt(512) + bias: every modulated activation x * s ~ gain * x
+    sd = {"G." + k: v.clone() for k, v in gen.state_dict().items()}
+    return gen, sd
+
+
+def _inputs(size, bs, ncls=12):
+    n_latent = int(np.log2(size)) * 2 - 2
+    lab = seeded.blocky_labels(31, bs, ncls, 512, cells=16)
+    codes = seeded.seeded_codes(23, bs, ncls, n_latent, seeded.seeded_latent_avg(2, n_latent))
+    return codes, seeded.labels_to_onehot(lab, ncls)
+
+
+@pytest.mark.parametrize("hostile_layer", [5, 8])       # convs[5]: 32 x 32 same-resolution layer; convs[8]: the 64 -> 128 up layer (composed form)
+def test_generator_heals_an_f16_overflow(hostile_layer):
+    if ops.mx_arith() != 1:
+        pytest.skip("the f16 + fp6 arithmetic is off (E4S_MX)")
+    size, rli, bs = 256, 13, 1
+    gen, sd = _generator(size, rli, hostile_layer)
+    codes, mask = _inputs(size, bs)
+    ref, _ = O.generator_forward(sd, codes, mask, None, size=size, remaining_layer_idx=rli, split_layer_idx=5)
+    assert torch.isfinite(ref).all()
+    gen = gen.to(DEV).eval()
+    ops.mx_overflowed()                                   # clear the sticky bit
+    before = ops.mx_fallbacks
+    with torch.no_grad():
+        img, _, _ = gen([codes.to(DEV)], None, mask.to(DEV), input_is_latent=True, randomize_noise=False)
+    assert ops.mx_fallbacks == before + 1, "the guard must have re-run the pass exactly once"
+    assert ops.mx_overflowed(), "the kernels must have reported the overflow"
+    d = (img.cpu() - ref).abs().max().item()
+    record_parity(f"f16_guard.generator256.hostile_convs{hostile_layer}.pixels_vs_oracle", d, 1e-3)
+    assert torch.isfinite(img).all() and d <= 1e-3
+    # the unguarded pass really is broken (otherwise this test tests nothing): a caller-owned guard sees it and the image is not finite / far off
+    with torch.no_grad(), ops.mx_guard_scope() as g:
+        bad, _, _ = gen([codes.to(DEV)], None, mask.to(DEV), input_is_latent=True, randomize_noise=False)
+        g.arm()
+    assert g.tripped()
+    assert (not torch.isfinite(bad).all()) or (bad.cpu() - ref).abs().max().item() > 1e-2
+    # ... and a healthy network costs no re-run
+    gen2, sd2 = _generator(size, rli)
+    gen2 = gen2.to(DEV).eval()
+    ops.mx_overflowed()                                   # (the deliberately unguarded pass above raised the sticky bit again)
+    before = ops.mx_fallbacks
+    with torch.no_grad():
+        img2, _, _ = gen2([codes.to(DEV)], None, mask.to(DEV), input_is_latent=True, randomize_noise=False)
+    assert ops.mx_fallbacks == before and not ops.mx_overflowed()
+    ref2, _ = O.generator_forward(sd2, codes, mask, None, size=size, remaining_layer_idx=rli, split_layer_idx=5)
+    assert (img2.cpu() - ref2).abs().max().item() <= 1e-3
+
+
+def test_trained_like_gains_show_where_the_default_path_trips():
+    """Per-layer activation magnitudes 10^2 .. 10^5 (seeded weights x a growing modulation gain): below the f16 range the default path holds the bar
+    without a re-run, above it the guard takes over; either way the pixels stay within 1e-3 of the fp32 oracle."""
+    if ops.mx_arith() != 1:
+        pytest.skip("the f16 + fp6 arithmetic is off (E4S_MX)")
+    size, rli, bs = 128, 13, 1
+    codes, mask = _inputs(size, bs)
+    tripped_at = {}
+    for gain in (1e2, 1e3, 1e4, 1e5):
+        install_dropin()
+        from models.stylegan2.model import Generator
+        gen = Generator(size, 512, 8, split_layer_idx=5, remaining_layer_idx=rli)
+        seeded.apply_seeded(gen, 21, "net3", prefix="G.")
+        with torch.no_grad():
+            for c in gen.convs:
+                c.conv.modulation.bias.fill_(gain)
+        sd = {"G." + k: v.clone() for k, v in gen.state_dict().items()}
+        ref, _ = O.generator_forward(sd, codes, mask, None, size=size, remaining_layer_idx=rli, split_layer_idx=5)
+        gen = gen.to(DEV).eval()
+        before = ops.mx_fallbacks
+        with torch.no_grad():
+            img, _, _ = gen([codes.to(DEV)], None, mask.to(DEV), input_is_latent=True, randomize_noise=False)
+        tripped_at[gain] = ops.mx_fallbacks - before
+        d = (img.cpu() - ref).abs().max().item()
+        record_parity(f"f16_guard.generator128.gain{gain:g}.pixels_vs_oracle", d, 1e-3)
+        assert torch.isfinite(img).all() and d <= 1e-3, (gain, d)
+    ops.mx_overflowed()
+    assert tripped_at[1e2] == 0 and tripped_at[1e5] == 1, tripped_at       # activations are O(1): gain 1e2 stays in range, 1e5 cannot
+
+
+def test_encoder_unit_heals_an_f16_overflow():
+    """One IR-SE unit of the regional-style encoder (models/encoders/helpers.py:122-144) on the f16 + fp6 convolution kernels with an input whose
+    instance-normalised values reach past the f16 range: a plane that is zero except for one spike normalises to ~ sqrt(H W) at the spike — at 512 x 512
+    that is 512, so the unit is fed a pre-normalised tensor scaled instead (the convolution kernel takes its statistics as an argument)."""
+    if ops.mx_arith() != 1:
+        pytest.skip("the f16 + fp6 arithmetic is off (E4S_MX)")
+    g = torch.Generator(device=DEV).manual_seed(5)
+    bs, cin, cout, h = 16, 256, 256, 64
+    x = torch.randn(bs, cin, h, h, device=DEV, generator=g)
+    w = torch.randn(cout, cin, 3, 3, device=DEV, generator=g) / (cin * 9) ** 0.5
+    x[3, 7, 10, 11] = 2.0e5                                # one activation outside the f16 range; mean 0 / rstd 1 statistics keep it there
+    mean, rstd = torch.zeros(bs, cin, device=DEV), torch.ones(bs, cin, device=DEV)
+    caches = (ops.PreparedConv(), ops.PreparedWinograd(), ops.PreparedWinogradSplit(), ops.PreparedMx())
+    with torch.no_grad():
+        assert ops.mx_conv_eligible(x, cout)
+        ops.mx_overflowed()
+        before = ops.mx_fallbacks
+        out = ops.guarded(lambda: ops.conv3x3_s1(x, w, caches, in_norm=(mean, rstd)))
+        assert ops.mx_fallbacks == before + 1 and ops.mx_overflowed()
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    d = (out.double() - ref).abs().max().item() / ref.abs().max().item()
+    record_parity("f16_guard.encoder_conv256@64.vs_float64", d, 2e-5)
+    assert torch.isfinite(out).all() and d <= 2e-5
+
+
+def test_swap_batch_defers_and_heals(gpu_net3, bisenet_sd):
+    """pipeline.swap_batch brackets parser + encoder + synthesis with ONE guard: by default it waits for it and re-runs; with guard=[] the caller does."""
+    from e4s2024_amd import pipeline
+    install_dropin()
+    from swap_face_fine.face_parsing.face_parsing_demo import FaceParser
+    parser = FaceParser(seg_ckpt=None, device=DEV)
+    parser.seg.load_state_dict(bisenet_sd)
+    parser.seg.eval()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    drv = torch.tanh(torch.randn(2, 3, 1024, 1024, device=DEV, generator=g))
+    tgt = torch.tanh(torch.randn(2, 3, 1024, 1024, device=DEV, generator=g))
+    ops.mx_overflowed()
+    guards = []
+    frames, labs = pipeline.swap_batch(gpu_net3, parser, drv, tgt, guard=guards)
+    assert len(guards) == 1 and not guards[0].tripped()
+    before = ops.mx_fallbacks
+    frames2, _ = pipeline.swap_batch(gpu_net3, parser, drv, tgt)
+    assert ops.mx_fallbacks == before and torch.equal(frames, frames2)
+    # a generator whose 32 x 32 layer leaves the f16 range (the shared fixture's modulation bias is restored afterwards; parser and encoder clamp /
+    # normalise their inputs, so the synthesis is the part of the swap that real weights can push out of range)
+    bias = gpu_net3.G.convs[5].conv.modulation.bias
+    saved = bias.detach().clone()
+    try:
+        with torch.no_grad():
+            bias.fill_(3e4)
+        before = ops.mx_fallbacks
+        f3, _ = pipeline.swap_batch(gpu_net3, parser, drv, tgt)
+        assert ops.mx_fallbacks == before + 1 and ops.mx_overflowed()
+        with ops.mx_exact():
+            f4, _ = pipeline.swap_batch(gpu_net3, parser, drv, tgt)
+        assert torch.equal(f3, f4)
+        guards = []
+        pipeline.swap_batch(gpu_net3, parser, drv, tgt, guard=guards)
+        assert guards[0].tripped()
+        ops.mx_overflowed()
+    finally:
+        with torch.no_grad():
+            bias.copy_(saved)
