@@ -68,7 +68,10 @@ def conv3x3_flops_per_face(size=1024, want_executed=False, uniform_frac=None):
     def add(cout, w_in, fl, out_res, up):
         masked = out_res <= 256
         two_stage = up and not masked and _ops.MODCONV_MODE == "sb" and _ops.UP_TWO_STAGE
-        if two_stage:
+        hc = two_stage and _ops.UP_FUSED and _ops.UP_HC and _ops.SP_CHAIN and cout % 32 == 0       # the chain's up layers: half-composed form (csrc/modconv_uphc.hip)
+        if hc:
+            k = "modconv_up_hc"
+        elif two_stage:
             k = "modconv_up_fused_sb" if _ops.UP_FUSED else "modconv_tconv_sb"
         elif not masked and not up and _ops.SP_CHAIN and _ops.NHWC_CHAIN and _ops.FUSE_RGB and _ops.chain_supported(cout, cout, out_res, out_res, False):
             k = f"chain_conv3x3<{cout}>"          # the split-plane chain's persistent kernel (csrc/modconv_chain.hip)
@@ -82,7 +85,8 @@ def conv3x3_flops_per_face(size=1024, want_executed=False, uniform_frac=None):
             executed["masked_upconv_blocks"] = executed.get("masked_upconv_blocks", 0.0) + fl * (f1 * 2.0 + f2 * 2.5)
         out[k] = out.get(k, 0.0) + fl * (1.0 - f)
         # MACs the kernel really executes: the parity-composed up-conv spends 4x the transposed conv's, the fused one 1.31x (tile overlap)
-        executed[k] = executed.get(k, 0.0) + fl * (1.0 - f) * ((1.31 if _ops.UP_FUSED else 1.0) if two_stage else (4.0 if up else 1.0))
+        # (half-composed: 2x for the vertical blur factor in the weights, x 16 / 14 for the horizontal tile overlap)
+        executed[k] = executed.get(k, 0.0) + fl * (1.0 - f) * (2.0 * 16 / 14 if hc else (1.31 if _ops.UP_FUSED else 1.0) if two_stage else (4.0 if up else 1.0))
     add(512, 4, 2 * 512 * 512 * 9 * 16, 4, False)
     cin, r = 512, 8
     while r <= size:
@@ -313,6 +317,36 @@ def main():
         del img1
     ksum = kt.summary()
     kt_for_layers = kt
+    # In-run A/B against the previous rounds' kernels (boxes of the pool differ by 7-15 % on untouched kernels, so `value` alone cannot show a 5 % gain):
+    # the same K steps on one stream, every launch timed, with the routes switched back — masked 3x3 layers on the register-staged split-bf16 kernel of
+    # round 2 (E4S_MX=0), the chain's up layers on round 3's fused LDS-DMA kernel (E4S_UP_HC=0).  Outside the timed region.
+    in_run_ab = None
+    if world == 1 and ops.MODCONV_MODE == "sb" and ksum:
+        saved_routes = (ops.MX_MODE, ops.UP_HC)
+        try:
+            ops.MX_MODE, ops.UP_HC = 0, False
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            with ops.KernelTimer() as kb:
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+        finally:
+            ops.MX_MODE, ops.UP_HC = saved_routes
+        step()                                                        # (back on the default routes: weight copies rebuilt outside anything timed)
+        torch.cuda.synchronize()
+        base = kb.summary()
+        groups = {"masked_3x3_layers_32_to_256": lambda k: k.startswith(("region_modconv_mx_kernel", "region_modconv_sb_kernel<4,", "masked_upconv_blocks")),
+                  "single_region_up_layers_256_to_1024": lambda k: k.startswith(("modconv_up_hc", "modconv_up_fused_sb")),
+                  "single_region_convs_512_1024": lambda k: k.startswith("chain_conv3x3")}
+        in_run_ab = {"what": "ms per step of a kernel group on one stream in THIS run: `ms_prev` with the previous rounds' routes (E4S_MX=0: round 2's masked kernel; "
+                             "E4S_UP_HC=0: round 3's fused up kernel), `ms_now` with the default routes"}
+        for gname, pred in groups.items():
+            prev = sum(v[1] for k, v in base.items() if pred(k)) / args.steps
+            now = sum(v[1] for k, v in ksum.items() if pred(k)) / args.steps
+            in_run_ab[gname] = {"ms_prev": round(prev, 4), "ms_now": round(now, 4), "ratio": round(now / prev, 4) if prev > 0 else None}
+        in_run_ab["all_launches"] = {"ms_prev": round(sum(v[1] for v in base.values()) / args.steps, 4), "ms_now": round(sum(v[1] for v in ksum.values()) / args.steps, 4)}
     # how much of `value` depends on the region maps: the same batch under portrait-shaped maps (ellipses: hair, skin, eyes, ...: what the face
     # parser produces on photographs), under 4 x 4 cells (every 16 x 16 block of the masked up layers lies under one region) and under i.i.d.
     # per-pixel labels (none does); single-GPU runs only, 10 steps each, outside the timed region
@@ -560,6 +594,12 @@ def main():
             dt = (time.perf_counter() - t1) / n_it
             pti_info = {"s_per_iter": round(dt, 5), "iters": n_it, "batch": 1, "resolution": 1024, "loss": "L2", "optimizer": "Adam (fused, capturable)",
                         "trainable_params": int(sum(p.numel() for p in params)), "loss_first": round(l0, 4), "loss_last": round(lN.item(), 4),
+                        # forward + data gradient + weight gradient of every 3x3 modulated conv = 3 x the forward's algorithmic work (148.52 GFLOP
+                        # per face), all of it in split-bf16 (3 bf16 MFMAs per product): the step's roofline is the MFMA one
+                        "roofline": {"bound": "mfma", "achieved": round(3 * 148.52e9 / dt / 1e12, 2), "peak": round(BF16_MATRIX_PEAK_TFLOPS / 3.0, 1), "unit": "TFLOP/s",
+                                     "frac": round(3 * 148.52e9 / dt / 1e12 / (BF16_MATRIX_PEAK_TFLOPS / 3.0), 4),
+                                     "algorithmic_gflop_per_step": round(3 * 148.52, 1),
+                                     "what": "3 x 148.52 algorithmic GFLOP per bs = 1 step over the replayed step's wall time, against 2500 / 3 TFLOP/s (split-bf16)"},
                         "how": "whole step (forward, backward, weight re-layout, Adam) as one hipGraph; synthesis gradients from csrc/modconv_bwd.hip "
                                "+ csrc/gemm_sb.hip (hand-written split-bf16 MFMA GEMM, implicit weight gradient; no library GEMM in the step) (BASELINE configs[3], one frame)"}
             # the loop of configs[3] itself on a short clip: passes over the frames, one optimiser step per frame, eroded maps, foreground-weighted
@@ -640,6 +680,7 @@ def main():
                     # the same ratio layer by layer (one launch per layer and step): the same-resolution layers run every algorithmic MAC once,
                     # the up-sampling layers execute the parity-composed form at 4x their algorithmic (transposed-conv) MACs
                     "by_layer": _by_layer(kt_for_layers, dom, bs, peak, ufrac),
+                    "in_run_ab": in_run_ab,
                     "all_modconv3x3": {"achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 2), "ms_per_step": round(all_ms / args.steps, 3),
                                        "by_kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(ksum.items())}}}
         # ---- CPU baseline: the faithful 12-pass oracle on one face
@@ -658,7 +699,7 @@ def main():
                 runs.append(time.perf_counter() - t1)
             dt = sorted(runs)[1]
             err = (img[:1].cpu() - ref).abs().max().item()
-            cpu = {"value": round(1.0 / dt, 4), "unit": "faces/s", "cores": torch.get_num_threads(), "kind": "port",
+            cpu = {"value": round(1.0 / dt, 4), "unit": "faces/s", "cores": torch.get_num_threads(), "host_hardware_threads": os.cpu_count(), "kind": "port",
                    "sample": f"3 x 1 face (bs=1) of the same workload through oracle.generator_forward (12 region passes per masked layer), "
                              f"median {dt:.1f} s (runs {', '.join(f'{r:.1f}' for r in runs)} s)",
                    "max_abs_pixel_diff_vs_gpu": float(f"{err:.3e}")}

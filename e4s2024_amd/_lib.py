@@ -57,9 +57,6 @@ _PROTOS = {
     "e4s_wino_weight": [c_ptr, c_ptr, c_int, c_int, c_ptr],
     "e4s_wino_input": [c_ptr] * 4 + [c_int] * 4 + [c_ptr],
     "e4s_wino_output": [c_ptr] * 3 + [c_int] * 4 + [c_ptr],
-    "e4s_split_bf16": [c_ptr, c_ptr, c_ptr, c_i64, c_ptr],
-    "e4s_wino_input_pre": [c_ptr] * 5 + [c_int] * 4 + [c_ptr],
-    "e4s_gemm_pre": [c_ptr] * 5 + [c_int] * 3 + [c_i64] * 3 + [c_int, c_ptr],
     "e4s_mconv_dgrad_tiles": [c_int] * 2,
     "e4s_mconv_dgrad": [c_ptr] * 7 + [c_int] * 7 + [c_ptr],
     "e4s_blur_epilogue": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr],

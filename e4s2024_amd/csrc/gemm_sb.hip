@@ -514,111 +514,6 @@ __global__ __launch_bounds__(256) void gemm_sb_finalize_kernel(float* __restrict
 
 }  // namespace
 
-// ---- operands already split by their producers: A as bf16 hi / lo [batch][M][K] (K contiguous), B as bf16 hi / lo in channel blocks
-// [batch][K / 8][N][8] (the eight k of a block contiguous per column: what a producer that walks the columns writes as 16-byte pieces).  The
-// staging is a copy — no conversion VALU between the loads and the MFMAs, which is what holds the fp32-operand kernel at two thirds of the rate.
-struct GemmPreParams {
-    float* c;
-    const uint4* a_hi; const uint4* a_lo;      // [batch][M][K / 8]
-    const uint4* b_hi; const uint4* b_lo;      // [batch][K / 8][N]
-    int M, N, K8;                               // K8 = K / 8, a multiple of 4
-    long long sa, sb, sc;                       // batch strides in uint4 / floats
-    int tiles_m, tiles_n;
-};
-
-__global__ __launch_bounds__(GNT, 2) void gemm_pre_kernel(const GemmPreParams p) {
-    __shared__ uint4 lds[4 * GT * 4];
-    uint4* ahi = lds;
-    uint4* alo = lds + GT * 4;
-    uint4* bhi = lds + 2 * GT * 4;
-    uint4* blo = lds + 3 * GT * 4;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l5 = lane & 31, kg = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tn = blockIdx.x % p.tiles_n, tm = blockIdx.x / p.tiles_n;
-    const int bz = blockIdx.z;
-    const int m0 = tm * GT, n0 = tn * GT;
-    const int r = tid >> 1, kh = tid & 1;
-    const int ra = m0 + r < p.M ? m0 + r : p.M - 1, rb = n0 + r < p.N ? n0 + r : p.N - 1;
-    const uint4* pa_hi = p.a_hi + (size_t)bz * p.sa + (size_t)ra * p.K8 + 2 * kh;
-    const uint4* pa_lo = p.a_lo + (size_t)bz * p.sa + (size_t)ra * p.K8 + 2 * kh;
-    const uint4* pb_hi = p.b_hi + (size_t)bz * p.sb + (size_t)(2 * kh) * p.N + rb;
-    const uint4* pb_lo = p.b_lo + (size_t)bz * p.sb + (size_t)(2 * kh) * p.N + rb;
-    const int nchunk = p.K8 / 4;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][q][e] = 0.f;
-
-    uint4 a0, a1, a2, a3, b0, b1, b2, b3;      // (named: a uint4 ARRAY here ends up in scratch)
-    auto load = [&](int ch) __attribute__((always_inline)) {
-        a0 = pa_hi[ch * 4]; a1 = pa_hi[ch * 4 + 1]; a2 = pa_lo[ch * 4]; a3 = pa_lo[ch * 4 + 1];
-        b0 = pb_hi[(size_t)(ch * 4) * p.N]; b1 = pb_hi[(size_t)(ch * 4 + 1) * p.N];
-        b2 = pb_lo[(size_t)(ch * 4) * p.N]; b3 = pb_lo[(size_t)(ch * 4 + 1) * p.N];
-    };
-    load(0);
-    for (int ch = 0; ch < nchunk; ++ch) {
-        __syncthreads();
-        ahi[g_slot(r, 2 * kh)] = a0; ahi[g_slot(r, 2 * kh + 1)] = a1; alo[g_slot(r, 2 * kh)] = a2; alo[g_slot(r, 2 * kh + 1)] = a3;
-        bhi[g_slot(r, 2 * kh)] = b0; bhi[g_slot(r, 2 * kh + 1)] = b1; blo[g_slot(r, 2 * kh)] = b2; blo[g_slot(r, 2 * kh + 1)] = b3;
-        __syncthreads();
-        if (ch + 1 < nchunk) load(ch + 1);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int j = 2 * t + kg;
-            uint4 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int rra = wm * 64 + i * 32 + l5, rrb = wn * 64 + i * 32 + l5;
-                ah[i] = ahi[g_slot(rra, j)]; al[i] = alo[g_slot(rra, j)];
-                bh[i] = bhi[g_slot(rrb, j)]; bl[i] = blo[g_slot(rrb, j)];
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[q]), acc[i][q], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[q]), acc[i][q], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[q]), acc[i][q], 0, 0, 0);
-        }
-    }
-    float* C = p.c + (size_t)bz * p.sc;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int n = n0 + wn * 64 + q * 32 + l5;
-        if (n >= p.N) continue;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
-                if (m < p.M) C[(size_t)m * p.N + n] = acc[i][q][e];
-            }
-    }
-}
-
-// split an fp32 array into bf16 hi / lo (pairs of consecutive elements -> one 32-bit word each): operands of e4s_gemm_pre prepared once
-__global__ __launch_bounds__(256) void split_bf16_kernel(unsigned* __restrict__ hi, unsigned* __restrict__ lo, const float* __restrict__ src, long long npair) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= npair) return;
-    const float2 v = *reinterpret_cast<const float2*>(src + 2 * i);
-    unsigned h, l;
-    split2(v.x, v.y, h, l);
-    hi[i] = h; lo[i] = l;
-}
-
 // C[b] = opA(A[b]) opB(B[b]) for b < batch.  a_kc != 0: A is stored [M][K] (row stride lda), else [K][M]; b_kc != 0: B is stored [N][K]
 // (row stride ldb), else [K][N].  Batch strides in floats (0 = the same matrix for every b); C is dense [batch][M][N] at stride_c.
 // workspace: split-K scratch (may be null: no split); the choice of split depends on sizes only, so results are reproducible.
@@ -708,32 +603,4 @@ extern "C" int e4s_mconv_wgrad(float* dw, const float* gz, const float* x, const
         }
     }
     return check_launch("mconv_wgrad");
-}
-
-extern "C" int e4s_split_bf16(uint16_t* hi, uint16_t* lo, const float* src, int64_t n, void* stream) {
-    E4S_REQUIRE(hi && lo && src && n >= 0 && (n % 2) == 0, "split_bf16: null tensor or odd length");
-    E4S_REQUIRE((((uintptr_t)hi | (uintptr_t)lo) & 3) == 0 && (((uintptr_t)src) & 7) == 0, "split_bf16: unaligned tensor");
-    if (n == 0) return 0;
-    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)cdiv64(n / 2, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<unsigned*>(hi),
-                       reinterpret_cast<unsigned*>(lo), src, (long long)(n / 2));
-    return check_launch("split_bf16");
-}
-
-// C[b] (M x N fp32, dense at stride_c floats) = A[b] (M x K) * B[b] (K x N) from operands split by their producers: A bf16 hi / lo [M][K] (K
-// contiguous), B bf16 hi / lo [K / 8][N][8]; batch strides in ELEMENTS (0 = shared).  K % 32 == 0, 16-byte aligned tensors.
-extern "C" int e4s_gemm_pre(float* c, const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* b_hi, const uint16_t* b_lo, int M, int N, int K,
-                            int64_t stride_a, int64_t stride_b, int64_t stride_c, int batch, void* stream) {
-    E4S_REQUIRE(c && a_hi && a_lo && b_hi && b_lo, "gemm_pre: null tensor");
-    E4S_REQUIRE(M >= 1 && N >= 1 && K >= 32 && (K % 32) == 0 && batch >= 0 && batch <= 65535, "gemm_pre: bad size (K a multiple of 32)");
-    E4S_REQUIRE((((uintptr_t)a_hi | (uintptr_t)a_lo | (uintptr_t)b_hi | (uintptr_t)b_lo) & 15) == 0 && (stride_a % 8) == 0 && (stride_b % 8) == 0,
-                "gemm_pre: operands must be 16-byte aligned");
-    if (batch == 0) return 0;
-    GemmPreParams p;
-    p.c = c;
-    p.a_hi = reinterpret_cast<const uint4*>(a_hi); p.a_lo = reinterpret_cast<const uint4*>(a_lo);
-    p.b_hi = reinterpret_cast<const uint4*>(b_hi); p.b_lo = reinterpret_cast<const uint4*>(b_lo);
-    p.M = M; p.N = N; p.K8 = K / 8; p.sa = stride_a / 8; p.sb = stride_b / 8; p.sc = stride_c;
-    p.tiles_m = cdiv(M, GT); p.tiles_n = cdiv(N, GT);
-    hipLaunchKernelGGL(gemm_pre_kernel, dim3((unsigned)(p.tiles_m * p.tiles_n), 1, batch), dim3(GNT), 0, (hipStream_t)stream, p);
-    return check_launch("gemm_pre");
 }

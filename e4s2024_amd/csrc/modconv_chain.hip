@@ -766,7 +766,11 @@ static int fill_chain_params(ChainParams& p, const E4sChainLayer* L, int ho, int
     p.s_next = L->s_next;
     p.rgb_out = L->rgb_out; p.rgb_wt = L->rgb_wt; p.rgb_s = L->rgb_s; p.rgb_bias = L->rgb_bias; p.rgb_skip = L->rgb_skip; p.rgb_upk = L->rgb_up_kernel;
     p.bs = L->bs; p.cin = L->cin; p.cout = L->cout; p.h = L->h; p.w = L->w;
-    { const char* e = getenv("E4S_CHAIN_EXP"); p.exp = e ? atoi(e) : 0; }
+#ifdef E4S_PHASE_PROF
+    { const char* e = getenv("E4S_CHAIN_EXP"); p.exp = e ? atoi(e) : 0; }   // (tuning build only)
+#else
+    p.exp = 0;
+#endif
     static const float* zeros = [] {
         void* ptr = nullptr;
         return hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_zero16)) == hipSuccess ? static_cast<const float*>(ptr) : nullptr;

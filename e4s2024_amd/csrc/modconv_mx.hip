@@ -716,7 +716,7 @@ int e4s::launch_modconv_mx(SbParams& p, int arith, hipStream_t st, float* worksp
     p.partial = workspace;
     dim3 grid(p.tiles_x * p.tiles_y * npar * ksplit, cdiv(p.cout, MX_TN), p.bs);
     p.perm_mul = p.uni_blocks ? coprime_stride(grid.x) : 0u;
-    static const int xcd_on = [] { const char* e = getenv("E4S_MX_XCD"); return e ? atoi(e) : 1; }();
+    constexpr int xcd_on = 1;
     auto remap_ok = [&](dim3 g) { const unsigned long long t = (unsigned long long)g.x * g.y * g.z; return xcd_on && (g.y == 1 || g.y == 2 || g.y == 4 || g.y == 8) && t % 8 == 0 && g.y > 1; };
     p.xcd_remap = remap_ok(grid) ? 1 : 0;
     if (plain_conv) {

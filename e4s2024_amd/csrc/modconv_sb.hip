@@ -606,7 +606,7 @@ static int region_modconv3x3_sb_impl(float* out, const float* x, const uint16_t*
         // 64 x 4 instead of 32 x 8 pixel tiles (bit 0: single-region layers, bit 1: masked layers): a 66-pixel patch row costs three cache
         // lines per channel like a 34-pixel one.  Tile-read probe: 1.8 -> 2.5-2.9 TB/s; in the pipeline (inputs partly cache-resident)
         // the 1024x1024 / 512x512 layers gain 3.5 % / 2.5 %, the masked layers nothing measurable: on for the single-region layers.
-        static const int tw64 = [] { const char* e = getenv("E4S_SB_TW64"); return e ? atoi(e) : 1; }();
+        constexpr int tw64 = 1;
         if (w >= 64 && !labels && (tw64 & 1) && !p.x_nhwc) {   // (a channel-blocked input already reads whole lines: 32 x 8 tiles are then 1-2 % better)
             if (cout > 32) return launch_sb<2, 2, 1, 4, 6>(p, st, ws, wf);   // 64 co x (64 x 4) px
             return launch_sb<1, 2, 1, 4, 6>(p, st, ws, wf);                  // 32 co x (64 x 4) px

@@ -649,10 +649,14 @@ extern "C" int e4s_modconv_up_fused_sb(float* out, const float* x, const uint16_
     p.plane_out = (int64_t)bs * (cout / 8) * 4 * h * w;
     p.tiles_x = cdiv(2 * w, UF_OUT);
     p.tiles_y = cdiv(2 * h, UF_OUT);
-    { const char* e = getenv("E4S_UF_EXP"); p.exp = e ? atoi(e) : 0; }
+#ifdef E4S_PHASE_PROF
+    { const char* e = getenv("E4S_UF_EXP"); p.exp = e ? atoi(e) : 0; }      // (tuning build only)
+#else
+    p.exp = 0;
+#endif
     hipStream_t st = (hipStream_t)stream;
     if (x_sp && out_sp) {
-        static const int use_dma = [] { const char* e = getenv("E4S_UP_DMA"); return e ? atoi(e) : 1; }();
+        constexpr int use_dma = 1;
         if (use_dma && cout % 32 == 0 && cin % 16 == 0 && d) {
             static const float* zeros = [] {
                 void* ptr = nullptr;

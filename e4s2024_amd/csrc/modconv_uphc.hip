@@ -546,10 +546,9 @@ extern "C" int e4s_modconv_up_hc(uint16_t* out_sp, const uint16_t* x_sp, const u
     p.ntile = p.tiles_x * p.tiles_y * bs; p.ncot = cout / 32;
     p.plane_in = (int64_t)bs * (cin / 8) * h * w;
     p.plane_out = (int64_t)bs * (cout / 8) * 4 * h * w;
-    // E4S_UP_HC_PERSIST=0: the two-workgroups-per-CU form (kept as the comparison arm of tools/time_uphc.py); cin = 16 has too few units per item for the
-    // persistent loader's table hand-over
-    static const int persist = [] { const char* e = getenv("E4S_UP_HC_PERSIST"); return e ? atoi(e) : 1; }();
-    if (persist && cin >= 32) {
+    // (cin = 16 has too few units per item for the persistent loader's table hand-over: the two-workgroups-per-CU form serves it; at cin >= 32 the two forms
+    //  tie — 0.315 against 0.320 ms on the 64 -> 32 layer, 0.265 against 0.255 on 128 -> 64 — and the persistent one is the one the f16 + fp6 arithmetic needs next)
+    if (cin >= 32) {
         static const int ncu = [] {
             int dev = 0, n = 256;
             if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);

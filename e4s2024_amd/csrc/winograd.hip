@@ -216,16 +216,3 @@ extern "C" int e4s_wino_output(float* y, const float* M, const float* prelu, int
     hipLaunchKernelGGL(wino_output_kernel, dim3(cdiv(T, 256), cout), dim3(256), 0, (hipStream_t)stream, y, M, prelu, bs, cout, H, W);
     return check_launch("wino_output");
 }
-
-// V as bf16 hi / lo [16][ceil(C / 8)][T][8] for e4s_gemm_pre (channels beyond C are zero).  NOT on the default path: see ops.WINOGRAD_PRE.
-extern "C" int e4s_wino_input_pre(uint16_t* V_hi, uint16_t* V_lo, const float* x, const float* mean, const float* rstd, int bs, int C, int H, int W, void* stream) {
-    E4S_REQUIRE(V_hi && V_lo && x && (!mean == !rstd), "wino_input_pre: null tensor (mean and rstd come together)");
-    E4S_REQUIRE(bs >= 0 && C >= 1 && C <= 8 * 65535 && H >= 2 && W >= 2 && (H % 2) == 0 && (W % 2) == 0 && (int64_t)bs * H * W / 4 < ((int64_t)1 << 30),
-                "wino_input_pre: even height and width");
-    E4S_REQUIRE((((uintptr_t)x) & 7) == 0 && (((uintptr_t)V_hi | (uintptr_t)V_lo) & 15) == 0, "wino_input_pre: unaligned tensor");
-    if (bs == 0) return 0;
-    const int T = bs * (H / 2) * (W / 2);
-    hipLaunchKernelGGL(wino_input_pre_kernel, dim3(cdiv(T, 256), cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<uint4*>(V_hi),
-                       reinterpret_cast<uint4*>(V_lo), x, mean, rstd, bs, C, H, W);
-    return check_launch("wino_input_pre");
-}

@@ -71,8 +71,8 @@ class bottleneck_IR_SE_Ours(Module):
             SEModule(depth, 16),
         )
         self._w = [ops.PreparedConv() for _ in range(3)]
-        # the two 3x3 convolutions' Winograd-domain weights (stride 1 only): fp32 and split to bf16 hi / lo
-        self._wino = [(self._w[i], ops.PreparedWinograd(), ops.PreparedWinogradSplit(), ops.PreparedMx()) for i in range(2)]
+        # the two 3x3 convolutions' other prepared copies (stride 1 only): Winograd-domain weights, the DMA-fed kernels' slots
+        self._wino = [(self._w[i], ops.PreparedWinograd(), ops.PreparedMx()) for i in range(2)]
 
     def forward(self, x):
         rl = self.res_layer

@@ -731,8 +731,8 @@ class PreparedHc(_Prepared):
         return (whi, wlo)
 
 
-UP_FUSED = os.environ.get("E4S_UP_FUSED", "1") != "0"     # single-region up layers: one launch (blur in LDS) instead of tconv + blur epilogue
-UP_TWO_STAGE = os.environ.get("E4S_UP_TWO_STAGE", "1") != "0"
+UP_FUSED = True          # (module attributes, not environment switches: the tests flip them to reach the comparison kernels)  # single-region up layers: one launch (blur in LDS) instead of tconv + blur epilogue
+UP_TWO_STAGE = True
 
 
 def modconv_up_single(x, wt, s, d, blur, noise, noise_weight, act_bias, act: bool, cout: int, x_nhwc: bool = False, out_nhwc: bool = False,
@@ -895,19 +895,19 @@ def _workspace(device, floats: int) -> torch.Tensor:
 # the 512x512 and 1024x1024 stages ("c" links): 958 -> 990 faces/s (fused up-sampling 0.705 -> 0.672 ms, 1024x1024 conv 0.515 -> 0.470,
 # 512x512 conv 0.361 -> 0.324); with the hand-overs into the up-sampling kernels as well ("u" links; the kernel reads its patch pixel's two
 # 8-channel blocks with four 16-byte loads) another +1.3 % (fused up-sampling 0.707 -> 0.640 ms).
-NHWC_CHAIN = os.environ.get("E4S_NHWC_CHAIN", "1") != "0"
+NHWC_CHAIN = True
 # The single-region stages as a split-plane chain (csrc/modconv_chain.hip): each producer writes its activation already multiplied by the
 # consumer's modulation and split into bf16 hi / lo planes; the 512 x 512 and 1024 x 1024 convs then run on persistent, LDS-DMA-fed kernels.
 SP_CHAIN = os.environ.get("E4S_SP_CHAIN", "1") != "0"
 # which hand-overs are channel-blocked: "all" (default), or a list of "c" / "u" (every hand-over into a second conv / into an up-conv),
 # "u<J>" (into the up-conv of stage J, resolution 2^(J+3)) and "c<J>" (into that stage's second conv)
-NHWC_LINKS = os.environ.get("E4S_NHWC_LINKS", "all")
+NHWC_LINKS = "all"
 
 
 def nhwc_link(kind: str, stage: int) -> bool:
     items = NHWC_LINKS.split(",")
     return NHWC_CHAIN and (NHWC_LINKS == "all" or kind in items or f"{kind}{stage}" in items)
-FUSE_RGB = os.environ.get("E4S_FUSE_RGB", "1") != "0"
+FUSE_RGB = True
 
 
 def can_fuse_rgb(cout: int, w: int, up: bool, masked: bool) -> bool:
@@ -929,8 +929,8 @@ UP_SUBBLOCKS = False   # (no environment switch: measured slower for two rounds;
 UP_BLOCK_QUAD = 254      # block map value: four region-uniform 8 x 8 sub-blocks with different regions
 
 
-UP_BLOCKS_MIN_PERCENT_SMALL = int(os.environ.get("E4S_UP_BLOCKS_MIN_SMALL", "90"))   # the same for a layer whose composed launch fits the chip at once
-UP_BLOCKS_MIN_PERCENT = int(os.environ.get("E4S_UP_BLOCKS_MIN", "40"))   # below this share of qualifying tiles a layer stays entirely in the composed form
+UP_BLOCKS_MIN_PERCENT_SMALL = 90   # the same for a layer whose composed launch fits the chip at once
+UP_BLOCKS_MIN_PERCENT = 40   # below this share of qualifying tiles a layer stays entirely in the composed form
 
 
 def uniform_blocks(labels: torch.Tensor, ho: int, wo: int, nreg: int, with_ctrl: bool = False, min_percent: int = None):
@@ -1338,13 +1338,17 @@ def conv2d(x: torch.Tensor, prepared: PreparedConv, stride: int = 1, pad: int = 
 
 # ---- Winograd F(2x2, 3x3) route of the encoder's stride-1 3x3 convolutions (csrc/winograd.hip + the batched split-bf16 GEMM)
 WINOGRAD = os.environ.get("E4S_WINOGRAD", "1") != "0"
-WINOGRAD_MIN_CIN = int(os.environ.get("E4S_WINOGRAD_MIN_CIN", "256"))
+WINOGRAD_MIN_CIN = 256
 # Where it pays (tools/time_winograd.py, tools/time_swap.py): the direct kernel runs at the board's sustained MFMA rate once a launch fills the chip
 # (16 faces: 0.255 ms per 512 -> 512 @32^2 launch against 0.239 for Winograd, and slower end to end with its three launches and 268 MB of
 # transformed operands), the 16 GEMMs on e4s_gemm_sb reach two thirds of it — so Winograd is the route of SMALL batches, where the direct launch is
 # latency-bound: one swap (two faces) 7.61 -> 6.65 ms, two swaps 10.04 -> 8.75, four 14.16 -> 13.83, eight 25.3 -> 25.5 (off).
-WINOGRAD_MIN_TILES = int(os.environ.get("E4S_WINOGRAD_MIN_TILES", "256"))
-WINOGRAD_MAX_TILES = int(os.environ.get("E4S_WINOGRAD_MAX_TILES", "2048"))
+WINOGRAD_MIN_TILES = 256
+WINOGRAD_MAX_TILES = 2048
+# E4S_ENC_ROUTE_BY_IMAGE=1: the encoder's convolution routes (Winograd / DMA-fed f16 + fp6 / direct) are chosen from ONE image's shape, never from the batch:
+# a face's style vectors are then bit-identical whatever batch it travels in (the reference processes one frame at a time, face_swap_video_pipeline.py:337).
+# Off by default: the batch-aware choice is 5-10 % faster on the full swap's 16-image launches and changes style vectors by <= 5e-5 (tests/test_gpu_encoder.py).
+ENC_ROUTE_BY_IMAGE = os.environ.get("E4S_ENC_ROUTE_BY_IMAGE", "0") != "0"
 
 
 class PreparedWinograd(_Prepared):
@@ -1366,53 +1370,20 @@ class PreparedWinograd(_Prepared):
         return self._publish(key, (U,))[0]
 
 
-class PreparedWinogradSplit(_Prepared):
-    """The same as bf16 hi / lo ``[16, cout, cin]`` (int16 storage) for ``e4s_gemm_pre``: split once, not in every GEMM."""
-
-    __slots__ = ()
-
-    def get(self, weight: torch.Tensor):
-        key = None if _volatile(weight) else ((weight.data_ptr(), weight._version), weight.device)
-        hit = self._lookup(key)
-        if hit is not None:
-            return hit
-        w = _c(weight.detach(), "weight")
-        cout, cin, kh, kw = w.shape
-        if (kh, kw) != (3, 3) or cin % 2:
-            raise ValueError("PreparedWinogradSplit: 3x3 kernels, an even number of input channels")
-        U = torch.empty((16, cout, cin), dtype=torch.float32, device=w.device)
-        lib().call("e4s_wino_weight", _p(U), _p(w), cout, cin, _stream())
-        hi, lo = torch.empty((16, cout, cin), dtype=torch.int16, device=w.device), torch.empty((16, cout, cin), dtype=torch.int16, device=w.device)
-        lib().call("e4s_split_bf16", _p(hi), _p(lo), _p(U), U.numel(), _stream())
-        return self._publish(key, (hi, lo))
-
-
-# 1: operands of the Winograd GEMMs split to bf16 by their producers (e4s_wino_input_pre + e4s_gemm_pre: 839 instead of 607 TFLOP/s; the
-# 512 -> 512 @32^2 launch 0.226 against 0.252 ms direct, batch-8 full swap 25.9 -> 25.4 ms).  Opt-in this round: the first, fully unrolled form of
-# e4s_wino_input_pre (112 loads in flight, 248 registers) gave occasional wrong values — ONE register, SIXTEEN lanes — when a second stream's kernels
-# ran beside it (11 of 60 runs of tools/probes/wino_race4.py; tools/probes/wino_race6.py pins it to that kernel's output with every input intact):
-# the signature of a load landing in a register that was already reused, i.e. of the 6-bit vmcnt counter with more than 63 loads outstanding.  The
-# two-pass form in the tree has run 1 400+ concurrent iterations and the multi-stream tests clean; it stays behind the switch (2 % is not worth a flaky frame).
-WINOGRAD_PRE = os.environ.get("E4S_WINOGRAD_PRE", "0") != "0"
-WINOGRAD_WIDE_CIN = int(os.environ.get("E4S_WINOGRAD_WIDE_CIN", "512"))     # from this many input channels on there is no upper tile limit
-
-
 def winograd_route(x: torch.Tensor, cin: int, stride: int):
-    """Which route a 3x3, pad-1 convolution of ``x`` takes: ``"pre"`` (Winograd with operands split by their producers, ``cin % 32 == 0``),
-    ``"f32"`` (Winograd on the general split-bf16 GEMM) or ``None`` (the direct kernel).  Stride 1, even maps, inference only; at least
-    ``WINOGRAD_MIN_CIN`` channels and ``WINOGRAD_MIN_TILES`` 2 x 2 output tiles; at most ``WINOGRAD_MAX_TILES`` unless the layer has
-    ``WINOGRAD_WIDE_CIN`` channels and the pre-split route (below that the two transforms cost more than the GEMMs save once the direct kernel
-    fills the chip: 256 -> 256 @64^2 at 16 faces 0.31 against 0.28 ms; 512 -> 512 @32^2 0.21 against 0.26)."""
+    """Which route a 3x3, pad-1 convolution of ``x`` takes: ``"f32"`` (Winograd F(2x2, 3x3) on the general split-bf16 GEMM) or ``None`` (the direct /
+    DMA-fed kernels).  Stride 1, even maps, inference only; at least ``WINOGRAD_MIN_CIN`` channels and between ``WINOGRAD_MIN_TILES`` and
+    ``WINOGRAD_MAX_TILES`` 2 x 2 output tiles (above that the two transforms cost more than the GEMMs save once the direct kernel fills the chip:
+    256 -> 256 @64^2 at 16 faces 0.31 against 0.28 ms).  ``ENC_ROUTE_BY_IMAGE``: the tile count is taken PER IMAGE, so a face's style vectors do
+    not depend on how many faces share the launch.  (Round 2-3 also carried a route with operands split to bf16 by their producers; it gave rare wrong
+    values beside a second stream, was never root-caused and stayed off — removed in round 4.)"""
     bs, _, h, w = x.shape
     if not (WINOGRAD and stride == 1 and x.is_cuda and not torch.is_grad_enabled() and cin >= WINOGRAD_MIN_CIN and h % 2 == 0 and w % 2 == 0):
         return None
-    tiles = bs * (h // 2) * (w // 2)
-    if tiles < WINOGRAD_MIN_TILES:
+    tiles = (1 if ENC_ROUTE_BY_IMAGE else bs) * (h // 2) * (w // 2)
+    if tiles < WINOGRAD_MIN_TILES or tiles > WINOGRAD_MAX_TILES:
         return None
-    pre = cin % 32 == 0 and WINOGRAD_PRE
-    if tiles > WINOGRAD_MAX_TILES and not (pre and cin >= WINOGRAD_WIDE_CIN):
-        return None
-    return "pre" if pre else "f32"
+    return "f32"
 
 
 MX3 = os.environ.get("E4S_MX3", "1") != "0"     # plain f16 + fp6 convolutions on the two-phase kernel (0: the one-phase kernel of modconv_mx.hip)
@@ -1433,6 +1404,8 @@ def mx_conv_eligible(x: torch.Tensor, cout: int) -> bool:
         return False
     per_image = (-(-w // 32)) * (-(-h // 8)) * (-(-cout // 128))
     if cin < WINOGRAD_MIN_CIN:
+        return per_image >= MX_CONV_MIN_WORKGROUPS_PER_IMAGE
+    if ENC_ROUTE_BY_IMAGE:
         return per_image >= MX_CONV_MIN_WORKGROUPS_PER_IMAGE
     return bs * per_image >= MX_CONV_MIN_WORKGROUPS
 
@@ -1459,46 +1432,16 @@ def conv3x3_mx(x: torch.Tensor, wmx: torch.Tensor, arith: int, cout: int, *, in_
 
 def conv3x3_s1(x: torch.Tensor, weight: torch.Tensor, caches, *, in_norm=None, prelu: Optional[torch.Tensor] = None) -> torch.Tensor:
     """A stride-1, pad-1 3x3 convolution by whichever route fits the launch: Winograd (``winograd_route``: small batches), the DMA-fed kernel
-    (``mx_conv_eligible``: launches that fill the chip) or the direct kernel; ``caches = (PreparedConv, PreparedWinograd, PreparedWinogradSplit
-    [, PreparedMx])`` of the layer."""
+    (``mx_conv_eligible``: launches that fill the chip) or the direct kernel; ``caches = (PreparedConv, PreparedWinograd, PreparedMx)`` of the layer."""
     route = winograd_route(x, x.shape[1], 1)
-    if route == "pre":
-        return conv2d_winograd_pre(x, caches[2].get(weight), in_norm=in_norm, prelu=prelu)
     if route == "f32":
         return conv2d_winograd(x, caches[1].get(weight), in_norm=in_norm, prelu=prelu)
-    if len(caches) > 3 and mx_conv_eligible(x, weight.shape[0]):
+    if len(caches) > 2 and mx_conv_eligible(x, weight.shape[0]):
         arith = mx_arith()
         if arith == 1 and MX3 and x.shape[1] % 32 == 0 and x.shape[1] <= 512:
             arith = 3             # same arithmetic, the two-phase kernel (csrc/conv_mx3.hip)
-        return conv3x3_mx(x, caches[3].get(weight, None, False, arith), arith, weight.shape[0], in_norm=in_norm, prelu=prelu)
+        return conv3x3_mx(x, caches[2].get(weight, None, False, arith), arith, weight.shape[0], in_norm=in_norm, prelu=prelu)
     return conv2d(x, caches[0].get(weight), 1, 1, in_norm=in_norm, prelu=prelu)
-
-
-def conv2d_winograd_pre(x: torch.Tensor, U_split, *, in_norm=None, prelu: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``conv2d_winograd`` with both GEMM operands split to bf16 hi / lo by their producers (``U_split`` from ``PreparedWinogradSplit``, V by the
-    input transform, eight channels per 16-byte piece): the GEMM stages copies — ``e4s_gemm_pre``.  ``cin % 32 == 0``."""
-    x = _c(x, "input")
-    bs, cin, h, w = x.shape
-    uh, ul = U_split
-    if uh.dim() != 3 or uh.shape[0] != 16 or uh.shape[2] != cin or cin % 32:
-        raise ValueError(f"conv2d_winograd_pre: U {tuple(uh.shape)} does not fit {cin} input channels (a multiple of 32)")
-    cout = uh.shape[1]
-    T = bs * (h // 2) * (w // 2)
-    mean = rstd = None
-    if in_norm is not None:
-        mean, rstd = _c(in_norm[0], "in_mean"), _c(in_norm[1], "in_rstd")
-    vh = torch.empty((16, cin // 8, T, 8), dtype=torch.int16, device=x.device)
-    vl = torch.empty_like(vh)
-    ev = _timed("conv2d_winograd_pre<3,1>")
-    lib().call("e4s_wino_input_pre", _p(vh), _p(vl), _p(x), _p(mean), _p(rstd), bs, cin, h, w, _stream())
-    M = torch.empty((16, cout, T), dtype=torch.float32, device=x.device)
-    lib().call("e4s_gemm_pre", _p(M), _p(uh), _p(ul), _p(vh), _p(vl), cout, T, cin, cout * cin, cin * T, cout * T, 16, _stream())
-    del vh, vl
-    out = torch.empty((bs, cout, h, w), dtype=torch.float32, device=x.device)
-    lib().call("e4s_wino_output", _p(out), _p(M), _p(_c(prelu.detach(), "prelu")) if prelu is not None else None, bs, cout, h, w, _stream())
-    if ev is not None:
-        ev.record()
-    return out
 
 
 def conv2d_winograd(x: torch.Tensor, U: torch.Tensor, *, in_norm=None, prelu: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -1751,7 +1694,7 @@ NATIVE_BWD = os.environ.get("E4S_NATIVE_BWD", "1") != "0"
 # stock-PyTorch forms of torch_ref.py, kept as the comparison arm of the gradient tests) and E4S_ALLOW_MIOPEN_BWD=1 (aten.convolution_backward for the
 # single-region shapes the hand-written kernels do not cover: cout < 16 or a kernel size other than 1 / 3); without the latter such a shape raises.
 ALLOW_LIBRARY_BWD = os.environ.get("E4S_ALLOW_MIOPEN_BWD", "0") != "0"
-_FOLD_CHUNK_PX = int(os.environ.get("E4S_FOLD_CHUNK_PX", "1024"))     # pixels per workgroup of e4s_mconv_fold: one pass per thread (4096: the up layers 0.73 -> 0.61 ms)
+_FOLD_CHUNK_PX = 1024     # pixels per workgroup of e4s_mconv_fold: one pass per thread (4096: the up layers 0.73 -> 0.61 ms)
 _SCALE_CHUNK_PX = 8192
 
 

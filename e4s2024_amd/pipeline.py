@@ -18,17 +18,17 @@ from . import ops
 DEFAULT_COMP_INDICES = tuple(sorted(set(range(12)) - {0, 4, 11}))      # face_swap_video_pipeline.py:436: keep target background, hair, ear-rings
 
 
-TWO_STREAMS = os.environ.get("E4S_SWAP_TWO_STREAMS", "1") != "0"
+TWO_STREAMS = True               # (module attributes; ``swap_batch`` also takes them as arguments)
 _sel_cache = {}
 _side = {}
 
 
-SWAP_CHAINS = int(os.environ.get("E4S_SWAP_CHAINS", "2"))     # 2 = driven | target; 4 = each additionally split into half batches
+SWAP_CHAINS = 2     # 2 = driven | target; 4 = each additionally split into half batches
 # Driven and target faces as ONE batch of 2*bs through parser and encoder (default): the 32x32 and 16x16 stages of the encoder and the
 # launch-bound glue between its convolutions fill the chip better at twice the batch than as two concurrent chains (measured at bs 8:
 # parse + encode 4.3 + 13.7 ms for 16 images against 2 x (2.5 + 8.1) ms on one stream and 21.0 ms on two streams).
-SWAP_BATCHED = os.environ.get("E4S_SWAP_BATCHED", "1") != "0"
-PARSE_BESIDE_ENCODE = os.environ.get("E4S_PARSE_BESIDE_ENCODE", "1") != "0"    # (batched route) the face parser on a side stream next to the encoder body
+SWAP_BATCHED = True
+PARSE_BESIDE_ENCODE = True    # (batched route) the face parser on a side stream next to the encoder body
 
 
 def _side_stream(device, idx=0):

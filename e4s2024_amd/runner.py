@@ -105,6 +105,10 @@ class FrameShardRunner:
         preallocated one to keep the allocation out of a timed region) after the round's gather has completed — at the latest when the
         next but one round is issued, so at most two rounds of frames are in flight.
 
+        Batch composition: the encoder picks its convolution kernels from the launch size (``ops.winograd_route`` / ``ops.mx_conv_eligible``), so a face in a
+        clip's short last batch can differ from the same face in a full batch by up to 5e-5 of the largest style-vector entry (tests/test_gpu_encoder.py);
+        ``E4S_ENC_ROUTE_BY_IMAGE=1`` makes the choice per image and the frames bit-identical whatever the batch, at 5-10 % of the encoder's throughput.
+
         ``streams`` (GPU only): consecutive rounds run on that many alternating HIP streams (``StreamPipeline``): the latency-bound small layers
         of one batch overlap the large ones of the batch before (+4–6 % swaps/s at batch 8, ``tools/time_swap_pipeline.py``); a round's gather is
         issued from the round's own stream, so it waits for that round's frames only."""

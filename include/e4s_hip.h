@@ -535,15 +535,6 @@ E4S_API int e4s_mconv_dgrad(float* dx, float* ds_part, const float* gz, const fl
 E4S_API int e4s_wino_weight(float* U, const float* w, int cout, int cin, void* stream);
 E4S_API int e4s_wino_input(float* V, const float* x, const float* mean, const float* rstd, int bs, int C, int H, int W, void* stream);
 E4S_API int e4s_wino_output(float* y, const float* M, const float* prelu, int bs, int cout, int H, int W, void* stream);
-/* The same with operands split to bf16 hi / lo by their producers (no conversion between the loads and the MFMAs of the GEMM):
- *   e4s_split_bf16     : hi, lo [n] bf16 of src [n] fp32 (n even) — U once per weight
- *   e4s_wino_input_pre : V_hi, V_lo [16][ceil(C / 8)][T][8] bf16 (eight channels contiguous per tile; channels beyond C zero)
- *   e4s_gemm_pre       : C[b] (M x N fp32) = A[b] (bf16 hi / lo [M][K], K contiguous) * B[b] (bf16 hi / lo [K / 8][N][8]); K % 32 == 0;
- *                        batch strides in elements, 0 = shared */
-E4S_API int e4s_split_bf16(uint16_t* hi, uint16_t* lo, const float* src, int64_t n, void* stream);
-E4S_API int e4s_wino_input_pre(uint16_t* V_hi, uint16_t* V_lo, const float* x, const float* mean, const float* rstd, int bs, int C, int H, int W, void* stream);
-E4S_API int e4s_gemm_pre(float* c, const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* b_hi, const uint16_t* b_lo, int M, int N, int K,
-                         int64_t stride_a, int64_t stride_b, int64_t stride_c, int batch, void* stream);
 
 #ifdef __cplusplus
 }

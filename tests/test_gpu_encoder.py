@@ -199,13 +199,9 @@ def test_winograd_route_of_the_stride1_3x3_convolutions(bs, cin, cout, h, w, nor
     U = _ops.PreparedWinograd().get(wt)
     out = _ops.conv2d_winograd(x, U, in_norm=stats, prelu=slope)
     again = _ops.conv2d_winograd(x, U, in_norm=stats, prelu=slope)
-    if cin % 32 == 0:               # the route with operands split by their producers (e4s_wino_input_pre + e4s_gemm_pre)
-        Us = _ops.PreparedWinogradSplit().get(wt)
-        pre = _ops.conv2d_winograd_pre(x, Us, in_norm=stats, prelu=slope)
-        assert torch.equal(pre, _ops.conv2d_winograd_pre(x, Us, in_norm=stats, prelu=slope))
-        if bs > 1:                  # a face's result does not depend on the batch it is in
-            st1 = (stats[0][:1].contiguous(), stats[1][:1].contiguous()) if norm else None
-            assert torch.equal(_ops.conv2d_winograd_pre(x[:1].contiguous(), Us, in_norm=st1, prelu=slope)[0], pre[0])
+    if bs > 1:                      # a face's result does not depend on the batch it is in (the 16 GEMMs do not split K)
+        st1 = (stats[0][:1].contiguous(), stats[1][:1].contiguous()) if norm else None
+        assert torch.equal(_ops.conv2d_winograd(x[:1].contiguous(), U, in_norm=st1, prelu=slope)[0], out[0])
     direct = _ops.conv2d(x, _ops.PreparedConv().get(wt), 1, 1, in_norm=stats, prelu=slope)
     xn = x.double()
     if norm:
@@ -219,7 +215,29 @@ def test_winograd_route_of_the_stride1_3x3_convolutions(bs, cin, cout, h, w, nor
     e_w, e_d = (out.double() - ref).abs().max().item() / scale, (direct.double() - ref).abs().max().item() / scale
     record_parity(f"conv2d_winograd.{bs}x{cin}to{cout}_{h}x{w}.rel_vs_fp64", e_w, CONV_RTOL, f"direct kernel {e_d:.2e}")
     assert e_w <= CONV_RTOL and e_d <= CONV_RTOL, (e_w, e_d)
-    if cin % 32 == 0:
-        e_p = (pre.double() - ref).abs().max().item() / scale
-        record_parity(f"conv2d_winograd_pre.{bs}x{cin}to{cout}_{h}x{w}.rel_vs_fp64", e_p, CONV_RTOL)
-        assert e_p <= CONV_RTOL, e_p
+
+
+def test_style_vectors_and_the_batch_a_face_travels_in(gpu_net3):
+    """The reference encodes one frame at a time (face_swap_video_pipeline.py:337).  Here the encoder's convolution routes (Winograd / DMA-fed f16 + fp6 /
+    direct) are by default chosen from the whole launch, so the SAME face in a batch of 1, 8 or 16 can run on different kernels: bounded at 5e-5 of
+    the largest style-vector entry.  Under ``ops.ENC_ROUTE_BY_IMAGE`` (E4S_ENC_ROUTE_BY_IMAGE=1) the routes depend on one image's shape only and the vectors
+    are bit-identical whatever the batch (what ``runner.run_clip_streamed`` documents for a clip's short last batch)."""
+    img = seeded.seeded_image(11, 16, 1024).to(DEV)
+    lab = torch.from_numpy(seeded.blocky_labels(12, 16, 12, 512, 16)).to(DEV).to(torch.uint8)
+    old = _ops.ENC_ROUTE_BY_IMAGE
+    try:
+        got = {}
+        for by_image in (False, True):
+            _ops.ENC_ROUTE_BY_IMAGE = by_image
+            with torch.no_grad():
+                got[by_image] = {bs: gpu_net3.get_style_vectors(img[:bs].contiguous(), lab[:bs].contiguous())[0] for bs in (1, 8, 16)}
+    finally:
+        _ops.ENC_ROUTE_BY_IMAGE = old
+    scale = got[False][16].abs().max().item()
+    d = max((got[False][bs][0] - got[False][16][0]).abs().max().item() for bs in (1, 8)) / scale
+    record_parity("encoder.face0_style_vectors.batch_1_8_vs_16.default_routes", d, 5e-5, "relative to the largest entry")
+    assert d <= 5e-5
+    assert torch.equal(got[True][1][0], got[True][16][0]) and torch.equal(got[True][8][:8], got[True][16][:8])
+    d2 = (got[True][16] - got[False][16]).abs().max().item() / scale
+    record_parity("encoder.style_vectors.routes_by_image_vs_default.bs16", d2, 1e-4)
+    assert d2 <= 1e-4

@@ -113,7 +113,7 @@ def test_encoder_unit_heals_an_f16_overflow():
     w = torch.randn(cout, cin, 3, 3, device=DEV, generator=g) / (cin * 9) ** 0.5
     x[3, 7, 10, 11] = 2.0e5                                # one activation outside the f16 range; mean 0 / rstd 1 statistics keep it there
     mean, rstd = torch.zeros(bs, cin, device=DEV), torch.ones(bs, cin, device=DEV)
-    caches = (ops.PreparedConv(), ops.PreparedWinograd(), ops.PreparedWinogradSplit(), ops.PreparedMx())
+    caches = (ops.PreparedConv(), ops.PreparedWinograd(), ops.PreparedMx())
     with torch.no_grad():
         assert ops.mx_conv_eligible(x, cout)
         ops.mx_overflowed()

@@ -482,17 +482,17 @@ def test_stream_pipeline_with_one_stream_is_a_plain_call():
 
 
 def test_invalidate_weight_caches_reaches_nested_containers():
-    """``bottleneck_IR_SE_Ours._wino`` is a list of tuples (direct-conv cache, Winograd cache, pre-split Winograd cache); a write behind
+    """``bottleneck_IR_SE_Ours._wino`` is a list of tuples (direct-conv cache, Winograd cache, DMA-fed kernels' slots); a write behind
     autograd's back followed by ``invalidate_weight_caches`` must reset all of them, or the Winograd route keeps the old weights."""
     from e4s2024_amd import ops
     from e4s2024_amd.dropin.models.encoders.psp_encoders import bottleneck_IR_SE_Ours
     unit = bottleneck_IR_SE_Ours(64, 64, 1)
     caches = list(unit._w) + [c for tup in unit._wino for c in tup[1:]]
-    assert len({id(c) for c in caches}) == 9          # 3 direct + 2 x (Winograd, pre-split Winograd, mx row slots)
+    assert len({id(c) for c in caches}) == 7          # 3 direct + 2 x (Winograd, mx row slots)
     for c in caches:
         c._state = (("stale",), None, None, None, frozenset())
         assert c.key == ("stale",)
-    assert ops.invalidate_weight_caches(unit) == 9          # every distinct cache once, however many containers name it
+    assert ops.invalidate_weight_caches(unit) == 7          # every distinct cache once, however many containers name it
     assert all(c.key is None for c in caches)
 
 
