@@ -46,6 +46,7 @@ struct UpHcParams {
     int bs, cin, cout, h, w;
     int tiles_x, tiles_y;
     int ntile, ncot;                 // (persistent form) tiles_x * tiles_y * bs, cout / 32
+    int exp;                         // tuning experiments of the -DE4S_PHASE_PROF build (E4S_HC_EXP): 1 = no epilogue, 2 = no MFMAs
     int64_t plane_in, plane_out;     // uint4 per plane
 };
 
@@ -69,6 +70,52 @@ __device__ __forceinline__ float dpp_row(float v) {
 }
 constexpr int DPP_ROW_SHL1 = 0x101;              // lane i <- lane i + 1
 constexpr int DPP_ROW_SHR1 = 0x111;              // lane i <- lane i - 1
+
+// One unit (16-channel chunk x row parity PAR) of the K loop: nine taps (dyi, kx) x three split-bf16 MFMAs into accs[2 PAR + (kx & 1)].  `xs` = this lane's
+// patch element (its position's row m - 1, column b - 1) in the hi plane of its K half (+ 2 * HC_PATCH = lo plane), `whalf` = its weight fragment of tap 0.
+// LDS traffic is what these kernels are short of (tuning build: DMA, MFMA and epilogue times ADD — the compute waves' fragment reads and the DMA writes share one
+// LDS port), so the activation fragment of input row dyi is read ONCE: taps kx = 0 and kx = 1 both multiply x[m - 1 + dyi][b], and tap kx = 2 multiplies
+// x[..][b - 1] = the LEFT neighbour lane's fragment, a DPP row shift (lane ptx = 0 receives zeros there: its kx = 2 term only enters column parity 0 of a
+// position whose outputs are discarded, and its right neighbour's filter reads its parity-1 value only) — 24 LDS reads per unit instead of 36.
+__device__ __forceinline__ uint4 dpp_row_shr1(uint4 v) {
+    uint4 r;
+    r.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.x, DPP_ROW_SHR1, 0xf, 0xf, true);
+    r.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.y, DPP_ROW_SHR1, 0xf, 0xf, true);
+    r.z = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.z, DPP_ROW_SHR1, 0xf, 0xf, true);
+    r.w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.w, DPP_ROW_SHR1, 0xf, 0xf, true);
+    return r;
+}
+template <int PAR>
+__device__ __forceinline__ void hc_unit(f32x16 (&accs)[4], const uint4* xs, const uint4* whalf) {
+    uint4 bh[2], bl[2], ah[2], al[2];
+    auto fetch_b = [&](int dyi, int slot) __attribute__((always_inline)) {
+        bh[slot] = xs[dyi * HC_PW + 1];
+        bl[slot] = xs[2 * HC_PATCH + dyi * HC_PW + 1];
+    };
+    auto fetch_a = [&](int tap, int slot) __attribute__((always_inline)) {
+        ah[slot] = whalf[tap * 64];
+        al[slot] = whalf[18 * 32 + tap * 64];
+    };
+    fetch_b(0, 0);
+    fetch_a(0, 0);
+#pragma unroll
+    for (int dyi = 0; dyi < 3; ++dyi) {
+        const int bs = dyi & 1;
+        if (dyi + 1 < 3) fetch_b(dyi + 1, bs ^ 1);
+        const uint4 sh = dpp_row_shr1(bh[bs]), sl = dpp_row_shr1(bl[bs]);          // column b - 1
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int tap = dyi * 3 + kx, cs = tap & 1;
+            if (tap + 1 < 9) fetch_a(tap + 1, cs ^ 1);
+            const uint4 xh = kx == 2 ? sh : bh[bs], xl = kx == 2 ? sl : bl[bs];
+            const int ai = 2 * PAR + (kx & 1);
+            accs[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[cs]), __builtin_bit_cast(bf16x8, xh), accs[ai], 0, 0, 0);
+            accs[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[cs]), __builtin_bit_cast(bf16x8, xl), accs[ai], 0, 0, 0);
+            accs[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[cs]), __builtin_bit_cast(bf16x8, xh), accs[ai], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
 
 E4S_PROF_DECL(g_prof_hc)
 
@@ -250,26 +297,7 @@ __global__ __launch_bounds__(HC_NT, 4) void up_hc_kernel(const UpHcParams p) {
             asm volatile("" : "+v"(xb_i), "+v"(wb_i));
             const uint4* xs = lds4 + xb_i;
             const uint4* whalf = lds4 + wb_i;
-            uint4 bh[2], bl[2], ah[2], al[2];
-            auto fetch = [&](int tap, int slot) __attribute__((always_inline)) {
-                const int dyi = tap / 3, kx = tap % 3;                         // input row m - 1 + dyi, column b - (kx >> 1)
-                const int eo = dyi * HC_PW + (1 - (kx >> 1));
-                bh[slot] = xs[eo];
-                bl[slot] = xs[2 * HC_PATCH + eo];
-                ah[slot] = whalf[tap * 64];
-                al[slot] = whalf[18 * 32 + tap * 64];
-            };
-            fetch(0, 0);
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int cs = tap & 1;
-                if (tap + 1 < 9) fetch(tap + 1, cs ^ 1);
-                const int ai = 2 * par + ((tap % 3) & 1);
-                accs[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[cs]), __builtin_bit_cast(bf16x8, bh[cs]), accs[ai], 0, 0, 0);
-                accs[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[cs]), __builtin_bit_cast(bf16x8, bl[cs]), accs[ai], 0, 0, 0);
-                accs[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[cs]), __builtin_bit_cast(bf16x8, bh[cs]), accs[ai], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            if (par == 0) hc_unit<0>(accs, xs, whalf); else hc_unit<1>(accs, xs, whalf);
             E4S_LDS_BARRIER();                                   // everyone is done with this unit's weight slot (and, behind par 1, with the chunk's buffer)
             if (!last) {
                 issue_w(2 * c + par + 2);
@@ -292,19 +320,23 @@ __global__ __launch_bounds__(HC_NT, 4) void up_hc_kernel(const UpHcParams p) {
 // The persistent form (default).  Measured on the kernel above: 0.315 ms for the 64 -> 32 layer at batch 4 where its MFMAs need 0.12 — a workgroup lives
 // 35 us for 3.4 us of matrix work because its ring is ONE unit deep (two workgroups of 76 KB per CU leave no room for more): every unit waits a memory round
 // trip for a request issued 0.4 us earlier, and every workgroup pays the launch + first-chunk latency again.  Here ONE workgroup per CU walks over its
-// tiles (modconv_chain.hip's roles): eight compute waves + one loader wave that issues every LDS-DMA three units ahead (ring: three activation chunks + four
-// weight units = 129 KB), across tile boundaries — the next tile's first chunks land under this tile's epilogue.  Compute waves never touch vmcnt except
-// for their own noise loads; the loader's counted wait (56 = the two youngest groups: 38 + 18 requests) keeps the 6-bit vmcnt counter in range.
+// tiles (modconv_chain.hip's roles): eight compute waves + TWO loader waves that issue every LDS-DMA ahead of its use, across tile boundaries — the next
+// tile's first chunks land under this tile's epilogue.  Compute waves never touch vmcnt except for their own noise loads.
+// Why two loaders.  Tuning build, 64 -> 32 layer at batch 4 (E4S_HC_EXP): the full kernel 0.311 ms; without its epilogue 0.208; without its MFMAs 0.214;
+// with neither 0.098 — the three parts ADD.  Every persistent kernel of the chain sits at ~70 - 115 cycles per 1 KB request that enters or leaves a CU
+// (this kernel: 224 KB of DMA + 114 KB of stores per tile), whatever its arithmetic: a wave's vmcnt is a 6-bit counter, so ONE loader wave keeps at most 63
+// requests = 63 KB in flight per CU, and what is in flight / latency is the CU's ingest rate (Little's law: 63 KB / ~3 us under LDS contention = 21 GB/s per
+// CU = 5.4 TB/s for the chip).  Each loader wave has its own counter: wave 8 owns the weight ring (four units, three in flight: 54 requests), wave 9 the
+// activation ring (four chunks, three in flight: 60 requests) — 114 KB in flight per CU instead of 56.
 // A tile's co tiles (cout / 32) are consecutive items of the SAME workgroup, so the second one's activation patch comes out of this XCD's L2.
-constexpr int HP_NCW = 8;                                   // compute waves; wave HP_NCW is the loader
-constexpr int HP_NT = 64 * (HP_NCW + 1);                    // 576 threads
-constexpr int HP_NX = 3, HP_NW = 4, HP_D = 3;               // activation buffers, weight slots, units requested ahead
+constexpr int HP_NCW = 8;                                   // compute waves; wave 8 loads weights (+ the epilogue tables), wave 9 activations
+constexpr int HP_NT = 64 * (HP_NCW + 2);                    // 640 threads
+constexpr int HP_NX = 4, HP_NW = 4;                         // activation buffers (chunks), weight slots (units)
 constexpr int HP_W0 = HP_NX * HC_XB4;                       // uint4 offset of the weight ring
-constexpr int HP_BODY = (HP_NX * HC_XB4 + HP_NW * HC_W4) * 16;     // 132 480
-constexpr int HP_LDS = HP_BODY + HC_EP_FLOATS * 4;          // 133 248
+constexpr int HP_BODY = (HP_NX * HC_XB4 + HP_NW * HC_W4) * 16;     // 152 064
+constexpr int HP_LDS = HP_BODY + HC_EP_FLOATS * 4;          // 152 832
 constexpr int HP_GX = 20, HP_GW = 18;                       // requests of one activation chunk / one weight unit
-static_assert(HP_LDS <= 160 * 1024 && (HP_D - 1) * ((HP_GX + 2 * HP_GW + 1) / 2 + 1) <= 63 && HP_GX + 2 * HP_GW <= 63, "LDS per CU; vmcnt is a 6-bit counter");
-#define HP_WAIT_YOUNGEST_TWO() asm volatile("s_waitcnt vmcnt(56)" ::: "memory")        // HP_GX + 2 * HP_GW: one group with and one without an activation chunk
+static_assert(HP_LDS <= 160 * 1024 && (HP_NX - 1) * HP_GX <= 63 && (HP_NW - 1) * HP_GW + 3 <= 63, "LDS per CU; vmcnt is a 6-bit counter");
 
 __global__ __launch_bounds__(HP_NT) void up_hcp_kernel(const UpHcParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -318,6 +350,7 @@ __global__ __launch_bounds__(HP_NT) void up_hcp_kernel(const UpHcParams p) {
     const int my_tiles = (p.ntile - first + stride - 1) / stride;
     const int my_items = my_tiles * p.ncot;
     const int per_img = p.tiles_x * p.tiles_y;
+    const int total = my_items * NU;                                       // units of this workgroup's walk = barriers every wave passes
     // item i of this workgroup: tile first + (i / ncot) * stride, co tile i % ncot
     auto item_coords = [&](int i, int& b, int& cot, int& tyt, int& txt) __attribute__((always_inline)) {
         i = i < my_items ? i : my_items - 1;                               // (ghost items past the end repeat the last one)
@@ -330,34 +363,13 @@ __global__ __launch_bounds__(HP_NT) void up_hcp_kernel(const UpHcParams p) {
     };
 
     if (wave == HP_NCW) {
-        // =================================================================================== loader
-        const int cb8 = p.cin >> 3;
+        // =================================================================================== weight loader: unit k lives in slot k % 4; after barrier B_k
+        // every compute wave has finished unit k - 1, whose slot takes unit k + 3
         lds_byte* const lds_b = (lds_byte*)lds_raw;
-        const unsigned zero_off = (unsigned)(2 * p.plane_in * 16);
-        auto issue_group = [&](int k) __attribute__((always_inline)) {       // unit k of this workgroup's walk: item k / NU, chunk (k % NU) / 2, row parity k & 1
+        auto issue_w = [&](int k) __attribute__((always_inline)) {           // unit k of the walk: item k / NU, chunk (k % NU) / 2, row parity k & 1
             const int u = k % NU, c = u >> 1, par = u & 1;
             int b, cot, tyt, txt;
             item_coords(k / NU, b, cot, tyt, txt);
-            if (par == 0) {
-                const unsigned xst = (unsigned)(((k >> 1) % HP_NX) * (HC_XB4 * 16));
-                const int m0 = tyt * HC_T, p0x = txt * HC_STEP - 1;
-                const unsigned cb0 = (unsigned)((b * cb8 + 2 * c) * hw);
-#pragma unroll
-                for (int j = 0; j < 5; ++j) {                                 // this lane's patch pixel of piece j: the same for the 4 (plane, half)
-                    const int e = j * 64 + lane;
-                    const int py = e / HC_PW, px = e - py * HC_PW;
-                    const int gy = m0 - 1 + py, gx = p0x - 1 + px;
-                    const bool inb = gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
-                    const unsigned pix = (unsigned)(gy * p.w + gx);
-                    if (e < HC_PATCH) {
-#pragma unroll
-                        for (int combo = 0; combo < 4; ++combo) {
-                            const unsigned cbase = (unsigned)((combo >> 1) * p.plane_in) + cb0 + (unsigned)((combo & 1) * hw);
-                            dma16(p.x, inb ? (cbase + pix) * 16u : zero_off, lds_b + xst + (combo * HC_PATCH + j * 64) * 16);
-                        }
-                    }
-                }
-            }
             const unsigned wst = (unsigned)((HP_W0 + (k % HP_NW) * HC_W4) * 16);
 #pragma unroll
             for (int piece = 0; piece < HP_GW; ++piece) {
@@ -366,7 +378,7 @@ __global__ __launch_bounds__(HP_NT) void up_hcp_kernel(const UpHcParams p) {
                 dma16(hl ? p.wlo : p.whi, (unsigned)(((((par * nchunk + c) * 18 + (rem >> 5)) * p.cout) + cot * 32 + (rem & 31)) * 16), lds_b + wst + piece * 1024);
             }
         };
-        auto item_setup = [&](int i) __attribute__((always_inline)) {         // d / s_next / bias of the item's 32 channels: read in its epilogue, NU - 1 >= 3 groups later
+        auto item_setup = [&](int i) __attribute__((always_inline)) {         // d / s_next / bias of the item's 32 channels: read in its epilogue, NU - 1 >= 3 units later
             int b, cot, tyt, txt;
             item_coords(i, b, cot, tyt, txt);
             const unsigned co4 = (unsigned)((cot * 32 + (lane & 31)) * 4);
@@ -376,18 +388,58 @@ __global__ __launch_bounds__(HP_NT) void up_hcp_kernel(const UpHcParams p) {
         };
         item_setup(0);
 #pragma unroll
-        for (int k = 0; k < HP_D; ++k) issue_group(k);
-        const int total = my_items * NU;
+        for (int k = 0; k < HP_NW - 1; ++k) issue_w(k);
 #pragma unroll 1
         for (int k = 0; k < total; ++k) {
-            // unit k has landed: everything this wave requested except (at most) the two youngest groups — one of them carries an activation chunk, one does
-            // not, 56 requests; an item's three table requests in between only make the wait a little earlier than necessary
-            HP_WAIT_YOUNGEST_TWO();
+            // unit k has landed: everything this wave requested except (at most) the two youngest units, 36 requests; an item's three table requests in
+            // between only make the wait a little earlier than necessary
+            E4S_WAIT_VM(2 * HP_GW);
             E4S_LDS_BARRIER();
             if (k > 0 && k % NU == 0) item_setup(k / NU);
-            issue_group(k + HP_D);
+            issue_w(k + HP_NW - 1);
         }
-        E4S_WAIT_VM(0);   // ghost groups must land before the workgroup's LDS is released
+        E4S_WAIT_VM(0);   // ghost units must land before the workgroup's LDS is released
+        return;
+    }
+    if (wave == HP_NCW + 1) {
+        // =================================================================================== activation loader: chunk q (= unit 2q, 2q + 1) lives in buffer
+        // q % 4; after barrier B_2q every compute wave has finished chunk q - 1, whose buffer takes chunk q + 3
+        const int cb8 = p.cin >> 3;
+        lds_byte* const lds_b = (lds_byte*)lds_raw;
+        const unsigned zero_off = (unsigned)(2 * p.plane_in * 16);
+        auto issue_x = [&](int q) __attribute__((always_inline)) {           // chunk q of the walk: item q / nchunk, its chunk q % nchunk
+            const int c = q % nchunk;
+            int b, cot, tyt, txt;
+            item_coords(q / nchunk, b, cot, tyt, txt);
+            const unsigned xst = (unsigned)((q % HP_NX) * (HC_XB4 * 16));
+            const int m0 = tyt * HC_T, p0x = txt * HC_STEP - 1;
+            const unsigned cb0 = (unsigned)((b * cb8 + 2 * c) * hw);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {                                     // this lane's patch pixel of piece j: the same for the 4 (plane, half)
+                const int e = j * 64 + lane;
+                const int py = e / HC_PW, px = e - py * HC_PW;
+                const int gy = m0 - 1 + py, gx = p0x - 1 + px;
+                const bool inb = gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+                const unsigned pix = (unsigned)(gy * p.w + gx);
+                if (e < HC_PATCH) {
+#pragma unroll
+                    for (int combo = 0; combo < 4; ++combo) {
+                        const unsigned cbase = (unsigned)((combo >> 1) * p.plane_in) + cb0 + (unsigned)((combo & 1) * hw);
+                        dma16(p.x, inb ? (cbase + pix) * 16u : zero_off, lds_b + xst + (combo * HC_PATCH + j * 64) * 16);
+                    }
+                }
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < HP_NX - 1; ++q) issue_x(q);
+#pragma unroll 1
+        for (int k = 0; k < total; ++k) {
+            if (k & 1) { E4S_LDS_BARRIER(); continue; }                       // (a chunk's second unit: nothing to publish, nothing to refill)
+            E4S_WAIT_VM(2 * HP_GX);                                           // chunk k / 2 has landed: all but the two youngest chunks' requests
+            E4S_LDS_BARRIER();
+            issue_x((k >> 1) + HP_NX - 1);
+        }
+        E4S_WAIT_VM(0);
         return;
     }
 
@@ -396,7 +448,7 @@ __global__ __launch_bounds__(HP_NT) void up_hcp_kernel(const UpHcParams p) {
     const int pty = 2 * wave + (l5 >> 4), ptx = l5 & 15;
     const int xoff = pty * HC_PW + ptx;
     if (blockIdx.x == 0 && tid < 1) p.out[(size_t)p.plane_out * 2] = make_uint4(0u, 0u, 0u, 0u);   // the zero element behind the output planes
-    int xbuf = 0;                                        // (k >> 1) % HP_NX, carried along
+    int xbuf = 0;                                        // (chunk of the walk) % HP_NX, carried along
 #pragma unroll 1
     for (int ti = 0; ti < my_items; ++ti) {
         int b, cot, tyt, txt;
@@ -425,29 +477,16 @@ __global__ __launch_bounds__(HP_NT) void up_hcp_kernel(const UpHcParams p) {
                 asm volatile("" : "+v"(xb_i), "+v"(wb_i));
                 const uint4* xs = lds4 + xb_i;
                 const uint4* whalf = lds4 + wb_i;
-                uint4 bh[2], bl[2], ah[2], al[2];
-                auto fetch = [&](int tap, int slot) __attribute__((always_inline)) {
-                    const int dyi = tap / 3, kx = tap % 3;
-                    const int eo = dyi * HC_PW + (1 - (kx >> 1));
-                    bh[slot] = xs[eo];
-                    bl[slot] = xs[2 * HC_PATCH + eo];
-                    ah[slot] = whalf[tap * 64];
-                    al[slot] = whalf[18 * 32 + tap * 64];
-                };
-                fetch(0, 0);
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int cs = tap & 1;
-                    if (tap + 1 < 9) fetch(tap + 1, cs ^ 1);
-                    const int ai = 2 * par + ((tap % 3) & 1);
-                    accs[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[cs]), __builtin_bit_cast(bf16x8, bh[cs]), accs[ai], 0, 0, 0);
-                    accs[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[cs]), __builtin_bit_cast(bf16x8, bl[cs]), accs[ai], 0, 0, 0);
-                    accs[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[cs]), __builtin_bit_cast(bf16x8, bh[cs]), accs[ai], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+#ifdef E4S_PHASE_PROF
+                if (p.exp & 2) continue;
+#endif
+                if (par == 0) hc_unit<0>(accs, xs, whalf); else hc_unit<1>(accs, xs, whalf);
             }
             xbuf = xbuf + 1 < HP_NX ? xbuf + 1 : 0;
         }
+#ifdef E4S_PHASE_PROF
+        if (p.exp & 1) { asm volatile("" :: "v"(accs[0][0]), "v"(accs[1][0]), "v"(accs[2][0]), "v"(accs[3][0])); continue; }
+#endif
         hc_epilogue(p, accs, lds_raw, HP_BODY, nz, lane_ok, b, cot * 32, pm, pbx, khalf);
     }
 }
@@ -546,6 +585,11 @@ extern "C" int e4s_modconv_up_hc(uint16_t* out_sp, const uint16_t* x_sp, const u
     p.ntile = p.tiles_x * p.tiles_y * bs; p.ncot = cout / 32;
     p.plane_in = (int64_t)bs * (cin / 8) * h * w;
     p.plane_out = (int64_t)bs * (cout / 8) * 4 * h * w;
+#ifdef E4S_PHASE_PROF
+    { const char* e = getenv("E4S_HC_EXP"); p.exp = e ? atoi(e) : 0; }      // (tuning build only)
+#else
+    p.exp = 0;
+#endif
     // (cin = 16 has too few units per item for the persistent loader's table hand-over: the two-workgroups-per-CU form serves it; at cin >= 32 the two forms
     //  tie — 0.315 against 0.320 ms on the 64 -> 32 layer, 0.265 against 0.255 on 128 -> 64 — and the persistent one is the one the f16 + fp6 arithmetic needs next)
     if (cin >= 32) {
