@@ -46,7 +46,7 @@ struct UpHcParams {
     int bs, cin, cout, h, w;
     int tiles_x, tiles_y;
     int ntile, ncot;                 // (persistent form) tiles_x * tiles_y * bs, cout / 32
-    int exp;                         // tuning experiments of the -DE4S_PHASE_PROF build (E4S_HC_EXP): 1 = no epilogue, 2 = no MFMAs
+    int exp;                         // tuning experiments of the -DE4S_PHASE_PROF build (E4S_HC_EXP): 1 = no epilogue, 2 = no MFMAs, 4 = no output stores
     int64_t plane_in, plane_out;     // uint4 per plane
 };
 
@@ -188,6 +188,9 @@ __device__ __forceinline__ void hc_epilogue(const UpHcParams& p, const f32x16 (&
                 auto r2 = __builtin_amdgcn_permlane32_swap(le[q], lo_[q], false, false);
                 le[q] = r2[0]; lo_[q] = r2[1];
             }
+#ifdef E4S_PHASE_PROF
+            if ((p.exp & 4) && he[0] != 0x12345678u) continue;        // experiment: everything but the stores
+#endif
             if (lane_ok) {
                 const size_t o4 = o_base + (size_t)g * opl + (size_t)pa * wo;
                 p.out[o4] = make_uint4(he[0], he[1], ho_[0], ho_[1]);

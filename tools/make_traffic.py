@@ -33,11 +33,13 @@ KEYS = {
                                     "once); dword activation loads, 16-byte weight DMA: FETCH uncorrected (a lower bound on the weight share)",
                                     (823900000 - 4 * (256 * 128 * 128 * 4 + 128 * 256 * 256 * 4)) // 7),
     "region_modconv_mx_kernel<0>": (["region_modconv_mx_kernel<0"], 1.0, "as <1> with the split-bf16 arithmetic", (823900000 - 4 * (256 * 128 * 128 * 4 + 128 * 256 * 256 * 4)) // 7),
-    "masked_upconv_blocks": (["masked_up_block_kernel"], 1.0, "3 launches per step (the masked up layers of width >= 32); on the benchmark maps only the 128->256 "
-                             "layer has region-uniform blocks, the other two launches leave at once: averages over all three; dword loads",
-                             4 * (256 * 128 * 128 * 4 + 128 * 256 * 256 * 4) // 3),
+    "masked_upconv_blocks": (["masked_up_block_kernel"], 1.0, "1 launch per step (the 256 -> 128 @128 masked up layer: every 16 x 16 output block of the benchmark maps lies under one "
+                             "region); algorithmic bytes = its input [4,256,128,128] + its output [4,128,256,256], fp32; dword loads",
+                             4 * (256 * 128 * 128 * 4 + 128 * 256 * 256 * 4)),
     "chain_conv3x3<32>": (["chain_conv_kernel<1, 2"], 2.0, "LDS-DMA dwordx4 only: FETCH_SIZE x2 (guide)", 4 * (32 * 1024 * 1024 * 4 + 3 * 1024 * 1024 * 4 + 3 * 512 * 512 * 4)),
     "chain_conv3x3<64>": (["chain_conv_kernel<2, 4"], 2.0, "LDS-DMA dwordx4 only: FETCH_SIZE x2 (guide)", 4 * (2 * 64 * 512 * 512 * 4 + 3 * 512 * 512 * 4 + 3 * 256 * 256 * 4)),
+    "modconv_up_hc": (["up_hcp_kernel"], 2.0, "2 launches per step (256->512, 512->1024), half-composed form, split-plane in/out, LDS-DMA dwordx4 only: FETCH_SIZE x2 (guide)",
+                      (4 * (128 * 256 * 256 * 4 + 64 * 512 * 512 * 4) + 4 * (64 * 512 * 512 * 4 + 32 * 1024 * 1024 * 4)) // 2),
     "modconv_up_fused_sb": (["up_fused"], 2.0, "2 launches per step (256->512, 512->1024), split-plane in/out, 16-byte loads: FETCH_SIZE x2 (guide)",
                             (4 * (128 * 256 * 256 * 4 + 64 * 512 * 512 * 4) + 4 * (64 * 512 * 512 * 4 + 32 * 1024 * 1024 * 4)) // 2),
 }
