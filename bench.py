@@ -185,6 +185,8 @@ def main():
                     help="region maps: 16 x 16 constant cells on the 512 x 512 map (default, BASELINE configs[1]), 4 x 4 cells (face-sized regions), or i.i.d. per pixel")
     ap.add_argument("--soak-seconds", type=float, default=2.0, help="after the timed K steps: the same steps for at least this long (sustained rate, a side field); 0 skips it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-in-run-ab", action="store_true", help="skip the extra one-stream pass on the previous rounds' kernels (roofline.in_run_ab); the profiling scripts use it "
+                                                                   "so that their kernel tables list the default routes only")
     ap.add_argument("--no-full-swap", action="store_true", help="skip the secondary full-swap p50 measurement")
     ap.add_argument("--no-pti", action="store_true", help="skip the secondary PTI step measurement (BASELINE configs[3])")
     ap.add_argument("--clip", type=int, default=256, help="frames of the clip-mode measurement (BASELINE configs[4]); 0 skips it")
@@ -321,7 +323,7 @@ def main():
     # the same K steps on one stream, every launch timed, with the routes switched back — masked 3x3 layers on the register-staged split-bf16 kernel of
     # round 2 (E4S_MX=0), the chain's up layers on round 3's fused LDS-DMA kernel (E4S_UP_HC=0).  Outside the timed region.
     in_run_ab = None
-    if world == 1 and ops.MODCONV_MODE == "sb" and ksum:
+    if world == 1 and ops.MODCONV_MODE == "sb" and ksum and not args.no_in_run_ab:
         saved_routes = (ops.MX_MODE, ops.UP_HC)
         try:
             ops.MX_MODE, ops.UP_HC = 0, False

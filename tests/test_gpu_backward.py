@@ -498,14 +498,17 @@ def test_pti_step_gradients_1024_vs_oracle_autograd(net3_sd):
 
     def rel(a, b):
         return (a.detach().cpu() - b).abs().max().item() / max(1e-12, b.abs().max().item())
-    # Tolerance: as for the 64 x 64 whole-network check above — a random-weight generator is ill-conditioned for gradients (leaky-relu
-    # branch flips under 1e-5 activation changes; the fp32 oracle is itself ~1e-2 from an fp64 evaluation), so 3e-2 of each gradient's
-    # largest entry pins wiring and scaling of every parameter kind; the tight per-layer checks (3e-5) are the fp64 tests above.
-    TOL = 3e-2
+    # Tolerances per parameter, from the measured worst of each (profiles/r04_final_parity.json; round 3 had a blanket 3e-2): 27 of the 28 sampled parameters
+    # and the style vectors agree with autograd through the oracle to <= 1.1e-3 of their gradient's largest entry — bar 3e-3.  The exception is the weight of
+    # the 4 -> 8 up layer (G.convs.0): its gradient sums over the 64 pixels of an 8 x 8 map, so ONE leaky-ReLU branch that flips under the forward's 1e-5-level
+    # difference moves 1/64 of an entry (measured 9.6e-3; the fp32 oracle itself is ~1e-2 from an fp64 evaluation there) — bar 2e-2 for that layer only.
+    # The tight checks of the kernels' arithmetic (3e-5 against fp64) are the per-layer tests above; this one pins wiring and scaling of every parameter kind.
+    def tol_of(name):
+        return 2e-2 if name.startswith("G.convs.0.") else 3e-3
     r = rel(vec_g.grad, vec_o.grad)
-    record_parity("pti1024.grad.style_vectors.rel_vs_oracle", r, TOL)
-    worst = ("style_vectors", r)
-    assert r <= TOL
+    record_parity("pti1024.grad.style_vectors.rel_vs_oracle", r, 3e-3)
+    worst = ("style_vectors", r, r / 3e-3)
+    assert r <= 3e-3
     scalar_scale = max(sd_o[k].grad.abs().max().item() for k in subset if k.endswith("noise.weight"))
     for k in subset:
         go, gg = sd_o[k].grad, named[k].grad
@@ -514,11 +517,11 @@ def test_pti_step_gradients_1024_vs_oracle_autograd(net3_sd):
             r = (gg.cpu() - go).abs().item() / scalar_scale
         else:
             r = rel(gg, go)
-        record_parity(f"pti1024.grad.{k}.rel_vs_oracle", r, TOL)
-        if r > worst[1]:
-            worst = (k, r)
-        assert r <= TOL, (k, r)
-    record_parity("pti1024.grad.worst_of_subset", worst[1], TOL, worst[0])
+        record_parity(f"pti1024.grad.{k}.rel_vs_oracle", r, tol_of(k))
+        if r / tol_of(k) > worst[2]:
+            worst = (k, r, r / tol_of(k))
+        assert r <= tol_of(k), (k, r)
+    record_parity("pti1024.grad.worst_share_of_its_bar", worst[2], 1.0, worst[0])
 
 
 def test_pti_step_1024_runs_no_library_gemm_or_convolution(net3_sd):

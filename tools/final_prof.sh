@@ -6,10 +6,10 @@ timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/${T}_g
 cp gpurun_out/parity.json gpurun_out/${T}_parity.json 2>/dev/null
 timeout 900 python bench.py 2> gpurun_out/${T}_bench.err | grep '^{' > gpurun_out/${T}_bench.json; cut -c1-300 gpurun_out/${T}_bench.json
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench -o bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-full-swap --no-pti --clip 0 --soak-seconds 0 > $R/gpurun_out/prof_bench.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench -o bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-in-run-ab --no-full-swap --no-pti --clip 0 --soak-seconds 0 > $R/gpurun_out/prof_bench.log 2>&1
 grep '^{' $R/gpurun_out/prof_bench.log > $R/gpurun_out/${T}_bench_under_rocprof.json
 # the same on one stream: the kernel durations the bench's roofline object is computed from (under the default two-stream overlap a kernel shares the chip)
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench1 -o bench -- python3 $R/bench.py --streams 1 --steps 10 --warmup 3 --no-cpu-baseline --no-full-swap --no-pti --clip 0 --no-mask-sensitivity --soak-seconds 0 > $R/gpurun_out/prof_bench1.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench1 -o bench -- python3 $R/bench.py --streams 1 --steps 10 --warmup 3 --no-cpu-baseline --no-in-run-ab --no-full-swap --no-pti --clip 0 --no-mask-sensitivity --soak-seconds 0 > $R/gpurun_out/prof_bench1.log 2>&1
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_swap -o swap -- python3 $R/tools/time_swap.py 8 6 > $R/gpurun_out/prof_swap.log 2>&1
 cd $R
 python tools/rocpd_summary.py gpurun_out/prof_bench/bench_results.db | cut -c1-260 > gpurun_out/${T}_bench_kernel_stats.txt
