@@ -189,6 +189,7 @@ def main():
                                                                    "so that their kernel tables list the default routes only")
     ap.add_argument("--no-full-swap", action="store_true", help="skip the secondary full-swap p50 measurement")
     ap.add_argument("--no-pti", action="store_true", help="skip the secondary PTI step measurement (BASELINE configs[3])")
+    ap.add_argument("--pti-passes", type=int, default=5, help="passes of the PTI clip loop over its 32 frames (BASELINE configs[3] states 200: ~80 s on one GPU; default 5)")
     ap.add_argument("--clip", type=int, default=256, help="frames of the clip-mode measurement (BASELINE configs[4]); 0 skips it")
     ap.add_argument("--clip-batch", type=int, default=SWAP_BATCH)
     ap.add_argument("--clip-unit", choices=["swap", "gen"], default="swap",
@@ -607,7 +608,7 @@ def main():
             # the loop of configs[3] itself on a short clip: passes over the frames, one optimiser step per frame, eroded maps, foreground-weighted
             # L2 (pti.tune_clip: training/video_swap_ft_coach.py:242-317); the first two steps run eagerly, the rest replays one captured step
             del step
-            nf, passes = 32, 5                   # BASELINE configs[3]'s clip length (its 200 passes are 40 of these)
+            nf, passes = 32, max(1, args.pti_passes)      # BASELINE configs[3]'s clip length; --pti-passes 200 = its stated size
             vecs = torch.from_numpy(seeded.seeded_array(42, "vecs", (nf, 12, 1280), dist="normal")).to(dev)
             labs = torch.from_numpy(seeded.blocky_labels(43, nf, 12, 512, 16)).to(dev).to(torch.uint8)
             imgs = torch.tanh(torch.from_numpy(seeded.seeded_array(44, "imgs", (nf, 3, 1024, 1024), dist="normal"))).to(dev)
@@ -616,7 +617,7 @@ def main():
             hist = pti.tune_clip(tnet, topt, imgs, labs, vecs, steps=passes, erode_radius=3)
             torch.cuda.synchronize()
             pti_info["clip_loop"] = {"frames": nf, "passes": passes, "optimizer_steps": nf * passes, "seconds": round(time.perf_counter() - t2, 4),
-                                     "mean_loss_per_pass": [round(h, 4) for h in hist],
+                                     "mean_loss_per_pass": [round(h, 4) for h in (hist if len(hist) <= 10 else hist[:5] + hist[-5:])],
                                      "seconds_per_pass": round((time.perf_counter() - t2) / passes, 4),
                                      "what": "pti.tune_clip on configs[3]'s 32-frame clip at 1024 x 1024: erode_mask radius 3 + foreground-weighted L2, the first 2 steps eagerly on the "
                                              "capture stream, then one captured step replayed per frame (includes the capture); BASELINE configs[3] is 200 such passes, sharded over 4 GPUs "
