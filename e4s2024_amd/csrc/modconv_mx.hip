@@ -32,6 +32,9 @@ using namespace e4s;
 
 // Tuning builds only (-DMX_ABL=bits, never the product library; results are then meaningless; tools/build_abl.sh): 1 = the plain-convolution f16 + fp6 K loop without
 // its MFMAs, 2 = without its LDS operand reads (operands from registers), 4 = without barriers / waits / DMA.  What is left tells which part bounds the loop.
+// The MASKED f16 + fp6 loop: 8 = without the per-tap modulate / split / range VALU work (raw patch words as operands), 16 = without the fp6 half (conversions, their
+// MFMAs and operand reads), 32 = without the weight refills, waits and barriers, 64 = without the activation prefetch and its LDS store, 128 = without the f16
+// weight-fragment reads, 256 = without the f16 MFMAs, 512 = the K loop runs no chunk at all (prologue + epilogue), 1024 = no epilogue.
 #ifndef MX_ABL
 #define MX_ABL 0
 #endif
@@ -394,15 +397,16 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
     // the accumulators (LLVM sinks a row's last MFMAs behind the next barrier otherwise — 60 registers).
     bool ovf = false;       // (f16 arithmetic) a modulated activation of this lane left the f16 range
 #pragma unroll 1
-    for (int chunk = ch_begin; chunk < ch_end; ++chunk) {
+    for (int chunk = ch_begin; chunk < ((MX_ABL & 512) ? ch_begin : ch_end); ++chunk) {
         const int cur = (chunk - ch_begin) & 1;
         const bool more = chunk + 1 < ch_end;
-        if (more) load_x(chunk + 1);                       // lands during this chunk (row 0's wait), written to the other patch buffer before its last barrier
+        if (more && !(!ENC && (MX_ABL & 64))) load_x(chunk + 1);                       // lands during this chunk (row 0's wait), written to the other patch buffer before its last barrier
         // (masked f16 + fp6 loop) the refill of the ring slot the previous row left is requested behind the row's first MFMAs instead of right behind the barrier:
         // a request stalls the issuing in-order wave on the CU's address unit (~30 cycles per 1 KB request: conv_mx3.hip's stamps), and in front of the row's
         // LDS reads that stall delayed the operands of all of its MFMAs (in-run ratio to the split-bf16 variant of this kernel 0.879 -> 0.859; moving the patch
         // prefetch behind row 0's first MFMAs as well gives 0.881: its loads then have less of row 0 to land in)
         auto deferred_refill = [&](int row) __attribute__((always_inline)) {
+            if constexpr (!ENC && (MX_ABL & 32)) return;
             if (row == 0) {
                 if (chunk > ch_begin) dma_row(chunk, 2);
             } else if (more) {
@@ -534,11 +538,19 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) wv[t][i] = w1half[t * 2 * MX_TN + i * 32];
+                    for (int i = 0; i < 4; ++i) {
+                        if constexpr (MX_ABL & 128) { wv[t][i] = make_uint4(tid, t, i, row); asm volatile("" : "+v"(wv[t][i].x)); }
+                        else wv[t][i] = w1half[t * 2 * MX_TN + i * 32];
+                    }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     const float xv[8] = {xa[t].x, xa[t].y, xa[t].z, xa[t].w, xb[t].x, xb[t].y, xb[t].z, xb[t].w};
+                    if constexpr (MX_ABL & 8) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { v1[t * 4 + j] = __builtin_bit_cast(unsigned, xv[2 * j]); v2[t * 4 + j] = __builtin_bit_cast(unsigned, xv[2 * j + 1]); }
+                        amax = 1.0f;
+                    } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float a = xv[2 * j] * sv[2 * j], bq = xv[2 * j + 1] * sv[2 * j + 1];
@@ -547,17 +559,21 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
                         v2[t * 4 + j] = resid_pair_f16(xv[2 * j], sv[2 * j], xv[2 * j + 1], sv[2 * j + 1], v1[t * 4 + j]);
                         amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(bq)));
                     }
+                    }
                     const uint4 b1 = make_uint4(v1[t * 4], v1[t * 4 + 1], v1[t * 4 + 2], v1[t * 4 + 3]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wv[t][i]), __builtin_bit_cast(f16x8, b1), acc[i][0], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) {
+                        if constexpr (MX_ABL & 256) { asm volatile("" :: "v"(wv[t][i].x), "v"(wv[t][i].y), "v"(wv[t][i].z), "v"(wv[t][i].w), "v"(b1.x), "v"(b1.y), "v"(b1.z), "v"(b1.w)); }
+                        else acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wv[t][i]), __builtin_bit_cast(f16x8, b1), acc[i][0], 0, 0, 0);
+                    }
                     if (t == 0) deferred_refill(row);
                 }
                 // block scales of this lane's 24 values: 2^(E - 2) for fp6(a1), 2^(E - 13) for fp6(a - a1)  (|a - a1| <= 2^(E - 11));  E >= 16 leaves f16
                 ex = (__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu;
                 ovf |= amax >= 65520.f;            // exactly the values f16 rounds to infinity (65520 is the tie between 65504 and 2^16)
                 }
-                if constexpr (!ENC) {
+                if constexpr (!ENC && (MX_ABL & 16)) { asm volatile("" :: "v"(v1[0]), "v"(v2[0]), "v"(ex)); }
+                if constexpr (!ENC && !(MX_ABL & 16)) {
                 const unsigned e1 = ex > 3u ? ex - 2u : 1u, e2 = ex > 14u ? ex - 13u : 1u;
                 // (positions 24..31 meet zero weights and every fp6 code is finite: registers 12..15 of the tuples are left undefined — no moves)
                 const u32x6 p1 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, v1), __builtin_bit_cast(float, e1 << 23));
@@ -584,9 +600,9 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
                 }
                 }
             }
-            if (row == 2 && more) store_x(cur ^ 1, chunk + 1);         // (its last readers passed the previous chunk's last barrier)
+            if (row == 2 && more && !(!ENC && (MX_ABL & 64))) store_x(cur ^ 1, chunk + 1);         // (its last readers passed the previous chunk's last barrier)
             // everything this wave issued so far has landed; then: every wave is done with this row's slot (and, after row 2, with the patch)
-            if constexpr (!(ENC && (MX_ABL & 4))) {
+            if constexpr (!(ENC && (MX_ABL & 4)) && !(!ENC && (MX_ABL & 32))) {
                 E4S_WAIT_VM(0);
                 E4S_LDS_BARRIER();
                 if constexpr (ARITH == 0 || ENC) { if (more) dma_row(chunk + 1, row); }
@@ -635,6 +651,7 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
         }
         return;
     }
+    if constexpr (MX_ABL & 1024) { if (acc[0][0][0] == 12345.f) p.out[tid] = acc[1][0][1] + acc[2][0][2] + acc[3][0][3]; return; }
     sb_epilogue<C, 4, 1, 8, RGB, OSP>(p, lds_raw, acc, cls, co0, b, y0, x0, pa, pb_, ho, wo, ub_skip);
 }
 

@@ -6,10 +6,10 @@
 set -e
 cd "$(dirname "$0")/.."
 python -m e4s2024_amd.build > /dev/null
-for a in "$@"; do
+build_one() { a=$1
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -Wno-unused-function -Wno-unused-variable -Wno-unused-but-set-variable -fvisibility=hidden -DMX_ABL=$a \
       -c e4s2024_amd/csrc/modconv_mx.hip -o /tmp/modconv_mx_abl$a.o
   objs=$(ls e4s2024_amd/build/*.o | grep -v modconv_mx.o)
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o e4s2024_amd/lib/libe4s_abl$a.so $objs /tmp/modconv_mx_abl$a.o
-  echo "built e4s2024_amd/lib/libe4s_abl$a.so"
-done
+  echo "built e4s2024_amd/lib/libe4s_abl$a.so"; }
+for a in "$@"; do build_one $a & if (( $(jobs -r | wc -l) >= 4 )); then wait -n; fi; done; wait
