@@ -41,17 +41,30 @@ static inline unsigned coprime_stride(unsigned n) {
 }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// wave64 sum via DPP-lowered shuffles
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// wave64 butterfly reductions: v[l] (op) v[l ^ 32], then ^ 16, ^ 8, ^ 4, ^ 2, ^ 1 — every lane ends with the result.  The partner values come over the VALU's own
+// lane-permute paths (v_permlane32_swap / v_permlane16_swap for the two row exchanges, DPP row_ror:8, row_half_mirror + quad_perm[3,2,1,0] = l ^ 4, quad_perm for ^ 2 and
+// ^ 1): the same operands in the same order as the __shfl_xor loop these replace — bit-identical sums — without its six ds_bpermute round trips through the LDS pipeline
+// per reduction (hipcc lowers every __shfl_xor to ds_bpermute_b32: 240 of them in the style-table kernel, which they bounded).
+template <int CTRL>
+__device__ __forceinline__ float e4s_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <class Op>
+__device__ __forceinline__ float wave_butterfly(float v, Op op) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto r32 = __builtin_amdgcn_permlane32_swap(u, u, false, false);      // [rows 0 1 0 1], [rows 2 3 2 3]
+    v = op(__builtin_bit_cast(float, (unsigned)r32[0]), __builtin_bit_cast(float, (unsigned)r32[1]));
+    const unsigned w = __builtin_bit_cast(unsigned, v);
+    auto r16 = __builtin_amdgcn_permlane16_swap(w, w, false, false);      // [rows 0 0 2 2], [rows 1 1 3 3]
+    v = op(__builtin_bit_cast(float, (unsigned)r16[0]), __builtin_bit_cast(float, (unsigned)r16[1]));
+    v = op(v, e4s_dpp<0x128>(v));                                          // row_ror:8           = l ^ 8
+    v = op(v, e4s_dpp<0x1B>(e4s_dpp<0x141>(v)));                           // row_half_mirror (l ^ 7), quad_perm [3,2,1,0] (^ 3) = l ^ 4
+    v = op(v, e4s_dpp<0x4E>(v));                                           // quad_perm [2,3,0,1] = l ^ 2
+    v = op(v, e4s_dpp<0xB1>(v));                                           // quad_perm [1,0,3,2] = l ^ 1
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return wave_butterfly(v, [](float a, float b) { return a + b; }); }
+__device__ __forceinline__ float wave_max(float v) { return wave_butterfly(v, [](float a, float b) { return fmaxf(a, b); }); }
 
 // PyTorch 'nearest' source index: floor(dst * scale) clamped (ATen nearest_neighbor_compute_source_index)
 __device__ __forceinline__ int nearest_src(int dst, float scale, int in_size) {

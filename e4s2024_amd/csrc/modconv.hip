@@ -256,9 +256,11 @@ __global__ __launch_bounds__(256) void style_batched_kernel(const JobTable t, in
     }
 }
 
+constexpr int DEMOD_MAX_CIN = 512;      // widest layer whose style rows a block keeps in LDS (wider ones read them as scalar loads, as before round 4)
 __global__ __launch_bounds__(256) void demod_batched_kernel(const JobTable t, int bs) {
     const E4sStyleJob& J = t.j[blockIdx.z];
     __shared__ float part[DEMOD_ROWS][4][64];
+    __shared__ __attribute__((aligned(16))) float srow[DEMOD_MAX_CIN][DEMOD_ROWS];     // the block's eight style rows, [ci][row]: one channel's eight values = two 16-byte reads
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int co = blockIdx.x * 64 + lane;
     const int nbr = bs * J.nreg;
@@ -266,20 +268,44 @@ __global__ __launch_bounds__(256) void demod_batched_kernel(const JobTable t, in
     if (!J.d || br0 >= nbr || blockIdx.x * 64 >= J.cout) return;   // block-uniform exits
     const int per = (J.cin + 3) / 4;
     const int c0 = wave * per, c1 = (c0 + per < J.cin) ? c0 + per : J.cin;
+    // The style rows used to come in as wave-uniform scalar loads inside the channel loop: 16 per step, and scalar loads return out of order, so every step waited for
+    // all of its own (64 dependent round trips for a 512-channel layer: 38-43 us for tables whose bytes take 5).  Staged in LDS once, the loop's only memory traffic is
+    // the coalesced wsq stream, several steps in flight.
+    const bool in_lds = J.cin <= DEMOD_MAX_CIN;
+    if (in_lds) {
+        for (int i = threadIdx.x; i < DEMOD_ROWS * J.cin; i += 256) {
+            const int q = i / J.cin, ci = i - q * J.cin;
+            srow[ci][q] = J.s[(size_t)(br0 + q < nbr ? br0 + q : nbr - 1) * J.cin + ci];
+        }
+        __syncthreads();
+    }
     // per row the two partial sums (even / odd input channels of this wave's quarter) of the one-row-per-block version, in its order
     float a0[DEMOD_ROWS], a1[DEMOD_ROWS];
 #pragma unroll
     for (int q = 0; q < DEMOD_ROWS; ++q) a0[q] = a1[q] = 0.f;
     if (co < J.cout) {
         int ci = c0;
-        for (; ci + 1 < c1; ci += 2) {
-            const float w0 = J.wsq[(size_t)ci * J.cout + co], w1 = J.wsq[(size_t)(ci + 1) * J.cout + co];
+        if (in_lds) {
+#pragma unroll 4
+            for (; ci + 1 < c1; ci += 2) {
+                const float w0 = J.wsq[(size_t)ci * J.cout + co], w1 = J.wsq[(size_t)(ci + 1) * J.cout + co];
 #pragma unroll
-            for (int q = 0; q < DEMOD_ROWS; ++q) {
-                const float* sv = J.s + (size_t)(br0 + q < nbr ? br0 + q : nbr - 1) * J.cin;     // wave-uniform: scalar loads
-                const float t0 = sv[ci], t1 = sv[ci + 1];
-                a0[q] += t0 * t0 * w0;
-                a1[q] += t1 * t1 * w1;
+                for (int q = 0; q < DEMOD_ROWS; ++q) {
+                    const float t0 = srow[ci][q], t1 = srow[ci + 1][q];
+                    a0[q] += t0 * t0 * w0;
+                    a1[q] += t1 * t1 * w1;
+                }
+            }
+        } else {
+            for (; ci + 1 < c1; ci += 2) {
+                const float w0 = J.wsq[(size_t)ci * J.cout + co], w1 = J.wsq[(size_t)(ci + 1) * J.cout + co];
+#pragma unroll
+                for (int q = 0; q < DEMOD_ROWS; ++q) {
+                    const float* sv = J.s + (size_t)(br0 + q < nbr ? br0 + q : nbr - 1) * J.cin;     // wave-uniform: scalar loads
+                    const float t0 = sv[ci], t1 = sv[ci + 1];
+                    a0[q] += t0 * t0 * w0;
+                    a1[q] += t1 * t1 * w1;
+                }
             }
         }
         if (ci < c1) {
@@ -747,20 +773,24 @@ __global__ __launch_bounds__(256) void region_torgb_kernel(float* __restrict__ o
 }
 
 // Masked ToRGB at low resolution (<= 128^2, Cin 256..512): few pixels and a long reduction, so the block is 64 pixels wide and
-// its 4 waves split the input-channel range; partial RGB sums meet in LDS.
-__global__ __launch_bounds__(256) void region_torgb_splitc_kernel(float* __restrict__ out, const float* __restrict__ x,
+// its NW waves split the input-channel range; partial RGB sums meet in LDS.  NW = 16 (round 4; 4 before): the launch is a chain of dependent round trips
+// (table staging, then cin / NW channels per wave, eight loads at a time) and there are never enough pixels to fill the chip — 14 us per launch at 4 waves,
+// eight launches per synthesis step.
+constexpr int TORGB_NW = 16;
+__global__ __launch_bounds__(64 * TORGB_NW) void region_torgb_splitc_kernel(float* __restrict__ out, const float* __restrict__ x,
                                                                   const float* __restrict__ wt, const float* __restrict__ s,
                                                                   const uint8_t* __restrict__ labels, int lh, int lw, float lsy, float lsx,
                                                                   const float* __restrict__ bias, const float* __restrict__ skip,
                                                                   const float* __restrict__ upk, int cin, int h, int w, int nreg) {
+    constexpr int NW = TORGB_NW, NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* st = sm;                     // [nreg][cin]
     float* wl = sm + nreg * cin;        // [cin][3]
     float* kf = wl + cin * 3;           // [16]
-    float* red = kf + 16;               // [4][3][64]
+    float* red = kf + 16;               // [NW][3][64]
     const int b = blockIdx.y;
-    for (int i = threadIdx.x; i < nreg * cin; i += 256) st[i] = s[(size_t)b * nreg * cin + i];
-    for (int i = threadIdx.x; i < cin * 3; i += 256) wl[i] = wt[i];
+    for (int i = threadIdx.x; i < nreg * cin; i += NT) st[i] = s[(size_t)b * nreg * cin + i];
+    for (int i = threadIdx.x; i < cin * 3; i += NT) wl[i] = wt[i];
     if (threadIdx.x < 16) kf[threadIdx.x] = upk ? upk[15 - threadIdx.x] : 0.f;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -771,8 +801,8 @@ __global__ __launch_bounds__(256) void region_torgb_splitc_kernel(float* __restr
     int c = 0;
     if (labels && ok) c = labels[((size_t)b * lh + nearest_src(y, lsy, lh)) * lw + nearest_src(xx, lsx, lw)];
     const int cls = c < nreg ? c : -1;
-    const int per = (cin + 3) / 4;
-    const int c0 = wave * per, c1 = (c0 + per < cin) ? c0 + per : cin;
+    const int per = (cin + NW - 1) / NW;
+    const int c0 = wave * per < cin ? wave * per : cin, c1 = (c0 + per < cin) ? c0 + per : cin;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     if (ok && cls >= 0) {
         const float* xb = x + (size_t)b * cin * hw + pix;
@@ -793,7 +823,11 @@ __global__ __launch_bounds__(256) void region_torgb_splitc_kernel(float* __restr
     const int hs = h >> 1, wsk = w >> 1;
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
-        float v = ((red[(0 * 3 + o) * 64 + lane] + red[(1 * 3 + o) * 64 + lane]) + (red[(2 * 3 + o) * 64 + lane] + red[(3 * 3 + o) * 64 + lane])) + bias[o];
+        float q4[4];                    // four groups of four consecutive channel slices, each ((a + b) + (c + d)), then the same over the groups
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            q4[g] = (red[((4 * g + 0) * 3 + o) * 64 + lane] + red[((4 * g + 1) * 3 + o) * 64 + lane]) + (red[((4 * g + 2) * 3 + o) * 64 + lane] + red[((4 * g + 3) * 3 + o) * 64 + lane]);
+        float v = ((q4[0] + q4[1]) + (q4[2] + q4[3])) + bias[o];
         if (skip) {
             const int iy0 = (y - 1) >> 1, ix0 = (xx - 1) >> 1;
             const int ky0 = 2 * iy0 + 2 - y, kx0 = 2 * ix0 + 2 - xx;
@@ -826,11 +860,11 @@ extern "C" int e4s_region_torgb(float* out, const float* x, const float* wt, con
     E4S_REQUIRE(!skip || (up_kernel && (h % 2) == 0), "region_torgb: skip needs the 4x4 upsample kernel and even size");
     E4S_REQUIRE(bs <= 65535, "region_torgb: batch too large");
     if (bs == 0) return 0;
-    const size_t shm = ((size_t)nreg * cin + cin * 3 + 16 + 4 * 3 * 64) * sizeof(float);
+    const size_t shm = ((size_t)nreg * cin + cin * 3 + 16 + TORGB_NW * 3 * 64) * sizeof(float);
     E4S_REQUIRE(shm <= 64 * 1024, "region_torgb: style table does not fit LDS (cin=%d nreg=%d)", cin, nreg);
     const float lsy = labels ? (float)lh / (float)h : 1.f, lsx = labels ? (float)lw / (float)w : 1.f;
     if ((w % 4) != 0 || (int64_t)h * w * bs < 262144) {  // small maps (or ragged widths): 64-pixel blocks, channels split over the waves
-        hipLaunchKernelGGL(region_torgb_splitc_kernel, dim3(cdiv(h * w, 64), bs), dim3(256), shm, (hipStream_t)stream, out, x, wt, s, labels, lh,
+        hipLaunchKernelGGL(region_torgb_splitc_kernel, dim3(cdiv(h * w, 64), bs), dim3(64 * TORGB_NW), shm, (hipStream_t)stream, out, x, wt, s, labels, lh,
                            lw, lsy, lsx, bias, skip, up_kernel, cin, h, w, nreg);
         return check_launch("region_torgb");
     }
