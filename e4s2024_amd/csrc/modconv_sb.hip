@@ -617,6 +617,9 @@ static int region_modconv3x3_sb_impl(float* out, const float* x, const uint16_t*
         if (cout > 32) return launch_sb<2, 2, 1, 4, 5>(p, st, ws, wf);   // 64 co x 256 px
         return launch_sb<1, 2, 1, 4, 5>(p, st, ws, wf);                  // 32 co x 256 px
     }
+    // masked 16 x 16 layers: 128 co x 256 px (the whole map) per workgroup — a weight byte is then read by 4 workgroups (the batch) instead of 8: the 16 -> 32 up layer
+    // streams 151 MB instead of 302 MB (batch 4, in-run: 114 -> 88 us; the same-resolution layer 46 -> 39 us)
+    if (w >= 16 && labels && cout >= 128) return launch_sb<4, 1, 1, 8, 4>(p, st, ws, wf);
     if (w >= 16) return launch_sb<1, 2, 2, 2, 4>(p, st, ws, wf);         // 64 co x 128 px (16 x 8)
     if (w >= 8) return launch_sb<1, 1, 2, 2, 3>(p, st, ws, wf);          // 64 co x  64 px (8 x 8)
     return launch_sb<1, 1, 2, 2, 2>(p, st, ws, wf);                      // 64 co x  64 px (4 x 16)
