@@ -310,9 +310,10 @@ def mask_to_labels(mask: torch.Tensor, strict: Optional[bool] = None) -> torch.T
     if ncls > MAX_REGIONS:
         raise ValueError(f"{ncls} regions > {MAX_REGIONS}")
     labels = torch.empty((bs, h, w), dtype=torch.uint8, device=m.device)
-    flag = torch.zeros(1, dtype=torch.int32, device=m.device)
+    check = STRICT_MASK if strict is None else strict
+    flag = torch.zeros(1, dtype=torch.int32, device=m.device) if check else None      # (unchecked: no flag word, no fill launch)
     lib().call("e4s_onehot_to_labels", _p(labels), _p(flag), _p(m), bs, ncls, h, w, _stream())
-    if STRICT_MASK if strict is None else strict:
+    if check:
         f = int(flag.item())
         if f:
             raise ValueError("mask is not one-hot (" + ("values other than 0/1; " if f & 1 else "") + ("several classes per pixel" if f & 2 else "") +
