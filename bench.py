@@ -350,6 +350,22 @@ def main():
             now = sum(v[1] for k, v in ksum.items() if pred(k)) / args.steps
             in_run_ab[gname] = {"ms_prev": round(prev, 4), "ms_now": round(now, 4), "ratio": round(now / prev, 4) if prev > 0 else None}
         in_run_ab["all_launches"] = {"ms_prev": round(sum(v[1] for v in base.values()) / args.steps, 4), "ms_now": round(sum(v[1] for v in ksum.values()) / args.steps, 4)}
+        # ... and the masked up layers with / without the four-parity kernel of round 4 (csrc/modconv_mx4.hip; everything else on the default routes)
+        if ops.UP_MX4 and dom0:
+            try:
+                ops.UP_MX4 = False
+                step()
+                torch.cuda.synchronize()
+                with ops.KernelTimer() as k4:
+                    for _ in range(args.steps):
+                        step()
+                    torch.cuda.synchronize()
+            finally:
+                ops.UP_MX4 = True
+            prev4, now4 = k4.by_detail(dom0), kt_for_layers.by_detail(dom0)
+            in_run_ab["masked_up_layers_four_parity_kernel"] = {
+                d: {"ms_composed_kernel_alone": round(prev4[d][1] / prev4[d][0], 4), "ms_now": round(now4[d][1] / now4[d][0], 4)}
+                for d in sorted(now4) if d.endswith(" up") and d in prev4 and now4[d][0] and prev4[d][0]}
     # how much of `value` depends on the region maps: the same batch under portrait-shaped maps (ellipses: hair, skin, eyes, ...: what the face
     # parser produces on photographs), under 4 x 4 cells (every 16 x 16 block of the masked up layers lies under one region) and under i.i.d.
     # per-pixel labels (none does); single-GPU runs only, 10 steps each, outside the timed region

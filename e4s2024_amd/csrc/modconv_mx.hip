@@ -262,6 +262,13 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
         if (ub_skip == 0xfu) return;
     }
 
+    if constexpr (!ENC) {
+        if (p.up && p.quad_skip) {      // (workgroup-uniform) tiles whose positions' four outputs share one region belong to modconv_mx4.hip
+            int c_unused;
+            if (quad_uniform_tile(p, b, y0, x0, wave, l5, c_unused, reinterpret_cast<volatile int*>(lds_raw + L::BYTES))) return;     // (the word behind the LDS plan: launch_mx_variant asks for 16 more bytes)
+        }
+    }
+
     // (a thread's patch pixel: threads 0..339, see store_x) its region / patch position as an output pixel (lane l5 of tile row `wave`)
     const float* xb = p.x + (size_t)b * p.cin * hw;
     const float* sb = p.s + (size_t)b * p.nreg * p.cin;
@@ -657,7 +664,7 @@ __global__ __launch_bounds__(512, 2) void region_modconv_mx_kernel(const SbParam
 
 template <int ARITH, bool RGB, bool OSP, bool ENC = false>
 int launch_mx_variant(const SbParams& p, dim3 grid, hipStream_t st) {
-    constexpr int lds = MxLds<ARITH>::BYTES + (ENC ? MX_NORM_BYTES : 0);
+    constexpr int lds = MxLds<ARITH>::BYTES + (ENC ? MX_NORM_BYTES : 16);
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&region_modconv_mx_kernel<ARITH, RGB, OSP, ENC>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr != hipSuccess) return fail((int)attr, "region_modconv3x3_mx: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
@@ -727,7 +734,7 @@ int e4s::launch_modconv_mx(SbParams& p, int arith, hipStream_t st, float* worksp
         if (p.cout > MX_TN || p.up) return fail(E4S_ERR_ARG, "region_modconv3x3_mx: fused ToRGB needs all %d output channels in one workgroup tile", p.cout);
         ksplit = 1;
     }
-    if (p.uni_blocks) ksplit = 1;
+    if (p.uni_blocks || p.quad_skip) ksplit = 1;       // (the tiles another kernel computes are decided per workgroup: no second pass over the output)
     p.ksplit = ksplit;
     p.chunks_per = cdiv(nchunk, ksplit);
     p.partial = workspace;

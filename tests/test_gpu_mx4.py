@@ -1,0 +1,117 @@
+"""GPU parity of the four-parity masked up kernel (csrc/modconv_mx4.hip, round 4): the reference's up-sampling StyledConv (models/stylegan2/model.py:287-300 per
+region, mixed per output pixel :385-400).  The tiles whose positions' 2 x 2 outputs share a region run on it, the composed kernel (csrc/modconv_mx.hip) computes the
+others into the same tensor: the result must equal the composed kernel alone BIT FOR BIT (same products, same order) — on maps where every tile qualifies, where some
+do, where none does, with region-less pixels, ragged sizes and an output-channel tail — and meet the layer bar against the faithful CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import install_dropin, record_parity
+from e4s2024_amd import ops
+from oracle import e4s_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+MX_LAYER_TOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def sg2():
+    install_dropin()
+    from models.stylegan2 import model
+    return model
+
+
+def _labels(kind, rs, bs, nreg, lh, lw, ho, wo):
+    """Region maps at the label resolution; what matters is the map sampled 'nearest' at the output resolution (ho, wo)."""
+    if kind == "iid":                                   # no position has four equal outputs (almost surely): every tile stays with the composed kernel
+        return rs.randint(0, nreg, (bs, lh, lw)).astype(np.uint8)
+    cell = {"cells8": 8, "cells2": 2, "mixed": 8}[kind] * (lh // ho)          # cells of 8 / 2 OUTPUT pixels, aligned to even output coordinates
+    gy, gx = -(-lh // cell), -(-lw // cell)
+    lab = np.repeat(np.repeat(rs.randint(0, nreg, (bs, gy, gx)), cell, 1), cell, 2)[:, :lh, :lw].astype(np.uint8)
+    if kind == "mixed":                                 # the right half: borders on ODD output columns -> those tiles do not qualify; plus a region-less block
+        sh = lh // ho
+        lab[:, :, lw // 2:] = np.roll(lab, sh, axis=2)[:, :, lw // 2:]
+        lab[:, : lh // 4, : lw // 4] = 255
+    return lab
+
+
+#         bs cin cout  h   w  nreg lh   lw
+SHAPES = [(2, 64, 128, 16, 64, 12, 128, 512),      # two tile rows, labels at 4x the output resolution
+          (1, 48, 136, 20, 40, 5, 40, 80),         # ragged: partial tiles, an output-channel tail (136 = 2 x 64 + 8)
+          (4, 512, 256, 64, 64, 12, 512, 512)]     # the generator's 64 -> 128 layer at the benchmark's batch
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("kind", ["cells8", "cells2", "mixed", "iid"])
+def test_four_parity_kernel_plus_composed_kernel_equal_the_composed_kernel_alone(sg2, shape, kind):
+    bs, cin, cout, h, w, nreg, lh, lw = shape
+    rs = np.random.RandomState(17 * cin + h + len(kind))
+    lab = _labels(kind, rs, bs, nreg, lh, lw, 2 * h, 2 * w)
+    g = torch.Generator(device=DEV).manual_seed(cin + h)
+    x = torch.randn(bs, cin, h, w, device=DEV, generator=g)
+    wgt = torch.randn(1, cout, cin, 3, 3, device=DEV, generator=g)
+    s = 1.0 + 0.3 * torch.randn(bs, nreg, cin, device=DEV, generator=g)
+    d = torch.rand(bs, nreg, cout, device=DEV, generator=g) + 0.5
+    nz = torch.randn(bs, 1, 2 * h, 2 * w, device=DEV, generator=g)
+    nw, ab = torch.tensor([0.17], device=DEV), 0.1 * torch.randn(cout, device=DEV, generator=g)
+    blur = torch.tensor([1., 3., 3., 1.], device=DEV)
+    blur = blur[:, None] * blur[None, :]
+    blur = blur / blur.sum() * 4
+    labels = T(lab).to(DEV)
+    wt, _ = ops.PreparedWeights().get(wgt, blur, True, True)
+    wmx = ops.PreparedMx().get(wgt, blur, True, 1)
+    wmx4 = ops.PreparedMx().get(wgt, blur, True, 4)
+    ops.mx_overflowed()
+    keep = ops.SPLITK_MAX_OUT_FLOATS
+    try:
+        ops.SPLITK_MAX_OUT_FLOATS = 0                    # (no split-K for the small test layers: its partial sums are added in another order)
+        composed = ops.region_modconv3x3(x, wt, s, d, labels, nz, nw, ab, True, cout, True, mx=(wmx, 1))
+        poison = torch.full_like(composed, float("nan"))     # the next allocation of this size: every output pixel must be written by one of the two launches
+        torch.cuda.synchronize()
+        del poison
+        out = ops.region_modconv3x3(x, wt, s, d, labels, nz, nw, ab, True, cout, True, mx=(wmx, 1), mx4=wmx4)
+    finally:
+        ops.SPLITK_MAX_OUT_FLOATS = keep
+    assert torch.isfinite(out).all()
+    assert torch.equal(out, composed), (shape, kind, float((out - composed).abs().max()))
+    assert not ops.mx_overflowed()
+
+
+@pytest.mark.parametrize("shape", [SHAPES[0], SHAPES[1]])
+def test_four_parity_kernel_against_the_oracle(sg2, shape):
+    """``StyledConv(upsample=True, mask_op=True)`` through the module (model.py routes the layer itself) on a map made of 8-pixel cells: every tile on the new kernel."""
+    bs, cin, cout, h, w, nreg, lh, lw = shape
+    rs = np.random.RandomState(5 * cin + w)
+    lab = _labels("cells8", rs, bs, nreg, lh, lw, 2 * h, 2 * w)
+    onehot = torch.zeros(bs, nreg, lh, lw)
+    for c in range(nreg):
+        onehot[:, c] = T((lab == c).astype(np.float32))
+    m = sg2.StyledConv(cin, cout, 3, 512, upsample=True, mask_op=True)
+    with torch.no_grad():
+        m.conv.weight.copy_(T(rs.standard_normal(m.conv.weight.shape).astype(np.float32)))
+        m.conv.modulation.weight.copy_(T(rs.standard_normal(m.conv.modulation.weight.shape).astype(np.float32)))
+        m.noise.weight.fill_(0.21)
+        m.activate.bias.copy_(T(0.1 * rs.standard_normal(cout).astype(np.float32)))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = T(rs.standard_normal((bs, cin, h, w)).astype(np.float32))
+    st = T(rs.standard_normal((bs, nreg, 512)).astype(np.float32))
+    nz = T(rs.standard_normal((bs, 1, 2 * h, 2 * w)).astype(np.float32))
+    m = m.to(DEV)
+    keep = (ops.UP_MX4, ops.mx4_eligible)
+    try:
+        ops.mx4_eligible = lambda *a: ops.UP_MX4          # (the module asks this; small test layers would not fill the chip)
+        with torch.no_grad():
+            ops.UP_MX4 = True
+            y4 = m(x.to(DEV), st.to(DEV), T(lab).to(DEV), noise=nz.to(DEV)).cpu()
+            ops.UP_MX4 = False
+            y1 = m(x.to(DEV), st.to(DEV), T(lab).to(DEV), noise=nz.to(DEV)).cpu()
+    finally:
+        ops.UP_MX4, ops.mx4_eligible = keep
+    assert float((y4 - y1).abs().max()) <= 2e-5 * max(1.0, float(y1.abs().max()))      # (the composed kernel splits K on a layer this small: another summation order)
+    ref = O.styled_conv(sd, "", x, st, onehot, nz, masked=True, upsample=True)
+    scale = max(1.0, float(ref.abs().max()))
+    e = float((y4 - ref).abs().max()) / scale
+    record_parity(f"mx4_layer_up_{cin}to{cout}_{h}x{w}", e, MX_LAYER_TOL, note=f"four-parity up kernel against the oracle, relative to the output scale {scale:.1f}")
+    assert e <= MX_LAYER_TOL
