@@ -6,30 +6,16 @@
 // and feeds it to 4 parities x 64 output channels (8 accumulator blocks per wave instead of 4): a quarter of the per-tap VALU work, of the activation reads and of
 // the two 32-value fp6 conversions per kernel row, and half the barriers per MFMA (the loop's time is the SUM of those parts and its MFMAs — DESIGN.md section 8,
 // "what the masked f16 + fp6 loop's time is made of").  The tile's outputs leave as 8-byte stores of (pb = 0, pb = 1) pairs.
-// A workgroup whose tile has a position with mixed regions exits at once — e4s_region_modconv3x3_mx (flag E4S_SKIP_QUAD_TILES) computes exactly those tiles, and skips
-// the others; both kernels evaluate the same predicate (quad_uniform_tile, modconv_sb.h).  Same products in the same order as that kernel: bit-identical outputs.
-// f16 + 2 x MX-fp6 arithmetic only (the split-bf16 re-run of an overflowed pass uses the composed kernel for every tile).
+// A tile with a position of mixed regions is computed, in the same launch, as the composed kernel computes it (its tile is a device function, modconv_mx_tile.h): every
+// workgroup decides for its tile (quad_uniform_tile, modconv_sb.h) and takes one of the two roles — see the kernel at the end of the file.  Same products in the same
+// order either way: the layer's output is bit-identical to e4s_region_modconv3x3_mx's on every map, and a map without a single qualifying tile costs what it cost before.
+// f16 + 2 x MX-fp6 arithmetic only (the split-bf16 re-run of an overflowed pass uses the composed kernel).
 // Weights (e4s_modconv_prep_weights_mx4): one ROW SLOT per (chunk, 64-co tile, kernel row) = the four parities' [w1 f16 [tap 3][half 2][co 64] x 16 B |
 // fp6 codes first 16 B [term 2][half 2][co 64] | last 8 B [term][half][co] | E8M0 scales [half 2][co 64] x 4 B, padded to 1 KB] = 4 x 13 312 B, DMA'd as 52 pieces of
 // 1 KB into a ring of TWO slots (the request for row g + 1 goes out behind row g's first MFMAs, into the slot row g - 1 left at the last barrier).
-#include <stdlib.h>
-
-#include "common.h"
-#include "sb_common.h"
-#include "modconv_sb.h"
-
-using namespace e4s;
+#include "modconv_mx_tile.h"
 
 namespace {
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
-typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
-typedef int i32x8 __attribute__((ext_vector_type(8)));
-typedef int i32x4v __attribute__((ext_vector_type(4)));
-typedef int i32x2v __attribute__((ext_vector_type(2)));
 
 constexpr int Q_TN = 64;                                       // output channels per workgroup
 constexpr int Q_W1B = 3 * 2 * Q_TN * 16;                       // 6 144
@@ -39,7 +25,7 @@ constexpr int Q_SCB = 1024;                                    // 2 * 64 * 4 = 5
 constexpr int Q_PARB = Q_W1B + Q_F6LO + Q_F6HI + Q_SCB;        // 13 312 per parity
 constexpr int Q_ROWB = 4 * Q_PARB;                             // 53 248
 constexpr int Q_NPIECE = Q_ROWB / 1024;                        // 52
-using C = SbCfg<2, 1, 1, 8, 5>;                                // 64 co x (32 x 8) positions, 512 threads; wave w = tile row w
+using CQ = SbCfg<2, 1, 1, 8, 5>;                               // 64 co x (32 x 8) positions, 512 threads; wave w = tile row w
 constexpr int Q_PSTRIDE = 352;
 constexpr int Q_PATCHB = 4 * Q_PSTRIDE * 16;                   // 22 528: fp32 [16-B slot 4][pixel 352], as modconv_mx.hip
 constexpr int Q_SSB = E4S_MAX_REGIONS * CKS * 4;               // 1 024
@@ -49,27 +35,6 @@ static_assert(Q_LDS + 16 <= 160 * 1024 && (E4S_MAX_REGIONS + 1) * Q_TN * 4 <= Q_
 // "nothing moves across": the scheduling fence alone does not keep instruction selection from hoisting later LDS reads (a row's 16 fp6 operand tuples at once: 100
 // registers, accumulators spilled); the empty asm with a memory clobber does
 #define Q_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-
-__device__ __forceinline__ unsigned pack_f16_rne(float a, float b) {
-    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, f16x2));
-}
-__device__ __forceinline__ unsigned resid_pair_f16(float xa, float sa, float xb, float sb, unsigned a1) {       // (modconv_mx.hip)
-    unsigned r;
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(xa), "v"(sa), "v"(a1));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(r) : "v"(xb), "v"(sb), "v"(a1));
-    return r;
-}
-__device__ __forceinline__ i32x8 mx_op6(u32x6 c) {
-    typedef unsigned u32x8v __attribute__((ext_vector_type(8)));
-    const u32x8v w = __builtin_shufflevector(c, c, 0, 1, 2, 3, 4, 5, -1, -1);
-    return __builtin_bit_cast(i32x8, w);
-}
-__device__ __forceinline__ i32x8 mx_op6(uint4 lo, uint2 hi) {
-    const i32x4v a = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w};
-    const i32x2v b2 = {(int)hi.x, (int)hi.y};
-    const i32x4v b = __builtin_shufflevector(b2, b2, 0, 1, -1, -1);
-    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, -1, -1);
-}
 
 // ============================================================================ weight preparation
 // One thread per (chunk, co tile, row, par, half, co): the lane's 24 values of that kernel row — value for value e4s_modconv_prep_weights_mx's f16 + fp6 form.
@@ -133,41 +98,22 @@ __global__ __launch_bounds__(256) void prep_weights_mx4_kernel(unsigned char* __
     }
 }
 
-// ============================================================================ the kernel
-__global__ __launch_bounds__(512, 2) void region_upconv_mx4_kernel(const SbParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+// ============================================================================ the four-parity tile
+// One workgroup tile: the four parities x 64 output channels (64 cotile .. + 63) of the 32 x 8 positions of `tile`, image b; `c_own` = the raw label of this lane's position
+// (quad_uniform_tile: all four of its outputs carry it).
+__device__ __forceinline__ void q_tile_body(const SbParams& p, unsigned char* lds_raw, const int tile, const int cotile, const int b, const int c_own) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l5 = lane & 31, khalf = lane >> 5;
-
-    // XCD affinity as in modconv_mx.hip: an XCD's workgroups share ONE co tile's weights (5.1 MB for 512 input channels: more than its L2, but its 32 workgroups start
-    // together and stream the same rows at the same time)
-    unsigned bx_g = blockIdx.x, cot_g = blockIdx.y, b_g = blockIdx.z;
-    if (p.xcd_remap) {
-        const unsigned nx = gridDim.x, ncg = gridDim.y;
-        const unsigned lin = blockIdx.x + nx * (blockIdx.y + ncg * blockIdx.z);
-        const unsigned per = 8u / ncg;
-        const unsigned xcd = lin & 7u, q = lin >> 3;
-        cot_g = xcd / per;
-        const unsigned r = q * per + (xcd % per);
-        bx_g = r % nx;
-        b_g = r / nx;
-    }
-    const int tile = (int)bx_g;
-    const int y0 = (tile / p.tiles_x) * C::TH, x0 = (tile % p.tiles_x) * C::TW;
-    const int cotile = (int)cot_g;
+    const int y0 = (tile / p.tiles_x) * CQ::TH, x0 = (tile % p.tiles_x) * CQ::TW;
     const int co0 = cotile * Q_TN;
-    const int b = (int)b_g;
     const int hw = p.h * p.w;
     const int ho = 2 * p.h, wo = 2 * p.w;
     const int nchunk = (p.cin + CKS - 1) / CKS;
     const int ncot = (p.cout + Q_TN - 1) / Q_TN;
-
-    int c_own;
-    if (!quad_uniform_tile(p, b, y0, x0, wave, l5, c_own, reinterpret_cast<volatile int*>(lds_raw + Q_LDS))) return;           // (workgroup-uniform: the composed kernel computes this tile)
     const int cls = c_own < p.nreg ? c_own : -1;
-    const int xoff = wave * C::PW + l5;
+    const int xoff = wave * CQ::PW + l5;
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -183,15 +129,15 @@ __global__ __launch_bounds__(512, 2) void region_upconv_mx4_kernel(const SbParam
     // and written to the other patch buffer at the start of row 1, half 1 requested there and written at the start of row 2 (every row ends with vmcnt(0)).
     float xr[8];
     float sr = 0.f;
-    const int ppy = tid / C::PW, ppx = tid - ppy * C::PW;
+    const int ppy = tid / CQ::PW, ppx = tid - ppy * CQ::PW;
     const int pgy = y0 - 1 + ppy, pgx = x0 - 1 + ppx;
-    const bool p_in = tid < C::PATCH && pgy >= 0 && pgy < p.h && pgx >= 0 && pgx < p.w;
+    const bool p_in = tid < CQ::PATCH && pgy >= 0 && pgy < p.h && pgx >= 0 && pgx < p.w;
     const int goffs = p_in ? pgy * p.w + pgx : 0;
     const int s_r = tid / CKS < p.nreg ? tid / CKS : p.nreg - 1, s_c = tid % CKS;
     auto load_x = [&](int chunk, int hf) __attribute__((always_inline)) {       // (unconditional loads from clamped addresses: see modconv_mx.hip)
         const int ci0 = chunk * CKS;
         const int cmax = p.cin - 1 - ci0;
-        if (wave < (C::PATCH + 63) / 64) {
+        if (wave < (CQ::PATCH + 63) / 64) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) xr[c] = xb[(size_t)(ci0 + (8 * hf + c < cmax ? 8 * hf + c : cmax)) * hw + goffs];
         }
@@ -199,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void region_upconv_mx4_kernel(const SbParam
     };
     auto store_x = [&](int buf, int chunk, int hf) __attribute__((always_inline)) {
         float4* xf4 = reinterpret_cast<float4*>(lds_raw + Q_PATCH0 + buf * Q_PATCHB);
-        if (tid < C::PATCH) {
+        if (tid < CQ::PATCH) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) xr[c] = p_in ? xr[c] : 0.f;
 #pragma unroll
@@ -251,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void region_upconv_mx4_kernel(const SbParam
             // (B) the 24 f16 MFMAs, weight fragments four at a time; (C) the two conversions and the 16 fp6 MFMAs, operands read right in front of each.
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
-                const int e = xoff + row * C::PW + t;
+                const int e = xoff + row * CQ::PW + t;
                 const float4 xa = xf4[(2 * khalf) * Q_PSTRIDE + e], xq = xf4[(2 * khalf + 1) * Q_PSTRIDE + e];
                 const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xq.x, xq.y, xq.z, xq.w};
 #pragma unroll
@@ -370,6 +316,44 @@ __global__ __launch_bounds__(512, 2) void region_upconv_mx4_kernel(const SbParam
         }
 }
 
+// ============================================================================ the kernel
+// gridDim.x = 2 * PA workgroups, PA = (tiles x images) x G with G = cout / 64 (cout % 128 == 0).  Workgroup lin belongs to phase lin / PA and, inside the phase, to
+// (item, c) — item = a tile of an image, c = 0 .. G - 1.  Where the item's positions all have four outputs of one region, phase-0 workgroup (item, c) computes its four
+// parities for output channels 64 c .. + 63 and the phase-1 workgroup exits; otherwise each of the two runs one tile of the composed kernel (modconv_mx_tile.h): output
+// channels 128 (c / 2) .. + 127 at parity 2 phase + (c & 1) — the eight (parity, 128-channel) tiles of the item between them.  A map of aligned cells is then ONE round of
+// working workgroups followed by workgroups that leave after reading four labels; a map with no such tile is the composed kernel's launch, workgroup for workgroup.
+// XCD affinity (workgroup lin runs on XCD lin % 8, each with its own L2): for G in {1, 2, 4, 8} the 8 / G XCDs of a group share c — one 64-channel weight set in the
+// four-parity role, (a half of) one 128-channel set in the composed role — as modconv_mx.hip's launcher arranges it for its own grid.
+__global__ __launch_bounds__(512, 2) void region_upconv_mx4_kernel(const SbParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const unsigned PA = gridDim.x >> 1;
+    const unsigned phase = blockIdx.x >= PA ? 1u : 0u;
+    const unsigned l = blockIdx.x - phase * PA;
+    const unsigned G = (unsigned)(p.cout / Q_TN);
+    unsigned c, item;
+    if ((G == 1u || G == 2u || G == 4u || G == 8u) && (PA & 7u) == 0u) {
+        const unsigned per = 8u / G, xcd = l & 7u, q = l >> 3;
+        c = xcd / per;
+        item = q * per + xcd % per;
+    } else {
+        c = l % G;
+        item = l / G;
+    }
+    const int ntile = p.tiles_x * p.tiles_y;
+    const int tile = (int)(item % (unsigned)ntile), b = (int)(item / (unsigned)ntile);
+    const int y0 = (tile / p.tiles_x) * CQ::TH, x0 = (tile % p.tiles_x) * CQ::TW;
+    int c_own;
+    const bool uni = quad_uniform_tile(p, b, y0, x0, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 31), c_own, reinterpret_cast<volatile int*>(lds_raw + Q_LDS));
+    if (uni) {
+        if (phase) return;
+        q_tile_body(p, lds_raw, tile, (int)c, b, c_own);
+    } else {
+        SbParams pc = p;                                    // (the composed kernel's weights travel in the unused split-bf16 slab pointer)
+        pc.wmx = reinterpret_cast<const unsigned char*>(p.whi);
+        mx_tile_body<1, false, false, false>(pc, lds_raw, tile, (int)(2u * phase + (c & 1u)), 0, (int)(c >> 1), b);
+    }
+}
+
 }  // namespace
 
 extern "C" int e4s_modconv_mx4_weight_bytes(int cout, int cin, int64_t* bytes) {
@@ -388,31 +372,35 @@ extern "C" int e4s_modconv_prep_weights_mx4(void* dst, const float* weight, cons
     return check_launch("modconv_prep_weights_mx4");
 }
 
-extern "C" int e4s_region_upconv_mx4(float* out, const float* x, const void* wmx4, int* flags, const float* s, const float* d, const uint8_t* labels, int lh, int lw,
-                                     const float* noise, int noise_bs, const float* noise_weight, const float* act_bias, int act, int bs, int cin, int cout, int h,
-                                     int w, int nreg, void* stream) {
-    E4S_REQUIRE(out && x && wmx4 && s && labels, "region_upconv_mx4: null tensor");
-    E4S_REQUIRE(bs >= 0 && bs <= 65535 && cin >= CKS && cin % CKS == 0 && cout >= 1 && h >= 1 && w >= 32, "region_upconv_mx4: bad size (cin %% 16 == 0, width >= 32)");
+extern "C" int e4s_region_upconv_mx4(float* out, const float* x, const void* wmx4, const void* wmx, int* flags, const float* s, const float* d, const uint8_t* labels,
+                                     int lh, int lw, const float* noise, int noise_bs, const float* noise_weight, const float* act_bias, int act, int bs, int cin,
+                                     int cout, int h, int w, int nreg, void* stream) {
+    E4S_REQUIRE(out && x && wmx4 && wmx && s && labels, "region_upconv_mx4: null tensor");
+    E4S_REQUIRE(bs >= 0 && bs <= 65535 && cin >= CKS && cin % CKS == 0 && cout >= 128 && cout % 128 == 0 && h >= 1 && w >= 32,
+                "region_upconv_mx4: bad size (cin %% 16 == 0, cout %% 128 == 0, width >= 32)");
     E4S_REQUIRE(nreg >= 1 && nreg <= E4S_MAX_REGIONS && lh >= 1 && lw >= 1, "region_upconv_mx4: bad region map");
     E4S_REQUIRE(!noise || (noise_weight && (noise_bs == 1 || noise_bs == bs)), "region_upconv_mx4: noise needs its weight and batch 1 or bs");
-    E4S_REQUIRE((((uintptr_t)wmx4 | (uintptr_t)out) & 15) == 0 && (!noise || ((uintptr_t)noise & 7) == 0), "region_upconv_mx4: weights / output must be 16-byte aligned, noise 8-byte");
+    E4S_REQUIRE((((uintptr_t)wmx4 | (uintptr_t)wmx | (uintptr_t)out) & 15) == 0 && (!noise || ((uintptr_t)noise & 7) == 0),
+                "region_upconv_mx4: weights / output must be 16-byte aligned, noise 8-byte");
     if (bs == 0) return 0;
     SbParams p;
     memset(&p, 0, sizeof(p));
-    p.out = out; p.x = x; p.wmx = reinterpret_cast<const unsigned char*>(wmx4); p.flags = flags; p.s = s; p.d = d;
+    p.out = out; p.x = x; p.wmx = reinterpret_cast<const unsigned char*>(wmx4); p.whi = reinterpret_cast<const uint4*>(wmx); p.flags = flags; p.s = s; p.d = d;
     p.labels = labels; p.lh = lh; p.lw = lw; p.noise = noise; p.noise_weight = noise_weight; p.act_bias = act_bias; p.act = act;
     p.bs = bs; p.cin = cin; p.cout = cout; p.h = h; p.w = w; p.nreg = nreg; p.up = 1;
     p.lscale_y = (float)lh / (float)(2 * h);
     p.lscale_x = (float)lw / (float)(2 * w);
     p.noise_bstride = (noise && noise_bs > 1) ? 4 * h * w : 0;
-    p.tiles_x = cdiv(w, C::TW);
-    p.tiles_y = cdiv(h, C::TH);
+    p.tiles_x = cdiv(w, CQ::TW);
+    p.tiles_y = cdiv(h, CQ::TH);
     p.ksplit = 1;
-    dim3 grid(p.tiles_x * p.tiles_y, cdiv(cout, Q_TN), bs);
-    const unsigned long long tot = (unsigned long long)grid.x * grid.y * grid.z;
-    p.xcd_remap = ((grid.y == 2 || grid.y == 4 || grid.y == 8) && tot % 8 == 0) ? 1 : 0;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&region_upconv_mx4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS + 16);
+    p.chunks_per = cdiv(cin, CKS);
+    const int64_t pa = (int64_t)p.tiles_x * p.tiles_y * bs * (cout / Q_TN);
+    E4S_REQUIRE(2 * pa <= 0x7fffffff, "region_upconv_mx4: launch too large");
+    constexpr int lds = Q_LDS + 16;                        // (+ the tile predicate's word; the composed tile's plan is smaller)
+    static_assert(MxLds<1>::BYTES <= Q_LDS, "the composed tile runs inside this kernel's LDS allocation");
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&region_upconv_mx4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr != hipSuccess) return fail((int)attr, "region_upconv_mx4: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
-    hipLaunchKernelGGL(region_upconv_mx4_kernel, grid, dim3(512), Q_LDS + 16, (hipStream_t)stream, p);      // (+ the tile predicate's word)
+    hipLaunchKernelGGL(region_upconv_mx4_kernel, dim3((unsigned)(2 * pa)), dim3(512), lds, (hipStream_t)stream, p);
     return check_launch("region_upconv_mx4");
 }

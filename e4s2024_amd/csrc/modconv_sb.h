@@ -47,7 +47,6 @@ struct SbParams {
     const float* slope;        // (plain-convolution mode) PReLU slopes [cout] or NULL
     int xcd_remap;             // (modconv_mx.hip) 1: workgroups are re-indexed so that each XCD (own L2) works on one co tile's weights
     int* flags;                // (modconv_mx.hip, f16 arithmetic) flags[0] |= 1 when a modulated activation leaves the f16 range
-    int quad_skip;             // (modconv_mx.hip, up layers) 1: tiles whose positions' four outputs share one region are left to modconv_mx4.hip (E4S_SKIP_QUAD_TILES)
     unsigned perm_mul;       // (with uni_blocks) workgroup i works on tile slot (i * perm_mul) % gridDim.x: consecutive workgroups go to the 8 XCDs
                              // round-robin, so a skip pattern with a period of 2 / 4 / 8 tiles would idle whole XCDs; a golden-ratio stride
                              // coprime with the grid spreads any spatially coherent skip set evenly
@@ -104,7 +103,7 @@ __device__ __forceinline__ float sb_weff(const float* __restrict__ weight, const
 
 // (masked up layers) Do the four outputs (2y + pa, 2x + pb) of EVERY position of the 32 x 8 tile at (y0, x0) carry one region?  Workgroup-uniform (one barrier); every
 // thread passes its position (tile row ty = its wave, column tx = lane & 31: the half-waves hold the same positions); `c_own` = the raw label of the position's outputs
-// (E4S_LABEL_NONE outside the map).  modconv_mx4.hip computes the tiles for which this holds, modconv_mx.hip (quad_skip) the others: both call this function.
+// (E4S_LABEL_NONE outside the map).  modconv_mx4.hip runs its four-parity tile where this holds and the composed kernel's tile (modconv_mx_tile.h) where it does not.
 // `flagw` = one LDS word of the caller's own dynamic allocation that nothing else uses.  (NOT __syncthreads_and: the device library's workgroup reduction brings 256 bytes
 // of STATIC LDS with it, the dynamic region then starts at 256, and these kernels hand absolute LDS addresses to their LDS-DMA.)
 __device__ __forceinline__ bool quad_uniform_tile(const SbParams& p, int b, int y0, int x0, int ty, int tx, int& c_own, volatile int* flagw) {

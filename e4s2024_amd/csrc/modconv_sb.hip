@@ -549,9 +549,7 @@ static int region_modconv3x3_sb_impl(float* out, const float* x, const uint16_t*
                                      const float* rgb_bias, const float* rgb_skip, const float* rgb_up_kernel, const float* s_next,
                                      const uint8_t* uniform_blocks, const int* uniform_ctrl, const void* wmx, int arith, int* flags, void* stream) {
     const int layout = up & (E4S_X_NHWC | E4S_OUT_NHWC | E4S_OUT_SP);
-    const int quad_skip = (up & E4S_SKIP_QUAD_TILES) ? 1 : 0;
     up &= 1;
-    E4S_REQUIRE(!quad_skip || (wmx && up && labels && arith == 1 && !uniform_blocks), "region_modconv3x3_mx: E4S_SKIP_QUAD_TILES goes with a masked up layer in the f16 + fp6 arithmetic (no uniform-block map)");
     E4S_REQUIRE(!(layout & E4S_OUT_SP) || (s_next && rgb_out && out && cout % 8 == 0 && !(layout & E4S_OUT_NHWC) && ((uintptr_t)out & 15) == 0),
                 "region_modconv3x3_sb: split-plane output needs s_next, the fused ToRGB, cout %% 8 == 0 and a 16-byte aligned tensor");
     E4S_REQUIRE((out || rgb_out) && x && ((whi && wlo) || wmx) && s, "region_modconv3x3_sb: null tensor");
@@ -586,7 +584,6 @@ static int region_modconv3x3_sb_impl(float* out, const float* x, const uint16_t*
     E4S_REQUIRE(!uniform_blocks || uniform_ctrl, "region_modconv3x3_sb: the uniform-block map comes with its control words (e4s_uniform_blocks)");
     p.uni_blocks = uniform_blocks;
     p.uni_ctrl = uniform_ctrl;
-    p.quad_skip = quad_skip;
     p.perm_mul = 0;
     p.wmx = reinterpret_cast<const unsigned char*>(wmx);
     p.flags = flags;

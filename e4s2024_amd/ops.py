@@ -966,8 +966,8 @@ def uniform_blocks(labels: torch.Tensor, ho: int, wo: int, nreg: int, with_ctrl:
 def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: bool, cout: int, up: bool, rgb=None, want_out: bool = True,
                       x_nhwc: bool = False, out_nhwc: bool = False, s_next=None, up_blocks=None, mx=None, mx4=None):
     """``mx = (wmx, arith)`` (``PreparedMx``, a layer ``mx_eligible`` accepts): run on the DMA-fed kernel of csrc/modconv_mx.hip.
-    ``mx4`` (with ``mx``, arith 1, an up layer ``mx4_eligible`` accepts; ``PreparedMx.get(..., arith=4)``): the tiles whose positions' 2 x 2 outputs share a
-    region run on the four-parity kernel of csrc/modconv_mx4.hip, the composed kernel computes the others (bit-identical results either way).
+    ``mx4`` (with ``mx``, arith 1, an up layer ``mx4_eligible`` accepts; ``PreparedMx.get(..., arith=4)``): one launch of csrc/modconv_mx4.hip — the tiles whose
+    positions' 2 x 2 outputs share a region as four-parity tiles, the others as the composed kernel's tiles (bit-identical results either way).
     ``rgb = (wt_rgb [cout,3], s_rgb [bs,1,cout], bias [1,3,1,1], skip or None, up_kernel)`` fuses the following single-region
     ToRGB; the call then returns ``(out, rgb_image)``.  ``want_out=False`` (with ``rgb``) skips writing the layer's own activation
     and returns ``(None, rgb_image)``.  ``x_nhwc`` / ``out_nhwc``: the activation is channel-blocked, ``[bs, c/8, h, w, 8]`` (split-bf16
@@ -1042,15 +1042,14 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
         if labels is None or w < 32 or cout < 128 or cin % 16 or x_nhwc or out_nhwc:
             raise ValueError("region_modconv3x3: the mx kernel is built for masked layers of width >= 32, cout >= 128, cin % 16 == 0, channels-first")
         wmx, arith = mx
-        quad = 0
-        if mx4 is not None and up and arith == 1 and blocks is None and rgb is None and sn is None:
-            lib().call("e4s_region_upconv_mx4", _p(out), _p(x), _p(mx4), _p(mx_flags(x.device)), _p(s), _p(d), _p(labels), lh, lw, _p(nz), nbs or 0,
+        if mx4 is not None and up and arith == 1 and blocks is None and rgb is None and sn is None and cout % 128 == 0:
+            lib().call("e4s_region_upconv_mx4", _p(out), _p(x), _p(mx4), _p(wmx), _p(mx_flags(x.device)), _p(s), _p(d), _p(labels), lh, lw, _p(nz), nbs or 0,
                        _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, _stream())
-            quad = 32         # E4S_SKIP_QUAD_TILES: the composed kernel leaves those tiles alone
-        lib().call("e4s_region_modconv3x3_mx", _p(out), _p(x), _p(wmx), arith, _p(mx_flags(x.device)) if arith else None, _p(s), _p(d), _p(labels), lh, lw,
-                   _p(nz), nbs or 0, _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg,
-                   (1 if up else 0) | (16 if sn is not None else 0) | quad, _p(ws), wsn, *rgb_args, _p(sn),
-                   _p(blocks), _p(bctrl) if blocks is not None else None, _stream())
+        else:
+            lib().call("e4s_region_modconv3x3_mx", _p(out), _p(x), _p(wmx), arith, _p(mx_flags(x.device)) if arith else None, _p(s), _p(d), _p(labels), lh, lw,
+                       _p(nz), nbs or 0, _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg,
+                       (1 if up else 0) | (16 if sn is not None else 0), _p(ws), wsn, *rgb_args, _p(sn),
+                       _p(blocks), _p(bctrl) if blocks is not None else None, _stream())
     elif sb:
         lib().call("e4s_region_modconv3x3_sb", _p(out), _p(x), _p(wt[0]), _p(wt[1]), _p(s), _p(d), _p(labels), lh, lw, _p(nz), nbs or 0,
                    _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg,
@@ -1414,7 +1413,7 @@ def mx4_eligible(cin: int, cout: int, h: int, w: int, bs: int) -> bool:
     """Does a masked up layer ``[bs, cin, h, w] -> [bs, cout, 2h, 2w]`` (one ``mx_eligible`` accepts, f16 + fp6 arithmetic in force) try the four-parity kernel?
     Its workgroup is 64 output channels x (32 x 8) positions x 4 parities — twice the composed kernel's work — so the launch must still fill the chip (one workgroup
     per CU), and the layer must not be one the region-uniform block path takes (``UP_BLOCKS_MIN_WIDTH``)."""
-    if not UP_MX4 or cin % 16 or w < 32 or (UP_BLOCKS and w >= UP_BLOCKS_MIN_WIDTH and cout >= 128):
+    if not UP_MX4 or cin % 16 or cout % 128 or w < 32 or (UP_BLOCKS and w >= UP_BLOCKS_MIN_WIDTH and cout >= 128):
         return False
     return (-(-w // 32)) * (-(-h // 8)) * (-(-cout // 64)) * bs >= 256
 

@@ -146,9 +146,6 @@ E4S_API int e4s_region_modconv3x3_sb(float* out, const float* x, const uint16_t*
  * fall back by itself (no host synchronisation in the ABI): the host layer snapshots flags[1] before and after a forward pass and re-runs a pass that moved
  * it with arith 0 (e4s2024_amd/ops.py MxGuard; the reference computes these layers in fp32, models/stylegan2/model.py:276-320).
  * e4s_modconv_mx_weight_bytes: size of the prepared copy.  All other arguments as e4s_region_modconv3x3_sb. */
-/* E4S_SKIP_QUAD_TILES (OR-ed into `up` of e4s_region_modconv3x3_mx; masked up layer, arith 1, no workspace): the 32 x 8-position tiles in which the four outputs
- * (2y + pa, 2x + pb) of every position carry one region are left untouched — e4s_region_upconv_mx4 (below) computes exactly those. */
-#define E4S_SKIP_QUAD_TILES 32
 E4S_API int e4s_modconv_mx_weight_bytes(int cout, int cin, int up, int arith, int64_t* bytes);
 E4S_API int e4s_modconv_prep_weights_mx(void* dst, const float* weight, const float* blur, int cout, int cin, int up, int arith, void* stream);
 E4S_API int e4s_region_modconv3x3_mx(float* out, const float* x, const void* wmx, int arith, int* flags, const float* s, const float* d,
@@ -160,15 +157,16 @@ E4S_API int e4s_region_modconv3x3_mx(float* out, const float* x, const void* wmx
                                      const float* rgb_up_kernel, const float* s_next, const uint8_t* uniform_blocks, const int* uniform_ctrl,
                                      void* stream);
 /* Round 4: the masked up layer (models/stylegan2/model.py:287-300 with the per-region mixing of :385-400) with the four output parities of a position in ONE workgroup
- * (csrc/modconv_mx4.hip): where a position's 2 x 2 outputs share a region, the modulated / split / fp6-converted activation operand is prepared once for the four
- * composed 3x3 kernels.  Computes ONLY the 32 x 8-position tiles in which that holds for every position (the others are e4s_region_modconv3x3_mx's, called with
- * E4S_SKIP_QUAD_TILES on the same `out`); f16 + 2 x MX fp6 arithmetic, results bit-identical to that kernel's.  wmx4 from e4s_modconv_prep_weights_mx4
- * (weight [1,cout,cin,3,3], blur [4,4]; size e4s_modconv_mx4_weight_bytes); cin % 16 == 0, w >= 32, out 16-byte aligned, noise 8-byte aligned; flags as above. */
+ * (csrc/modconv_mx4.hip): where the 2 x 2 outputs of every position of a 32 x 8-position tile share a region, the modulated / split / fp6-converted activation operand
+ * is prepared once for the four composed 3x3 kernels; the other tiles are computed, inside the same launch, exactly as e4s_region_modconv3x3_mx (arith 1) computes them.
+ * The result is bit-identical to that call on every map.  f16 + 2 x MX fp6 arithmetic; wmx4 from e4s_modconv_prep_weights_mx4 (weight [1,cout,cin,3,3], blur [4,4];
+ * size e4s_modconv_mx4_weight_bytes), wmx from e4s_modconv_prep_weights_mx(up = 1, arith = 1); cin % 16 == 0, cout % 128 == 0, w >= 32, out 16-byte aligned, noise
+ * 8-byte aligned; flags and all other arguments as for e4s_region_modconv3x3_mx. */
 E4S_API int e4s_modconv_mx4_weight_bytes(int cout, int cin, int64_t* bytes);
 E4S_API int e4s_modconv_prep_weights_mx4(void* dst, const float* weight, const float* blur, int cout, int cin, void* stream);
-E4S_API int e4s_region_upconv_mx4(float* out, const float* x, const void* wmx4, int* flags, const float* s, const float* d, const uint8_t* labels, int lh, int lw,
-                                  const float* noise, int noise_bs, const float* noise_weight, const float* act_bias, int act, int bs, int cin, int cout, int h,
-                                  int w, int nreg, void* stream);
+E4S_API int e4s_region_upconv_mx4(float* out, const float* x, const void* wmx4, const void* wmx, int* flags, const float* s, const float* d, const uint8_t* labels,
+                                  int lh, int lw, const float* noise, int noise_bs, const float* noise_weight, const float* act_bias, int act, int bs, int cin,
+                                  int cout, int h, int w, int nreg, void* stream);
 /* The regional-style encoder's stride-1, pad-1 3x3 convolutions (models/encoders/helpers.py:128-139) on the same kernel in its plain-convolution mode:
  *   out[bs,cout,h,w] = PReLU( conv3x3( (x - in_mean[b,ci]) * in_rstd[b,ci], W ) )          in_mean / in_rstd (together) and prelu_slope optional
  * cin % 16 == 0; padding is exactly 0 (the normalisation applies to in-image pixels only).  wmx from e4s_conv_prep_weights_mx (weight [cout,cin,3,3],

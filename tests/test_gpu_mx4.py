@@ -1,7 +1,7 @@
 """GPU parity of the four-parity masked up kernel (csrc/modconv_mx4.hip, round 4): the reference's up-sampling StyledConv (models/stylegan2/model.py:287-300 per
-region, mixed per output pixel :385-400).  The tiles whose positions' 2 x 2 outputs share a region run on it, the composed kernel (csrc/modconv_mx.hip) computes the
-others into the same tensor: the result must equal the composed kernel alone BIT FOR BIT (same products, same order) — on maps where every tile qualifies, where some
-do, where none does, with region-less pixels, ragged sizes and an output-channel tail — and meet the layer bar against the faithful CPU oracle."""
+region, mixed per output pixel :385-400).  The tiles whose positions' 2 x 2 outputs share a region run as four-parity tiles, the others — in the same launch — as the
+composed kernel's tiles (csrc/modconv_mx_tile.h): the result must equal the composed kernel's own launch BIT FOR BIT (same products, same order) — on maps where every
+tile qualifies, where some do, where none does, with region-less pixels and ragged sizes — and meet the layer bar against the faithful CPU oracle."""
 import numpy as np
 import pytest
 import torch
@@ -39,13 +39,14 @@ def _labels(kind, rs, bs, nreg, lh, lw, ho, wo):
 
 #         bs cin cout  h   w  nreg lh   lw
 SHAPES = [(2, 64, 128, 16, 64, 12, 128, 512),      # two tile rows, labels at 4x the output resolution
-          (1, 48, 136, 20, 40, 5, 40, 80),         # ragged: partial tiles, an output-channel tail (136 = 2 x 64 + 8)
+          (1, 48, 128, 20, 40, 5, 40, 80),         # ragged: partial tiles, a channel tail in the last chunk, labels at the output resolution
+          (3, 32, 384, 8, 32, 7, 64, 256),         # three 128-channel tiles (six 64-channel ones: no XCD grouping), one tile per image
           (4, 512, 256, 64, 64, 12, 512, 512)]     # the generator's 64 -> 128 layer at the benchmark's batch
 
 
 @pytest.mark.parametrize("shape", SHAPES)
 @pytest.mark.parametrize("kind", ["cells8", "cells2", "mixed", "iid"])
-def test_four_parity_kernel_plus_composed_kernel_equal_the_composed_kernel_alone(sg2, shape, kind):
+def test_four_parity_launch_equals_the_composed_kernel(sg2, shape, kind):
     bs, cin, cout, h, w, nreg, lh, lw = shape
     rs = np.random.RandomState(17 * cin + h + len(kind))
     lab = _labels(kind, rs, bs, nreg, lh, lw, 2 * h, 2 * w)
@@ -68,7 +69,7 @@ def test_four_parity_kernel_plus_composed_kernel_equal_the_composed_kernel_alone
     try:
         ops.SPLITK_MAX_OUT_FLOATS = 0                    # (no split-K for the small test layers: its partial sums are added in another order)
         composed = ops.region_modconv3x3(x, wt, s, d, labels, nz, nw, ab, True, cout, True, mx=(wmx, 1))
-        poison = torch.full_like(composed, float("nan"))     # the next allocation of this size: every output pixel must be written by one of the two launches
+        poison = torch.full_like(composed, float("nan"))     # the next allocation of this size: every output pixel must be written
         torch.cuda.synchronize()
         del poison
         out = ops.region_modconv3x3(x, wt, s, d, labels, nz, nw, ab, True, cout, True, mx=(wmx, 1), mx4=wmx4)

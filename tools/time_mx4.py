@@ -1,4 +1,4 @@
-"""Masked up layers (batch 4) with and without the four-parity kernel (csrc/modconv_mx4.hip), interleaved rounds, median ms per call (both launches of the pair)."""
+"""Masked up layers (batch 4) with and without the four-parity kernel (csrc/modconv_mx4.hip), interleaved rounds, median ms per call."""
 import os, sys, statistics, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from e4s2024_amd import ops, seeded
