@@ -676,7 +676,12 @@ def main():
             job_cost = sum(fl[k] * (mfma_cost_per_product(k) if sb else 16.0) for k in fl) / sum(fl.values())
             job_peak = BF16_MATRIX_PEAK_TFLOPS / job_cost
             job_ach = value * 148.52e9 / 1e12 / world
-            roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            roof = {"bound": "mfma", "kernel": dom,
+                    **({"kernel_launches": "region_modconv_mx_kernel<1, ...> (csrc/modconv_mx.hip) and, for masked up layers whose launch fills the chip with 64-channel tiles "
+                                           "(512->256 @64 at this batch), region_upconv_mx4_kernel (csrc/modconv_mx4.hip): the same tile code or its four-parity form, "
+                                           "chosen per workgroup — profiler tables list the two names, this object counts them as one kernel"}
+                       if (ops.UP_MX4 and dom and dom.startswith("region_modconv_mx_kernel<1")) else {}),
+                    "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": _pmc_traffic(dom)[0], "traffic_source": _pmc_traffic(dom)[1],
                     "peak_basis": ((f"dense bf16 MFMA 2500 TFLOP/s / {cost:.3f} bf16-MFMA multiply-adds of matrix-pipe time per fp32-accurate product ("
                                     + ("f16 MFMA + 2 MX-fp6 MFMAs at 4x the rate, 24 of 32 K slots used" if cost < 3 else "split-bf16: 3 bf16 MFMAs") + ")") if sb else "fp32 MFMA 157.3 TFLOP/s"),

@@ -27,7 +27,7 @@ python tools/rocpd_summary.py gpurun_out/prof_pti/pti_results.db 60 | cut -c1-26
 grep "PTI step" gpurun_out/prof_pti.log > gpurun_out/${T}_pti_timing.txt
 rm -rf gpurun_out/prof_pti
 bash tools/pmc_pass.sh "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" pmc_sq
-cd $R; python tools/rocpd_pmc.py gpurun_out/pmc_sq/pmc_results.db region_modconv > gpurun_out/${T}_pmc_sq.txt; python tools/rocpd_pmc.py gpurun_out/pmc_sq/pmc_results.db up_hc >> gpurun_out/${T}_pmc_sq.txt; python tools/rocpd_pmc.py gpurun_out/pmc_sq/pmc_results.db masked_up_block >> gpurun_out/${T}_pmc_sq.txt
+cd $R; python tools/rocpd_pmc.py gpurun_out/pmc_sq/pmc_results.db region_modconv > gpurun_out/${T}_pmc_sq.txt; python tools/rocpd_pmc.py gpurun_out/pmc_sq/pmc_results.db region_upconv >> gpurun_out/${T}_pmc_sq.txt; python tools/rocpd_pmc.py gpurun_out/pmc_sq/pmc_results.db up_hc >> gpurun_out/${T}_pmc_sq.txt; python tools/rocpd_pmc.py gpurun_out/pmc_sq/pmc_results.db masked_up_block >> gpurun_out/${T}_pmc_sq.txt
 python tools/rocpd_pmc.py gpurun_out/pmc_sq/pmc_results.db chain_conv >> gpurun_out/${T}_pmc_sq.txt; rm -rf gpurun_out/pmc_sq
 bash tools/pmc_pass.sh "FETCH_SIZE" pmc_fetch
 cd $R; python tools/rocpd_pmc.py gpurun_out/pmc_fetch/pmc_results.db > gpurun_out/${T}_pmc_fetch.txt; rm -rf gpurun_out/pmc_fetch

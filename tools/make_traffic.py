@@ -28,9 +28,10 @@ KEYS = {
                                             "7 launches per step (6 plain + 1 with fused ToRGB and split-plane output; on the benchmark maps the 128->256 up "
                                             "layer's launch leaves at once: its blocks are all region-uniform and run in masked_up_block_kernel); dword activation "
                                             "loads: no FETCH correction", (823900000 - 4 * (256 * 128 * 128 * 4 + 128 * 256 * 256 * 4)) // 7),
-    "region_modconv_mx_kernel<1>": (["region_modconv_mx_kernel<1"], 1.0,
-                                    "7 launches per step (the DMA-fed masked kernel, f16 + 2 x MX fp6; on the benchmark maps the 128->256 up layer's launch leaves at "
-                                    "once); dword activation loads, 16-byte weight DMA: FETCH uncorrected (a lower bound on the weight share)",
+    "region_modconv_mx_kernel<1>": (["region_modconv_mx_kernel<1|region_upconv_mx4_kernel"], 1.0,
+                                    "7 launches per step (the DMA-fed masked kernel, f16 + 2 x MX fp6 — six launches of region_modconv_mx_kernel and, for the 512 -> 256 @64 up "
+                                    "layer, one of region_upconv_mx4_kernel, which runs the same tile code or its four-parity form per workgroup; on the benchmark maps the "
+                                    "128->256 up layer's launch leaves at once); dword activation loads, 16-byte weight DMA: FETCH uncorrected (a lower bound on the weight share)",
                                     (823900000 - 4 * (256 * 128 * 128 * 4 + 128 * 256 * 256 * 4)) // 7),
     "region_modconv_mx_kernel<0>": (["region_modconv_mx_kernel<0"], 1.0, "as <1> with the split-bf16 arithmetic", (823900000 - 4 * (256 * 128 * 128 * 4 + 128 * 256 * 256 * 4)) // 7),
     "masked_upconv_blocks": (["masked_up_block_kernel"], 1.0, "1 launch per step (the 256 -> 128 @128 masked up layer: every 16 x 16 output block of the benchmark maps lies under one "
@@ -49,8 +50,9 @@ def main(fetch_path, write_path, out_path):
     f, w = parse(fetch_path), parse(write_path)
     doc = {}
     for key, (subs, corr, note, alg) in KEYS.items():
-        fk = [(n, v["FETCH_SIZE"]) for n, v in f.items() if all(s in n for s in subs) and "FETCH_SIZE" in v]
-        wk = [(n, v["WRITE_SIZE"]) for n, v in w.items() if all(s in n for s in subs) and "WRITE_SIZE" in v]
+        hit = lambda n: all(any(a in n for a in s.split("|")) for s in subs)      # ("a|b": either name)
+        fk = [(n, v["FETCH_SIZE"]) for n, v in f.items() if hit(n) and "FETCH_SIZE" in v]
+        wk = [(n, v["WRITE_SIZE"]) for n, v in w.items() if hit(n) and "WRITE_SIZE" in v]
         if not fk or not wk:
             continue
         nf, nw = sum(c for _, (c, _) in fk), sum(c for _, (c, _) in wk)
