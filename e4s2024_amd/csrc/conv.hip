@@ -302,6 +302,89 @@ static int dispatch2d(Conv2dParams& p, hipStream_t st) {
     return launch2d<KS, S, CKK, 1, 1, 2, 2, 4>(p, st);                                                           //  64 co x 64 px (16 x 4)
 }
 
+// ------------------------------------------------------------------------------------ the 3-channel stems
+// Cin <= 4 (the regional-style encoder's input layer, psp_encoders.py:335: 3 -> 64, 3x3; BiSeNet's ResNet stem, face_parsing/resnet.py: 3 -> 64, 7x7 stride 2): K = Cin k^2 is
+// 27 / 147, far too short for the implicit-GEMM tiles above (their 16-channel chunks are 13 / 16 padding), and the layers are bound by their 268 MB of output per batch of
+// 16 images.  One thread = one output pixel x 64 output channels in registers: its k^2 Cin inputs arrive row by row from global memory (coalesced across the threads of
+// a row), the weights [k][64] sit in LDS and are read as broadcast float4s, plain fp32 FMAs (two channels per v_pk_fma_f32), every store a fully used line per channel.
+template <int KS>
+__global__ __launch_bounds__(256) void conv_small_cin_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
+                                                             const float* __restrict__ slope, int act, int cin, int cout, int h, int w, int ho, int wo, int stride, int pad) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // [cin * KS * KS][64], then bias [64], slope [64]
+    const int nk = cin * KS * KS;
+    const int co0 = blockIdx.y * 64, b = blockIdx.z;
+    for (int e = threadIdx.x; e < nk * 64; e += 256) {
+        const int k = e >> 6, n = e & 63;
+        wl[e] = co0 + n < cout ? wt[(size_t)k * cout + co0 + n] : 0.f;
+    }
+    float* bl = wl + nk * 64;
+    float* sl = bl + 64;
+    if (threadIdx.x < 64) {
+        const int co = co0 + threadIdx.x;
+        bl[threadIdx.x] = (bias && co < cout) ? bias[co] : 0.f;
+        sl[threadIdx.x] = (act == 2 && co < cout) ? slope[co] : (act == 1 ? 0.f : 1.f);      // (ReLU = PReLU with slope 0)
+    }
+    __syncthreads();
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = pix < ho * wo;
+    const int oy = ok ? pix / wo : 0, ox = ok ? pix - (pix / wo) * wo : 0;
+    f2 acc[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) acc[j] = (f2){bl[2 * j], bl[2 * j + 1]};
+    const int ix0 = ox * stride - pad, iy0 = oy * stride - pad;
+    for (int ci = 0; ci < cin; ++ci) {
+        const float* xp = x + ((size_t)b * cin + ci) * h * w;
+#pragma unroll 1
+        for (int ky = 0; ky < KS; ++ky) {
+            const int iy = iy0 + ky;
+            const bool row_ok = ok && iy >= 0 && iy < h;
+            float in[KS];
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const int ix = ix0 + kx;
+                const bool in_ok = row_ok && ix >= 0 && ix < w;
+                const float v = xp[in_ok ? (size_t)iy * w + ix : 0];      // (unconditional load from a valid address)
+                in[kx] = in_ok ? v : 0.f;
+            }
+            const float4* wrow = reinterpret_cast<const float4*>(wl + (size_t)((ci * KS + ky) * KS) * 64);
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const f2 vv = (f2){in[kx], in[kx]};
+#pragma unroll
+                for (int n4 = 0; n4 < 16; ++n4) {
+                    const float4 w4 = wrow[kx * 16 + n4];
+                    acc[2 * n4] = (f2){w4.x, w4.y} * vv + acc[2 * n4];
+                    acc[2 * n4 + 1] = (f2){w4.z, w4.w} * vv + acc[2 * n4 + 1];
+                }
+            }
+        }
+    }
+    if (!ok) return;
+    float* op = out + ((size_t)b * cout + co0) * ho * wo + pix;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int n = 2 * j + e;
+            if (co0 + n >= cout) break;
+            float v = acc[j][e];
+            if (act) v = v > 0.f ? v : v * sl[n];
+            op[(size_t)n * ho * wo] = v;
+        }
+    }
+}
+
+template <int KS>
+static int launch_small_cin(float* out, const float* x, const float* wt, const float* bias, const float* slope, int act, int bs, int cin, int cout, int h, int w, int ho, int wo,
+                            int stride, int pad, hipStream_t st) {
+    const int lds = (cin * KS * KS * 64 + 128) * 4;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_cin_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (4 * KS * KS * 64 + 128) * 4);
+    if (attr != hipSuccess) return fail((int)attr, "conv2d: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+    hipLaunchKernelGGL(conv_small_cin_kernel<KS>, dim3(cdiv(ho * wo, 256), cdiv(cout, 64), bs), dim3(256), lds, st, out, x, wt, bias, slope, act, cin, cout, h, w, ho, wo, stride, pad);
+    return check_launch("conv2d (small cin)");
+}
+
 extern "C" int e4s_conv2d(float* out, const float* x0, const float* x1, int cin0, const float* wt, const float* bias, const float* in_mean,
                           const float* in_rstd, const float* prelu_slope, const float* residual, int act, int bs, int cin, int cout, int h, int w,
                           int ks, int stride, int pad, void* stream) {
@@ -320,6 +403,10 @@ extern "C" int e4s_conv2d(float* out, const float* x0, const float* x1, int cin0
     p.wo = (w + 2 * pad - ks) / stride + 1;
     E4S_REQUIRE(p.ho >= 1 && p.wo >= 1, "conv2d: empty output");
     hipStream_t st = (hipStream_t)stream;
+    if (cin <= 4 && !x1 && !in_mean && !residual && (ks == 3 || ks == 7) && (int64_t)p.ho * p.wo >= 4096) {      // the 3-channel stems
+        if (ks == 3) return launch_small_cin<3>(out, x0, wt, bias, prelu_slope, act, bs, cin, cout, h, w, p.ho, p.wo, stride, pad, st);
+        return launch_small_cin<7>(out, x0, wt, bias, prelu_slope, act, bs, cin, cout, h, w, p.ho, p.wo, stride, pad, st);
+    }
     if (ks == 3 && stride == 1) return dispatch2d<3, 1, 8>(p, st);
     if (ks == 3 && stride == 2) return dispatch2d<3, 2, 8>(p, st);
     if (ks == 1 && stride == 1) return dispatch2d<1, 1, 32>(p, st);

@@ -110,38 +110,55 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
     return i;
 }
 
+// One block = a (64 / (F / 2)) x (16 / (F / 2)) tile of outputs (64 x 16 for F = 2, 32 x 8 for F = 4).  The input region (F * tile + K - F on a side, reflect-padded) is read
+// ONCE, coalesced, into LDS; the vertical pass writes a [tile rows][region columns] buffer; the horizontal pass reads it.  Sums in the order of the direct form this replaces
+// (column: taps i = 0 .. K - 1 ascending; then the row taps j ascending) — value for value the same results; the direct form read 64 (F = 2) scattered values per output
+// from global memory: 434 us for the sixteen 1024^2 images of a swap batch whose bytes take 60.
 template <int F>
 __global__ __launch_bounds__(256) void bicubic_down_norm_kernel(float* __restrict__ out, const float* __restrict__ in,
                                                                 const float* __restrict__ taps, const float* __restrict__ mean,
                                                                 const float* __restrict__ stdv, int C, int h, int w, int oh, int ow, int do_norm) {
     constexpr int K = 4 * F;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= ow || y >= oh) return;
+    constexpr int TW = 128 / F, TH = 32 / F;                  // output tile
+    constexpr int RW = TW * F + K - F, RH = TH * F + K - F;   // input region
+    constexpr int PADT = (K - F) / 2;
+    __shared__ float reg[RH][RW + 1];
+    __shared__ float colb[TH][RW + 1];
     const int plane = blockIdx.z;
     const float* p = in + (size_t)plane * h * w;
-    constexpr int PADT = (K - F) / 2;
+    const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
+    const int ix0 = ox0 * F - PADT, iy0 = oy0 * F - PADT;
     float t[K];
 #pragma unroll
     for (int i = 0; i < K; ++i) t[i] = taps[i];
-    float acc = 0.f;
-#pragma unroll
-    for (int j = 0; j < K; ++j) {                 // horizontal tap j of the second pass ...
-        const int ix = reflect_idx(x * F - PADT + j, w);
+    for (int e = threadIdx.x; e < RH * RW; e += 256) {
+        const int ry = e / RW, rx = e - ry * RW;
+        reg[ry][rx] = p[(size_t)reflect_idx(iy0 + ry, h) * w + reflect_idx(ix0 + rx, w)];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < TH * RW; e += 256) {       // vertical pass (first pass of the reference's separable filter)
+        const int ty = e / RW, rx = e - ty * RW;
         float col = 0.f;
 #pragma unroll
-        for (int i = 0; i < K; ++i) {             // ... applied to the vertically filtered column (first pass)
-            const int iy = reflect_idx(y * F - PADT + i, h);
-            col += t[i] * p[(size_t)iy * w + ix];
+        for (int i = 0; i < K; ++i) col += t[i] * reg[ty * F + i][rx];
+        colb[ty][rx] = col;
+    }
+    __syncthreads();
+    const int c = plane % C;
+    const float m = do_norm ? mean[c] : 0.f, sd = do_norm ? stdv[c] : 1.f;
+    for (int e = threadIdx.x; e < TH * TW; e += 256) {       // horizontal pass
+        const int ty = e / TW, tx = e - ty * TW;
+        const int x = ox0 + tx, y = oy0 + ty;
+        if (x >= ow || y >= oh) continue;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc += t[j] * colb[ty][tx * F + j];
+        if (do_norm) {
+            acc = fminf(fmaxf(acc, 0.f), 1.f);
+            acc = (acc - m) / sd;
         }
-        acc += t[j] * col;
+        out[((size_t)plane * oh + y) * ow + x] = acc;
     }
-    if (do_norm) {
-        const int c = plane % C;
-        acc = fminf(fmaxf(acc, 0.f), 1.f);
-        acc = (acc - mean[c]) / stdv[c];
-    }
-    out[((size_t)plane * oh + y) * ow + x] = acc;
 }
 
 __global__ __launch_bounds__(256) void clamp_normalize_kernel(float* __restrict__ out, const float* __restrict__ in, const float* __restrict__ mean,
@@ -172,7 +189,7 @@ extern "C" int e4s_bicubic_down_normalize(float* out, const float* in, const flo
     if (bs == 0) return 0;
     // conv output size with pad (K - F) and stride F: (h + K - F - K) / F + 1 = h / F  (floor)
     const int oh = (h - factor) / factor + 1, ow = (w - factor) / factor + 1;
-    dim3 grid(cdiv(ow, 64), cdiv(oh, 4), bs * C);
+    dim3 grid(cdiv(ow, 128 / factor), cdiv(oh, 32 / factor), bs * C);
     hipStream_t st = (hipStream_t)stream;
     if (factor == 2)
         hipLaunchKernelGGL(bicubic_down_norm_kernel<2>, grid, dim3(256), 0, st, out, in, taps, mean, stdv, C, h, w, oh, ow, mean ? 1 : 0);
