@@ -303,9 +303,8 @@ static int dispatch2d(Conv2dParams& p, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------ the 3-channel stems
-// Cin <= 4 (the regional-style encoder's input layer, psp_encoders.py:335: 3 -> 64, 3x3; BiSeNet's ResNet stem, face_parsing/resnet.py: 3 -> 64, 7x7 stride 2): K = Cin k^2 is
-// 27 / 147, far too short for the implicit-GEMM tiles above (their 16-channel chunks are 13 / 16 padding), and the layers are bound by their 268 MB of output per batch of
-// 16 images.  One thread = one output pixel x 64 output channels in registers: its k^2 Cin inputs arrive row by row from global memory (coalesced across the threads of
+// Cin <= 4 with a 3 x 3 kernel (the regional-style encoder's input layer, psp_encoders.py:335: 3 -> 64): K = 27 is far too short for the implicit-GEMM tiles above (their
+// 16-channel chunks are 13 / 16 padding), and the layer is bound by its 268 MB of output per batch of 16 images (351 us on the implicit GEMM, 125 us here).  One thread = one output pixel x 64 output channels in registers: its k^2 Cin inputs arrive row by row from global memory (coalesced across the threads of
 // a row), the weights [k][64] sit in LDS and are read as broadcast float4s, plain fp32 FMAs (two channels per v_pk_fma_f32), every store a fully used line per channel.
 template <int KS>
 __global__ __launch_bounds__(256) void conv_small_cin_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
@@ -403,10 +402,10 @@ extern "C" int e4s_conv2d(float* out, const float* x0, const float* x1, int cin0
     p.wo = (w + 2 * pad - ks) / stride + 1;
     E4S_REQUIRE(p.ho >= 1 && p.wo >= 1, "conv2d: empty output");
     hipStream_t st = (hipStream_t)stream;
-    if (cin <= 4 && !x1 && !in_mean && !residual && (ks == 3 || ks == 7) && (int64_t)p.ho * p.wo >= 4096) {      // the 3-channel stems
-        if (ks == 3) return launch_small_cin<3>(out, x0, wt, bias, prelu_slope, act, bs, cin, cout, h, w, p.ho, p.wo, stride, pad, st);
-        return launch_small_cin<7>(out, x0, wt, bias, prelu_slope, act, bs, cin, cout, h, w, p.ho, p.wo, stride, pad, st);
-    }
+    // the 3 x 3 stem (K = 27): the direct kernel above.  (The 7 x 7 stride-2 stem, K = 147, stays on the implicit GEMM: 19.7 GFLOP per 16 images are 290 us of fp32 VALU at
+    // its peak — measured 424 us in this form, 568 us with four pixels per thread, 1 580 us with the weights as scalar loads, against 403 us here.)
+    if (cin <= 4 && !x1 && !in_mean && !residual && ks == 3 && (int64_t)p.ho * p.wo >= 4096)
+        return launch_small_cin<3>(out, x0, wt, bias, prelu_slope, act, bs, cin, cout, h, w, p.ho, p.wo, stride, pad, st);
     if (ks == 3 && stride == 1) return dispatch2d<3, 1, 8>(p, st);
     if (ks == 3 && stride == 2) return dispatch2d<3, 2, 8>(p, st);
     if (ks == 1 && stride == 1) return dispatch2d<1, 1, 32>(p, st);
