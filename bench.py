@@ -73,7 +73,7 @@ def conv3x3_flops_per_face(size=1024, want_executed=False, uniform_frac=None):
             k = "modconv_up_hc"
         elif two_stage:
             k = "modconv_up_fused_sb" if _ops.UP_FUSED else "modconv_tconv_sb"
-        elif not masked and not up and _ops.SP_CHAIN and _ops.NHWC_CHAIN and _ops.FUSE_RGB and _ops.chain_supported(cout, cout, out_res, out_res, False):
+        elif not masked and not up and _ops.SP_CHAIN and _ops.NHWC_CHAIN and _ops.FUSE_RGB and _ops.chain_supported(cout, cout, out_res, out_res, False, last=(out_res == size)):
             k = f"chain_conv3x3<{cout}>"          # the split-plane chain's persistent kernel (csrc/modconv_chain.hip)
         else:
             k = modconv_kernel_name(cout, w_in, None, masked, cin=None)
