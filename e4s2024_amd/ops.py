@@ -697,20 +697,21 @@ _blur_rank1 = {}
 
 
 def blur_is_rank1(blur: torch.Tensor) -> bool:
-    """Is the 4 x 4 blur kernel an outer product (to fp32 rounding)?  One device -> host copy per kernel tensor version, then cached."""
-    key = (blur.data_ptr(), blur._version, blur.device)
-    hit = _blur_rank1.get(key)
-    if hit is None:
-        k = blur.detach().double().cpu()
-        tot = float(k.sum())
-        ok = tuple(k.shape) == (4, 4) and tot > 0
-        if ok:
-            outer = k.sum(1, keepdim=True) * k.sum(0, keepdim=True) / tot
-            ok = bool((outer - k).abs().max() <= 1e-6 * k.abs().max())
-        if len(_blur_rank1) > 64:
-            _blur_rank1.clear()
-        hit = _blur_rank1[key] = ok
-    return hit
+    """Is the 4 x 4 blur kernel an outer product (to fp32 rounding)?  One device -> host copy per kernel tensor OBJECT and version, then cached (keyed by the object, with
+    a weak reference: a data pointer alone comes back when the allocator reuses a freed tensor's memory — a different kernel would then inherit the old answer)."""
+    ent = _blur_rank1.get(id(blur))
+    if ent is not None and ent[0]() is blur and ent[1] == blur._version:
+        return ent[2]
+    k = blur.detach().double().cpu()
+    tot = float(k.sum())
+    ok = tuple(k.shape) == (4, 4) and tot > 0
+    if ok:
+        outer = k.sum(1, keepdim=True) * k.sum(0, keepdim=True) / tot
+        ok = bool((outer - k).abs().max() <= 1e-6 * k.abs().max())
+    if len(_blur_rank1) > 64:
+        _blur_rank1.clear()
+    _blur_rank1[id(blur)] = (weakref.ref(blur), blur._version, ok)
+    return ok
 
 
 class PreparedHc(_Prepared):

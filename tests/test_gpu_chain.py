@@ -9,7 +9,7 @@ import torch
 from conftest import record_parity
 from e4s2024_amd import ops, seeded
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(ops.MODCONV_MODE != "sb", reason="these kernels are the split-arithmetic routes (E4S_MODCONV=f32 switches them off)")]
 DEV = "cuda:0"
 
 
@@ -108,6 +108,8 @@ def _up_reference_f64(L, w, cout, bs, blur, act=True, noise=True):
 def test_half_composed_up_layer(cin, cout, res, bs, asym):
     """csrc/modconv_uphc.hip (vertical blur factor in the weights, horizontal factor on the accumulators in registers) against a float64 evaluation of the
     reference form and against the fused kernel it replaces; ragged sizes (tile edges in both directions), one chunk, three co tiles, an asymmetric rank-1 kernel."""
+    if not (ops.UP_HC and ops.MODCONV_MODE == "sb"):
+        pytest.skip("the half-composed route is switched off (E4S_UP_HC / E4S_MODCONV)")
     g = torch.Generator(device=DEV).manual_seed(700 + cin + res)
     r = lambda *s: torch.randn(*s, device=DEV, generator=g)  # noqa: E731
     w = r(1, cout, cin, 3, 3)
