@@ -133,7 +133,9 @@ __global__ __launch_bounds__(256) void bicubic_down_norm_kernel(float* __restric
     for (int i = 0; i < K; ++i) t[i] = taps[i];
     for (int e = threadIdx.x; e < RH * RW; e += 256) {
         const int ry = e / RW, rx = e - ry * RW;
-        reg[ry][rx] = p[(size_t)reflect_idx(iy0 + ry, h) * w + reflect_idx(ix0 + rx, w)];
+        // (rows / columns of a partial tile far outside the image feed no stored output: reflected once, then clamped so that the read stays inside the plane)
+        const int sy = min(max(reflect_idx(iy0 + ry, h), 0), h - 1), sx = min(max(reflect_idx(ix0 + rx, w), 0), w - 1);
+        reg[ry][rx] = p[(size_t)sy * w + sx];
     }
     __syncthreads();
     for (int e = threadIdx.x; e < TH * RW; e += 256) {       // vertical pass (first pass of the reference's separable filter)

@@ -50,6 +50,12 @@ def test_g10_bicubic_downsample_and_preprocess(parser):
     ds4 = BicubicDownSample(factor=4)
     img = seeded.seeded_image(7, 1, 64)
     assert maxdiff(ds4(img.to(DEV)), O.bicubic_downsample(img, 4)) <= 2e-6
+    # ragged sizes: partial tiles of the LDS-tiled kernel in both directions, images smaller and larger than one tile
+    gen = torch.Generator().manual_seed(3)
+    for (hh, ww, f) in ((50, 70, 2), (130, 258, 2), (36, 44, 4), (140, 132, 4)):
+        im = torch.rand(2, 3, hh, ww, generator=gen)
+        dsf = BicubicDownSample(factor=f)
+        assert maxdiff(dsf(im.to(DEV)), O.bicubic_downsample(im, f)) <= 2e-6, (hh, ww, f)
 
 
 def test_g9_bisenet_logits_and_argmax(parser, bisenet_sd):
