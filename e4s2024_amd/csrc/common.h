@@ -66,6 +66,44 @@ __device__ __forceinline__ float wave_butterfly(float v, Op op) {
 __device__ __forceinline__ float wave_sum(float v) { return wave_butterfly(v, [](float a, float b) { return a + b; }); }
 __device__ __forceinline__ float wave_max(float v) { return wave_butterfly(v, [](float a, float b) { return fmaxf(a, b); }); }
 
+// 32 wave sums at once.  v[k] (k = 0 .. 31) are 32 independent per-lane values; on return lane l holds, in the return value, the wave sum of v[k(l)] with
+// k(l) = bits 5..1 of l read as (b5 b4 b3 b2 b1) — every value ends up in one lane pair.  At step `xor o` of the butterfly each lane keeps the half of its values
+// whose index bit matches its own lane bit and hands the other half to its partner, so the number of live values halves with every step: 31 exchanges + 31 additions
+// for all 32 sums, where 32 separate butterflies cost 192 of each.  Per value the additions are those of wave_sum, in its order: bit-identical.
+__device__ __forceinline__ float wave_sum_x32(float (&v)[32]) {
+    const int lane = threadIdx.x & 63;
+    float a[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {            // xor 32: lanes < 32 go on with value k, lanes >= 32 with value k + 16
+        auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v[k]), __builtin_bit_cast(unsigned, v[k + 16]), false, false);
+        a[k] = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
+    float b[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {             // xor 16: rows 0 / 2 go on with k, rows 1 / 3 with k + 8
+        auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a[k]), __builtin_bit_cast(unsigned, a[k + 8]), false, false);
+        b[k] = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
+    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0;
+    float c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {             // xor 8
+        const float keep = b3 ? b[k + 4] : b[k], send = b3 ? b[k] : b[k + 4];
+        c[k] = keep + e4s_dpp<0x128>(send);
+    }
+    float d[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {             // xor 4
+        const float keep = b2 ? c[k + 2] : c[k], send = b2 ? c[k] : c[k + 2];
+        d[k] = keep + e4s_dpp<0x1B>(e4s_dpp<0x141>(send));
+    }
+    const float keep = b1 ? d[1] : d[0], send = b1 ? d[0] : d[1];      // xor 2
+    const float e = keep + e4s_dpp<0x4E>(send);
+    return e + e4s_dpp<0xB1>(e);                                        // xor 1
+}
+// the value index lane l's result of wave_sum_x32 belongs to
+__device__ __forceinline__ int wave_sum_x32_index(int lane) { return ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1); }
+
 // PyTorch 'nearest' source index: floor(dst * scale) clamped (ATen nearest_neighbor_compute_source_index)
 __device__ __forceinline__ int nearest_src(int dst, float scale, int in_size) {
     int s = (int)floorf((float)dst * scale);

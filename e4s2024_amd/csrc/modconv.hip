@@ -211,21 +211,29 @@ __global__ __launch_bounds__(256) void style_batched_kernel(const JobTable t, in
             sv[q][0] = *reinterpret_cast<const float4*>(sp + lane * 4);
             sv[q][1] = *reinterpret_cast<const float4*>(sp + 256 + lane * 4);
         }
+        // the block's 4 channels x 8 rows = 32 dot products: per-lane partial sums first, then ONE transposing butterfly for all 32 (wave_sum_x32: the additions of 32
+        // separate wave sums, bit-identical, at a sixth of their cross-lane traffic — the reductions were this kernel's time)
+        float part[32];
 #pragma unroll
         for (int c = 0; c < STYLE_CI; ++c) {
-            const int ci = ci0 + c;
-            if (ci >= J.cin) break;
+            const int ci = ci0 + c < J.cin ? ci0 + c : J.cin - 1;
             const float* wrow = J.mod_weight + (size_t)ci * sdim;
             const float4 w0 = *reinterpret_cast<const float4*>(wrow + lane * 4), w1 = *reinterpret_cast<const float4*>(wrow + 256 + lane * 4);
-            const float mb = J.mod_bias ? J.mod_bias[ci] : 0.f;
 #pragma unroll
             for (int q = 0; q < STYLE_ROWS; ++q) {
                 // (same summation order as the one-channel-per-wave version: two float4 steps of j = lane * 4 and 256 + lane * 4)
                 float a = (sv[q][0].x * w0.x + sv[q][0].y * w0.y) + (sv[q][0].z * w0.z + sv[q][0].w * w0.w);
                 a += (sv[q][1].x * w1.x + sv[q][1].y * w1.y) + (sv[q][1].z * w1.z + sv[q][1].w * w1.w);
-                a = wave_sum(a);
-                if (lane == 0 && br0 + q < nbr) J.s[(size_t)(br0 + q) * J.cin + ci] = a * scale + mb;
+                part[c * STYLE_ROWS + q] = a;
             }
+        }
+        static_assert(STYLE_CI * STYLE_ROWS == 32, "wave_sum_x32 reduces 32 values");
+        const float tot = wave_sum_x32(part);
+        const int k = wave_sum_x32_index(lane);
+        const int c = k / STYLE_ROWS, q = k - c * STYLE_ROWS;
+        if ((lane & 1) == 0 && ci0 + c < J.cin && br0 + q < nbr) {
+            const float mb = J.mod_bias ? J.mod_bias[ci0 + c] : 0.f;
+            J.s[(size_t)(br0 + q) * J.cin + ci0 + c] = tot * scale + mb;
         }
         return;
     }

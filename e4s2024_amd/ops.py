@@ -696,6 +696,12 @@ UP_HC = os.environ.get("E4S_UP_HC", "1") != "0"
 _blur_rank1 = {}
 
 
+def _blur_rank1_known(blur: torch.Tensor) -> bool:
+    """Has ``blur_is_rank1`` already looked at this kernel tensor?  (It costs a device -> host copy, which a stream capture cannot take.)"""
+    ent = _blur_rank1.get(id(blur))
+    return ent is not None and ent[0]() is blur and ent[1] == blur._version
+
+
 def blur_is_rank1(blur: torch.Tensor) -> bool:
     """Is the 4 x 4 blur kernel an outer product (to fp32 rounding)?  One device -> host copy per kernel tensor OBJECT and version, then cached (keyed by the object, with
     a weak reference: a data pointer alone comes back when the allocator reuses a freed tensor's memory — a different kernel would then inherit the old answer)."""
@@ -724,7 +730,7 @@ class PreparedHc(_Prepared):
         if not (UP_HC and MODCONV_MODE == "sb"):         # (the only caller is the split-plane chain, an inference route: the copy is always cacheable)
             return None
         _, cout, cin, k, _ = weight.shape
-        if k != 3 or cin % 16 or cout % 32 or torch.cuda.is_current_stream_capturing() and (blur.data_ptr(), blur._version, blur.device) not in _blur_rank1:
+        if k != 3 or cin % 16 or cout % 32 or torch.cuda.is_current_stream_capturing() and not _blur_rank1_known(blur):
             return None
         if not blur_is_rank1(blur):
             return None

@@ -403,3 +403,28 @@ def test_masked_up_layer_uniform_blocks_against_oracle_and_composed_form(sg2, sh
     # composed kernel on the f16 + MX-fp6 arithmetic (E4S_MX=2, cout >= 128) the difference is that arithmetic's own error (measured 2e-5 of scale)
     co_tol = 6e-5 if (_ops.mx_arith() == 1 and cout >= 128 and cin % 16 == 0) else 2e-5
     assert d_or <= LAYER_TOL * scale and d_co <= co_tol * scale, (shape, d_or, d_co, scale)
+
+def test_batched_style_tables_match_the_one_layer_launches():
+    """``ops.style_demod_plan`` (every layer's modulation / demodulation table in two launches: EqualLinear of model.py:262-274 and the demodulation of :276-285; the
+    32 dot products of a block reduced by one transposing butterfly — bit-identical to 32 wave sums: tools/probes/wave_sum_probe.hip — the style rows of the
+    demodulation staged in LDS) against ``ops.style_demod`` layer by layer, to an ulp or two (the two kernels' per-lane products contract into FMAs differently) — ragged channel counts, strided style views (one W+ index of a [bs, regions, 18, 512] latent), a layer without demodulation, 13 (batch, region) rows."""
+    from e4s2024_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(5)
+    bs, nreg = 3, 7
+    latent = torch.randn(bs, nreg, 18, 512, device=DEV, generator=g)
+    layers = [(512, 512, 0), (512, 256, 3), (72, 40, 5), (30, 3, 7), (256, 128, 9), (1024, 64, 11)]
+    jobs, want = [], {}
+    for i, (cin, cout, widx) in enumerate(layers):
+        styles = latent[:, :, widx]                                 # strided view, unit inner stride
+        mw = torch.randn(cin, 512, device=DEV, generator=g)
+        mb = torch.randn(cin, device=DEV, generator=g)
+        wsq = None if i == 3 else torch.rand(cin, cout, device=DEV, generator=g) + 0.1
+        jobs.append((i, styles, mw, mb, wsq, cout))
+        want[i] = ops.style_demod(styles, mw, mb, wsq, cout)
+    ops.style_demod_plan(jobs)
+    for i, (cin, cout, widx) in enumerate(layers):
+        s, d = ops.style_demod_planned(i, jobs[i][1])
+        assert float((s - want[i][0]).abs().max()) <= 2e-6 * float(want[i][0].abs().max()), (i, float((s - want[i][0]).abs().max()))
+        assert (d is None) == (want[i][1] is None)
+        if d is not None:
+            assert float(((d - want[i][1]) / want[i][1]).abs().max()) <= 2e-6, i

@@ -7,6 +7,17 @@
 using namespace e4s;
 __device__ __forceinline__ float ref_sum(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
 __device__ __forceinline__ float ref_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64)); return v; }
+__global__ void k32(const float* x, unsigned* out) {      // 32 values per lane: wave_sum_x32 against 32 x wave_sum
+    const int lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    float v[32], ref[32];
+    for (int j = 0; j < 32; ++j) { v[j] = x[(wave * 32 + j) * 64 + lane]; ref[j] = ref_sum(v[j]); }
+    const float got = wave_sum_x32(v);
+    const int kk = wave_sum_x32_index(lane);
+    float want = 0.f;
+    for (int j = 0; j < 32; ++j) if (j == kk) want = ref[j];
+    out[2 * (wave * 64 + lane)] = __builtin_bit_cast(unsigned, got);
+    out[2 * (wave * 64 + lane) + 1] = __builtin_bit_cast(unsigned, want);
+}
 __global__ void k(const float* x, unsigned* out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const float v = x[i];
@@ -34,5 +45,11 @@ int main() {
     long bad = 0;
     for (int i = 0; i < n; ++i) bad += (ho[4 * i] != ho[4 * i + 1]) + (ho[4 * i + 2] != ho[4 * i + 3]);
     printf("wave_sum / wave_max butterfly vs __shfl_xor loop: %ld mismatching values of %d\n", bad, 2 * n);
-    return bad != 0;
+    const int nw = n / 64 / 32;               // waves of the 32-value test
+    hipLaunchKernelGGL(k32, dim3(nw * 64 / 256), dim3(256), 0, 0, dx, dout);
+    hipMemcpy(ho, dout, (size_t)nw * 64 * 8, hipMemcpyDeviceToHost);
+    long bad32 = 0;
+    for (int i = 0; i < nw * 64; ++i) bad32 += ho[2 * i] != ho[2 * i + 1];
+    printf("wave_sum_x32 vs 32 x __shfl_xor loop: %ld mismatching lanes of %d\n", bad32, nw * 64);
+    return bad != 0 || bad32 != 0;
 }
