@@ -116,3 +116,35 @@ def test_four_parity_kernel_against_the_oracle(sg2, shape):
     e = float((y4 - ref).abs().max()) / scale
     record_parity(f"mx4_layer_up_{cin}to{cout}_{h}x{w}", e, MX_LAYER_TOL, note=f"four-parity up kernel against the oracle, relative to the output scale {scale:.1f}")
     assert e <= MX_LAYER_TOL
+
+def test_four_parity_launch_is_bit_stable_across_repeats_and_streams(sg2):
+    """The launch's LDS protocol (two-slot weight ring refilled by LDS-DMA behind a row's first MFMAs, double-buffered patch, role chosen per workgroup) has no
+    data-dependent control flow: 24 launches of the generator's 64 -> 128 layer at the benchmark's batch, alternating over two streams, give 24 identical tensors."""
+    bs, cin, cout, h, w, nreg, lh, lw = SHAPES[2]
+    rs = np.random.RandomState(3)
+    lab = _labels("mixed", rs, bs, nreg, lh, lw, 2 * h, 2 * w)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn(bs, cin, h, w, device=DEV, generator=g)
+    wgt = torch.randn(1, cout, cin, 3, 3, device=DEV, generator=g)
+    s = 1.0 + 0.3 * torch.randn(bs, nreg, cin, device=DEV, generator=g)
+    d = torch.rand(bs, nreg, cout, device=DEV, generator=g) + 0.5
+    nz = torch.randn(bs, 1, 2 * h, 2 * w, device=DEV, generator=g)
+    nw, ab = torch.tensor([0.17], device=DEV), 0.1 * torch.randn(cout, device=DEV, generator=g)
+    blur = torch.tensor([1., 3., 3., 1.], device=DEV)
+    blur = blur[:, None] * blur[None, :]
+    blur = blur / blur.sum() * 4
+    labels = T(lab).to(DEV)
+    wt, _ = ops.PreparedWeights().get(wgt, blur, True, True)
+    wmx = ops.PreparedMx().get(wgt, blur, True, 1)
+    wmx4 = ops.PreparedMx().get(wgt, blur, True, 4)
+    ref = ops.region_modconv3x3(x, wt, s, d, labels, nz, nw, ab, True, cout, True, mx=(wmx, 1), mx4=wmx4)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+    outs = []
+    for i in range(24):
+        with torch.cuda.stream(streams[i & 1]):
+            outs.append(ops.region_modconv3x3(x, wt, s, d, labels, nz, nw, ab, True, cout, True, mx=(wmx, 1), mx4=wmx4))
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, ref) for o in outs)
+    for st in streams:
+        ops.release_stream_context(st)
