@@ -1554,6 +1554,28 @@ def se_gate(pooled: torch.Tensor, fc1_weight: torch.Tensor, fc2_weight: torch.Te
     return gate
 
 
+# The squeeze-excite gate of an IR-SE unit is sigmoid(fc2 . relu(fc1 . mean(IN(r)))) with bias-free 1x1 convolutions (helpers.py:56-72) behind an affine-free
+# InstanceNorm2d (helpers.py:128-139): the pooled vector is the mean of an instance-normalised plane — exactly 0 — so the gate is sigmoid(0) = 1/2 for every channel of
+# every image.  What the reference's own launches compute there is the rounding noise of that mean (1e-8 .. 1e-6 of a unit: whatever order its sums ran in) pushed through
+# two small matrices: 0.5 to within 1e-6.  True: the unit multiplies by the constant and launches no gate kernel (24 latency-bound launches, 0.78 ms of the encoder's 10.3 ms
+# per 16 faces); False: the gate is computed from the normalised plane's measured mean as before (tests/test_gpu_encoder.py measures both and their difference).
+SE_GATE_IS_HALF = True
+_half_gates = {}
+
+
+def half_gate(bs: int, C: int, device) -> torch.Tensor:
+    """``[bs, C]`` filled with 0.5 (cached per shape and device; inside a stream capture an uncached shape gets a fresh tensor that is not kept)."""
+    key = (torch.device(device), bs, C)
+    t = _half_gates.get(key)
+    if t is None:
+        t = torch.full((bs, C), 0.5, dtype=torch.float32, device=device)
+        if not torch.cuda.is_current_stream_capturing():
+            if len(_half_gates) > 64:
+                _half_gates.clear()
+            _half_gates[key] = t
+    return t
+
+
 NGA_STATS_MAX_PIXELS = 16384          # planes a single workgroup holds in registers (e4s_norm_gate_add_stats)
 
 

@@ -164,6 +164,37 @@ def test_net3_forward_end_to_end(gpu_net3, net3_sd):
     assert maxdiff(out, ref_img) <= 1e-3 and maxdiff(feats, ref_feats) <= 1e-3
 
 
+def test_se_gate_behind_instance_norm_is_one_half(gpu_net3):
+    """reference helpers.py:128-139 + 56-72: the SE squeeze of an IR-SE unit is the mean of an (affine-free) instance-normalised plane, i.e. 0, and its gate — two bias-free
+    1x1 convolutions and a sigmoid — 1/2.  Measured here on the seeded network: every gate the COMPUTED route produces is 0.5 to within 1e-5 (it is the rounding noise of
+    that mean; measured: one ulp of 0.5), and the style vectors of the two routes (``ops.SE_GATE_IS_HALF``) agree to 1e-4 of their scale (measured 1.8e-5: 24 units of one-ulp gate
+    differences amplified by the instance norms between them — the size of the split arithmetic's own per-layer noise)."""
+    from e4s2024_amd import ops
+    img = seeded.seeded_image(6, 2, 1024).to(DEV)
+    mask = seeded.labels_to_onehot(seeded.blocky_labels(8, 2, 12, 512, cells=8), 12).to(DEV)
+    keep, real = ops.SE_GATE_IS_HALF, ops.se_gate
+    worst = [0.0]
+
+    def spy(pooled, w1, w2):
+        g = real(pooled, w1, w2)
+        worst[0] = max(worst[0], float((g - 0.5).abs().max()))
+        return g
+    try:
+        with torch.no_grad():
+            ops.SE_GATE_IS_HALF = True
+            v_half, _ = gpu_net3.get_style_vectors(img, mask)
+            ops.SE_GATE_IS_HALF = False
+            ops.se_gate = spy
+            v_comp, _ = gpu_net3.get_style_vectors(img, mask)
+    finally:
+        ops.SE_GATE_IS_HALF, ops.se_gate = keep, real
+    d = float((v_half - v_comp).abs().max()) / float(v_comp.abs().max())
+    record_parity("encoder.se_gate_computed_vs_one_half.max_gate_deviation", worst[0], 1e-5)
+    record_parity("encoder.se_gate_computed_vs_one_half.style_vectors_rel", d, 1e-4)
+    assert worst[0] <= 1e-5
+    assert d <= 1e-4
+
+
 def test_fused_se_gate_and_statistics_emitting_norm_gate_add_match_the_separate_launches():
     """The encoder's fused glue against the launches it replaces: ``se_gate`` == two ``vec_fc`` calls; ``norm_gate_add(stats_eps=...)`` ==
     ``norm_gate_add`` followed by ``plane_stats`` of its result (output and mean bit for bit, rstd to an ulp or two; every plane-size class
