@@ -77,6 +77,7 @@ _PROTOS = {
     "e4s_norm_gate_add": [c_ptr] * 8 + [c_int, c_ptr, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_se_gate": [c_ptr] * 4 + [c_int] * 3 + [c_ptr],
     "e4s_norm_gate_add_stats": [c_ptr] * 10 + [c_int, c_ptr, c_int, c_int, c_int, c_int, c_f32, c_ptr],
+    "e4s_norm_self_gate_add_stats": [c_ptr] * 4 + [c_f32] + [c_ptr] * 4 + [c_int, c_ptr, c_int, c_int, c_int, c_int, c_f32, c_ptr],
     "e4s_masked_avg_pool": [c_ptr, c_ptr, c_ptr] + [c_int] * 7 + [c_ptr],
     "e4s_bilinear_resize": [c_ptr, c_ptr] + [c_int] * 6 + [c_ptr],
     "e4s_maxpool3x3s2": [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],

@@ -231,17 +231,21 @@ extern "C" int e4s_se_gate(float* gate, const float* pooled, const float* w1, co
 // The next IR-SE unit starts with an InstanceNorm of this output: one workgroup per plane keeps the plane's output values in registers
 // (IT float4 per thread: planes up to 1024 * IT pixels) and produces mean / rstd with the very sums of plane_stats_kernel (same thread ->
 // element mapping, same two passes), so a unit no longer needs a statistics launch of its own.
-template <int IT>
+// SELF: the statistics of the INPUT plane are computed here too (in_eps; `mean` / `rstd` unused) — the plane sits in registers anyway, and its sums are plane_stats_kernel's
+// (same thread -> element mapping, same two passes): a unit whose gate does not depend on them (ops.SE_GATE_IS_HALF) then needs no statistics launch between its second
+// convolution and this kernel.
+template <int IT, bool SELF = false>
 __global__ __launch_bounds__(256) void norm_gate_add_stats_kernel(float* __restrict__ out, float* __restrict__ omean, float* __restrict__ orstd,
                                                                   const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                   const float* __restrict__ gate, const float* __restrict__ sc, const float* __restrict__ sc_mean,
                                                                   const float* __restrict__ sc_rstd, int ss, const float* __restrict__ prelu, int C, int h, int w,
-                                                                  float eps) {
+                                                                  float eps, float in_eps) {
     __shared__ float sh[4];
     const int plane = blockIdx.x;  // b*C + c
     const int c = plane % C;
     const int hw = h * w;
-    const float m = mean ? mean[plane] : 0.f, r = rstd ? rstd[plane] : 1.f, g = gate ? gate[plane] : 1.f;
+    float m = mean ? mean[plane] : 0.f, r = rstd ? rstd[plane] : 1.f;
+    const float g = gate ? gate[plane] : 1.f;
     const float sm = sc_mean ? sc_mean[plane] : 0.f, sr = sc_rstd ? sc_rstd[plane] : 1.f;
     const float sl = prelu ? prelu[c] : 1.f;
     const float* xp = x + (size_t)plane * hw;
@@ -249,13 +253,36 @@ __global__ __launch_bounds__(256) void norm_gate_add_stats_kernel(float* __restr
     const float* sp = sc ? sc + (size_t)plane * hw * ss * ss : nullptr;
     const int ws_ = w * ss;
     float4 v[IT];
+    if constexpr (SELF) {
+        float s0 = 0.f;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int i = threadIdx.x * 4 + it * 1024;
+            v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < hw) {
+                v[it] = *reinterpret_cast<const float4*>(xp + i);
+                s0 += (v[it].x + v[it].y) + (v[it].z + v[it].w);
+            }
+        }
+        m = block_sum(s0, sh) / (float)hw;
+        float q0 = 0.f;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int i = threadIdx.x * 4 + it * 1024;
+            if (i < hw) {
+                const float a = v[it].x - m, b2 = v[it].y - m, c2 = v[it].z - m, d = v[it].w - m;
+                q0 += (a * a + b2 * b2) + (c2 * c2 + d * d);
+            }
+        }
+        r = 1.0f / sqrtf(block_sum(q0, sh) / (float)hw + in_eps);
+    }
     float s = 0.f;
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int i = threadIdx.x * 4 + it * 1024;
-        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (!SELF) v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < hw) {
-            const float4 t = *reinterpret_cast<const float4*>(xp + i);
+            const float4 t = SELF ? v[it] : *reinterpret_cast<const float4*>(xp + i);
             float e[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -302,12 +329,33 @@ extern "C" int e4s_norm_gate_add_stats(float* out, float* out_mean, float* out_r
     const dim3 grid(bs * C), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (hw <= 1024)
-        hipLaunchKernelGGL(norm_gate_add_stats_kernel<1>, grid, block, 0, st, out, out_mean, out_rstd, x, mean, rstd, gate, shortcut, sc_mean, sc_rstd, ss, prelu, C, h, w, eps);
+        hipLaunchKernelGGL((norm_gate_add_stats_kernel<1, false>), grid, block, 0, st, out, out_mean, out_rstd, x, mean, rstd, gate, shortcut, sc_mean, sc_rstd, ss, prelu, C, h, w, eps, 0.f);
     else if (hw <= 4096)
-        hipLaunchKernelGGL(norm_gate_add_stats_kernel<4>, grid, block, 0, st, out, out_mean, out_rstd, x, mean, rstd, gate, shortcut, sc_mean, sc_rstd, ss, prelu, C, h, w, eps);
+        hipLaunchKernelGGL((norm_gate_add_stats_kernel<4, false>), grid, block, 0, st, out, out_mean, out_rstd, x, mean, rstd, gate, shortcut, sc_mean, sc_rstd, ss, prelu, C, h, w, eps, 0.f);
     else
-        hipLaunchKernelGGL(norm_gate_add_stats_kernel<16>, grid, block, 0, st, out, out_mean, out_rstd, x, mean, rstd, gate, shortcut, sc_mean, sc_rstd, ss, prelu, C, h, w, eps);
+        hipLaunchKernelGGL((norm_gate_add_stats_kernel<16, false>), grid, block, 0, st, out, out_mean, out_rstd, x, mean, rstd, gate, shortcut, sc_mean, sc_rstd, ss, prelu, C, h, w, eps, 0.f);
     return check_launch("norm_gate_add_stats");
+}
+
+extern "C" int e4s_norm_self_gate_add_stats(float* out, float* out_mean, float* out_rstd, const float* x, float in_eps, const float* gate, const float* shortcut,
+                                            const float* sc_mean, const float* sc_rstd, int sc_stride, const float* prelu, int bs, int C, int h, int w, float eps,
+                                            void* stream) {
+    E4S_REQUIRE(out && out_mean && out_rstd && x, "norm_self_gate_add_stats: null tensor");
+    E4S_REQUIRE(bs >= 0 && C >= 1 && h >= 1 && w >= 1 && (int64_t)bs * C <= 0x7fffffff, "norm_self_gate_add_stats: bad size");
+    E4S_REQUIRE(((h * w) & 3) == 0 && h * w <= 16384, "norm_self_gate_add_stats: planes of 4 .. 16384 pixels, a multiple of 4");
+    E4S_REQUIRE((sc_mean == nullptr) == (sc_rstd == nullptr), "norm_self_gate_add_stats: sc_mean / sc_rstd go together");
+    E4S_REQUIRE(!shortcut || sc_stride >= 1, "norm_self_gate_add_stats: bad shortcut stride");
+    if (bs == 0) return 0;
+    const int hw = h * w, ss = shortcut ? sc_stride : 1;
+    const dim3 grid(bs * C), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (hw <= 1024)
+        hipLaunchKernelGGL((norm_gate_add_stats_kernel<1, true>), grid, block, 0, st, out, out_mean, out_rstd, x, nullptr, nullptr, gate, shortcut, sc_mean, sc_rstd, ss, prelu, C, h, w, eps, in_eps);
+    else if (hw <= 4096)
+        hipLaunchKernelGGL((norm_gate_add_stats_kernel<4, true>), grid, block, 0, st, out, out_mean, out_rstd, x, nullptr, nullptr, gate, shortcut, sc_mean, sc_rstd, ss, prelu, C, h, w, eps, in_eps);
+    else
+        hipLaunchKernelGGL((norm_gate_add_stats_kernel<16, true>), grid, block, 0, st, out, out_mean, out_rstd, x, nullptr, nullptr, gate, shortcut, sc_mean, sc_rstd, ss, prelu, C, h, w, eps, in_eps);
+    return check_launch("norm_self_gate_add_stats");
 }
 
 // ------------------------------------------------------------------------------------ masked average pooling per region

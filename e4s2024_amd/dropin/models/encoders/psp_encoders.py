@@ -9,10 +9,10 @@ default ``--fsencoder_type psp`` and out of scope.
 
 The torch.nn layers below are *parameter holders* that give the state_dict the reference's key names
 (``res_layer.{1,2,3}.weight``, ``res_layer.5.fc{1,2}.weight``, ``shortcut_layer.0.weight``); the arithmetic runs in
-libe4s_hip.so (conv.hip / conv_mx3.hip / norm.hip).  One unit (inference) = four launches, six with a shortcut convolution:
+libe4s_hip.so (conv.hip / conv_mx3.hip / norm.hip).  One unit (inference) = three launches, five with a shortcut convolution:
 
-    conv3x3(IN(x) applied while staging, PReLU epilogue) -> conv3x3(stride) -> IN statistics
-             -> [shortcut conv1x1(stride) -> stats] -> IN apply * gate + shortcut add (+ the statistics of the result for the next unit)
+    conv3x3(IN(x) applied while staging, PReLU epilogue) -> conv3x3(stride)
+             -> [shortcut conv1x1(stride) -> stats] -> IN statistics + IN apply * gate + shortcut add (+ the statistics of the result for the next unit)
 
 (the SE gate behind the affine-free InstanceNorm is the constant 1/2 — ops.SE_GATE_IS_HALF; computed from the plane's measured mean when that is switched off)
 """
@@ -90,9 +90,11 @@ class bottleneck_IR_SE_Ours(Module):
             r = ops.conv3x3_s1(r, rl[3].weight, self._wino[1])
         else:
             r = ops.conv2d(r, self._w[1].get(rl[3].weight), self.stride, 1)
-        if ops.SE_GATE_IS_HALF and not torch.is_grad_enabled():
-            # SEModule behind an affine-free InstanceNorm: its squeeze is the mean of a normalised plane = 0, its bias-free gate sigmoid(0) = 1/2 (ops.SE_GATE_IS_HALF)
-            m2, r2 = ops.plane_stats(r, rl[4].eps)
+        self_stats = ops.SE_GATE_IS_HALF and not torch.is_grad_enabled()
+        if self_stats:
+            # SEModule behind an affine-free InstanceNorm: its squeeze is the mean of a normalised plane = 0, its bias-free gate sigmoid(0) = 1/2 (ops.SE_GATE_IS_HALF);
+            # nothing then needs r's statistics before the unit's last launch, which computes them itself
+            m2 = r2 = None
             gate = ops.half_gate(r.shape[0], r.shape[1], r.device)
         else:
             m2, r2, pooled = ops.plane_stats(r, rl[4].eps, want_nmean=True)             # IN statistics + mean of the normalised map
@@ -105,7 +107,7 @@ class bottleneck_IR_SE_Ours(Module):
         if torch.is_grad_enabled():
             out = ops.norm_gate_add(r, m2, r2, gate, sc, sc_stats, sc_stride)
             return ops._attach("bottleneck_IR_SE_Ours", out, x, *[p for p in self.parameters()])
-        out, om, orr = ops.norm_gate_add(r, m2, r2, gate, sc, sc_stats, sc_stride, stats_eps=rl[0].eps)
+        out, om, orr = ops.norm_gate_add(r, m2, r2, gate, sc, sc_stats, sc_stride, stats_eps=rl[0].eps, self_eps=rl[4].eps if self_stats else None)
         out._e4s_in_stats = (om, orr, rl[0].eps)        # every unit's first InstanceNorm has the default eps
         return out
 

@@ -1579,11 +1579,19 @@ def half_gate(bs: int, C: int, device) -> torch.Tensor:
 NGA_STATS_MAX_PIXELS = 16384          # planes a single workgroup holds in registers (e4s_norm_gate_add_stats)
 
 
-def norm_gate_add(x, mean=None, rstd=None, gate=None, shortcut=None, sc_stats=None, sc_stride: int = 1, prelu=None, stats_eps: Optional[float] = None):
+def norm_gate_add(x, mean=None, rstd=None, gate=None, shortcut=None, sc_stats=None, sc_stride: int = 1, prelu=None, stats_eps: Optional[float] = None,
+                  self_eps: Optional[float] = None):
     """``prelu(((x - mean) * rstd) * gate + shortcut')``.  With ``stats_eps`` the InstanceNorm statistics of the RESULT come back as well:
-    ``(out, mean_out, rstd_out)`` — from the same launch for planes of up to 16384 pixels, from ``plane_stats`` otherwise."""
+    ``(out, mean_out, rstd_out)`` — from the same launch for planes of up to 16384 pixels, from ``plane_stats`` otherwise.  ``self_eps`` (instead of ``mean`` / ``rstd``,
+    with ``stats_eps``): the statistics of ``x`` itself are computed in that launch too (``e4s_norm_self_gate_add_stats``; ``plane_stats`` first where the plane does not fit)."""
     x = _c(x, "input")
     bs, C, h, w = x.shape
+    if self_eps is not None:
+        if mean is not None or rstd is not None or stats_eps is None:
+            raise ValueError("norm_gate_add: self_eps replaces mean / rstd and goes with stats_eps")
+        if not ((h * w) % 4 == 0 and h * w <= NGA_STATS_MAX_PIXELS):
+            mean, rstd = plane_stats(x, self_eps)
+            self_eps = None
     out = torch.empty_like(x)
     sc = scm = scr = None
     if shortcut is not None:
@@ -1593,6 +1601,12 @@ def norm_gate_add(x, mean=None, rstd=None, gate=None, shortcut=None, sc_stats=No
         if sc_stats is not None:
             scm, scr = _c(sc_stats[0], "sc_mean"), _c(sc_stats[1], "sc_rstd")
     pr = _p(_c(prelu.detach(), "prelu")) if prelu is not None else None
+    if self_eps is not None:
+        om = torch.empty((bs, C), dtype=torch.float32, device=x.device)
+        orr = torch.empty_like(om)
+        lib().call("e4s_norm_self_gate_add_stats", _p(out), _p(om), _p(orr), _p(x), float(self_eps), _p(gate), _p(sc), _p(scm), _p(scr), sc_stride, pr,
+                   bs, C, h, w, float(stats_eps), _stream())
+        return out, om, orr
     if stats_eps is not None and (h * w) % 4 == 0 and h * w <= NGA_STATS_MAX_PIXELS:
         om = torch.empty((bs, C), dtype=torch.float32, device=x.device)
         orr = torch.empty_like(om)

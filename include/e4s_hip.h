@@ -394,6 +394,12 @@ E4S_API int e4s_se_gate(float* gate, const float* pooled, const float* w1, const
 E4S_API int e4s_norm_gate_add_stats(float* out, float* out_mean, float* out_rstd, const float* x, const float* mean, const float* rstd,
                                     const float* gate, const float* shortcut, const float* sc_mean, const float* sc_rstd, int sc_stride,
                                     const float* prelu, int bs, int C, int h, int w, float eps, void* stream);
+/* The same with the InstanceNorm statistics of the INPUT x computed in the launch as well (mean and 1 / sqrt(var + in_eps) of every plane, exactly e4s_plane_stats' sums):
+ * out = prelu( IN(x) * gate + shortcut' ) and the statistics of out — InstanceNorm2d(depth) + SEModule + the shortcut add of bottleneck_IR_SE_Ours (helpers.py:128-144) in one
+ * launch, for a gate that does not depend on x (the host passes the constant 1/2: see ops.SE_GATE_IS_HALF). */
+E4S_API int e4s_norm_self_gate_add_stats(float* out, float* out_mean, float* out_rstd, const float* x, float in_eps, const float* gate, const float* shortcut,
+                                         const float* sc_mean, const float* sc_rstd, int sc_stride, const float* prelu, int bs, int C, int h, int w, float eps,
+                                         void* stream);
 
 /* Masked average pooling per region (psp_encoders.py:355-375): out[bs,nreg,C] = mean of feats[bs,C,h,w] over the pixels whose
  * label (uint8 [bs,lh,lw], sampled nearest at h x w) equals the region, zeros for an empty region. */

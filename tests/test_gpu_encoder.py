@@ -221,6 +221,11 @@ def test_fused_se_gate_and_statistics_emitting_norm_gate_add_match_the_separate_
         assert torch.equal(out, ref) and torch.equal(om, rm), (bs, C, h, ss)
         # rstd: the same sums, but the compiler contracts the squares into FMAs differently in the two kernels: an ulp or two
         assert ((orr - rr).abs() <= 4e-7 * rr.abs()).all(), (bs, C, h, ss, ((orr - rr).abs() / rr.abs()).max().item())
+        # ... and with the INPUT's statistics computed in the same launch (self_eps): what plane_stats + the launch above give, to the same ulp or two of rstd
+        out2, om2, orr2 = ops.norm_gate_add(x, None, None, gate, sc, scs, ss, pr, stats_eps=1e-5, self_eps=1e-5)
+        scale = float(ref.abs().max())
+        assert float((out2 - ref).abs().max()) <= 4e-6 * scale, (bs, C, h, ss, float((out2 - ref).abs().max()))
+        assert ((om2 - rm).abs() <= 4e-6 * scale).all() and ((orr2 - rr).abs() <= 1e-5 * rr.abs()).all()
 
 
 @pytest.mark.parametrize("bs,cin,cout,h,w,norm,act", [(2, 32, 48, 8, 12, True, True), (1, 64, 64, 32, 32, False, False), (3, 40, 24, 6, 10, True, False),
