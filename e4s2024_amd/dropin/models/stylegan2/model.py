@@ -455,6 +455,17 @@ class Generator(nn.Module):
         if noise is None:
             if randomize_noise:
                 noise = [None] * self.num_layers
+                st0 = styles[0] if isinstance(styles, (list, tuple)) else styles
+                if torch.is_tensor(st0) and st0.is_cuda:
+                    # one normal_() for every layer's fresh noise map (reference :331-333 draws one per layer: 17 launches per pass — in the PTI step they are 17 of
+                    # its ~600 launches); layer i's map is a view [bs, 1, H, W] of the flat draw
+                    bs_n = st0.shape[0]
+                    shapes = [tuple(getattr(self.noises, f"noise_{i}").shape[-2:]) for i in range(self.num_layers)]
+                    flat = torch.empty(bs_n * sum(h * w for h, w in shapes), dtype=torch.float32, device=st0.device).normal_()
+                    o = 0
+                    for i, (h, w) in enumerate(shapes):
+                        noise[i] = flat[o:o + bs_n * h * w].view(bs_n, 1, h, w)
+                        o += bs_n * h * w
             else:
                 noise = [getattr(self.noises, f"noise_{i}") for i in range(self.num_layers)]
 
