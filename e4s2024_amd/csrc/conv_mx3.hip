@@ -16,8 +16,10 @@
 //              E8M0 scales [half 2][co 128] x 4 B (byte 0: fp6(w1), byte 1: fp6(w - w1); k half = tap 2u / 2u + 1, its 32 channels in order)
 //   patch:     a1 f16 [16-B slot 4][pixel 352] (slot s = channels 8 s .. 8 s + 7) | codes first 16 B [term 2][pixel] | last 8 B [term][pixel] | scales [pixel] x 4 B
 // Every vector-memory request inside the loop is issued from inline asm (weight DMA and the next chunk's activation loads), so hipcc counts none of them and
-// the counted vmcnt waits below are exact; the activation loads' destination registers are first read in the store phase, behind such a wait, and the loads
-// have ONE call site (their results are asm outputs: a merge of two call sites' registers would copy them before the data has landed).
+// the counted vmcnt waits below are exact; the activation loads' destination registers are first read in the store phase, behind such a wait.  Their results are asm
+// outputs, so a register copy between the request and that wait would copy stale data: the prefetch is requested at the TOP of the iteration that consumes it (not in the
+// previous iteration's store phase, where it was one barrier earlier: measured <= 0.4 % of the encoder) — the registers are defined and used inside one iteration, there
+// is no loop-carried value for the compiler to merge, and the loop has ONE call site (the prologue's request is waited for and consumed before the loop).
 // Measured (16 images, in-run against e4s_conv3x3_mx): 512 -> 512 @32^2 0.1776 -> 0.1498 ms (516 algorithmic TFLOP/s), 256 -> 256 @64^2 0.184 -> 0.163;
 // cycle stamps (-DMX3_PROF): read phase 1 000 - 1 150 cycles (550 of LDS reads + the wave's share of the refill requests: the CU's address unit takes ~30
 // cycles per 1 KB request and stalls the issuing wave), MFMA phase 870; without the in-loop refills (-DMX3_NODMA) the kernel takes 0.134 ms.
@@ -323,7 +325,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
     E4S_WAIT_VM(0);
     E4S_LDS_BARRIER();          // (also: the norm table is written)
     store_x(0);
-    if (nchunk > 1) load_x(1);
     E4S_LDS_BARRIER();
     if (grp) E4S_LDS_BARRIER(); // waves 4-7: half a unit behind from here on
 
@@ -341,6 +342,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
 #pragma unroll 1
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         const bool more = chunk + 1 < nchunk;
+        // The next chunk's activations are requested HERE and consumed by this iteration's store phase: the prefetch registers are defined and used inside one iteration
+        // (no loop-carried value whose merge the compiler could materialise as a copy before the data has landed: round-3 advisor finding), with ONE in-loop call site.
+        if (more) load_x(chunk + 1);
 #pragma unroll
         for (int u = 0; u < NUNIT; ++u, ++g) {
             // ---------------- R phase: every operand of the unit into registers, one round of LDS reads
@@ -450,11 +454,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
         if (more) {
             // ---------------- store phase: the patch has ONE buffer, so between two chunks nobody reads.  Both groups convert at the same time — waves 0-3 after
             // their barrier, waves 4-7 (above) behind their last MFMA phase, in front of the same barrier — and one more barrier lets waves 0-3 run ahead
-            // again.  The prefetch registers are refilled as soon as they are free (its last part landed long ago: no wait).
-            // (ONE call site of load_x: its results come from asm and are valid only behind a later wait — a merge of two sites' registers would copy them early)
+            // again.  (The prefetch registers are refilled at the top of the next iteration: see there.)
             // (measured against the serial form — waves 0-3 convert during waves 4-7's last MFMA phase, then waves 4-7, two barriers: 0.1498 vs 0.1518 ms)
             if (!grp) store_x(chunk + 1);
-            if (chunk + 2 < nchunk) load_x(chunk + 2);
             E4S_LDS_BARRIER();
             MX3_STAMP(tST)
         }
