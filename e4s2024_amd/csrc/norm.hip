@@ -337,18 +337,99 @@ extern "C" int e4s_norm_gate_add_stats(float* out, float* out_mean, float* out_r
     return check_launch("norm_gate_add_stats");
 }
 
+// The same for planes of up to 65 536 pixels without a shortcut (the encoder's input layer, psp_encoders.py:335-336: InstanceNorm2d(64) + PReLU on 256 x 256 maps): 1 024 threads per
+// plane, 16 float4 each — statistics, normalisation, PReLU and the statistics of the result in one launch instead of plane_stats + norm_gate_add + plane_stats (three passes
+// over 268 MB per batch of 16 images).
+__device__ __forceinline__ float block_sum16(float v, float* sh) {       // 1 024 threads; result valid in every thread
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[k];
+    return t;
+}
+__global__ __launch_bounds__(1024) void norm_self_stats_big_kernel(float* __restrict__ out, float* __restrict__ omean, float* __restrict__ orstd, const float* __restrict__ x,
+                                                                   const float* __restrict__ gate, const float* __restrict__ prelu, int C, int hw, float eps, float in_eps) {
+    constexpr int IT = 16;
+    __shared__ float sh[16];
+    const int plane = blockIdx.x, c = plane % C;
+    const float g = gate ? gate[plane] : 1.f, sl = prelu ? prelu[c] : 1.f;
+    const float* xp = x + (size_t)plane * hw;
+    float* op = out + (size_t)plane * hw;
+    float4 v[IT];
+    float s0 = 0.f;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int i = threadIdx.x * 4 + it * 4096;
+        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < hw) {
+            v[it] = *reinterpret_cast<const float4*>(xp + i);
+            s0 += (v[it].x + v[it].y) + (v[it].z + v[it].w);
+        }
+    }
+    const float m = block_sum16(s0, sh) / (float)hw;
+    float q0 = 0.f;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int i = threadIdx.x * 4 + it * 4096;
+        if (i < hw) {
+            const float a = v[it].x - m, b2 = v[it].y - m, c2 = v[it].z - m, d = v[it].w - m;
+            q0 += (a * a + b2 * b2) + (c2 * c2 + d * d);
+        }
+    }
+    const float r = 1.0f / sqrtf(block_sum16(q0, sh) / (float)hw + in_eps);
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int i = threadIdx.x * 4 + it * 4096;
+        if (i < hw) {
+            float e[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float u = (e[j] - m) * r * g;
+                e[j] = u > 0.f ? u : u * sl;
+            }
+            *reinterpret_cast<float4*>(op + i) = make_float4(e[0], e[1], e[2], e[3]);
+            s += (e[0] + e[1]) + (e[2] + e[3]);
+        }
+    }
+    const float mo = block_sum16(s, sh) / (float)hw;          // (the barrier inside also orders this thread's stores before its re-reads below)
+    float q = 0.f;
+#pragma unroll 4
+    for (int it = 0; it < IT; ++it) {                          // second moment of the result: its values come back from the cache (128 registers per thread hold one copy of the plane, not two)
+        const int i = threadIdx.x * 4 + it * 4096;
+        if (i < hw) {
+            const float4 w4 = *reinterpret_cast<const float4*>(op + i);
+            const float a = w4.x - mo, b2 = w4.y - mo, c2 = w4.z - mo, d = w4.w - mo;
+            q += (a * a + b2 * b2) + (c2 * c2 + d * d);
+        }
+    }
+    const float var = block_sum16(q, sh) / (float)hw;
+    if (threadIdx.x == 0) {
+        omean[plane] = mo;
+        orstd[plane] = 1.0f / sqrtf(var + eps);
+    }
+}
+
 extern "C" int e4s_norm_self_gate_add_stats(float* out, float* out_mean, float* out_rstd, const float* x, float in_eps, const float* gate, const float* shortcut,
                                             const float* sc_mean, const float* sc_rstd, int sc_stride, const float* prelu, int bs, int C, int h, int w, float eps,
                                             void* stream) {
     E4S_REQUIRE(out && out_mean && out_rstd && x, "norm_self_gate_add_stats: null tensor");
     E4S_REQUIRE(bs >= 0 && C >= 1 && h >= 1 && w >= 1 && (int64_t)bs * C <= 0x7fffffff, "norm_self_gate_add_stats: bad size");
-    E4S_REQUIRE(((h * w) & 3) == 0 && h * w <= 16384, "norm_self_gate_add_stats: planes of 4 .. 16384 pixels, a multiple of 4");
+    E4S_REQUIRE(((h * w) & 3) == 0 && (h * w <= 16384 || (h * w <= 65536 && !shortcut)), "norm_self_gate_add_stats: planes of 4 .. 16384 pixels (65536 without a shortcut), a multiple of 4");
     E4S_REQUIRE((sc_mean == nullptr) == (sc_rstd == nullptr), "norm_self_gate_add_stats: sc_mean / sc_rstd go together");
     E4S_REQUIRE(!shortcut || sc_stride >= 1, "norm_self_gate_add_stats: bad shortcut stride");
     if (bs == 0) return 0;
     const int hw = h * w, ss = shortcut ? sc_stride : 1;
     const dim3 grid(bs * C), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (hw > 16384) {
+        hipLaunchKernelGGL(norm_self_stats_big_kernel, grid, dim3(1024), 0, st, out, out_mean, out_rstd, x, gate, prelu, C, hw, eps, in_eps);
+        return check_launch("norm_self_gate_add_stats");
+    }
     if (hw <= 1024)
         hipLaunchKernelGGL((norm_gate_add_stats_kernel<1, true>), grid, block, 0, st, out, out_mean, out_rstd, x, nullptr, nullptr, gate, shortcut, sc_mean, sc_rstd, ss, prelu, C, h, w, eps, in_eps);
     else if (hw <= 4096)

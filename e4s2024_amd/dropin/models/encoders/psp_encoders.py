@@ -149,11 +149,11 @@ class FSEncoder_PSP(Module):
         region map, so that a caller can run the face parser next to it (``pipeline.swap_batch``)."""
         il = self.input_layer
         y = ops.conv2d(x, self._w_in.get(il[0].weight), 1, 1)
-        mean, rstd = ops.plane_stats(y, il[1].eps)
         if torch.is_grad_enabled():
+            mean, rstd = ops.plane_stats(y, il[1].eps)
             x = ops.norm_gate_add(y, mean, rstd, prelu=il[2].weight)
-        else:
-            x, om, orr = ops.norm_gate_add(y, mean, rstd, prelu=il[2].weight, stats_eps=il[1].eps)
+        else:       # InstanceNorm2d(64) statistics + apply + PReLU + the statistics of the result (the first unit's InstanceNorm) in one launch
+            x, om, orr = ops.norm_gate_add(y, prelu=il[2].weight, stats_eps=il[1].eps, self_eps=il[1].eps)
             x._e4s_in_stats = (om, orr, il[1].eps)
         taps = {}
         for i, unit in enumerate(self.body):

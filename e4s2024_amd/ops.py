@@ -1589,7 +1589,7 @@ def norm_gate_add(x, mean=None, rstd=None, gate=None, shortcut=None, sc_stats=No
     if self_eps is not None:
         if mean is not None or rstd is not None or stats_eps is None:
             raise ValueError("norm_gate_add: self_eps replaces mean / rstd and goes with stats_eps")
-        if not ((h * w) % 4 == 0 and h * w <= NGA_STATS_MAX_PIXELS):
+        if not ((h * w) % 4 == 0 and (h * w <= NGA_STATS_MAX_PIXELS or (h * w <= 4 * NGA_STATS_MAX_PIXELS and shortcut is None))):
             mean, rstd = plane_stats(x, self_eps)
             self_eps = None
     out = torch.empty_like(x)

@@ -228,6 +228,23 @@ def test_fused_se_gate_and_statistics_emitting_norm_gate_add_match_the_separate_
         assert ((om2 - rm).abs() <= 4e-6 * scale).all() and ((orr2 - rr).abs() <= 1e-5 * rr.abs()).all()
 
 
+def test_input_layer_norm_in_one_launch():
+    """InstanceNorm2d(64) + PReLU of the encoder's input layer (psp_encoders.py:335-336) on 256 x 256 planes with the statistics of input AND result from the same
+    launch (1 024 threads per plane) against plane_stats + norm_gate_add + plane_stats; also a plane that is not a whole number of 4 096-element rounds."""
+    from e4s2024_amd import ops
+    g = torch.Generator().manual_seed(13)
+    for bs, C, h, w in ((2, 5, 256, 256), (1, 3, 200, 180)):
+        x = (torch.randn(bs, C, h, w, generator=g) * 2 + 0.3).to(DEV)
+        pr = torch.rand(C, generator=g).to(DEV)
+        mean, rstd = ops.plane_stats(x, 1e-5)
+        ref = ops.norm_gate_add(x, mean, rstd, prelu=pr)
+        rm, rr = ops.plane_stats(ref, 1e-5)
+        out, om, orr = ops.norm_gate_add(x, prelu=pr, stats_eps=1e-5, self_eps=1e-5)
+        scale = float(ref.abs().max())
+        assert float((out - ref).abs().max()) <= 4e-6 * scale
+        assert ((om - rm).abs() <= 4e-6 * scale).all() and ((orr - rr).abs() <= 1e-5 * rr.abs()).all()
+
+
 @pytest.mark.parametrize("bs,cin,cout,h,w,norm,act", [(2, 32, 48, 8, 12, True, True), (1, 64, 64, 32, 32, False, False), (3, 40, 24, 6, 10, True, False),
                                                       (16, 512, 512, 32, 32, True, True)])
 def test_winograd_route_of_the_stride1_3x3_convolutions(bs, cin, cout, h, w, norm, act):
