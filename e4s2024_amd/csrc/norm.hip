@@ -337,6 +337,84 @@ extern "C" int e4s_norm_gate_add_stats(float* out, float* out_mean, float* out_r
     return check_launch("norm_gate_add_stats");
 }
 
+// ... and for planes of at most 1 024 pixels (the 32 x 32 and 16 x 16 units: 17 of the encoder's 24) ONE WAVE per plane, four planes per block: the plane is 16 values per
+// lane, every reduction a wave butterfly, no barrier at all (a block per plane spent its time in four block reductions of two barriers each: 21 us per launch).
+__global__ __launch_bounds__(256) void norm_self_wave_kernel(float* __restrict__ out, float* __restrict__ omean, float* __restrict__ orstd, const float* __restrict__ x,
+                                                             const float* __restrict__ gate, const float* __restrict__ sc, const float* __restrict__ sc_mean,
+                                                             const float* __restrict__ sc_rstd, int ss, const float* __restrict__ prelu, int planes, int C, int h, int w,
+                                                             float eps, float in_eps) {
+    const int lane = threadIdx.x & 63;
+    const int plane = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const int c = plane % C;
+    const int hw = h * w;
+    const float g = gate ? gate[plane] : 1.f;
+    const float sm = sc_mean ? sc_mean[plane] : 0.f, sr = sc_rstd ? sc_rstd[plane] : 1.f;
+    const float sl = prelu ? prelu[c] : 1.f;
+    const float* xp = x + (size_t)plane * hw;
+    float* op = out + (size_t)plane * hw;
+    const float* sp = sc ? sc + (size_t)plane * hw * ss * ss : nullptr;
+    const int ws_ = w * ss;
+    float4 v[4];
+    float s0 = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = lane * 4 + it * 256;
+        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < hw) {
+            v[it] = *reinterpret_cast<const float4*>(xp + i);
+            s0 += (v[it].x + v[it].y) + (v[it].z + v[it].w);
+        }
+    }
+    const float m = wave_sum(s0) / (float)hw;
+    float q0 = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = lane * 4 + it * 256;
+        if (i < hw) {
+            const float a = v[it].x - m, b2 = v[it].y - m, c2 = v[it].z - m, d = v[it].w - m;
+            q0 += (a * a + b2 * b2) + (c2 * c2 + d * d);
+        }
+    }
+    const float r = 1.0f / sqrtf(wave_sum(q0) / (float)hw + in_eps);
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = lane * 4 + it * 256;
+        if (i < hw) {
+            float e[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float u = (e[j] - m) * r * g;
+                if (sp) {
+                    const int yy = (i + j) / w, xx = (i + j) - yy * w;
+                    const float sv = (ss == 1) ? sp[i + j] : sp[(size_t)yy * ss * ws_ + xx * ss];
+                    u += (sv - sm) * sr;
+                }
+                e[j] = u > 0.f ? u : u * sl;
+            }
+            v[it] = make_float4(e[0], e[1], e[2], e[3]);
+            *reinterpret_cast<float4*>(op + i) = v[it];
+            s += (e[0] + e[1]) + (e[2] + e[3]);
+        }
+    }
+    const float mo = wave_sum(s) / (float)hw;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = lane * 4 + it * 256;
+        if (i < hw) {
+            const float a = v[it].x - mo, b2 = v[it].y - mo, c2 = v[it].z - mo, d = v[it].w - mo;
+            q += (a * a + b2 * b2) + (c2 * c2 + d * d);
+        }
+    }
+    const float var = wave_sum(q) / (float)hw;
+    if (lane == 0) {
+        omean[plane] = mo;
+        orstd[plane] = 1.0f / sqrtf(var + eps);
+    }
+}
+
 // The same for planes of up to 65 536 pixels without a shortcut (the encoder's input layer, psp_encoders.py:335-336: InstanceNorm2d(64) + PReLU on 256 x 256 maps): 1 024 threads per
 // plane, 16 float4 each — statistics, normalisation, PReLU and the statistics of the result in one launch instead of plane_stats + norm_gate_add + plane_stats (three passes
 // over 268 MB per batch of 16 images).
@@ -431,7 +509,7 @@ extern "C" int e4s_norm_self_gate_add_stats(float* out, float* out_mean, float* 
         return check_launch("norm_self_gate_add_stats");
     }
     if (hw <= 1024)
-        hipLaunchKernelGGL((norm_gate_add_stats_kernel<1, true>), grid, block, 0, st, out, out_mean, out_rstd, x, nullptr, nullptr, gate, shortcut, sc_mean, sc_rstd, ss, prelu, C, h, w, eps, in_eps);
+        hipLaunchKernelGGL(norm_self_wave_kernel, dim3(cdiv(bs * C, 4)), block, 0, st, out, out_mean, out_rstd, x, gate, shortcut, sc_mean, sc_rstd, ss, prelu, bs * C, C, h, w, eps, in_eps);
     else if (hw <= 4096)
         hipLaunchKernelGGL((norm_gate_add_stats_kernel<4, true>), grid, block, 0, st, out, out_mean, out_rstd, x, nullptr, nullptr, gate, shortcut, sc_mean, sc_rstd, ss, prelu, C, h, w, eps, in_eps);
     else
