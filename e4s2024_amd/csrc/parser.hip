@@ -114,7 +114,8 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 // ONCE, coalesced, into LDS; the vertical pass writes a [tile rows][region columns] buffer; the horizontal pass reads it.  Sums in the order of the direct form this replaces
 // (column: taps i = 0 .. K - 1 ascending; then the row taps j ascending) — value for value the same results; the direct form read 64 (F = 2) scattered values per output
 // from global memory: 434 us for the sixteen 1024^2 images of a swap batch whose bytes take 60.
-template <int F>
+// PM1: the input is the swap pipeline's [-1, 1] image; (v + 1) * 0.5 on load is torch's ``(img + 1) / 2`` value for value (the pass this saves read and wrote the batch twice).
+template <int F, bool PM1>
 __global__ __launch_bounds__(256) void bicubic_down_norm_kernel(float* __restrict__ out, const float* __restrict__ in,
                                                                 const float* __restrict__ taps, const float* __restrict__ mean,
                                                                 const float* __restrict__ stdv, int C, int h, int w, int oh, int ow, int do_norm) {
@@ -135,7 +136,8 @@ __global__ __launch_bounds__(256) void bicubic_down_norm_kernel(float* __restric
         const int ry = e / RW, rx = e - ry * RW;
         // (rows / columns of a partial tile far outside the image feed no stored output: reflected once, then clamped so that the read stays inside the plane)
         const int sy = min(max(reflect_idx(iy0 + ry, h), 0), h - 1), sx = min(max(reflect_idx(ix0 + rx, w), 0), w - 1);
-        reg[ry][rx] = p[(size_t)sy * w + sx];
+        const float v = p[(size_t)sy * w + sx];
+        reg[ry][rx] = PM1 ? (v + 1.f) * 0.5f : v;
     }
     __syncthreads();
     for (int e = threadIdx.x; e < TH * RW; e += 256) {       // vertical pass (first pass of the reference's separable filter)
@@ -173,12 +175,13 @@ __global__ __launch_bounds__(256) void clamp_normalize_kernel(float* __restrict_
     }
 }
 
-extern "C" int e4s_bicubic_down_normalize(float* out, const float* in, const float* taps, const float* mean, const float* stdv, int bs, int C,
-                                          int h, int w, int factor, void* stream) {
+static int bicubic_down_normalize(float* out, const float* in, const float* taps, const float* mean, const float* stdv, int bs, int C, int h, int w, int factor,
+                                  bool pm1, void* stream) {
     E4S_REQUIRE(out && in, "bicubic_down_normalize: null tensor");
     E4S_REQUIRE(bs >= 0 && C >= 1 && (int64_t)bs * C <= 65535 && h >= 1 && w >= 1, "bicubic_down_normalize: bad size");
     if (factor == 1) {  // no resampling (input already at the parser resolution): clamp + normalise only
         E4S_REQUIRE(mean && stdv, "bicubic_down_normalize: factor 1 needs mean/std");
+        E4S_REQUIRE(!pm1, "bicubic_down_normalize: the [-1, 1] input form needs factor 2 or 4");
         if (bs == 0) return 0;
         const int gx = cdiv(h * w, 256) < 256 ? cdiv(h * w, 256) : 256;
         hipLaunchKernelGGL(clamp_normalize_kernel, dim3(gx, bs * C), dim3(256), 0, (hipStream_t)stream, out, in, mean, stdv, C, h * w);
@@ -193,11 +196,26 @@ extern "C" int e4s_bicubic_down_normalize(float* out, const float* in, const flo
     const int oh = (h - factor) / factor + 1, ow = (w - factor) / factor + 1;
     dim3 grid(cdiv(ow, 128 / factor), cdiv(oh, 32 / factor), bs * C);
     hipStream_t st = (hipStream_t)stream;
-    if (factor == 2)
-        hipLaunchKernelGGL(bicubic_down_norm_kernel<2>, grid, dim3(256), 0, st, out, in, taps, mean, stdv, C, h, w, oh, ow, mean ? 1 : 0);
+    const int nrm = mean ? 1 : 0;
+    if (factor == 2 && pm1)
+        hipLaunchKernelGGL((bicubic_down_norm_kernel<2, true>), grid, dim3(256), 0, st, out, in, taps, mean, stdv, C, h, w, oh, ow, nrm);
+    else if (factor == 2)
+        hipLaunchKernelGGL((bicubic_down_norm_kernel<2, false>), grid, dim3(256), 0, st, out, in, taps, mean, stdv, C, h, w, oh, ow, nrm);
+    else if (pm1)
+        hipLaunchKernelGGL((bicubic_down_norm_kernel<4, true>), grid, dim3(256), 0, st, out, in, taps, mean, stdv, C, h, w, oh, ow, nrm);
     else
-        hipLaunchKernelGGL(bicubic_down_norm_kernel<4>, grid, dim3(256), 0, st, out, in, taps, mean, stdv, C, h, w, oh, ow, mean ? 1 : 0);
+        hipLaunchKernelGGL((bicubic_down_norm_kernel<4, false>), grid, dim3(256), 0, st, out, in, taps, mean, stdv, C, h, w, oh, ow, nrm);
     return check_launch("bicubic_down_normalize");
+}
+
+extern "C" int e4s_bicubic_down_normalize(float* out, const float* in, const float* taps, const float* mean, const float* stdv, int bs, int C,
+                                          int h, int w, int factor, void* stream) {
+    return bicubic_down_normalize(out, in, taps, mean, stdv, bs, C, h, w, factor, false, stream);
+}
+
+extern "C" int e4s_bicubic_down_normalize_pm1(float* out, const float* in, const float* taps, const float* mean, const float* stdv, int bs, int C,
+                                              int h, int w, int factor, void* stream) {
+    return bicubic_down_normalize(out, in, taps, mean, stdv, bs, C, h, w, factor, true, stream);
 }
 
 // ------------------------------------------------------------------------------------ tensor2im

@@ -89,7 +89,7 @@ class FaceParser(nn.Module):
         self.seg.eval()
 
     # ---- tensor entry points -------------------------------------------------------------------------------------
-    def preprocess_tensor(self, img01, downsample=True):
+    def preprocess_tensor(self, img01, downsample=True, pm1=False, out=None):
         """``[bs, 3, S, S]`` in [0, 1] -> normalised ``[bs, 3, S / f, S / f]``.  As in the reference (:152-156) every image that is at
         least 512 wide goes through ``self.downsample``, whose factor ``f = self.size // 512`` is fixed by the constructor and NOT derived
         from the image: the default ``size=1024`` parser maps 1024 -> 512 (the only case on the swap path), 512 -> 256, 2048 -> 1024.
@@ -97,15 +97,33 @@ class FaceParser(nn.Module):
         and normalise only."""
         f = self.downsample.factor if downsample else 1
         if f == 1:
-            return ops.bicubic_down_normalize(img01, None, 1, self._mean, self._std)     # clamp + normalise only
+            if pm1:
+                img01 = (img01 + 1) / 2
+            return ops.bicubic_down_normalize(img01, None, 1, self._mean, self._std, out=out)     # clamp + normalise only
         if img01.shape[-1] % f or img01.shape[-2] % f:
             raise ValueError(f"image size {tuple(img01.shape[-2:])} is not a multiple of the parser's down-sampling factor {f}")
-        return ops.bicubic_down_normalize(img01, self.downsample.taps.to(img01.device), f, self._mean, self._std)
+        return ops.bicubic_down_normalize(img01, self.downsample.taps.to(img01.device), f, self._mean, self._std, out=out, pm1=pm1)
 
-    def parse_batch(self, img01, seg12=True):
-        """``[bs, 3, S, S]`` in [0, 1] -> uint8 labels ``[bs, 512, 512]`` (12-class when ``seg12``)."""
+    def parse_batch(self, img01, seg12=True, pm1=False):
+        """``[bs, 3, S, S]`` in [0, 1] -> uint8 labels ``[bs, 512, 512]`` (12-class when ``seg12``).  ``pm1``: the images are in [-1, 1] (the
+        pipeline's range) and ``(img + 1) / 2`` happens inside the down-sampling kernel.  ``img01`` may be a sequence of such batches (same
+        size each): they are parsed as ONE batch — every part is down-sampled into its slice of the network's input, no concatenated copy of
+        the full-size images is made."""
         with torch.no_grad():
-            return self.seg.parse(self.preprocess_tensor(img01), self._lut12 if seg12 else None)
+            if isinstance(img01, (list, tuple)):
+                f = self.downsample.factor
+                n = [int(t.shape[0]) for t in img01]
+                first = img01[0]
+                x = torch.empty((sum(n), first.shape[1], first.shape[2] // f, first.shape[3] // f), dtype=torch.float32, device=first.device)
+                lo = 0
+                for t, k in zip(img01, n):
+                    if tuple(t.shape[1:]) != tuple(first.shape[1:]):
+                        raise ValueError("parse_batch: the parts of a batch must have one image size")
+                    self.preprocess_tensor(t, pm1=pm1, out=x[lo:lo + k])
+                    lo += k
+            else:
+                x = self.preprocess_tensor(img01, pm1=pm1)
+            return self.seg.parse(x, self._lut12 if seg12 else None)
 
     # ---- reference API -------------------------------------------------------------------------------------------
     def preprocess_img(self, img):

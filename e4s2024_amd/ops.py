@@ -1628,10 +1628,19 @@ def masked_avg_pool(feats: torch.Tensor, labels: torch.Tensor, nreg: int) -> tor
     return out
 
 
-def bilinear_resize(x: torch.Tensor, size, align_corners: bool = False) -> torch.Tensor:
+def _out_like(out: Optional[torch.Tensor], shape, device, name: str) -> torch.Tensor:
+    """``out=`` of the resize ops: a contiguous float32 CUDA tensor of exactly ``shape`` (e.g. one half of a batch buffer), or a new one."""
+    if out is None:
+        return torch.empty(shape, dtype=torch.float32, device=device)
+    if not (isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == tuple(shape)):
+        raise ValueError(f"{name}: out= must be a contiguous float32 CUDA tensor of shape {tuple(shape)}")
+    return out
+
+
+def bilinear_resize(x: torch.Tensor, size, align_corners: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     x = _c(x, "input")
     bs, C, h, w = x.shape
-    out = torch.empty((bs, C, size[0], size[1]), dtype=torch.float32, device=x.device)
+    out = _out_like(out, (bs, C, size[0], size[1]), x.device, "bilinear_resize")
     lib().call("e4s_bilinear_resize", _p(out), _p(x), bs * C, h, w, size[0], size[1], 1 if align_corners else 0, _stream())
     return out
 
@@ -1664,12 +1673,13 @@ def bilinear_argmax(logits: torch.Tensor, size, lut: Optional[torch.Tensor] = No
 
 
 def bicubic_down_normalize(img01: torch.Tensor, taps: torch.Tensor, factor: int, mean: Optional[torch.Tensor] = None,
-                           std: Optional[torch.Tensor] = None) -> torch.Tensor:
+                           std: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, pm1: bool = False) -> torch.Tensor:
+    """``pm1``: the image is in [-1, 1] and ``(img + 1) / 2`` is applied on load (the same values; saves the pass that makes the [0, 1] copy)."""
     x = _c(img01, "image")
     bs, C, h, w = x.shape
-    out = torch.empty((bs, C, h // factor, w // factor), dtype=torch.float32, device=x.device)
-    lib().call("e4s_bicubic_down_normalize", _p(out), _p(x), _p(_c(taps, "taps")) if taps is not None else None, _p(mean), _p(std), bs, C, h, w,
-               factor, _stream())
+    out = _out_like(out, (bs, C, h // factor, w // factor), x.device, "bicubic_down_normalize")
+    lib().call("e4s_bicubic_down_normalize_pm1" if pm1 else "e4s_bicubic_down_normalize", _p(out), _p(x),
+               _p(_c(taps, "taps")) if taps is not None else None, _p(mean), _p(std), bs, C, h, w, factor, _stream())
     return out
 
 

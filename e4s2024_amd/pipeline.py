@@ -108,22 +108,27 @@ def _swap_batch_once(net, parser, driven, target, comp_indices, randomize_noise,
         two_streams = TWO_STREAMS
     if batched:
         bs = driven.shape[0]
-        both = torch.cat([driven, target])
         enc = getattr(net, "encoder", None)
         if PARSE_BESIDE_ENCODE and hasattr(enc, "features"):
             # the encoder needs the region maps only for its last step (masked average pooling): the parser runs on a side stream next to
-            # the encoder's body
+            # the encoder's body.  Driven and target faces go through both as ONE batch, but the 2 x bs full-size images are never concatenated,
+            # shifted to [0, 1] or copied: the two down-sampling kernels in front of parser and encoder read them where they are.
             main, side = torch.cuda.current_stream(), _side_stream(driven.device, 0)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                lab = parser.parse_batch((both + 1) / 2, seg12=True)      # uint8 [2 bs, 512, 512]
-            both.record_stream(side)
-            taps = enc.features(ops.bilinear_resize(both, (256, 256), align_corners=False))      # Net3._encode (networks.py:217)
+                lab = parser.parse_batch((driven, target), seg12=True, pm1=True)      # uint8 [2 bs, 512, 512]
+            driven.record_stream(side)
+            target.record_stream(side)
+            small = torch.empty((2 * bs, driven.shape[1], 256, 256), dtype=torch.float32, device=driven.device)
+            ops.bilinear_resize(driven, (256, 256), align_corners=False, out=small[:bs])             # Net3._encode (networks.py:217)
+            ops.bilinear_resize(target, (256, 256), align_corners=False, out=small[bs:])
+            taps = enc.features(small)
             main.wait_stream(side)
             lab.record_stream(main)
             vec, _ = enc.codes(taps, lab)
         else:
-            lab = parser.parse_batch((both + 1) / 2, seg12=True)          # uint8 [2 bs, 512, 512]
+            both = torch.cat([driven, target])
+            lab = parser.parse_batch(both, seg12=True, pm1=True)          # uint8 [2 bs, 512, 512]
             vec, _ = net.get_style_vectors(both, lab)
         lab_d, lab_t, vec_d, vec_t = lab[:bs], lab[bs:], vec[:bs], vec[bs:]
         mark("parse+encode_x2")

@@ -430,6 +430,11 @@ E4S_API int e4s_bilinear_argmax(uint8_t* labels, const float* logits, const uint
  * (NULL: plain down-sample, no clamp).  factor 2 or 4; factor 1 = clamp + normalise only (taps ignored). */
 E4S_API int e4s_bicubic_down_normalize(float* out, const float* in, const float* taps, const float* mean, const float* stdv,
                                        int bs, int C, int h, int w, int factor, void* stream);
+/* The same on an image in [-1, 1] (what the swap pipeline holds): the [0, 1] image the parser is given there
+ * (face_swap_video_pipeline.py:217-219: PIL frames -> ToTensor, face_parsing_demo.py:151-156) is (v + 1) * 0.5, applied on load — value for value
+ * what ``e4s_bicubic_down_normalize`` computes from ``(img + 1) / 2``.  factor 2 or 4. */
+E4S_API int e4s_bicubic_down_normalize_pm1(float* out, const float* in, const float* taps, const float* mean, const float* stdv,
+                                           int bs, int C, int h, int w, int factor, void* stream);
 
 /* tensor2im (utils/torch_utils.py:64-76): img [bs,3,h,w] in ~[-1,1] -> uint8 [bs,h,w,3] = trunc(clamp((x+1)/2, 0, 1) * 255). */
 E4S_API int e4s_tensor2im_u8(uint8_t* out, const float* img, int bs, int h, int w, void* stream);

@@ -5,7 +5,7 @@ import torch
 from PIL import Image
 
 from conftest import load_golden, install_dropin, record_parity
-from e4s2024_amd import seeded
+from e4s2024_amd import ops, seeded
 from oracle import e4s_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -122,6 +122,26 @@ def test_parse_batch_matches_single(parser):
     one = parser.parse_batch(img[1:2].contiguous())
     assert both.dtype == torch.uint8 and tuple(both.shape) == (2, 512, 512) and int(both.max()) <= 11
     assert torch.equal(both[1], one[0])
+
+
+def test_parse_batch_takes_the_pipelines_images_where_they_are(parser):
+    """pipeline.swap_batch hands the parser the driven and the target faces as two [-1, 1] tensors: the network input built from them (each part
+    down-sampled into its slice, ``(v + 1) * 0.5`` on load) must be the one built from ``(cat + 1) / 2`` bit for bit, and so must the labels."""
+    a, b = seeded.seeded_image(9, 2, 1024).to(DEV), seeded.seeded_image(10, 3, 1024).to(DEV)
+    ref_in = parser.preprocess_tensor((torch.cat([a, b]) + 1) / 2)
+    assert torch.equal(parser.preprocess_tensor(b, pm1=True), ref_in[2:])
+    out = torch.full((5, 3, 512, 512), float("nan"), device=DEV)
+    parser.preprocess_tensor(a, pm1=True, out=out[:2])
+    parser.preprocess_tensor(b, pm1=True, out=out[2:])
+    assert torch.equal(out, ref_in)
+    assert torch.equal(parser.parse_batch((a, b), pm1=True), parser.parse_batch((torch.cat([a, b]) + 1) / 2))
+    with pytest.raises(ValueError):
+        parser.preprocess_tensor(a, pm1=True, out=out[:3])
+    small = ops.bilinear_resize(torch.cat([a, b]), (256, 256))
+    part = torch.empty_like(small)
+    ops.bilinear_resize(a, (256, 256), out=part[:2])
+    ops.bilinear_resize(b, (256, 256), out=part[2:])
+    assert torch.equal(part, small)
 
 
 def test_training_mode_is_refused(parser):
