@@ -38,6 +38,9 @@ _PROTOS = {
     "e4s_conv3x3_mx3_weight_bytes": [c_int, c_int, c_ptr],
     "e4s_conv_prep_weights_mx3": [c_ptr, c_ptr, c_int, c_int, c_ptr],
     "e4s_conv3x3_mx3": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr],
+    "e4s_conv_prep_weights_mx3_s2": [c_ptr, c_ptr, c_int, c_int, c_ptr],
+    "e4s_conv3x3_s2_mx3": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr],
+    "e4s_conv3x3_mx3_phased": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_uniform_blocks": [c_ptr, c_ptr, c_ptr, c_ptr] + [c_int] * 8 + [c_ptr],
     "e4s_masked_upconv_blocks": [c_ptr] * 11 + [c_int, c_ptr, c_ptr] + [c_int] * 8 + [c_ptr],
     "e4s_modconv_tconv_sb": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr],

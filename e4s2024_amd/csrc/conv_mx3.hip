@@ -74,6 +74,8 @@ struct Mx3Params {
     const float* slope;          // [cout] or null
     int* flags;
     int bs, cin, cout, h, w_, tiles_x, tiles_y;
+    int ho, wo;                  // output size (= h, w_ at stride 1; h / 2, w_ / 2 at stride 2)
+    int phased;                  // stride 1: the OUTPUT is written as phase planes; stride 2: the INPUT is read as phase planes  ([b][c][2 py + px][h / 2][w / 2], h and w even)
 };
 
 __device__ __forceinline__ unsigned pack_f16_rne(float a, float b) {
@@ -111,7 +113,8 @@ __device__ __forceinline__ unsigned resid_pair_f16(float a, float b, unsigned a1
 
 // ============================================================================ weight preparation
 // One thread per (chunk, co tile, unit, k half, co): tap 2 unit + half, its 32 channels.
-__global__ __launch_bounds__(256) void prep_weights_mx3_kernel(unsigned char* __restrict__ dst, const float* __restrict__ weight, int cout, int cin) {
+// s2: the stride-2 kernel's units (see conv3x3_mx3_kernel<true>): unit u, half d = tap S2TAP[u][d] of the 3 x 3 kernel (-1: none, zero weights)
+__global__ __launch_bounds__(256) void prep_weights_mx3_kernel(unsigned char* __restrict__ dst, const float* __restrict__ weight, int cout, int cin, int s2) {
     const int nchunk = cin / CK, ntile = (cout + TN - 1) / TN;
     const int64_t total = (int64_t)nchunk * ntile * NUNIT * 2 * TN;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -121,7 +124,8 @@ __global__ __launch_bounds__(256) void prep_weights_mx3_kernel(unsigned char* __
         const int unit = (int)(r % NUNIT); r /= NUNIT;
         const int tile = (int)(r % ntile);
         const int chunk = (int)(r / ntile);
-        const int co = tile * TN + n, tap = 2 * unit + half;
+        const int s2tap = unit == 0 ? (half ? 2 : 0) : unit == 1 ? (half ? 8 : 6) : unit == 2 ? (half ? 5 : 3) : unit == 3 ? (half ? 7 : 1) : (half ? 9 : 4);
+        const int co = tile * TN + n, tap = s2 ? s2tap : 2 * unit + half;
         unsigned char* slot = dst + (((size_t)chunk * ntile + tile) * NUNIT + unit) * UNITB;
         u32x16 q1, q2;
         float m1 = 0.f, m2 = 0.f;
@@ -162,6 +166,15 @@ __global__ __launch_bounds__(256) void prep_weights_mx3_kernel(unsigned char* __
 }
 
 // ============================================================================ the kernel
+// S2 (round 4): the stride-2, pad-1 form (the regional-style encoder's second convolution of a stage's first unit, helpers.py:128-139 with stride 2).  Output (oy, ox)
+// reads input row 2 oy + ky - 1 = 2 (oy + dy) + py: with the input seen as four PHASE planes (py, px) at half resolution, tap ky = 0 is (py = 1, dy = -1), ky = 1 is
+// (py = 0, dy = 0), ky = 2 is (py = 1, dy = 0), columns alike — every tap is a stride-1 tap (dy, dx) in {-1, 0}^2 of ONE phase plane.  A 32-channel chunk therefore
+// takes FOUR stagings of the same 34 x 10 patch buffer (one per phase plane, pixel (ppy, ppx) = half-resolution position (y0 - 1 + ppy, x0 - 1 + ppx)) and the same
+// FIVE units, whose two K halves are now:  u0 = taps (0,0) (0,2), u1 = (2,0) (2,2) on phase (1,1);  u2 = (1,0) (1,2) on phase (0,1);  u3 = (0,1) (2,1) on phase (1,0);
+// u4 = (1,1) + nothing on phase (0,0) — each of the nine taps once.  (Phase order 3, 1, 2, 0: phases (py, 1) and (py, 0) share their cache lines, so the stagings
+// behind a one-unit sub-chunk — (1,0) after (0,1), (0,0) after (1,0) — find theirs in L2, and the cold lines of (0,1) are requested with two units of cover.)  Weight ring, refills, waits and the two-phase schedule are the stride-1 kernel's; a sub-chunk's
+// prefetch is requested at the top of its predecessor's first unit, so the one-unit sub-chunks have ONE unit of cover for it (the stride-1 kernel has five).
+template <bool S2>
 __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
@@ -207,32 +220,40 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
 
     // ---- staging: thread t < 340 owns patch pixel t; its 32 channels of the next chunk sit in registers from the chunk's start to the store phase
     // (the pixel's coordinates are recomputed from a pinned copy of the thread id where they are used: as loop invariants they would sit in registers the K loop needs)
-    auto patch_pixel = [&](bool& in) __attribute__((always_inline)) {
+    auto patch_pixel = [&](bool& in, int ph) __attribute__((always_inline)) {      // ph = 2 py + px: the phase plane (stride 2 only)
         int t = tid;
         pin_here(t);
         const int ppy = t / PW, ppx = t - ppy * PW;
-        const int pgy = y0 - 1 + ppy, pgx = x0 - 1 + ppx;
-        in = t < PATCH && pgy >= 0 && pgy < p.h && pgx >= 0 && pgx < p.w_;
-        return in ? (unsigned)(pgy * p.w_ + pgx) * 4u : 0u;
+        if constexpr (S2) {
+            const int qy = y0 - 1 + ppy, qx = x0 - 1 + ppx;                  // half-resolution position
+            in = t < PATCH && ppy <= TH && ppx <= TW && qy >= 0 && qy < p.ho && qx >= 0 && qx < p.wo;      // (taps reach rows 0 .. TH and columns 0 .. TW of the patch only)
+            // phase planes (the producer wrote them: consecutive lanes read consecutive floats) or the plain map (every other float of a row: twice the lines per request)
+            const unsigned off = p.phased ? (unsigned)(ph * (p.ho * p.wo) + qy * p.wo + qx) : (unsigned)((2 * qy + (ph >> 1)) * p.w_ + 2 * qx + (ph & 1));
+            return in ? off * 4u : 0u;
+        } else {
+            const int pgy = y0 - 1 + ppy, pgx = x0 - 1 + ppx;
+            in = t < PATCH && pgy >= 0 && pgy < p.h && pgx >= 0 && pgx < p.w_;
+            return in ? (unsigned)(pgy * p.w_ + pgx) * 4u : 0u;
+        }
     };
     float xr[CK];
     // the next chunk's 32 channels of this thread's pixel: requested between the store phase's barriers, where the wave would otherwise idle (spread over the
     // read phases the requests' issue — the address unit takes a wave request per ~18 cycles and stalls the issuing wave — made every read phase longer than
     // the MFMA phase beside it); waves 6 and 7 own no patch pixel and request nothing
-    auto load_x = [&](int chunk) __attribute__((always_inline)) {
+    auto load_x = [&](int chunk, int ph) __attribute__((always_inline)) {
         if (wave < 6) {
             bool p_in;
-            const unsigned goff = patch_pixel(p_in);
+            const unsigned goff = patch_pixel(p_in, ph);
 #pragma unroll
             for (int c = 0; c < CK; ++c) xr[c] = load_uncounted(xb + (size_t)(chunk * CK + c) * hw, goff);
         }
     };
     unsigned ovf = 0u;
-    auto store_x = [&](int chunk) __attribute__((always_inline)) {
+    auto store_x = [&](int chunk, int ph) __attribute__((always_inline)) {
         // Branch-free arithmetic for every lane (a first version read the table under per-lane conditions: hipcc made it eight dependent LDS round trips); pixels
         // outside the map and the threads beyond the patch compute on a clamped pixel's data and are zeroed afterwards; only the final writes are predicated.
         bool p_in;
-        (void)patch_pixel(p_in);
+        (void)patch_pixel(p_in, ph);
         const float4* nr = reinterpret_cast<const float4*>(lds + NORM0) + chunk * (CK / 4);
         const float4* nb = reinterpret_cast<const float4*>(lds + NORM0 + MAX_CIN * 4) + chunk * (CK / 4);
         u32x16 q1, q2;
@@ -321,10 +342,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
     dma_unit(0, 0);
     dma_unit(1, 1);
     dma_unit(2, 2);
-    load_x(0);
+    load_x(0, 3);
     E4S_WAIT_VM(0);
     E4S_LDS_BARRIER();          // (also: the norm table is written)
-    store_x(0);
+    store_x(0, 3);
     E4S_LDS_BARRIER();
     if (grp) E4S_LDS_BARRIER(); // waves 4-7: half a unit behind from here on
 
@@ -344,12 +365,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
         const bool more = chunk + 1 < nchunk;
         // The next chunk's activations are requested HERE and consumed by this iteration's store phase: the prefetch registers are defined and used inside one iteration
         // (no loop-carried value whose merge the compiler could materialise as a copy before the data has landed: round-3 advisor finding), with ONE in-loop call site.
-        if (more) load_x(chunk + 1);
+        if constexpr (!S2) { if (more) load_x(chunk + 1, 0); }
 #pragma unroll
         for (int u = 0; u < NUNIT; ++u, ++g) {
+            // sub-chunks (stagings of the patch): stride 1: the chunk's five units; stride 2: units {0, 1} {2} {3} {4} on the phase planes 3, 1, 2, 0
+            const bool first = S2 ? u != 1 : u == 0, last = S2 ? u != 0 : u == NUNIT - 1;
+            const bool nxt_here = S2 && u != NUNIT - 1;                        // the next staging belongs to this chunk
+            const bool have_next = nxt_here || more;
+            const int nchunk_i = nxt_here ? chunk : chunk + 1;
+            const int nph = u == 0 ? 1 : u == 2 ? 2 : u == 3 ? 0 : 3;
+            if constexpr (S2) { if (first && have_next) load_x(nchunk_i, nph); }
             // ---------------- R phase: every operand of the unit into registers, one round of LDS reads
             const int t0 = 2 * u, t1 = 2 * u + 1 < 9 ? 2 * u + 1 : 8;          // (tap 9: zero weights; its activations are tap 8's)
-            const int o0 = (t0 / 3) * PW + t0 % 3, o1 = (t1 / 3) * PW + t1 % 3; // patch-pixel offsets of the two taps
+            // patch-pixel offsets of the two taps (stride 2: (dy + 1) * PW + (dx + 1) of the unit's taps, see the kernel's header)
+            const int o0 = S2 ? (u == 0 ? 0 : u == 1 ? PW : u == 2 ? PW : u == 3 ? 1 : PW + 1) : (t0 / 3) * PW + t0 % 3;
+            const int o1 = S2 ? (u == 0 ? 1 : PW + 1) : (t1 / 3) * PW + t1 % 3;
             const int ok = khalf ? o1 : o0;                                       // the tap this lane's fp6 K half belongs to
             uint4 xa[2][2][2], wv[2][2][2];          // [pixel / co block][tap][K-step]
             uint4 calo[2][2], wclo[2][2];            // [block][term]
@@ -403,7 +433,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
             // which requests are younger than the refill that must have landed (the one of the previous read phase): this phase's refill and, in a chunk's first
             // unit, the prefetch requested in the store phase between the two
             const bool d_younger = g + 2 < nunits;
-            const bool lx_younger = more && u == 0;
+            const bool lx_younger = first && have_next;
             if (grp) wait_units(d_younger, lx_younger);
             __builtin_amdgcn_sched_barrier(0);
 #ifdef MX3_PROF
@@ -440,25 +470,35 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                 for (int pb = 0; pb < 2; ++pb) pin_here(acc[cb][pb]);
-            if (!grp) wait_units(d_younger, lx_younger);
+            if (!grp) wait_units(d_younger, lx_younger && !last);          // (a sub-chunk's last unit: the prefetch must have landed — the store phase follows)
             // waves 4-7 convert their pixels of the next chunk's patch right behind the chunk's last MFMAs — while waves 0-3 (one barrier ahead, done with the
             // patch like everyone: this group's last read phase was the last) convert theirs: see the store phase below
-            if (grp && more && u == NUNIT - 1) store_x(chunk + 1);
+            if (grp && last && have_next) {
+                if (lx_younger) wait_units(d_younger, false);               // (one-unit sub-chunk: this group's wait in the read phase let the prefetch stay in flight)
+                store_x(nchunk_i, nph);
+            }
             __builtin_amdgcn_sched_barrier(0);
             MX3_STAMP(tM)
             E4S_LDS_BARRIER();
             MX3_STAMP(tWM)
             __builtin_amdgcn_sched_barrier(0);
             slot = slot == 2 ? 0 : slot + 1;
-        }
-        if (more) {
+            if (S2 && last && have_next) {
             // ---------------- store phase: the patch has ONE buffer, so between two chunks nobody reads.  Both groups convert at the same time — waves 0-3 after
             // their barrier, waves 4-7 (above) behind their last MFMA phase, in front of the same barrier — and one more barrier lets waves 0-3 run ahead
             // again.  (The prefetch registers are refilled at the top of the next iteration: see there.)
             // (measured against the serial form — waves 0-3 convert during waves 4-7's last MFMA phase, then waves 4-7, two barriers: 0.1498 vs 0.1518 ms)
-            if (!grp) store_x(chunk + 1);
+            if (!grp) store_x(nchunk_i, nph);
             E4S_LDS_BARRIER();
             MX3_STAMP(tST)
+            }
+        }
+        if constexpr (!S2) {
+            if (more) {          // (stride 1: the store phase between two chunks, as above)
+                if (!grp) store_x(chunk + 1, 0);
+                E4S_LDS_BARRIER();
+                MX3_STAMP(tST)
+            }
         }
     }
     if (!grp) E4S_LDS_BARRIER();
@@ -478,8 +518,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
         const int y = y0 + 2 * pr + pb;
-        if (y < p.h && x < p.w_) {
-            float* op = p.out + (size_t)b * p.cout * hw + (size_t)y * p.w_ + x;
+        const int oh = S2 ? p.ho : p.h, ow = S2 ? p.wo : p.w_, ohw = S2 ? p.ho * p.wo : hw;      // (stride 1: the same registers as the input's)
+        if (y < oh && x < ow) {
+            // (stride 1, phased: pixel (y, x) of a channel plane goes to plane 2 (y & 1) + (x & 1), position (y / 2, x / 2) — the layout the stride-2 form reads coalesced)
+            const size_t pix = (!S2 && p.phased) ? (size_t)(2 * (y & 1) + (x & 1)) * (ohw >> 2) + (size_t)(y >> 1) * (ow >> 1) + (x >> 1) : (size_t)y * ow + x;
+            float* op = p.out + (size_t)b * p.cout * ohw + pix;
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -487,7 +530,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
                     const int n = chh * 64 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                     float v = acc[cb][pb][r];
                     v = v > 0.f ? v : v * sl[n];
-                    if (co0 + n < p.cout) op[(size_t)(co0 + n) * hw] = v;
+                    if (co0 + n < p.cout) op[(size_t)(co0 + n) * ohw] = v;
                 }
         }
     }
@@ -502,22 +545,33 @@ extern "C" int e4s_conv3x3_mx3_weight_bytes(int cout, int cin, int64_t* bytes) {
 }
 
 // weight [cout][cin][3][3] fp32 -> unit slots (see the header)
-extern "C" int e4s_conv_prep_weights_mx3(void* dst, const float* weight, int cout, int cin, void* stream) {
+static int prep_weights_mx3(void* dst, const float* weight, int cout, int cin, int s2, void* stream) {
     E4S_REQUIRE(dst && weight && cout >= 1 && cin >= CK && cin % CK == 0, "conv_prep_weights_mx3: bad arguments (cin %% 32 == 0)");
     E4S_REQUIRE(((uintptr_t)dst & 15) == 0, "conv_prep_weights_mx3: the destination must be 16-byte aligned");
     const int64_t total = (int64_t)(cin / CK) * cdiv(cout, TN) * NUNIT * 2 * TN;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(prep_weights_mx3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<unsigned char*>(dst), weight, cout, cin);
+    hipLaunchKernelGGL(prep_weights_mx3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<unsigned char*>(dst), weight, cout, cin, s2);
     return check_launch("conv_prep_weights_mx3");
+}
+
+extern "C" int e4s_conv_prep_weights_mx3(void* dst, const float* weight, int cout, int cin, void* stream) {
+    return prep_weights_mx3(dst, weight, cout, cin, 0, stream);
+}
+
+// the same bytes per layer (e4s_conv3x3_mx3_weight_bytes), units in the stride-2 kernel's tap order
+extern "C" int e4s_conv_prep_weights_mx3_s2(void* dst, const float* weight, int cout, int cin, void* stream) {
+    return prep_weights_mx3(dst, weight, cout, cin, 1, stream);
 }
 
 // out = PReLU(conv3x3(norm(x), W)), stride 1, pad 1.  in_mean / in_rstd [bs][cin] (optional, together), prelu_slope [cout] optional; flags[0] bit 0 is raised
 // when a normalised activation leaves the f16 range (the result is then invalid; the kernel does not fall back by itself — ops.MxGuard notices the counter flags[1] moving and the entry points re-run the pass on the split-bf16 kernels).
-extern "C" int e4s_conv3x3_mx3(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
-                               int bs, int cin, int cout, int h, int w, void* stream) {
+template <bool S2>
+static int conv3x3_mx3(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
+                       int bs, int cin, int cout, int h, int w, int phased, void* stream) {
     E4S_REQUIRE(out && x && wmx3, "conv3x3_mx3: null tensor");
     E4S_REQUIRE((in_mean == nullptr) == (in_rstd == nullptr), "conv3x3_mx3: in_mean and in_rstd go together");
     E4S_REQUIRE(bs >= 0 && bs <= 65535 && cin >= CK && cin % CK == 0 && cin <= MAX_CIN && cout >= 1 && h >= 1 && w >= 1, "conv3x3_mx3: bad size (cin %% 32 == 0, cin <= 512)");
+    E4S_REQUIRE(!(S2 || phased) || (h % 2 == 0 && w % 2 == 0), "conv3x3_mx3: stride 2 / phase planes need an even height and width");
     E4S_REQUIRE(((uintptr_t)wmx3 & 15) == 0, "conv3x3_mx3: the weights must be 16-byte aligned");
     E4S_REQUIRE((int64_t)cin * h * w * 4 < (int64_t)1 << 32, "conv3x3_mx3: a sample's input must stay below 4 GB (32-bit lane offsets)");
     if (bs == 0) return 0;
@@ -526,10 +580,31 @@ extern "C" int e4s_conv3x3_mx3(float* out, const float* x, const void* wmx3, int
     p.out = out; p.x = x; p.w = reinterpret_cast<const unsigned char*>(wmx3); p.flags = flags;
     p.in_mean = in_mean; p.in_rstd = in_rstd; p.slope = prelu_slope;
     p.bs = bs; p.cin = cin; p.cout = cout; p.h = h; p.w_ = w;
-    p.tiles_x = cdiv(w, TW); p.tiles_y = cdiv(h, TH);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mx3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    p.ho = S2 ? h / 2 : h; p.wo = S2 ? w / 2 : w;
+    p.phased = phased ? 1 : 0;
+    p.tiles_x = cdiv(p.wo, TW); p.tiles_y = cdiv(p.ho, TH);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mx3_kernel<S2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return fail((int)attr, "conv3x3_mx3: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
     dim3 grid(p.tiles_x * p.tiles_y, cdiv(cout, TN), bs);
-    hipLaunchKernelGGL(conv3x3_mx3_kernel, grid, dim3(512), LDS_BYTES, (hipStream_t)stream, p);
-    return check_launch("conv3x3_mx3");
+    hipLaunchKernelGGL(conv3x3_mx3_kernel<S2>, grid, dim3(512), LDS_BYTES, (hipStream_t)stream, p);
+    return check_launch(S2 ? "conv3x3_s2_mx3" : "conv3x3_mx3");
+}
+
+extern "C" int e4s_conv3x3_mx3(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
+                               int bs, int cin, int cout, int h, int w, void* stream) {
+    return conv3x3_mx3<false>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, 0, stream);
+}
+
+// e4s_conv3x3_mx3 whose result is written as PHASE PLANES, out[b][c][2 py + px][h / 2][w / 2] = result[b][c][2 y + py][2 x + px] (h, w even): the layout
+// e4s_conv3x3_s2_mx3(in_phased = 1) reads with consecutive lanes on consecutive floats
+extern "C" int e4s_conv3x3_mx3_phased(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
+                                      int bs, int cin, int cout, int h, int w, void* stream) {
+    return conv3x3_mx3<false>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, 1, stream);
+}
+
+// out [bs, cout, h / 2, w / 2] = PReLU(conv3x3(norm(x), W, stride 2, pad 1)); h, w even; weights from e4s_conv_prep_weights_mx3_s2; in_phased: x is in the phase-plane
+// layout of e4s_conv3x3_mx3_phased.  Everything else as e4s_conv3x3_mx3.
+extern "C" int e4s_conv3x3_s2_mx3(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
+                                  int bs, int cin, int cout, int h, int w, int in_phased, void* stream) {
+    return conv3x3_mx3<true>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, in_phased, stream);
 }

@@ -85,11 +85,15 @@ class bottleneck_IR_SE_Ours(Module):
             mean, rstd = st[0], st[1]
         else:
             mean, rstd = ops.plane_stats(x, rl[0].eps)
-        r = ops.conv3x3_s1(x, rl[1].weight, self._wino[0], in_norm=(mean, rstd), prelu=rl[2].weight)      # direct kernel or Winograd (ops.winograd_route)
+        # (a stride-2 unit whose two convolutions both run on the two-phase kernel hands r over as phase planes: the second reads it coalesced)
+        depth = rl[1].weight.shape[0]
+        phased = (self.stride == 2 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and ops.conv3x3_s1_takes_mx3(x, depth)
+                  and ops.conv3x3_s2_takes_mx(x.shape[0], depth, rl[3].weight.shape[0], x.shape[2], x.shape[3], x.device))
+        r = ops.conv3x3_s1(x, rl[1].weight, self._wino[0], in_norm=(mean, rstd), prelu=rl[2].weight, out_phased=phased)      # direct kernel or Winograd (ops.winograd_route)
         if self.stride == 1:
             r = ops.conv3x3_s1(r, rl[3].weight, self._wino[1])
         else:
-            r = ops.conv2d(r, self._w[1].get(rl[3].weight), self.stride, 1)
+            r = ops.conv3x3_s2(r, rl[3].weight, self._wino[1]) if self.stride == 2 else ops.conv2d(r, self._w[1].get(rl[3].weight), self.stride, 1)
         self_stats = ops.SE_GATE_IS_HALF and not torch.is_grad_enabled()
         if self_stats:
             # SEModule behind an affine-free InstanceNorm: its squeeze is the mean of a normalised plane = 0, its bias-free gate sigmoid(0) = 1/2 (ops.SE_GATE_IS_HALF);

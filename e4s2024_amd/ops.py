@@ -525,12 +525,12 @@ class PreparedMx(_Prepared):
             raise ValueError("the mx kernel is a 3x3 kernel")
         bk = _c(blur, "blur kernel") if up else None
         nbytes = ctypes.c_int64(0)
-        if arith == 3:            # the two-phase plain-convolution kernel's unit slots (csrc/conv_mx3.hip)
+        if arith in (3, 5):       # the two-phase plain-convolution kernel's unit slots (csrc/conv_mx3.hip); 5: in the tap order of its stride-2 form
             if not plain:
-                raise ValueError("arith 3 (conv_mx3) is a plain-convolution layout")
+                raise ValueError("arith 3 / 5 (conv_mx3) is a plain-convolution layout")
             lib().call("e4s_conv3x3_mx3_weight_bytes", cout, cin, ctypes.byref(nbytes))
             wmx = torch.empty((nbytes.value,), dtype=torch.uint8, device=w.device)
-            lib().call("e4s_conv_prep_weights_mx3", _p(wmx), _p(w), cout, cin, _stream())
+            lib().call("e4s_conv_prep_weights_mx3" if arith == 3 else "e4s_conv_prep_weights_mx3_s2", _p(wmx), _p(w), cout, cin, _stream())
             self._publish(key, (wmx,))
             return wmx
         if arith == 4:            # the four-parity up kernel's row slots (csrc/modconv_mx4.hip)
@@ -1444,11 +1444,24 @@ def mx_conv_eligible(x: torch.Tensor, cout: int) -> bool:
     return bs * per_image >= MX_CONV_MIN_WORKGROUPS
 
 
-def conv3x3_mx(x: torch.Tensor, wmx: torch.Tensor, arith: int, cout: int, *, in_norm=None, prelu: Optional[torch.Tensor] = None) -> torch.Tensor:
+def conv3x3_mx(x: torch.Tensor, wmx: torch.Tensor, arith: int, cout: int, *, in_norm=None, prelu: Optional[torch.Tensor] = None,
+               out_phased: bool = False) -> torch.Tensor:
     """``PReLU(conv3x3(norm(x), W))``, stride 1, pad 1, on ``e4s_conv3x3_mx`` / ``e4s_conv3x3_mx3`` (``arith`` 3) (``wmx`` from ``PreparedMx.get`` of the
-    plain weight with the same ``arith``)."""
+    plain weight with the same ``arith``).  ``out_phased`` (``arith`` 3, even maps): the result's MEMORY is phase planes — ``[bs, cout, 2, 2, h / 2, w / 2]``,
+    plane ``(py, px)`` = ``result[..., py::2, px::2]`` — which only ``conv3x3_s2_mx(in_phased=True)`` reads; the returned tensor has that shape."""
     x = _c(x, "input")
     bs, cin, h, w = x.shape
+    if out_phased:
+        if arith != 3 or h % 2 or w % 2:
+            raise ValueError("conv3x3_mx: out_phased needs the two-phase kernel (arith 3) and an even map")
+        out = torch.empty((bs, cout, 2, 2, h // 2, w // 2), dtype=torch.float32, device=x.device)
+        mean, rstd = (_c(in_norm[0], "in_mean"), _c(in_norm[1], "in_rstd")) if in_norm is not None else (None, None)
+        ev = _timed("conv3x3_mx<3>", f"{cin}->{cout} @{h}")
+        lib().call("e4s_conv3x3_mx3_phased", _p(out), _p(x), _p(wmx), _p(mx_flags(x.device)), _p(mean), _p(rstd),
+                   _p(_c(prelu.detach(), "prelu")) if prelu is not None else None, bs, cin, cout, h, w, _stream())
+        if ev is not None:
+            ev.record()
+        return out
     out = torch.empty((bs, cout, h, w), dtype=torch.float32, device=x.device)
     mean = rstd = None
     if in_norm is not None:
@@ -1464,9 +1477,76 @@ def conv3x3_mx(x: torch.Tensor, wmx: torch.Tensor, arith: int, cout: int, *, in_
     return out
 
 
-def conv3x3_s1(x: torch.Tensor, weight: torch.Tensor, caches, *, in_norm=None, prelu: Optional[torch.Tensor] = None) -> torch.Tensor:
+def conv3x3_s2_mx(x: torch.Tensor, wmx: torch.Tensor, cout: int, *, in_norm=None, prelu: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``PReLU(conv3x3(norm(x), W, stride 2, pad 1))`` on ``e4s_conv3x3_s2_mx3`` (f16 + 2 x MX fp6; ``wmx`` from ``PreparedMx.get(weight, None, False, 5)``);
+    the input's height and width must be even, ``cin % 32 == 0``, ``cin <= 512``.  A 6-D input ``[bs, cin, 2, 2, h / 2, w / 2]`` is the phase-plane
+    hand-over of ``conv3x3_mx(out_phased=True)``."""
+    x = _c(x, "input")
+    in_phased = x.dim() == 6
+    if in_phased:
+        if x.shape[2] != 2 or x.shape[3] != 2:
+            raise ValueError("conv3x3_s2_mx: a phase-plane input is [bs, cin, 2, 2, h / 2, w / 2]")
+        bs, cin, h, w = x.shape[0], x.shape[1], 2 * x.shape[4], 2 * x.shape[5]
+    else:
+        bs, cin, h, w = x.shape
+    if h % 2 or w % 2:
+        raise ValueError("conv3x3_s2_mx: the input height and width must be even")
+    out = torch.empty((bs, cout, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    mean = rstd = None
+    if in_norm is not None:
+        mean, rstd = _c(in_norm[0], "in_mean"), _c(in_norm[1], "in_rstd")
+    ev = _timed("conv3x3_s2_mx<3>", f"{cin}->{cout} @{h}")
+    pr = _p(_c(prelu.detach(), "prelu")) if prelu is not None else None
+    lib().call("e4s_conv3x3_s2_mx3", _p(out), _p(x), _p(wmx), _p(mx_flags(x.device)), _p(mean), _p(rstd), pr, bs, cin, cout, h, w, 1 if in_phased else 0, _stream())
+    if ev is not None:
+        ev.record()
+    return out
+
+
+S2_MX3 = True           # the encoder's stride-2 3x3 convolutions on the stride-2 form of csrc/conv_mx3.hip (attribute; off: the direct split-bf16 kernel)
+
+
+def conv3x3_s2_takes_mx(bs: int, cin: int, cout: int, h: int, w: int, device) -> bool:
+    """Does a stride-2 3x3 convolution of a ``[bs, cin, h, w]`` map run on ``e4s_conv3x3_s2_mx3``?  (``mx_conv_eligible`` of the output-sized launch.)"""
+    if not (S2_MX3 and MX3 and mx_arith() == 1 and cin % 32 == 0 and cin <= 512 and h % 2 == 0 and w % 2 == 0):
+        return False
+    return mx_conv_eligible(_ShapeOnly(bs, cin, h // 2, w // 2, device), cout)
+
+
+class _ShapeOnly:
+    """What ``mx_conv_eligible`` looks at of its input (shape, device kind) for a map that does not exist yet."""
+    __slots__ = ("shape", "is_cuda")
+
+    def __init__(self, bs, c, h, w, device):
+        self.shape = (bs, c, h, w)
+        self.is_cuda = torch.device(device).type == "cuda"
+
+
+def conv3x3_s2(x: torch.Tensor, weight: torch.Tensor, caches) -> torch.Tensor:
+    """A stride-2, pad-1 3x3 convolution: the DMA-fed f16 + fp6 kernel where it fits and fills the chip (``conv3x3_s2_takes_mx``), else the direct kernel.
+    ``caches = (PreparedConv, PreparedWinograd, PreparedMx)`` of the layer.  ``x`` may be the phase-plane hand-over of ``conv3x3_s1(out_phased=True)``."""
+    if x.dim() == 6:
+        return conv3x3_s2_mx(x, caches[2].get(weight, None, False, 5), weight.shape[0])
+    bs, cin, h, w = x.shape
+    if len(caches) > 2 and conv3x3_s2_takes_mx(bs, cin, weight.shape[0], h, w, x.device):
+        return conv3x3_s2_mx(x, caches[2].get(weight, None, False, 5), weight.shape[0])
+    return conv2d(x, caches[0].get(weight), 2, 1)
+
+
+def conv3x3_s1_takes_mx3(x: torch.Tensor, cout: int) -> bool:
+    """``conv3x3_s1`` runs this layer on the two-phase kernel (``e4s_conv3x3_mx3``)."""
+    return (winograd_route(x, x.shape[1], 1) != "f32" and mx_conv_eligible(x, cout) and mx_arith() == 1 and MX3
+            and x.shape[1] % 32 == 0 and x.shape[1] <= 512)
+
+
+def conv3x3_s1(x: torch.Tensor, weight: torch.Tensor, caches, *, in_norm=None, prelu: Optional[torch.Tensor] = None, out_phased: bool = False) -> torch.Tensor:
     """A stride-1, pad-1 3x3 convolution by whichever route fits the launch: Winograd (``winograd_route``: small batches), the DMA-fed kernel
-    (``mx_conv_eligible``: launches that fill the chip) or the direct kernel; ``caches = (PreparedConv, PreparedWinograd, PreparedMx)`` of the layer."""
+    (``mx_conv_eligible``: launches that fill the chip) or the direct kernel; ``caches = (PreparedConv, PreparedWinograd, PreparedMx)`` of the layer.
+    ``out_phased``: see ``conv3x3_mx`` — the caller has checked ``conv3x3_s1_takes_mx3``."""
+    if out_phased:
+        if not (len(caches) > 2 and conv3x3_s1_takes_mx3(x, weight.shape[0])):
+            raise RuntimeError("conv3x3_s1: out_phased on a layer that does not run on the two-phase kernel")
+        return conv3x3_mx(x, caches[2].get(weight, None, False, 3), 3, weight.shape[0], in_norm=in_norm, prelu=prelu, out_phased=True)
     route = winograd_route(x, x.shape[1], 1)
     if route == "f32":
         return conv2d_winograd(x, caches[1].get(weight), in_norm=in_norm, prelu=prelu)

@@ -183,6 +183,17 @@ E4S_API int e4s_conv3x3_mx3_weight_bytes(int cout, int cin, int64_t* bytes);
 E4S_API int e4s_conv_prep_weights_mx3(void* dst, const float* weight, int cout, int cin, void* stream);
 E4S_API int e4s_conv3x3_mx3(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
                             int bs, int cin, int cout, int h, int w, void* stream);
+/* The stride-2 form on the same kernel: out [bs,cout,h/2,w/2] = PReLU(conv3x3(norm(x), W, stride 2, pad 1)), h and w even — the second convolution of a stage's
+ * first bottleneck_IR_SE_Ours unit (models/encoders/helpers.py:128-139 with stride = 2, psp_encoders.py get_blocks).  The input is read as its four phase planes
+ * (x[2y+py][2x+px]), each a stride-1 operand of a subset of the nine taps; wmx3 from e4s_conv_prep_weights_mx3_s2 (same size as the stride-1 copy). */
+E4S_API int e4s_conv_prep_weights_mx3_s2(void* dst, const float* weight, int cout, int cin, void* stream);
+E4S_API int e4s_conv3x3_s2_mx3(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
+                               int bs, int cin, int cout, int h, int w, int in_phased, void* stream);
+/* e4s_conv3x3_mx3 with its result stored as PHASE PLANES: out[b][c][2 py + px][h/2][w/2] = result[b][c][2y+py][2x+px] (h, w even) — the hand-over between the two
+ * convolutions of a stride-2 unit (helpers.py:128-139): e4s_conv3x3_s2_mx3(in_phased = 1) then reads consecutive floats with consecutive lanes, where the plain
+ * map costs it two cache lines per useful one. */
+E4S_API int e4s_conv3x3_mx3_phased(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
+                                   int bs, int cin, int cout, int h, int w, void* stream);
 /* Masked up-sampling layers, region-uniform output blocks (model.py:287-300 per region == one transposed conv + blur where a block of output
  * pixels has ONE region):
  *   e4s_uniform_blocks: sub[b][2by+sy][2bx+sx] = the region of an 8 x 8 output sub-block (labels uint8 [bs][lh][lw] sampled 'nearest' at

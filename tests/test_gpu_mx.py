@@ -192,6 +192,69 @@ def test_conv3x3_mx3_against_fp64_and_the_direct_kernel(shape, norm_prelu):
     assert not ops.mx_overflowed()
 
 
+#                 bs cin cout  h    w      (input size, even; ragged output maps, an output-channel tail, one chunk / several, an output smaller than a tile, the encoder's three)
+CONV3_S2_SHAPES = [(2, 32, 136, 80, 72), (1, 96, 128, 14, 90), (3, 64, 128, 64, 64), (4, 128, 128, 128, 128), (2, 256, 256, 64, 64), (3, 512, 512, 64, 64)]
+
+
+@pytest.mark.parametrize("shape", CONV3_S2_SHAPES)
+@pytest.mark.parametrize("norm_prelu", [True, False])
+def test_conv3x3_s2_mx3_against_fp64_and_the_direct_kernel(shape, norm_prelu):
+    """``e4s_conv3x3_s2_mx3`` — the stride-2 3x3 convolution of a stage's first encoder unit (helpers.py:128-139 with stride 2) on the two-phase kernel, the input read
+    as four phase planes — against float64 and the direct split-bf16 kernel; run-to-run identical; the default encoder route takes it."""
+    bs, cin, cout, h, w = shape
+    g = torch.Generator().manual_seed(13 * cin + h)
+    x = torch.randn(bs, cin, h, w, generator=g) * 2.0 + 0.5
+    wgt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9.0)
+    slope = torch.rand(cout, generator=g) * 0.5
+    xd, wd = x.to(DEV), wgt.to(DEV)
+    mean = rstd = None
+    xn = x.double()
+    if norm_prelu:
+        mean = x.mean((2, 3))
+        rstd = 1.0 / torch.sqrt(x.var((2, 3), unbiased=False) + 1e-5)
+        xn = (x.double() - mean.double()[:, :, None, None]) * rstd.double()[:, :, None, None]
+    ref = torch.nn.functional.conv2d(xn, wgt.double(), stride=2, padding=1)
+    if norm_prelu:
+        ref = torch.where(ref > 0, ref, ref * slope.double()[None, :, None, None])
+    scale = float(ref.abs().max())
+    in_norm = (mean.to(DEV), rstd.to(DEV)) if norm_prelu else None
+    pr = slope.to(DEV) if norm_prelu else None
+    with torch.no_grad():
+        y_dir = ops.conv2d(xd, ops.PreparedConv().get(wd), 2, 1, in_norm=in_norm, prelu=pr).cpu()
+        w5 = ops.PreparedMx().get(wd, None, False, 5)
+        y = ops.conv3x3_s2_mx(xd, w5, cout, in_norm=in_norm, prelu=pr).cpu()
+        yb = ops.conv3x3_s2_mx(xd, w5, cout, in_norm=in_norm, prelu=pr).cpu()
+    assert tuple(y.shape) == tuple(ref.shape)
+    e = float((y.double() - ref).abs().max()) / scale
+    record_parity(f"conv3x3_s2_mx3_{cin}to{cout}_{h}x{w}_{'norm_prelu' if norm_prelu else 'plain'}", e, MX_LAYER_TOL,
+                  note=f"stride 2, f16 + 2 x MX fp6 against float64, relative to the output scale; direct kernel {float((y_dir.double() - ref).abs().max()) / scale:.2e}")
+    assert e <= MX_LAYER_TOL, (shape, e)
+    assert torch.equal(y, yb)
+    assert not ops.mx_overflowed()
+    # the phase-plane hand-over: the same input as four half-resolution planes per channel gives the same bits ...
+    x6 = torch.stack([torch.stack([xd[:, :, py::2, px::2] for px in (0, 1)], 2) for py in (0, 1)], 2).contiguous()
+    with torch.no_grad():
+        assert torch.equal(ops.conv3x3_s2_mx(x6, w5, cout, in_norm=in_norm, prelu=pr).cpu(), y)
+        # ... and the stride-1 kernel writes that layout itself (its values unchanged)
+        w3 = ops.PreparedMx().get(wd, None, False, 3)
+        plain = ops.conv3x3_mx(xd, w3, 3, cout, in_norm=in_norm, prelu=pr)
+        ph = ops.conv3x3_mx(xd, w3, 3, cout, in_norm=in_norm, prelu=pr, out_phased=True)
+        assert tuple(ph.shape) == (bs, cout, 2, 2, h // 2, w // 2)
+        for py in (0, 1):
+            for px in (0, 1):
+                assert torch.equal(ph[:, :, py, px], plain[:, :, py::2, px::2])
+    if not norm_prelu and ops.mx_arith() == 1 and ops.S2_MX3:
+        caches = (ops.PreparedConv(), ops.PreparedWinograd(), ops.PreparedMx())
+        with torch.no_grad():
+            routed = ops.conv3x3_s2(xd, wd, caches).cpu()
+            took = ops.mx_conv_eligible(xd[:, :, ::2, ::2], cout)
+            assert torch.equal(routed, y if took else y_dir)
+            with ops.mx_exact():
+                assert torch.equal(ops.conv3x3_s2(xd, wd, caches).cpu(), y_dir)         # the guard's re-run takes the split-bf16 kernel
+    with pytest.raises(ValueError):
+        ops.conv3x3_s2_mx(xd[:, :, 1:], w5, cout)
+
+
 def test_conv3x3_mx3_is_bit_stable_beside_another_stream():
     """The two-phase kernel counts its own vector-memory requests (weight DMA and activation prefetch are issued from asm, its ``vmcnt`` waits leave the younger
     ones in flight): a miscount would show as a changing value when memory gets slower — with another stream's kernels beside it.  Bounded (~8 s): the
