@@ -300,6 +300,28 @@ def test_conv3x3_mx3_raises_the_overflow_flag():
     assert not ops.mx_overflowed()
 
 
+def test_conv3x3_s2_mx3_raises_the_overflow_flag_and_the_guard_heals_it():
+    """The stride-2 form reports an activation beyond the f16 range like the stride-1 kernel, and ``ops.guarded`` re-runs the layer on the split-bf16 kernel."""
+    if ops.mx_arith() != 1 or not ops.S2_MX3:
+        pytest.skip("the f16 + fp6 arithmetic is off")
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn(16, 128, 64, 64, device=DEV, generator=g)
+    x[2, 5, 11, 13] = 1.0e5
+    wgt = torch.randn(128, 128, 3, 3, device=DEV, generator=g) / (128 * 9) ** 0.5
+    caches = (ops.PreparedConv(), ops.PreparedWinograd(), ops.PreparedMx())
+    with torch.no_grad():
+        assert ops.conv3x3_s2_takes_mx(16, 128, 128, 64, 64, x.device)
+        ops.mx_overflowed()
+        ops.conv3x3_s2(x, wgt, caches)
+        assert ops.mx_overflowed()
+        before = ops.mx_fallbacks
+        out = ops.guarded(lambda: ops.conv3x3_s2(x, wgt, caches))
+        assert ops.mx_fallbacks == before + 1
+    ops.mx_overflowed()
+    ref = torch.nn.functional.conv2d(x.double(), wgt.double(), stride=2, padding=1)
+    assert torch.isfinite(out).all() and float((out.double() - ref).abs().max() / ref.abs().max()) <= 2e-5
+
+
 def test_encoder_at_batch_16_takes_the_mx_route_and_matches_the_direct_route(mx_mode):
     """``FSEncoder_PSP`` on 16 images (what a batch-8 swap feeds it): its stride-1 3x3 convolutions with >= 128 output channels run on
     ``e4s_conv3x3_mx``; the style vectors must equal the all-direct route's (E4S_MX=0) within the encoder's parity bar."""
