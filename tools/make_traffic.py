@@ -3,8 +3,13 @@
     python tools/make_traffic.py gpurun_out/r02_final_pmc_fetch.txt gpurun_out/r02_final_pmc_write.txt profiles/r02_traffic.json
 
 Keys are the names bench.py's KernelTimer uses.  Counters are in KB (rocprofv3 derived metrics).  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE
-counts a 128-byte request of a wide (16 B per lane) streaming read as 64 bytes — such kernels (the LDS-DMA chain kernels, dwordx4 only) get the
-x2 correction, stated per entry; kernels whose activation loads are dwords (the masked conv: channels-first rows) are reported uncorrected."""
+counts a 128-byte request of a wide streaming read as 64 bytes and leaves other access widths to be calibrated on a known byte count in the kernel's
+own pattern.  Calibrated (tools/probes/fetch_calib_probe.hip, profiles/r04_fetch_calib.txt: 1 GiB read exactly once per launch): dword loads, dwordx4
+loads and LDS-DMA in rows of 128 B - 1 KB all report 0.500 of the true bytes, rows shifted by a halo pixel 0.53 (the shared lines), only isolated
+64-byte rows report 1.000 — the counter tallies every request at 64 B, a full 128-byte line included.  Every entry therefore gets the x2 correction
+(exact for the chain kernels' rows; an upper bound, by at most the half-line requests of the halo columns, for the masked kernels' 34-float rows — until
+this calibration those were reported uncorrected, i.e. too low).  WRITE_SIZE needs none (it equals the output bytes of every kernel here).  Infinity
+Cache hits are counted: this is fabric traffic of the L2s, not DRAM traffic."""
 import json
 import re
 import sys
@@ -24,18 +29,18 @@ def parse(path):
 
 # bench.py key -> (substrings the kernel name must contain, FETCH_SIZE correction, note, algorithmic bytes per launch at batch 4 or None)
 KEYS = {
-    "region_modconv_sb_kernel<4,1,1,8,5>": (["region_modconv_sb_kernel<4, 1, 1, 8, 5"], 1.0,
+    "region_modconv_sb_kernel<4,1,1,8,5>": (["region_modconv_sb_kernel<4, 1, 1, 8, 5"], 2.0,
                                             "7 launches per step (6 plain + 1 with fused ToRGB and split-plane output; on the benchmark maps the 128->256 up "
                                             "layer's launch leaves at once: its blocks are all region-uniform and run in masked_up_block_kernel); dword activation "
                                             "loads: no FETCH correction", (823900000 - 4 * (256 * 128 * 128 * 4 + 128 * 256 * 256 * 4)) // 7),
-    "region_modconv_mx_kernel<1>": (["region_modconv_mx_kernel<1|region_upconv_mx4_kernel"], 1.0,
+    "region_modconv_mx_kernel<1>": (["region_modconv_mx_kernel<1|region_upconv_mx4_kernel"], 2.0,
                                     "7 launches per step (the DMA-fed masked kernel, f16 + 2 x MX fp6 — six launches of region_modconv_mx_kernel and, for the 512 -> 256 @64 up "
                                     "layer, one of region_upconv_mx4_kernel, which runs the same tile code or its four-parity form per workgroup; on the benchmark maps the "
-                                    "128->256 up layer's launch leaves at once); dword activation loads, 16-byte weight DMA: FETCH uncorrected (a lower bound on the weight share)",
+                                    "128->256 up layer's launch leaves at once); dword activation loads, 16-byte weight DMA: FETCH_SIZE x2 (calibrated; an upper bound by the halo columns' half-line requests)",
                                     (823900000 - 4 * (256 * 128 * 128 * 4 + 128 * 256 * 256 * 4)) // 7),
-    "region_modconv_mx_kernel<0>": (["region_modconv_mx_kernel<0"], 1.0, "as <1> with the split-bf16 arithmetic", (823900000 - 4 * (256 * 128 * 128 * 4 + 128 * 256 * 256 * 4)) // 7),
-    "masked_upconv_blocks": (["masked_up_block_kernel"], 1.0, "1 launch per step (the 256 -> 128 @128 masked up layer: every 16 x 16 output block of the benchmark maps lies under one "
-                             "region); algorithmic bytes = its input [4,256,128,128] + its output [4,128,256,256], fp32; dword loads",
+    "region_modconv_mx_kernel<0>": (["region_modconv_mx_kernel<0"], 2.0, "as <1> with the split-bf16 arithmetic", (823900000 - 4 * (256 * 128 * 128 * 4 + 128 * 256 * 256 * 4)) // 7),
+    "masked_upconv_blocks": (["masked_up_block_kernel"], 2.0, "1 launch per step (the 256 -> 128 @128 masked up layer: every 16 x 16 output block of the benchmark maps lies under one "
+                             "region); algorithmic bytes = its input [4,256,128,128] + its output [4,128,256,256], fp32; dword loads, FETCH_SIZE x2 (calibrated)",
                              4 * (256 * 128 * 128 * 4 + 128 * 256 * 256 * 4)),
     "chain_conv3x3<32>": (["chain_conv_kernel<1, 2"], 2.0, "LDS-DMA dwordx4 only: FETCH_SIZE x2 (guide)", 4 * (32 * 1024 * 1024 * 4 + 3 * 1024 * 1024 * 4 + 3 * 512 * 512 * 4)),
     "chain_conv3x3<64>": (["chain_conv_kernel<2, 4"], 2.0, "LDS-DMA dwordx4 only: FETCH_SIZE x2 (guide)", 4 * (2 * 64 * 512 * 512 * 4 + 3 * 512 * 512 * 4 + 3 * 256 * 256 * 4)),
