@@ -305,12 +305,12 @@ def test_conv3x3_s2_mx3_raises_the_overflow_flag_and_the_guard_heals_it():
     if ops.mx_arith() != 1 or not ops.S2_MX3:
         pytest.skip("the f16 + fp6 arithmetic is off")
     g = torch.Generator(device=DEV).manual_seed(9)
-    x = torch.randn(16, 128, 64, 64, device=DEV, generator=g)
-    x[2, 5, 11, 13] = 1.0e5
+    x = torch.randn(2, 128, 256, 256, device=DEV, generator=g)              # (the encoder's first stride-2 layer)
+    x[1, 5, 11, 13] = 1.0e5
     wgt = torch.randn(128, 128, 3, 3, device=DEV, generator=g) / (128 * 9) ** 0.5
     caches = (ops.PreparedConv(), ops.PreparedWinograd(), ops.PreparedMx())
     with torch.no_grad():
-        assert ops.conv3x3_s2_takes_mx(16, 128, 128, 64, 64, x.device)
+        assert ops.conv3x3_s2_takes_mx(2, 128, 128, 256, 256, x.device)
         ops.mx_overflowed()
         ops.conv3x3_s2(x, wgt, caches)
         assert ops.mx_overflowed()
