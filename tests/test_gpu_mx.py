@@ -300,6 +300,36 @@ def test_conv3x3_mx3_raises_the_overflow_flag():
     assert not ops.mx_overflowed()
 
 
+def test_conv3x3_s2_mx3_is_bit_stable_beside_another_stream():
+    """The stride-2 form shares the stride-1 kernel's hand-counted waits (one more wait per one-unit sub-chunk): its results must not change when memory gets slower.
+    Bounded (~4 s): the encoder's 256 -> 256 @128 -> 64 layer, plain and from the phase-plane hand-over, beside a stream of stride-1 launches."""
+    import time
+    g = torch.Generator(device=DEV).manual_seed(4)
+    x = torch.randn(8, 256, 128, 128, device=DEV, generator=g)
+    w = torch.randn(256, 256, 3, 3, device=DEV, generator=g) * 0.03
+    x2 = torch.randn(8, 256, 64, 64, device=DEV, generator=g)
+    with torch.no_grad():
+        w5, w3 = ops.PreparedMx().get(w, None, False, 5), ops.PreparedMx().get(w, None, False, 3)
+        ref = ops.conv3x3_s2_mx(x, w5, 256).clone()
+        x6 = torch.stack([torch.stack([x[:, :, py::2, px::2] for px in (0, 1)], 2) for py in (0, 1)], 2).contiguous()
+        assert torch.equal(ops.conv3x3_s2_mx(x6, w5, 256), ref)
+        ref2 = ops.conv3x3_mx(x2, w3, 3, 256).clone()
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        t0, rounds, bad = time.time(), 0, 0
+        while time.time() - t0 < 3.0 and rounds < 300:
+            with torch.cuda.stream(s1):
+                outs = [ops.conv3x3_s2_mx(x if i % 2 else x6, w5, 256) for i in range(6)]
+            with torch.cuda.stream(s2):
+                outs2 = [ops.conv3x3_mx(x2, w3, 3, 256) for _ in range(6)]
+            torch.cuda.synchronize()
+            bad += sum(not torch.equal(o, ref) for o in outs) + sum(not torch.equal(o, ref2) for o in outs2)
+            rounds += 1
+    record_parity("conv3x3_s2_mx3.two_stream_mismatches", bad, 0, note=f"{rounds} rounds of 6 + 6 launches")
+    assert rounds >= 5 and bad == 0
+    assert not ops.mx_overflowed()
+
+
 def test_conv3x3_s2_mx3_raises_the_overflow_flag_and_the_guard_heals_it():
     """The stride-2 form reports an activation beyond the f16 range like the stride-1 kernel, and ``ops.guarded`` re-runs the layer on the split-bf16 kernel."""
     if ops.mx_arith() != 1 or not ops.S2_MX3:
