@@ -25,12 +25,36 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(float* __restrict__ o
     out[((size_t)blockIdx.z * oh + y) * ow + x] = m;
 }
 
+// Two adjacent outputs per thread (w % 4 == 0): output columns 2t, 2t + 1 see input columns 4t - 1 .. 4t + 3 — one aligned 16-byte load and one dword per input row instead
+// of nine dwords per output (the same maxima: max is exact in any order).  142 -> ~75 us on the parser's 16 x 64 planes of 256 x 256.
+__global__ __launch_bounds__(256) void maxpool3x3s2_x2_kernel(float* __restrict__ out, const float* __restrict__ in, int h, int w, int oh, int ow) {
+    const int t = blockIdx.x * 64 + (threadIdx.x & 63);          // output column pair
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (2 * t >= ow || y >= oh) return;
+    const float* p = in + (size_t)blockIdx.z * h * w;
+    float m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int iy = 2 * y + dy;
+        if (iy < 0 || iy >= h) continue;
+        const float* r = p + (size_t)iy * w + 4 * t;
+        const float4 v = *reinterpret_cast<const float4*>(r);
+        const float l = t > 0 ? r[-1] : -INFINITY;
+        m0 = fmaxf(m0, fmaxf(l, fmaxf(v.x, v.y)));
+        m1 = fmaxf(m1, fmaxf(v.y, fmaxf(v.z, v.w)));
+    }
+    *reinterpret_cast<float2*>(out + ((size_t)blockIdx.z * oh + y) * ow + 2 * t) = make_float2(m0, m1);
+}
+
 extern "C" int e4s_maxpool3x3s2(float* out, const float* in, int planes, int h, int w, void* stream) {
     E4S_REQUIRE(out && in, "maxpool3x3s2: null tensor");
     E4S_REQUIRE(planes >= 0 && planes <= 65535 && h >= 1 && w >= 1, "maxpool3x3s2: bad size");
     if (planes == 0) return 0;
     const int oh = (h + 2 - 3) / 2 + 1, ow = (w + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(cdiv(ow, 64), cdiv(oh, 4), planes), dim3(256), 0, (hipStream_t)stream, out, in, h, w, oh, ow);
+    if (w % 4 == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 7) == 0)       // (then ow = w / 2 is even: whole pairs)
+        hipLaunchKernelGGL(maxpool3x3s2_x2_kernel, dim3(cdiv(ow / 2, 64), cdiv(oh, 4), planes), dim3(256), 0, (hipStream_t)stream, out, in, h, w, oh, ow);
+    else
+        hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(cdiv(ow, 64), cdiv(oh, 4), planes), dim3(256), 0, (hipStream_t)stream, out, in, h, w, oh, ow);
     return check_launch("maxpool3x3s2");
 }
 

@@ -144,6 +144,15 @@ def test_parse_batch_takes_the_pipelines_images_where_they_are(parser):
     assert torch.equal(part, small)
 
 
+@pytest.mark.parametrize("shape", [(2, 5, 256, 256), (1, 3, 64, 36), (2, 2, 33, 47), (1, 1, 8, 4), (1, 4, 30, 62)])
+def test_maxpool3x3s2_equals_torch(shape):
+    """MaxPool2d(3, 2, 1) of the parser's ResNet stem (swap_face_fine/face_parsing/resnet.py:65): both kernels (two outputs per thread where the width is a
+    multiple of four, one otherwise) give torch's maxima exactly."""
+    g = torch.Generator(device=DEV).manual_seed(sum(shape))
+    x = torch.randn(*shape, device=DEV, generator=g)
+    assert torch.equal(ops.maxpool3x3s2(x), torch.nn.functional.max_pool2d(x, 3, 2, 1))
+
+
 def test_training_mode_is_refused(parser):
     parser.seg.train()
     try:
