@@ -1,5 +1,7 @@
 # FETCH_SIZE calibration on known byte counts (tools/probes/fetch_calib_probe.hip) -> gpurun_out/fetch_calib.txt
-export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out; cd /tmp
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out
+[ -x $R/tools/probes/fetch_calib_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 $R/tools/probes/fetch_calib_probe.hip -o $R/tools/probes/fetch_calib_probe
+cd /tmp
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/calib -o calib -- $R/tools/probes/fetch_calib_probe > $R/gpurun_out/calib.log 2>&1
 cd $R
 python tools/rocpd_pmc.py gpurun_out/calib/calib_results.db > gpurun_out/fetch_calib_raw.txt
