@@ -153,6 +153,33 @@ def test_maxpool3x3s2_equals_torch(shape):
     assert torch.equal(ops.maxpool3x3s2(x), torch.nn.functional.max_pool2d(x, 3, 2, 1))
 
 
+@pytest.mark.parametrize("shape", [(2, 19, 64, 64, 512, 512), (1, 5, 7, 9, 30, 50), (1, 19, 64, 64, 100, 130), (1, 3, 40, 40, 20, 24)])
+def test_bilinear_argmax_against_the_same_arithmetic_in_torch(shape):
+    """labels = argmax_c of the align_corners bilinear up-sampling of the logits (face_parsing/model.py:257 + face_parsing_demo.py:170), never materialised: the kernel
+    (LDS-staged where a block's corner of the logits fits, direct otherwise: the last shape down-samples) against the same fp32 expression evaluated by torch.
+    Where they differ (an FMA contraction can move a value by an ulp) the two classes' values must be that close."""
+    bs, ncls, ih, iw, oh, ow = shape
+    g = torch.Generator(device=DEV).manual_seed(ncls + ih)
+    lg = torch.randn(bs, ncls, ih, iw, device=DEV, generator=g)
+    got = ops.bilinear_argmax(lg, (oh, ow)).long()
+    f32 = torch.float32
+    sy = torch.tensor((ih - 1) / (oh - 1) if oh > 1 else 0.0, dtype=f32, device=DEV)
+    sx = torch.tensor((iw - 1) / (ow - 1) if ow > 1 else 0.0, dtype=f32, device=DEV)
+    fy = torch.arange(oh, device=DEV, dtype=f32) * sy
+    fx = torch.arange(ow, device=DEV, dtype=f32) * sx
+    y0 = fy.long().clamp(max=ih - 1); x0 = fx.long().clamp(max=iw - 1)
+    y1 = (y0 + 1).clamp(max=ih - 1); x1 = (x0 + 1).clamp(max=iw - 1)
+    ly = (fy - y0.to(f32))[:, None]; lx = (fx - x0.to(f32))[None, :]
+    hy, hx = 1 - ly, 1 - lx
+    q = lambda yy, xx: lg[:, :, yy][:, :, :, xx]
+    v = hy * (hx * q(y0, x0) + lx * q(y0, x1)) + ly * (hx * q(y1, x0) + lx * q(y1, x1))
+    ref = v.argmax(1)
+    bad = got != ref
+    if bad.any():
+        top2 = v.topk(2, dim=1).values
+        assert float((top2[:, 0] - top2[:, 1])[bad].max()) <= 1e-5 and int(bad.sum()) <= 8, int(bad.sum())
+
+
 def test_training_mode_is_refused(parser):
     parser.seg.train()
     try:
