@@ -86,6 +86,7 @@ _PROTOS = {
     "e4s_maxpool3x3s2": [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
     "e4s_gate_add_upsample": [c_ptr] * 5 + [c_int] * 4 + [c_ptr],
     "e4s_bilinear_argmax": [c_ptr, c_ptr, c_ptr] + [c_int] * 6 + [c_ptr],
+    "e4s_conv7x7s2_stem_f16x3": [c_ptr] * 4 + [c_int] * 5 + [c_ptr],
     "e4s_bicubic_down_normalize": [c_ptr] * 5 + [c_int] * 5 + [c_ptr],
     "e4s_bicubic_down_normalize_pm1": [c_ptr] * 5 + [c_int] * 5 + [c_ptr],
     "e4s_tensor2im_u8": [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],

@@ -1269,6 +1269,27 @@ class PreparedConv(_Prepared):
             return hit
         w = _c(weight.detach(), "weight")
         cout, cin, kh, kw = w.shape
+        if STEM7 and self.exact == "f16x3" and not mx_exact_active() and (cout, cin, kh, kw) == (64, 3, 7, 7) and conv_bias is None and w.is_cuda:
+            # the parser's 7x7 stem on its own kernel (csrc/stem7.hip): K = (c, ky, kx) flattened; the two f16 terms of the BN-folded weight x 2^kexp, built here
+            # (64 x 147 values, once per weight version; one host read of the largest folded weight like the f16x3 route below)
+            with torch.no_grad():
+                if bn is not None:
+                    if bn.training:
+                        raise RuntimeError("BatchNorm2d must be in eval mode to be folded into the convolution (the parser runs in eval mode)")
+                    sc = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + float(bn.eps))
+                    wf = w.float() * sc[:, None, None, None]
+                    bias = (bn.bias.detach().float() - bn.running_mean.float() * sc).contiguous()
+                else:
+                    wf, bias = w.float(), None
+                m = float(wf.abs().max().item())
+                kexp = 10 - int(math.ceil(math.log2(m))) if m > 0 and math.isfinite(m) else 0
+                kexp = max(-30, min(30, kexp))
+                wk = torch.zeros((64, 160), dtype=torch.float32, device=w.device)
+                wk[:, :147] = wf.reshape(64, 147) * float(2.0 ** kexp)
+                hi = wk.half()
+                lo = (wk - hi.float()).half()
+                wt = torch.stack([hi, lo]).view(2, 64, 10, 2, 8).permute(0, 2, 3, 1, 4).contiguous().view(torch.int16)
+            return self._publish(key, PreparedConv.Copy((wt, bias, (cout, cin, kh, kw), kexp, "stem7")))
         sb = self.use_sb(cin, kh, kw)
         if sb:
             shape = ((cin + 15) // 16, kh * kw, 2, cout, 8)
@@ -1309,6 +1330,9 @@ class PreparedConv(_Prepared):
         return self._publish(key, PreparedConv.Copy((wt, bias, (cout, cin, kh, kw), kexp, "f16x3" if sb == 4 else "")))
 
 
+STEM7 = True            # the parser's 7x7 stride-2 stem on csrc/stem7.hip (attribute; off: the exact-fp32 implicit GEMM of conv.hip)
+
+
 def _is_f16x3(prepared) -> bool:
     return len(prepared) > 4 and prepared[4] == "f16x3"
 
@@ -1338,6 +1362,14 @@ def conv2d(x: torch.Tensor, prepared: PreparedConv, stride: int = 1, pad: int = 
         res = _c(residual, "residual")
         if tuple(res.shape) != tuple(out.shape):
             raise ValueError(f"residual shape {tuple(res.shape)} != output {tuple(out.shape)}")
+    if len(prepared) > 4 and prepared[4] == "stem7":
+        if (stride, pad) != (2, 3) or x1 is not None or in_norm is not None or prelu is not None or residual is not None:
+            raise ValueError("this weight copy is the parser stem's (7x7, stride 2, pad 3, ReLU or nothing)")
+        ev = _timed("conv7x7s2_stem_f16x3")
+        lib().call("e4s_conv7x7s2_stem_f16x3", _p(out), _p(x), _p(prepared.wt), _p(prepared.bias), bs, h, w, 1 if relu else 0, prepared.kexp, _stream())
+        if ev is not None:
+            ev.record()
+        return out
     sb = isinstance(prepared.wt, tuple)
     ev = _timed(f"conv2d_{'sb_' if sb else ''}kernel<{kh},{stride}>")
     pr = _p(_c(prelu.detach(), "prelu")) if prelu is not None else None

@@ -430,6 +430,12 @@ E4S_API int e4s_maxpool3x3s2(float* out, const float* in, int planes, int h, int
 E4S_API int e4s_gate_add_upsample(float* out, const float* feat, const float* gate, const float* add_map, const float* add_vec,
                                   int planes, int h, int w, int up, void* stream);
 
+/* The face parser's ResNet stem, Conv2d(3, 64, 7, stride 2, pad 3) + folded BatchNorm + ReLU (swap_face_fine/face_parsing/resnet.py:57-58, 66), as an implicit
+ * GEMM over the flattened (channel, ky, kx) axis (K = 147 in ten 16-deep steps) in the two-term f16 split of e4s_conv2d_f16x3:
+ *   out [bs,64,ho,wo] = act(conv(x [bs,3,h,w]) * 2^-wscale_log2 + bias);  w = the two f16 terms of W * 2^wscale_log2 as [term 2][K step 10][K half 2][co 64][8],
+ *   K = (c*7 + ky)*7 + kx zero-padded to 160; bias [64] or NULL; relu 0 / 1. */
+E4S_API int e4s_conv7x7s2_stem_f16x3(float* out, const float* x, const void* w, const float* bias, int bs, int h, int wd, int relu, int wscale_log2, void* stream);
+
 /* labels[bs,oh,ow] (uint8) = lut[ argmax_c bilinear_align_corners(logits[bs,ncls,ih,iw]) ] — fuses F.interpolate(..., align_corners=True)
  * (face_parsing/model.py:257), torch.argmax (face_parsing_demo.py:170) and, through the optional 256-entry lut, the 19->12 remap
  * (datasets/dataset.py:58-108).  First maximum wins ties. */

@@ -180,6 +180,38 @@ def test_bilinear_argmax_against_the_same_arithmetic_in_torch(shape):
         assert float((top2[:, 0] - top2[:, 1])[bad].max()) <= 1e-5 and int(bad.sum()) <= 8, int(bad.sum())
 
 
+@pytest.mark.parametrize("shape", [(2, 512, 512), (1, 70, 90), (3, 33, 47), (1, 8, 260)])
+def test_stem7_kernel_against_float64(shape):
+    """Conv2d(3, 64, 7, 2, 3) + BatchNorm (eval) + ReLU of the parser's ResNet stem (face_parsing/resnet.py:57-58, 66) on csrc/stem7.hip (K = (c, ky, kx) flattened,
+    two-term f16 split) against float64, and against the exact-fp32 kernel it replaces; ragged and odd sizes."""
+    bs, h, w = shape
+    g = torch.Generator().manual_seed(h + w)
+    x = torch.randn(bs, 3, h, w, generator=g) * 1.2
+    conv = torch.nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+    bn = torch.nn.BatchNorm2d(64).eval()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(64, 3, 7, 7, generator=g) * 0.08)
+        bn.weight.copy_(torch.rand(64, generator=g) + 0.5); bn.bias.copy_(torch.randn(64, generator=g) * 0.2)
+        bn.running_mean.copy_(torch.randn(64, generator=g) * 0.1); bn.running_var.copy_(torch.rand(64, generator=g) + 0.5)
+    with torch.no_grad():
+        ref = torch.relu(bn.double()(conv.double()(x.double())))
+    conv, bn = conv.float().to(DEV), bn.float().to(DEV)
+    xd = x.to(DEV)
+    assert ops.STEM7 and ops.PARSER_EXACT == "f16x3"
+    with torch.no_grad():
+        prep = ops.PreparedConv(exact="f16x3").get(conv.weight, bn)
+        assert prep[4] == "stem7"
+        y = ops.conv2d(xd, prep, 2, 3, relu=True).cpu()
+        with ops.mx_exact():
+            y_exact = ops.conv2d(xd, ops.PreparedConv(exact="f16x3").get(conv.weight, bn), 2, 3, relu=True).cpu()
+    scale = float(ref.abs().max())
+    e, e_exact = float((y.double() - ref).abs().max()) / scale, float((y_exact.double() - ref).abs().max()) / scale
+    record_parity(f"parser_stem7_{bs}x{h}x{w}.vs_float64", e, 2e-6, note=f"exact-fp32 kernel: {e_exact:.2e}")
+    assert tuple(y.shape) == tuple(ref.shape) and e <= 2e-6, (shape, e, e_exact)
+    with pytest.raises(ValueError):
+        ops.conv2d(xd, prep, 1, 3)
+
+
 def test_training_mode_is_refused(parser):
     parser.seg.train()
     try:
