@@ -26,9 +26,9 @@ def timed(fn):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / iters, r
 with torch.no_grad():
-    lab = parser.parse_batch((img + 1) / 2, seg12=True)
+    lab = parser.parse_batch(img, seg12=True, pm1=True)
     if what in ("parse", "both"):
-        ms, lab = timed(lambda: parser.parse_batch((img + 1) / 2, seg12=True))
+        ms, lab = timed(lambda: parser.parse_batch(img, seg12=True, pm1=True))
         print(f"parse_batch        bs={bs}: {ms:7.3f} ms  ({ms / bs:.3f} ms per image)")
     if what in ("encode", "both"):
         ms, _ = timed(lambda: net.get_style_vectors(img, lab))
