@@ -15,3 +15,6 @@ with torch.no_grad():
     tot = 0
     for k, v in sorted(kt.summary().items(), key=lambda kv: -kv[1]["ms"] if isinstance(kv[1], dict) else 0)[:25]:
         print(k, v)
+    for name in ("conv3x3_mx<3>", "conv3x3_s2_mx<3>"):
+        for d, (c, t) in sorted(kt.by_detail(name).items()):
+            print(f"{name:20s} {d:18s} calls {c:3d}  {1e3 * t / c:7.1f} us each")
