@@ -33,6 +33,9 @@ _PROTOS = {
     "e4s_region_upconv_mx4": [c_ptr] * 8 + [c_int, c_int, c_ptr, c_int, c_ptr, c_ptr] + [c_int] * 7 + [c_ptr],
     "e4s_modconv_prep_weights_mx": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_region_modconv3x3_mx": [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr, c_int] + [c_int] * 7 + [c_ptr, c_i64] + [c_ptr] * 10,
+    "e4s_modconv_mxe_weight_bytes": [c_int, c_int, c_int, c_ptr],
+    "e4s_modconv_prep_weights_mxe": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
+    "e4s_region_modconv3x3_mxe": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr, c_int] + [c_int] * 7 + [c_ptr, c_i64] + [c_ptr] * 8,
     "e4s_conv_prep_weights_mx": [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
     "e4s_conv3x3_mx": [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_conv3x3_mx3_weight_bytes": [c_int, c_int, c_ptr],

@@ -127,7 +127,7 @@ __device__ __forceinline__ bool quad_uniform_tile(const SbParams& p, int b, int 
 
 // The one-pass epilogue of a workgroup tile.  `acc[i][q]` = raw sums of output-channel block i (32 channels) x pixel block q (32 pixels) of this wave;
 // `cls[q]` = region of the lane's pixel (-1: none); the tables overlay the first (MAX_REG + 5) * TN * 4 + 64 bytes of `lds_raw`, which the caller
-// must be done with.  Every global LOAD happens before the first store (one in-order vmcnt for both on gfx9).
+// must be done with (RGB with two wave groups per pixel: 3 * NPB * 32 more floats behind them).  Every global LOAD happens before the first store (one in-order vmcnt for both on gfx9).
 template <class C, int CB, int PB, int WP, bool RGB, bool OSP>
 __device__ __forceinline__ void sb_epilogue(const SbParams& p, unsigned char* lds_raw, f32x16 (&acc)[CB][PB], const int (&cls)[PB], int co0, int b, int y0, int x0,
                                             int pa, int pb_, int ho, int wo, unsigned ub_skip) {
@@ -135,6 +135,10 @@ __device__ __forceinline__ void sb_epilogue(const SbParams& p, unsigned char* ld
     const int lane = tid & 63, wave = tid >> 6;
     const int l5 = lane & 31, khalf = lane >> 5;
     const int wc = wave / WP, wp = wave % WP;
+    constexpr int WC_ = C::TN / (CB * 32);          // wave groups along the output channels
+    static_assert(!RGB || WC_ <= 2, "fused ToRGB: one or two wave groups per pixel");
+    float rgbp[PB][3];                              // (RGB, WC_ == 2) this wave's partial ToRGB sums
+    (void)rgbp;
     __syncthreads();
     float* dt = reinterpret_cast<float*>(lds_raw);  // [MAX_REG][TN] over the weight stage
     for (int v = tid; v < E4S_MAX_REGIONS * C::TN; v += C::NT) {
@@ -255,10 +259,38 @@ __device__ __forceinline__ void sb_epilogue(const SbParams& p, unsigned char* ld
             rgb0 += __shfl_xor(rgb0, 32, 64);
             rgb1 += __shfl_xor(rgb1, 32, 64);
             rgb2 += __shfl_xor(rgb2, 32, 64);
-            if (khalf == 0 && pix_ok) {
-                p.rgb_out[((size_t)b * 3 + 0) * ho * wo + opix] = rgb0 + rgbadd[q][0];
-                p.rgb_out[((size_t)b * 3 + 1) * ho * wo + opix] = rgb1 + rgbadd[q][1];
-                p.rgb_out[((size_t)b * 3 + 2) * ho * wo + opix] = rgb2 + rgbadd[q][2];
+            if constexpr (WC_ == 1) {
+                if (khalf == 0 && pix_ok) {
+                    p.rgb_out[((size_t)b * 3 + 0) * ho * wo + opix] = rgb0 + rgbadd[q][0];
+                    p.rgb_out[((size_t)b * 3 + 1) * ho * wo + opix] = rgb1 + rgbadd[q][1];
+                    p.rgb_out[((size_t)b * 3 + 2) * ho * wo + opix] = rgb2 + rgbadd[q][2];
+                }
+            } else {
+                rgbp[q][0] = rgb0; rgbp[q][1] = rgb1; rgbp[q][2] = rgb2;
+            }
+        }
+    }
+    if constexpr (RGB && WC_ == 2) {
+        // WC == 2 (modconv_mxe.hip: 2 x 64 channels per pixel in waves wc = 0 / 1): the upper channel half's partial sums cross through LDS behind the tables
+        float* xch = snt + C::TN;                    // [3][NPB * 32]
+        if (wc == 1 && khalf == 0) {
+#pragma unroll
+            for (int q = 0; q < PB; ++q)
+#pragma unroll
+                for (int o = 0; o < 3; ++o) xch[o * (C::NPB * 32) + (wp * PB + q) * 32 + l5] = rgbp[q][o];
+        }
+        __syncthreads();
+        if (wc == 0 && khalf == 0) {
+#pragma unroll
+            for (int q = 0; q < PB; ++q) {
+                const int pbk = wp * PB + q;
+                const int y = y0 + C::blk_y(pbk, l5), x = x0 + C::blk_x(pbk, l5);
+                if (y < p.h && x < p.w) {
+                    const size_t opix = (size_t)y * wo + x;        // (fused ToRGB: same-resolution layers only)
+#pragma unroll
+                    for (int o = 0; o < 3; ++o)
+                        p.rgb_out[((size_t)b * 3 + o) * ho * wo + opix] = rgbp[q][o] + xch[o * (C::NPB * 32) + pbk * 32 + l5] + rgbadd[q][o];
+                }
             }
         }
     }
@@ -266,5 +298,7 @@ __device__ __forceinline__ void sb_epilogue(const SbParams& p, unsigned char* ld
 
 // modconv_mx.hip: the DMA-fed 128 co x 256 px masked kernel (p.wmx set).  Returns E4S_OK or an error code.
 int launch_modconv_mx(SbParams& p, int arith, hipStream_t st, float* workspace, int64_t workspace_floats, bool plain_conv = false);
+// modconv_mxe.hip: the same tile on class-prepared operands (p.wmx = unit slots of e4s_modconv_prep_weights_mxe, p.whi = the row slots above for the tiles that fall back).
+int launch_modconv_mxe(SbParams& p, hipStream_t st, float* workspace, int64_t workspace_floats);
 
 }  // namespace e4s

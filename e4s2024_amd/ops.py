@@ -505,6 +505,15 @@ def mx_eligible(cin: int, cout: int, w: int, masked: bool) -> bool:
     return mx_arith() is not None and masked and w >= 32 and cout >= 128 and cin % 16 == 0 and not torch.is_grad_enabled()
 
 
+# Round 5: the masked same-resolution layers with class-prepared operands (csrc/modconv_mxe.hip): entries = (patch pixel, region) pairs prepared once per 32-channel chunk,
+# conversion-free two-phase K loop; tiles with more than 512 entries run the kernel above's tile inside the same launch.  E4S_MXE=0 keeps the round-3 kernel everywhere.
+MXE = os.environ.get("E4S_MXE", "1") != "0"
+
+
+def mxe_eligible(cin: int, cout: int, w: int, masked: bool, up: bool) -> bool:
+    return MXE and mx_arith() == 1 and mx_eligible(cin, cout, w, masked) and not up and cin % 32 == 0
+
+
 class PreparedMx(_Prepared):
     """A ModulatedConv2d weight as the row slots ``e4s_region_modconv3x3_mx`` DMAs (``e4s_modconv_prep_weights_mx``); rebuilt when the parameter,
     the blur buffer or the arithmetic changes.  Inference only (``mx_eligible``), so the copy is always cacheable."""
@@ -531,6 +540,14 @@ class PreparedMx(_Prepared):
             lib().call("e4s_conv3x3_mx3_weight_bytes", cout, cin, ctypes.byref(nbytes))
             wmx = torch.empty((nbytes.value,), dtype=torch.uint8, device=w.device)
             lib().call("e4s_conv_prep_weights_mx3" if arith == 3 else "e4s_conv_prep_weights_mx3_s2", _p(wmx), _p(w), cout, cin, _stream())
+            self._publish(key, (wmx,))
+            return wmx
+        if arith == 6:            # the entry kernel's unit slots (csrc/modconv_mxe.hip)
+            if plain:
+                raise ValueError("arith 6 (modconv_mxe) is a ModulatedConv2d layout")
+            lib().call("e4s_modconv_mxe_weight_bytes", cout, cin, 1 if up else 0, ctypes.byref(nbytes))
+            wmx = torch.empty((nbytes.value,), dtype=torch.uint8, device=w.device)
+            lib().call("e4s_modconv_prep_weights_mxe", _p(wmx), _p(w), _p(bk), cout, cin, 1 if up else 0, _stream())
             self._publish(key, (wmx,))
             return wmx
         if arith == 4:            # the four-parity up kernel's row slots (csrc/modconv_mx4.hip)
@@ -971,10 +988,12 @@ def uniform_blocks(labels: torch.Tensor, ho: int, wo: int, nreg: int, with_ctrl:
 
 
 def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: bool, cout: int, up: bool, rgb=None, want_out: bool = True,
-                      x_nhwc: bool = False, out_nhwc: bool = False, s_next=None, up_blocks=None, mx=None, mx4=None):
+                      x_nhwc: bool = False, out_nhwc: bool = False, s_next=None, up_blocks=None, mx=None, mx4=None, mxe=None):
     """``mx = (wmx, arith)`` (``PreparedMx``, a layer ``mx_eligible`` accepts): run on the DMA-fed kernel of csrc/modconv_mx.hip.
     ``mx4`` (with ``mx``, arith 1, an up layer ``mx4_eligible`` accepts; ``PreparedMx.get(..., arith=4)``): one launch of csrc/modconv_mx4.hip — the tiles whose
     positions' 2 x 2 outputs share a region as four-parity tiles, the others as the composed kernel's tiles (bit-identical results either way).
+    ``mxe`` (with ``mx``, arith 1; ``PreparedMx.get(..., arith=6)``, a layer ``mxe_eligible`` accepts): the launch of csrc/modconv_mxe.hip — class-prepared operands,
+    the tiles with too many (pixel, region) pairs as the round-3 kernel's tiles.
     ``rgb = (wt_rgb [cout,3], s_rgb [bs,1,cout], bias [1,3,1,1], skip or None, up_kernel)`` fuses the following single-region
     ToRGB; the call then returns ``(out, rgb_image)``.  ``want_out=False`` (with ``rgb``) skips writing the layer's own activation
     and returns ``(None, rgb_image)``.  ``x_nhwc`` / ``out_nhwc``: the activation is channel-blocked, ``[bs, c/8, h, w, 8]`` (split-bf16
@@ -1032,7 +1051,9 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
                    nbs or 0, _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, int(UP_SUBBLOCKS), _stream())
         if evb is not None:
             evb.record()
-    ev = _timed(modconv_kernel_name(cout, w, sb, labels is not None, cin, mx[1] if (sb and mx is not None) else None), f"{cin}->{cout} @{h}{' up' if up else ''}")
+    use_mxe = sb and mx is not None and mxe is not None and mx[1] == 1 and blocks is None and cin % 32 == 0
+    ev = _timed("region_conv_mxe_kernel" if use_mxe else modconv_kernel_name(cout, w, sb, labels is not None, cin, mx[1] if (sb and mx is not None) else None),
+                f"{cin}->{cout} @{h}{' up' if up else ''}")
     rgb_out = None
     if rgb is not None:
         if not sb:
@@ -1049,7 +1070,11 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
         if labels is None or w < 32 or cout < 128 or cin % 16 or x_nhwc or out_nhwc:
             raise ValueError("region_modconv3x3: the mx kernel is built for masked layers of width >= 32, cout >= 128, cin % 16 == 0, channels-first")
         wmx, arith = mx
-        if mx4 is not None and up and arith == 1 and blocks is None and rgb is None and sn is None and cout % 128 == 0:
+        if use_mxe:
+            lib().call("e4s_region_modconv3x3_mxe", _p(out), _p(x), _p(mxe), _p(wmx), _p(mx_flags(x.device)), _p(s), _p(d), _p(labels), lh, lw,
+                       _p(nz), nbs or 0, _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg,
+                       (1 if up else 0) | (16 if sn is not None else 0), _p(ws), wsn, *rgb_args, _p(sn), _stream())
+        elif mx4 is not None and up and arith == 1 and blocks is None and rgb is None and sn is None and cout % 128 == 0:
             lib().call("e4s_region_upconv_mx4", _p(out), _p(x), _p(mx4), _p(wmx), _p(mx_flags(x.device)), _p(s), _p(d), _p(labels), lh, lw, _p(nz), nbs or 0,
                        _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, _stream())
         else:

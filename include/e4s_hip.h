@@ -167,6 +167,21 @@ E4S_API int e4s_modconv_prep_weights_mx4(void* dst, const float* weight, const f
 E4S_API int e4s_region_upconv_mx4(float* out, const float* x, const void* wmx4, const void* wmx, int* flags, const float* s, const float* d, const uint8_t* labels,
                                   int lh, int lw, const float* noise, int noise_bs, const float* noise_weight, const float* act_bias, int act, int bs, int cin,
                                   int cout, int h, int w, int nreg, void* stream);
+/* Round 5: the same masked layer (models/stylegan2/model.py:276-320, 385-400) with CLASS-PREPARED operands (csrc/modconv_mxe.hip): the unit of staging is an entry =
+ * (patch pixel, region) for every region that occurs among the output pixels reading that patch pixel; x * s[region] is split into f16 + two MX-fp6 terms ONCE per entry
+ * and 32-channel chunk, and the K loop (conv_mx3's two-phase loop) only reads LDS and issues MFMAs.  A 32 x 8-pixel tile with more than 512 entries runs the tile of
+ * e4s_region_modconv3x3_mx inside the same launch (wmx: e4s_modconv_prep_weights_mx(up, arith 1)).  wmxe from e4s_modconv_prep_weights_mxe (size
+ * e4s_modconv_mxe_weight_bytes); cin % 32 == 0, cout >= 128, w >= 32; every other argument as for e4s_region_modconv3x3_mx (up: bit 0 = up layer in the composed
+ * four-parity form, bit 4 = split-plane output with the fused ToRGB). */
+E4S_API int e4s_modconv_mxe_weight_bytes(int cout, int cin, int up, int64_t* bytes);
+E4S_API int e4s_modconv_prep_weights_mxe(void* dst, const float* weight, const float* blur, int cout, int cin, int up, void* stream);
+E4S_API int e4s_region_modconv3x3_mxe(float* out, const float* x, const void* wmxe, const void* wmx, int* flags, const float* s, const float* d,
+                                      const uint8_t* labels, int lh, int lw,
+                                      const float* noise, int noise_bs, const float* noise_weight, const float* act_bias, int act,
+                                      int bs, int cin, int cout, int h, int w, int nreg, int up,
+                                      float* workspace, int64_t workspace_floats,
+                                      float* rgb_out, const float* rgb_wt, const float* rgb_s, const float* rgb_bias, const float* rgb_skip,
+                                      const float* rgb_up_kernel, const float* s_next, void* stream);
 /* The regional-style encoder's stride-1, pad-1 3x3 convolutions (models/encoders/helpers.py:128-139) on the same kernel in its plain-convolution mode:
  *   out[bs,cout,h,w] = PReLU( conv3x3( (x - in_mean[b,ci]) * in_rstd[b,ci], W ) )          in_mean / in_rstd (together) and prelu_slope optional
  * cin % 16 == 0; padding is exactly 0 (the normalisation applies to in-image pixels only).  wmx from e4s_conv_prep_weights_mx (weight [cout,cin,3,3],

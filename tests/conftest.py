@@ -23,7 +23,7 @@ _PARITY = {}
 
 def record_parity(name: str, value, tol=None, note: str = ""):
     """Remember a measured parity figure (max-abs diff, flipped-pixel count ...) of the running session; at session end everything recorded
-    is written to ``gpurun_out/parity.json`` (merged back from the GPU box) and, for the round's evidence, ``profiles/r04_parity.json``."""
+    is written to ``gpurun_out/parity.json`` (merged back from the GPU box) and, for the round's evidence, ``profiles/r05_parity.json``."""
     ent = {"value": (float(value) if not isinstance(value, (int, bool)) else int(value))}
     if tol is not None:
         ent["tol"] = float(tol)
@@ -38,7 +38,7 @@ def pytest_sessionfinish(session, exitstatus):
         return
     doc = {"device": torch.cuda.get_device_name(0) if torch.cuda.is_available() else "cpu", "exitstatus": int(exitstatus),
            "n": len(_PARITY), "parity": dict(sorted(_PARITY.items()))}
-    for rel in (("gpurun_out", "parity.json"), ("profiles", "r04_parity.json")):
+    for rel in (("gpurun_out", "parity.json"), ("profiles", "r05_parity.json")):
         path = os.path.join(ROOT, *rel)
         try:
             os.makedirs(os.path.dirname(path), exist_ok=True)
