@@ -54,9 +54,13 @@ static_assert(E4S_MAX_REGIONS * XE_CK == 512, "one modulation value per thread a
 
 using CE = SbCfg<2, 2, 2, 4, 5>;        // 2 x 2 blocks per wave, waves = 2 channel halves x 4 row pairs: 128 co x (32 x 8) px
 
-__device__ __forceinline__ float xe_load_uncounted(const float* gbase, unsigned voff) {      // (see conv_mx3.hip: valid only behind one of the kernel's own vmcnt waits)
+// A global load hipcc does not count (see conv_mx3.hip: the result is valid only behind one of the kernel's own vmcnt waits).  The s_nop: gfx9 requires five wait states
+// between a VALU instruction that writes an SGPR (v_readlane of a spilled SGPR, v_readfirstlane) and a vector-memory instruction that reads it; hipcc inserts them for its
+// own instructions but does not look into an asm block — without them a base restored from a spill lane right in front of the block is read before it is written
+// (observed: memory faults at addresses with a stale upper half, in builds whose register allocation put such a restore there).
+__device__ __forceinline__ float xe_load_uncounted(const float* gbase, unsigned voff) {
     float v;
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(gbase) : "memory");
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(gbase) : "memory");
     return v;
 }
 __device__ __forceinline__ unsigned xe_resid_pair(float a, float b, float sa, float sb_, unsigned a1) { return resid_pair_f16(a, sa, b, sb_, a1); }
@@ -170,6 +174,12 @@ __global__ __launch_bounds__(512, 2) void region_conv_mxe_kernel(const SbParams 
     const float* xb = p.x + (size_t)b * p.cin * hw;
     const float* sbase = p.s + (size_t)b * p.nreg * p.cin;
 
+#ifdef XE_PROF
+    unsigned long long tR = 0, tWR = 0, tM = 0, tWM = 0, tST = 0, tTop = 0, tS = __builtin_readcyclecounter(), tStart = tS, tPro = 0, tPro2 = 0, tLoop = 0;
+#define XE_STAMP(accum) { const unsigned long long tn = __builtin_readcyclecounter(); accum += tn - tS; tS = tn; }
+#else
+#define XE_STAMP(accum)
+#endif
     // ================================================================ prologue: the tile's entries
     auto out_class = [&](int ty, int tx) __attribute__((always_inline)) {        // region of output pixel (ty, tx) of the tile (255: none)
         const int y = y0 + ty, x = x0 + tx;
@@ -256,6 +266,7 @@ __global__ __launch_bounds__(512, 2) void region_conv_mxe_kernel(const SbParams 
     }
     __syncthreads();          // (everyone is done with the scratch: the entry planes may be written)
 
+    XE_STAMP(tPro)
     f32x16 acc[2][2];        // [co block][pixel block]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -265,7 +276,12 @@ __global__ __launch_bounds__(512, 2) void region_conv_mxe_kernel(const SbParams 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     unsigned ovf = 0u;
-    if (E > 0 && nunits > 0) {
+#ifdef XE_PROF
+    const unsigned dbg = p.perm_mul;      // (tuning build, E4S_MXE_DBG: 1 = no K loop, 2 = no epilogue)
+#else
+    constexpr unsigned dbg = 0u;
+#endif
+    if (E > 0 && nunits > 0 && !(dbg & 1u)) {
     const bool has_x = wave * 64 < E;                        // this wave owns entries (wave-uniform)
     const int PCS = wave < 5 ? 4 : 3;                        // this wave's pieces of a unit's 29 DMA requests
     const int NLD = (has_x ? XE_CK : 0) + 1;                 // this wave's requests of one prefetch: 32 activation loads + the modulation value
@@ -403,11 +419,13 @@ __global__ __launch_bounds__(512, 2) void region_conv_mxe_kernel(const SbParams 
     const unsigned* tbl = reinterpret_cast<const unsigned*>(lds + XE_TBL) + pix0;
     unsigned tw0 = tbl[0], tw1 = tbl[XE_TW];                 // tap entries of unit 0 for the two pixels (the next unit's are requested one unit ahead)
     int slot = 0, g = 0;
+    XE_STAMP(tPro2)
 #pragma unroll 1
     for (int chunk = ch_begin; chunk < ch_end; ++chunk) {
         const bool more = chunk + 1 < ch_end;
         const int kk = chunk - ch_begin;
         if (more) load_x(chunk + 1);
+        XE_STAMP(tTop)
 #pragma unroll
         for (int u = 0; u < XE_NUNIT; ++u, ++g) {
             const bool first = u == 0, last = u == XE_NUNIT - 1;
@@ -469,7 +487,12 @@ __global__ __launch_bounds__(512, 2) void region_conv_mxe_kernel(const SbParams 
             const bool lx_younger = first && more;
             if (grp) wait_units(d_younger, lx_younger);
             __builtin_amdgcn_sched_barrier(0);
+#ifdef XE_PROF
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            XE_STAMP(tR)
             E4S_LDS_BARRIER();
+            XE_STAMP(tWR)
             __builtin_amdgcn_sched_barrier(0);
             // ---------------- M phase: 16 f16 + 8 fp6 MFMAs, nothing else
 #pragma unroll
@@ -496,19 +519,23 @@ __global__ __launch_bounds__(512, 2) void region_conv_mxe_kernel(const SbParams 
                 for (int pb = 0; pb < 2; ++pb) pin_here(acc[cb][pb]);
             if (!grp) wait_units(d_younger, lx_younger && !last);
             // waves 4-7 convert their entries of the next chunk right behind the chunk's last MFMAs, waves 0-3 behind the barrier (conv_mx3.hip's store phase)
-            if (grp && last && more) store_x((kk + 1) & 1);
+            XE_STAMP(tM)
+            if (grp && last && more) { store_x((kk + 1) & 1); XE_STAMP(tST) }
             __builtin_amdgcn_sched_barrier(0);
             E4S_LDS_BARRIER();
+            XE_STAMP(tWM)
             __builtin_amdgcn_sched_barrier(0);
             slot = slot == 2 ? 0 : slot + 1;
         }
         if (more) {
-            if (!grp) store_x((kk + 1) & 1);
+            if (!grp) { store_x((kk + 1) & 1); XE_STAMP(tST) }
             E4S_LDS_BARRIER();
+            XE_STAMP(tWM)
         }
     }
     if (!grp) E4S_LDS_BARRIER();
     E4S_WAIT_VM(0);
+    XE_STAMP(tLoop)
     }
     if (p.flags && __builtin_amdgcn_ballot_w64(ovf != 0u) != 0 && lane == 0) { atomicOr(p.flags, 1); atomicAdd(p.flags + 1, 1); }      // one report per wave (ops.MxGuard)
 
@@ -519,6 +546,7 @@ __global__ __launch_bounds__(512, 2) void region_conv_mxe_kernel(const SbParams 
         const int c = out_class(2 * pr + q, l5);
         cls[q] = c != 255 ? c : -1;
     }
+    if (dbg & 2u) return;
     if (p.ksplit > 1) {
         float* part = p.partial + ((size_t)ks * p.bs + b) * p.cout * ho * wo;
 #pragma unroll
@@ -538,6 +566,11 @@ __global__ __launch_bounds__(512, 2) void region_conv_mxe_kernel(const SbParams 
         return;
     }
     sb_epilogue<CE, 2, 2, 4, RGB, OSP>(p, lds, acc, cls, co0, b, y0, x0, pa, pb_, ho, wo, 0u);
+#ifdef XE_PROF
+    if (blockIdx.x == 5 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0)
+        printf("wave %d: E %d total %llu | prologue %llu + %llu | top %llu  R %llu  wait after R %llu  M %llu  store %llu  wait after M %llu  tail %llu | epilogue %llu  (units %d)\n", wave, E,
+               __builtin_readcyclecounter() - tStart, tPro, tPro2, tTop, tR, tWR, tM, tST, tWM, tLoop, __builtin_readcyclecounter() - tS, nunits);
+#endif
 }
 
 template <bool RGB, bool OSP>
@@ -590,6 +623,9 @@ int e4s::launch_modconv_mxe(SbParams& p, hipStream_t st, float* workspace, int64
     p.chunks_per = nchunk16 / ksplit;
     p.partial = workspace;
     p.uni_blocks = nullptr; p.uni_ctrl = nullptr; p.perm_mul = 0u;
+#ifdef XE_PROF
+    { const char* e = getenv("E4S_MXE_DBG"); if (e) p.perm_mul = (unsigned)atoi(e); }
+#endif
     dim3 grid(p.tiles_x * p.tiles_y * npar * ksplit, cdiv(p.cout, XE_TN), p.bs);
     const unsigned long long tot = (unsigned long long)grid.x * grid.y * grid.z;
     p.xcd_remap = ((grid.y == 2 || grid.y == 4 || grid.y == 8) && tot % 8 == 0) ? 1 : 0;

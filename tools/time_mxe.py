@@ -13,6 +13,8 @@ from models.stylegan2 import model as sg2  # noqa: E402
 DEV = "cuda:0"
 bs = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+only_layer = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+only_maps = sys.argv[4].split(",") if len(sys.argv) > 4 else None
 LAYERS = [(512, 512, 32), (512, 512, 64), (256, 256, 128), (128, 128, 256)]
 MAPS = {"blocky16": lambda: seeded.blocky_labels(3, bs, 12, 512, 16), "coarse4": lambda: seeded.blocky_labels(3, bs, 12, 512, 4),
         "portrait": lambda: seeded.facelike_labels(3, bs, 512), "iid": lambda: seeded.iid_labels(3, bs, 12, 512)}
@@ -33,13 +35,17 @@ def time_layer(m, x, st, lab, nz):
 
 
 torch.manual_seed(0)
-for cin, cout, w in LAYERS:
+for li, (cin, cout, w) in enumerate(LAYERS):
+    if only_layer >= 0 and li != only_layer:
+        continue
     m = sg2.StyledConv(cin, cout, 3, 512, upsample=False, mask_op=True).to(DEV).eval()
     x = torch.randn(bs, cin, w, w, device=DEV)
     st = torch.randn(bs, 12, 512, device=DEV)
     nz = torch.randn(bs, 1, w, w, device=DEV)
     gf = 2.0 * cin * cout * 9 * w * w * bs / 1e9
     for name, mk in MAPS.items():
+        if only_maps and name not in only_maps:
+            continue
         lab = torch.from_numpy(mk()).to(DEV)
         ts = {}
         for on in (False, True):
