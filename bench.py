@@ -574,9 +574,10 @@ def main():
                 # the last batch of the LAST rank's block, recomputed here with the same batch composition, must equal what arrived
                 s_last, e_last = _runner.shard_range(n_frames, world - 1, world)
                 lo = s_last + ((e_last - s_last - 1) // cb) * cb
+                lo2 = max(s_last, e_last - cb) if e_last - lo < cb else lo        # (a short last round is computed on the block's last `cb` frames: runner.run_clip_streamed)
                 with torch.no_grad():
-                    again = synth(shared, frame_inputs(lo, e_last))
-                ok = bool(torch.equal(again, frames_all[lo:e_last]))
+                    again = synth(shared, frame_inputs(lo2, e_last))
+                ok = bool(torch.equal(again[lo - lo2:], frames_all[lo:e_last]))
             # the same clip three more times back to back (`sustained_frames_per_s` = the last repetition): before round 4's runner kept its streams, every clip ran on
             # fresh streams whose allocator pools were empty, and a repetition cost 25 % more than the first run
             sustained = None
@@ -594,6 +595,7 @@ def main():
                                                         f"async gather of uint8 frames ({cb} x 3 MB per rank per round) to rank 0",
                          "gathered_frames_match_recomputation": ok}
             del out_buf, frames_all
+            rn.close()              # (the runner's pipelines pin two streams' contexts — 128 MB of split-K workspace each — until closed)
         except Exception as e:      # noqa: BLE001 - secondary measurement
             clip_info = {"error": f"{type(e).__name__}: {e}"[:300]}
         net.latent_avg = la.to(dev)
@@ -660,6 +662,47 @@ def main():
         except Exception as e:      # noqa: BLE001 - secondary measurement
             pti_info = {"error": f"{type(e).__name__}: {e}"[:300]}
 
+    # ---- BASELINE configs[3] on several GPUs (--gpus N > 1): the clip loop block-sharded over the ranks, one optimiser step per ROUND (every rank's i-th frame) on
+    # gradients averaged over the ranks (pti.sync_gradients: the one collective of multi-GPU PTI, an all-reduce of ~111 MB of generator gradients per step over RCCL)
+    if world > 1 and not args.no_pti:
+        try:
+            from e4s2024_amd import pti
+            torch.cuda.synchronize()
+            tnet = Net3(_ap.Namespace(**{**vars(opts), "train_G": True}))
+            seeded.apply_seeded(tnet, 4, "net3")
+            tnet = tnet.to(dev).train()
+            tnet.latent_avg = net.latent_avg
+            params = pti.trainable_parameters(tnet)
+            topt = torch.optim.Adam(params, lr=1e-3)
+            nf, passes = 32, max(1, args.pti_passes)
+            from e4s2024_amd.runner import shard_range as _sr
+            lo_f, hi_f = _sr(nf, rank, world)
+            vecs = torch.from_numpy(seeded.seeded_array(42, "vecs", (nf, 12, 1280), dist="normal")).to(dev)
+            labs = torch.from_numpy(seeded.blocky_labels(43, nf, 12, 512, 16)).to(dev).to(torch.uint8)
+            imgs = torch.tanh(torch.from_numpy(seeded.seeded_array(44, "imgs", (nf, 3, 1024, 1024), dist="normal"))).to(dev)
+            pti.tune_clip(tnet, topt, imgs, labs, vecs, steps=1, erode_radius=3)             # warm-up pass (weight caches, allocator, RCCL buffers)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t2 = time.perf_counter()
+            hist = pti.tune_clip(tnet, topt, imgs, labs, vecs, steps=passes, erode_radius=3)
+            torch.cuda.synchronize()
+            dist.barrier()
+            tt = torch.tensor([time.perf_counter() - t2], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            secs = float(tt.item())
+            rounds = -(-nf // world)
+            pti_info = {"ranks": world, "frames": nf, "passes": passes, "rounds_per_pass": rounds, "optimizer_steps": rounds * passes, "seconds": round(secs, 4),
+                        "seconds_per_pass": round(secs / passes, 4), "s_per_iter": round(secs / (passes * rounds), 5), "batch": 1, "resolution": 1024, "loss": "L2 (foreground-weighted, eroded maps)",
+                        "mean_loss_per_pass": [round(h, 4) for h in (hist if len(hist) <= 10 else hist[:5] + hist[-5:])],
+                        "collective": "all-reduce (average) of the generator's gradients once per round (pti.sync_gradients over RCCL); one optimiser step per round on identical parameters",
+                        "what": "pti.tune_clip on configs[3]'s 32-frame clip at 1024 x 1024, frames block-sharded over the ranks (rank r tunes on shard_range(32, r, N)); eager steps "
+                                "(the graph-captured step has no gradient exchange); BASELINE configs[3] is 200 such passes on 4 GPUs — a batch-of-N step, not the reference's N "
+                                "sequential steps: no parity claim for this mode (SURVEY section 8e)"}
+            del topt, tnet, params, vecs, labs, imgs
+            torch.cuda.empty_cache()
+        except Exception as e:      # noqa: BLE001 - secondary measurement
+            pti_info = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         faces = bs * world * args.steps
@@ -694,7 +737,9 @@ def main():
             job_peak = BF16_MATRIX_PEAK_TFLOPS / job_cost
             job_ach = value * 148.52e9 / 1e12 / world
             roof = {"bound": "mfma", "kernel": dom,
-                    **({"kernel_launches": "region_modconv_mx_kernel<1, ...> (csrc/modconv_mx.hip) and, for masked up layers whose launch fills the chip with 64-channel tiles "
+                    **({"kernel_launches": ("region_conv_mxe_kernel (csrc/modconv_mxe.hip: the masked same-resolution layers with class-prepared operands; its tiles with more than 512 "
+                                            "(pixel, region) pairs run the tile of region_modconv_mx_kernel<1> inside the same launch), " if ops.MXE else "") +
+                                           "region_modconv_mx_kernel<1, ...> (csrc/modconv_mx.hip) and, for masked up layers whose launch fills the chip with 64-channel tiles "
                                            "(512->256 @64 at this batch), region_upconv_mx4_kernel (csrc/modconv_mx4.hip): the same tile code or its four-parity form, "
                                            "chosen per workgroup — profiler tables list the two names, this object counts them as one kernel"}
                        if (ops.UP_MX4 and dom and dom.startswith("region_modconv_mx_kernel<1")) else {}),

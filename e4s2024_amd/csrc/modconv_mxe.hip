@@ -180,6 +180,20 @@ __global__ __launch_bounds__(512, 2) void region_conv_mxe_kernel(const SbParams 
 #else
 #define XE_STAMP(accum)
 #endif
+    // ---- the first three weight units are requested before anything else: they land (3.5 us for 87 KB at a CU's LDS-DMA rate) while the entry table is built
+    const unsigned char* wbase = p.wmx + ((size_t)par * nchunk + ch_begin) * ncot * XE_NUNIT * XE_UNITB;
+    auto dma_unit = [&](int g, int slot) __attribute__((always_inline)) {      // unit g of this workgroup's K slice -> ring slot
+        const int chunk = g / XE_NUNIT, u = g - chunk * XE_NUNIT;
+        const unsigned char* src = wbase + (((size_t)chunk * ncot + cotile) * XE_NUNIT + u) * XE_UNITB;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int piece = wave + 8 * k;
+            if (piece < XE_NPIECE) dma16_asm(src + piece * 1024, (unsigned)(lane * 16), (unsigned)(XE_RING + slot * XE_UNITB + piece * 1024));
+        }
+    };
+    if (nunits > 0) dma_unit(0, 0);
+    if (nunits > 1) dma_unit(1, 1);
+    if (nunits > 2) dma_unit(2, 2);
     // ================================================================ prologue: the tile's entries
     auto out_class = [&](int ty, int tx) __attribute__((always_inline)) {        // region of output pixel (ty, tx) of the tile (255: none)
         const int y = y0 + ty, x = x0 + tx;
@@ -229,6 +243,7 @@ __global__ __launch_bounds__(512, 2) void region_conv_mxe_kernel(const SbParams 
     E = __builtin_amdgcn_readfirstlane(E);
     if (E > XE_EMAX) {
         // too many distinct (pixel, region) pairs for one entry per thread: the round-3 tile (per-tap operand preparation) computes this workgroup's tile
+        E4S_WAIT_VM(0);          // (the requested units land in the ring, whose bytes that tile's own LDS plan reuses)
         __syncthreads();
         SbParams pc = p;
         pc.wmx = reinterpret_cast<const unsigned char*>(p.whi);
@@ -378,22 +393,9 @@ __global__ __launch_bounds__(512, 2) void region_conv_mxe_kernel(const SbParams 
         }
         store_s(sbuf ^ 1);
     };
-    const unsigned char* wbase = p.wmx + ((size_t)par * nchunk + ch_begin) * ncot * XE_NUNIT * XE_UNITB;
-    auto dma_unit = [&](int g, int slot) __attribute__((always_inline)) {      // unit g of this workgroup's K slice -> ring slot
-        const int chunk = g / XE_NUNIT, u = g - chunk * XE_NUNIT;
-        const unsigned char* src = wbase + (((size_t)chunk * ncot + cotile) * XE_NUNIT + u) * XE_UNITB;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int piece = wave + 8 * k;
-            if (piece < XE_NPIECE) dma16_asm(src + piece * 1024, (unsigned)(lane * 16), (unsigned)(XE_RING + slot * XE_UNITB + piece * 1024));
-        }
-    };
     auto wait_units = [&](bool d, bool lx) __attribute__((always_inline)) { xe_wait_vm((d ? PCS : 0) + (lx ? NLD : 0)); };
 
-    // ---- first three units' weights, the first two modulation tables, the first chunk's entries
-    dma_unit(0, 0);
-    if (nunits > 1) dma_unit(1, 1);
-    if (nunits > 2) dma_unit(2, 2);
+    // ---- the first two modulation tables, the first chunk's entries
     {
         const int r = (tid >> 5) < p.nreg ? (tid >> 5) : p.nreg - 1;
         const int c1 = ch_begin + 1 < nchunk ? ch_begin + 1 : nchunk - 1;
@@ -537,6 +539,7 @@ __global__ __launch_bounds__(512, 2) void region_conv_mxe_kernel(const SbParams 
     E4S_WAIT_VM(0);
     XE_STAMP(tLoop)
     }
+    E4S_WAIT_VM(0);          // (a tile without entries ran no loop: its prologue's requests must land before the workgroup's LDS is released)
     if (p.flags && __builtin_amdgcn_ballot_w64(ovf != 0u) != 0 && lane == 0) { atomicOr(p.flags, 1); atomicAdd(p.flags + 1, 1); }      // one report per wave (ops.MxGuard)
 
     // ================================================================ epilogue

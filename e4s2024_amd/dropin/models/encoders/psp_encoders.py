@@ -94,7 +94,12 @@ class bottleneck_IR_SE_Ours(Module):
             r = ops.conv3x3_s1(r, rl[3].weight, self._wino[1])
         else:
             r = ops.conv3x3_s2(r, rl[3].weight, self._wino[1]) if self.stride == 2 else ops.conv2d(r, self._w[1].get(rl[3].weight), self.stride, 1)
-        self_stats = ops.SE_GATE_IS_HALF and not torch.is_grad_enabled()
+        # (the constant gate needs the reference's preconditions, checked on the modules as they are NOW: an affine-free InstanceNorm without running statistics in
+        #  front of bias-free fc1 / fc2 — a variant or a checkpoint with an affine norm or biases gets the computed gate)
+        se, nrm = rl[5], rl[4]
+        half_ok = (not getattr(nrm, "affine", False) and not getattr(nrm, "track_running_stats", False)
+                   and getattr(se.fc1, "bias", None) is None and getattr(se.fc2, "bias", None) is None)
+        self_stats = ops.SE_GATE_IS_HALF and half_ok and not torch.is_grad_enabled()
         if self_stats:
             # SEModule behind an affine-free InstanceNorm: its squeeze is the mean of a normalised plane = 0, its bias-free gate sigmoid(0) = 1/2 (ops.SE_GATE_IS_HALF);
             # nothing then needs r's statistics before the unit's last launch, which computes them itself

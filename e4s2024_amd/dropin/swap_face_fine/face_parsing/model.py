@@ -176,12 +176,12 @@ class BiSeNet(nn.Module):
             feat_out32 = self.conv_out32(feat_cp16)
             up = lambda t: ops.bilinear_resize(t, (H, W), align_corners=True)            # noqa: E731  (reference :257-259)
             return up(feat_out), up(feat_out16), up(feat_out32)
-        return ops.guarded(run)       # (the two-term f16 split of the convolutions: a pass that left the f16 range is re-run on the three-way bf16 split)
+        return ops.guarded(run, f16_under_grad=True)       # (the two-term f16 split of the convolutions: a pass that left the f16 range is re-run on the three-way bf16 split)
 
     def parse(self, x, lut=None):
         """Fused inference: uint8 ``[bs, H, W]`` = (lut of) argmax over the bilinearly up-sampled main-head logits."""
         H, W = x.size()[2:]
-        return ops.guarded(lambda: ops.bilinear_argmax(self._main_logits(x)[0], (H, W), lut))
+        return ops.guarded(lambda: ops.bilinear_argmax(self._main_logits(x)[0], (H, W), lut), f16_under_grad=True)
 
     def init_weight(self):
         _kaiming(self)

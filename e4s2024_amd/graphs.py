@@ -44,7 +44,10 @@ class GraphedCall:
         finally:
             ops.STRICT_MASK = self._strict
 
-    def __call__(self, *inputs: torch.Tensor):
+    def __call__(self, *inputs: torch.Tensor, guard: bool = False):
+        """Copy the inputs in and replay.  ``guard=True`` brackets the replay with an f16 range guard (two 4-byte stream-ordered copies into pinned memory,
+        outside the graph) and leaves it armed in ``self.guard`` for a caller that checks it where it synchronises anyway; the default replays bare — a
+        latency-bound batch-1 caller that never looks at the guard does not pay for it (``checked()`` = replay + check + self-healing)."""
         if len(inputs) != len(self.static_in):
             raise ValueError(f"expected {len(self.static_in)} inputs")
         for dst, src in zip(self.static_in, inputs):
@@ -54,15 +57,16 @@ class GraphedCall:
                 dst.copy_(src, non_blocking=True)
         # f16 range guard around the replay (the two snapshots are ordinary stream-ordered copies, outside the graph): ``self.guard.tripped()`` tells
         # the caller — where it synchronises anyway — whether this replay's frames can be trusted; ``checked()`` does that and heals by itself
-        self.guard = ops.MxGuard()
+        self.guard = ops.MxGuard() if guard else None
         self.graph.replay()
-        self.guard.arm()
+        if guard:
+            self.guard.arm()
         return self.static_out
 
     def checked(self, *inputs: torch.Tensor):
         """``__call__`` + the f16 range check (one host synchronisation): a replay whose arithmetic left the f16 range is repeated EAGERLY in the
         split-bf16 arithmetic (``ops.mx_exact``) and those results are returned instead of the static outputs."""
-        out = self(*inputs)
+        out = self(*inputs, guard=True)
         if self.guard.tripped():
             ops.mx_fallbacks += 1
             with torch.no_grad(), ops.mx_exact(), ops.mx_guard_scope():

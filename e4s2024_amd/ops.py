@@ -506,8 +506,10 @@ def mx_eligible(cin: int, cout: int, w: int, masked: bool) -> bool:
 
 
 # Round 5: the masked same-resolution layers with class-prepared operands (csrc/modconv_mxe.hip): entries = (patch pixel, region) pairs prepared once per 32-channel chunk,
-# conversion-free two-phase K loop; tiles with more than 512 entries run the kernel above's tile inside the same launch.  E4S_MXE=0 keeps the round-3 kernel everywhere.
-MXE = os.environ.get("E4S_MXE", "1") != "0"
+# conversion-free two-phase K loop; tiles with more than 512 entries run the kernel above's tile inside the same launch.  OPT-IN (E4S_MXE=1): measured in round 5 it ties
+# with the round-3 kernel inside the pipeline (1 359-1 365 against 1 354-1 374 faces/s on the benchmark's maps, 0.90-0.97 of its time on portrait-shaped maps layer by
+# layer: DESIGN.md section 4) — the loop's VALU work is gone but its read phase (38 LDS reads + 4 DMA requests per unit) is longer than the MFMA phase beside it.
+MXE = os.environ.get("E4S_MXE", "0") != "0"
 
 
 def mxe_eligible(cin: int, cout: int, w: int, masked: bool, up: bool) -> bool:
@@ -571,6 +573,8 @@ class PreparedMx(_Prepared):
 _mx_words = {}            # device index -> int32[4]: [0] sticky "some launch left the f16 range" bit, [1] a counter that moves whenever one does
 _mx_tls = threading.local()
 mx_fallbacks = 0          # passes re-run with the exact arithmetic since import (host counter; ``bench.py`` reports it)
+mx_false_trips = 0        # trips of guards whose window overlapped another live guard's: the device-wide counter may have been moved by the OTHER pass (upper bound of the false trips)
+_open_guards = []         # live guards between their first snapshot and their check (host bookkeeping for the line above)
 
 
 def mx_flags(device) -> torch.Tensor:
@@ -636,17 +640,29 @@ class MxGuard:
     ``Generator.forward`` / ``FSEncoder_PSP.forward`` / ``FaceParser`` do exactly that by themselves — unless a caller up the stack owns a guard already
     (``with ops.mx_guard_scope() as g:``): pipelines that must not synchronise per pass (``pipeline.swap_batch``, ``runner``, ``bench.py``) take the two
     snapshots around their whole unit of work, call ``g.arm()`` when it is queued, and look at ``g.tripped()`` where they synchronise anyway.
-    Graph replays: take the guard around ``graph.replay()`` (the snapshots are ordinary stream-ordered copies)."""
+    Graph replays: take the guard around ``graph.replay()`` (the snapshots are ordinary stream-ordered copies).
 
-    __slots__ = ("_before", "_after", "_ev", "_live")
+    The counter is DEVICE-WIDE, not per stream: an overflow on stream B between stream A's two snapshots trips A's guard as well.  That is conservative — A's pass is
+    re-run in the exact arithmetic although its own values were in range (never a missed overflow) — and such re-runs are counted separately: a pass whose exact
+    a trip of a guard whose window overlapped another live guard's (two batches in flight on two streams) MAY have been caused by the other one's pass;
+    ``ops.mx_false_trips`` counts those trips (an upper bound of the false ones: with a single guard in flight a trip is always the pass's own)."""
+
+    __slots__ = ("_before", "_after", "_ev", "_live", "_shared", "_done", "__weakref__")
 
     def __init__(self):
         self._before = self._after = self._ev = None
+        self._shared = self._done = False
         # (inside a hipGraph capture a guard is a no-op: no pinned allocation, no event wait — bracket graph.replay() instead)
         self._live = torch.cuda.is_available() and (MX_MODE >= 2 or PARSER_EXACT == "f16x3") and not mx_exact_active() \
             and not torch.cuda.is_current_stream_capturing()
         if self._live:
             self._before = self._snap()
+            for ref in _open_guards:               # windows overlap: either pass can move the counter the other one watches
+                other = ref()
+                if other is not None and not other._done:
+                    other._shared = self._shared = True
+            _open_guards[:] = [r for r in _open_guards if r() is not None and not r()._done]
+            _open_guards.append(weakref.ref(self))
 
     @staticmethod
     def _snap():
@@ -667,9 +683,15 @@ class MxGuard:
         """Did the counter move between the two snapshots?  Arms the guard if the caller has not, then waits for the "after" copy."""
         if not self._live:
             return False
+        global mx_false_trips
         self.arm()
         self._ev.synchronize()
-        return int(self._after[0]) != int(self._before[0])
+        moved = int(self._after[0]) != int(self._before[0])
+        if not self._done:
+            self._done = True
+            if moved and self._shared:
+                mx_false_trips += 1
+        return moved
 
 
 class mx_guard_scope:
@@ -691,13 +713,16 @@ def mx_guard_owned() -> bool:
     return getattr(_mx_tls, "owned", 0) > 0 or mx_exact_active()
 
 
-def guarded(fn):
+def guarded(fn, f16_under_grad: bool = False):
     """Run ``fn()`` under its own guard unless the caller owns one (or the exact arithmetic is already on): one re-run under ``mx_exact()`` if the f16
-    arithmetic overflowed.  What the drop-in modules wrap their forward passes in."""
+    arithmetic overflowed.  What the drop-in modules wrap their forward passes in.  ``f16_under_grad``: the pass takes an f16 route whatever the grad mode
+    (the parser's two-term f16 convolutions); the generator's and the encoder's f16 routes are inference-only (``mx_eligible`` / ``mx_conv_eligible``), so
+    under autograd they need no guard.  Cost: two 4-byte copies and ONE host synchronisation per call — callers that keep several calls in flight own a scope
+    instead (``mx_guard_scope``; ``StreamPipeline.submit`` does it for them)."""
     global mx_fallbacks
-    if getattr(_mx_tls, "owned", 0) > 0 or mx_exact_active() or torch.is_grad_enabled() or not torch.cuda.is_available() \
+    if getattr(_mx_tls, "owned", 0) > 0 or mx_exact_active() or (torch.is_grad_enabled() and not f16_under_grad) or not torch.cuda.is_available() \
             or torch.cuda.is_current_stream_capturing():
-        return fn()          # (under autograd the f16 routes are not taken at all: mx_eligible / mx_conv_eligible)
+        return fn()
     g = MxGuard()
     out = fn()
     if g.tripped():
@@ -1052,8 +1077,8 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
         if evb is not None:
             evb.record()
     use_mxe = sb and mx is not None and mxe is not None and mx[1] == 1 and blocks is None and cin % 32 == 0
-    ev = _timed("region_conv_mxe_kernel" if use_mxe else modconv_kernel_name(cout, w, sb, labels is not None, cin, mx[1] if (sb and mx is not None) else None),
-                f"{cin}->{cout} @{h}{' up' if up else ''}")
+    # (timing key: the entry kernel's launches count with the masked kernel they replace — bench.py prices the group as one kernel and says so)
+    ev = _timed(modconv_kernel_name(cout, w, sb, labels is not None, cin, mx[1] if (sb and mx is not None) else None), f"{cin}->{cout} @{h}{' up' if up else ''}")
     rgb_out = None
     if rgb is not None:
         if not sb:
@@ -1701,15 +1726,27 @@ _half_gates = {}
 
 
 def half_gate(bs: int, C: int, device) -> torch.Tensor:
-    """``[bs, C]`` filled with 0.5 (cached per shape and device; inside a stream capture an uncached shape gets a fresh tensor that is not kept)."""
+    """``[bs, C]`` filled with 0.5, cached per shape and device for the life of the process (a few KB each; never evicted: a captured hipGraph may have the
+    pointer baked in).  The fill runs on the stream that first asks; any other stream waits for its event before the first use (as ``_Prepared._lookup``
+    does for the weight copies).  Inside a stream capture an uncached shape gets a fresh tensor that is not kept."""
     key = (torch.device(device), bs, C)
-    t = _half_gates.get(key)
-    if t is None:
+    ent = _half_gates.get(key)
+    if ent is None:
         t = torch.full((bs, C), 0.5, dtype=torch.float32, device=device)
+        if torch.cuda.is_current_stream_capturing():
+            return t
+        ev = torch.cuda.Event()
+        ev.record()
+        ent = _half_gates[key] = [t, ev, {torch.cuda.current_stream().cuda_stream}]
+        return t
+    t, ev, seen = ent
+    sid = torch.cuda.current_stream().cuda_stream
+    if sid not in seen:
         if not torch.cuda.is_current_stream_capturing():
-            if len(_half_gates) > 64:
-                _half_gates.clear()
-            _half_gates[key] = t
+            torch.cuda.current_stream().wait_event(ev)
+            seen.add(sid)
+        else:
+            torch.cuda.current_stream().wait_event(ev)
     return t
 
 

@@ -47,6 +47,19 @@ class FrameShardRunner:
         self.device = device if device is not None else torch.device("cpu")
         self._pipes = {}          # stream count -> the StreamPipeline run_clip_streamed reuses (close() drops them)
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:          # (interpreter shutdown: the streams are gone already)
+            pass
+
     # ---- collectives ---------------------------------------------------------------------------------------------
     def broadcast_shared(self, tensor: Optional[torch.Tensor], shape: Sequence[int], dtype=torch.float32, src: int = 0) -> torch.Tensor:
         """Rank ``src`` provides ``tensor``; every rank returns its copy on ``self.device``."""
@@ -96,7 +109,7 @@ class FrameShardRunner:
     # ---- the clip loop -------------------------------------------------------------------------------------------
     def run_clip_streamed(self, n_frames: int, shared, frame_inputs: Callable[[int, int], object],
                           synth_fn: Callable[[object, object], torch.Tensor], batch: int = 4, dst: int = 0,
-                          out: Optional[torch.Tensor] = None, streams: int = 2) -> Optional[torch.Tensor]:
+                          out: Optional[torch.Tensor] = None, streams: int = 2, full_batches: bool = True) -> Optional[torch.Tensor]:
         """Like ``run_clip`` but the finished frames travel to rank ``dst`` batch by batch while the next batch is being computed, instead
         of in one padded gather at the end (face_swap_video_pipeline.py:404-486 writes each frame out as soon as it is done).
 
@@ -104,11 +117,14 @@ class FrameShardRunner:
         ``async_op``: the collective runs on the backend's own stream); a rank whose block has no ``k``-th batch, or a short last one,
         sends padding.  Rank ``dst`` scatters each round's buffers into ``out [n_frames, H, W, 3]`` (allocated on first use; pass a
         preallocated one to keep the allocation out of a timed region) after the round's gather has completed — at the latest when the
-        next but one round is issued, so at most two rounds of frames are in flight.
+        round after the next two is issued: one computed round waiting to be sent plus up to three sent rounds whose gathers have not been consumed, i.e. at
+        most FOUR rounds of frames (4 x batch x frame bytes per rank, world x that on rank ``dst``) are alive at a time — size ``out=`` / memory against that.
 
-        Batch composition: the encoder picks its convolution kernels from the launch size (``ops.winograd_route`` / ``ops.mx_conv_eligible``), so a face in a
-        clip's short last batch can differ from the same face in a full batch by up to 5e-5 of the largest style-vector entry (tests/test_gpu_encoder.py);
-        ``E4S_ENC_ROUTE_BY_IMAGE=1`` makes the choice per image and the frames bit-identical whatever the batch, at 5-10 % of the encoder's throughput.
+        Batch composition: the encoder picks its convolution kernels from the launch size (``ops.winograd_route`` / ``ops.mx_conv_eligible``), so the same face
+        could differ between a short and a full batch by up to 5e-5 of the largest style-vector entry (tests/test_gpu_encoder.py).  The loop therefore never
+        launches a short batch when its block holds a full one (``full_batches``, default): a block's last, short round is computed on the block's LAST ``batch``
+        frames (re-computing up to ``batch - 1`` of them) and only the new ones are sent — every frame of a clip goes through the same kernels whatever the clip
+        length and the world size.  (``E4S_ENC_ROUTE_BY_IMAGE=1`` makes the route choice per image instead: bit-identical at ANY batch, 5-10 % of the encoder's throughput.)
 
         ``streams`` (GPU only): consecutive rounds run on that many alternating HIP streams (``StreamPipeline``): the latency-bound small layers
         of one batch overlap the large ones of the batch before (+4–6 % swaps/s at batch 8, ``tools/time_swap_pipeline.py``); a round's gather is
@@ -164,9 +180,12 @@ class FrameShardRunner:
                     g.arm()
                 return f, g
             if hi > lo:
-                frames, guard = synth(lo, hi)
-                if frames.dtype != torch.uint8 or frames.shape[0] != hi - lo:
+                lo2 = max(start, hi - batch) if (full_batches and hi - lo < batch) else lo      # (a short last round: the block's last `batch` frames, see the docstring)
+                frames, guard = synth(lo2, hi)
+                if frames.dtype != torch.uint8 or frames.shape[0] != hi - lo2:
                     raise ValueError("synth_fn must return uint8 frames [n, H, W, 3] for the requested block")
+                if lo2 != lo:
+                    frames = frames[lo - lo2:]
                 shape = tuple(frames.shape[1:])
             elif shape is None:     # this rank has no frames at all: learn the frame shape from a probe, send padding
                 shape = tuple(synth(0, min(1, n_frames))[0].shape[1:])
@@ -203,6 +222,7 @@ class FrameShardRunner:
         pipe = self._pipes.get(key)
         if pipe is None:
             pipe = self._pipes[key] = StreamPipeline(key, device=self.device if on_gpu else None)
+            pipe.own_guards = False          # (every round takes its own guard: `compute`)
         with pipe:
             computed = None
             for k in range(rounds):
@@ -272,9 +292,12 @@ class StreamPipeline:
         self.streams = [torch.cuda.Stream(device=device) for _ in range(self.n)] if self.n > 1 else []
         self._i = 0
         self._main = None
+        self.guards = []          # one ops.MxGuard (or None) per submitted call since the last __enter__
+        self.own_guards = True    # False: the submitted functions bracket their own work (run_clip_streamed's rounds do)
 
     def __enter__(self):
         self._main = None
+        self.guards = []
         if self.streams:
             self._main = main = torch.cuda.current_stream()
             for st in self.streams:
@@ -292,14 +315,31 @@ class StreamPipeline:
                 self._hand_over(o, depth + 1)
 
     def submit(self, fn, *args, **kwargs):
+        """f16 range (``ops.MxGuard``): a drop-in module called without a guard scope checks its own pass — one host synchronisation per call, which would
+        serialise the batches this pipeline is there to overlap.  ``submit`` therefore owns the scope of every call that is not inside one already: the call's
+        armed guard is appended to ``self.guards`` (one per submitted call, ``None`` where the caller's own scope was in force) and the CALLER checks
+        ``sp.guards[i].tripped()`` where it synchronises anyway, recomputing that call under ``with ops.mx_exact():`` (``tripped_calls()`` lists them)."""
         if not self.streams:
             return fn(*args, **kwargs)
+        from . import ops
         st = self.streams[self._i % self.n]
         self._i += 1
         with torch.cuda.stream(st):
-            out = fn(*args, **kwargs)
+            if not self.own_guards or ops.mx_guard_owned():
+                out = fn(*args, **kwargs)
+                self.guards.append(None)
+            else:
+                with ops.mx_guard_scope() as g:
+                    out = fn(*args, **kwargs)
+                    g.arm()
+                self.guards.append(g)
         self._hand_over(out)
         return out
+
+    def tripped_calls(self):
+        """Indices (in submission order since the pipeline was entered) of the calls whose f16 arithmetic left its range: their results must be recomputed under
+        ``ops.mx_exact()``.  Waits for each call's guard (a host synchronisation with that call's stream)."""
+        return [i for i, g in enumerate(self.guards) if g is not None and g.tripped()]
 
     def __exit__(self, *exc):
         if self.streams:

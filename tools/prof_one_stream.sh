@@ -6,8 +6,4 @@ cd $R
 python tools/rocpd_summary.py gpurun_out/prof_bench1/bench_results.db | cut -c1-200 > gpurun_out/${T}_one_stream_kernel_stats.txt
 rm -rf gpurun_out/prof_bench1
 python bench.py --no-cpu-baseline --no-full-swap --no-pti --clip 0 --no-mask-sensitivity > gpurun_out/${T}_bench_quick.json 2> gpurun_out/${T}_bench_quick.err
-python - <<'PY'
-import json,sys,os
-T=os.environ.get("T","r04_mid")
-PY
 head -c 400 gpurun_out/${T}_bench_quick.json
