@@ -715,7 +715,7 @@ def main():
             for res in (64, 128, 256):
                 ub, _ = ops.uniform_blocks(labd, res, res, 12)
                 # (share under one region, share made of four uniform 8 x 8 sub-blocks): 2.0x / 2.5x their algorithmic MACs
-                ufrac[res] = (float((ub < 12).float().mean().item()), float((ub == ops.UP_BLOCK_QUAD).float().mean().item()))
+                ufrac[res] = (float((ub < 12).float().mean().item()), 0.0)
         fl, fl_exec = conv3x3_flops_per_face(want_executed=True, uniform_frac=ufrac)
         dom = max(ksum, key=lambda k: ksum[k][1]) if ksum else None
         roof = None

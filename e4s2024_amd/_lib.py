@@ -33,6 +33,9 @@ _PROTOS = {
     "e4s_region_upconv_mx4": [c_ptr] * 8 + [c_int, c_int, c_ptr, c_int, c_ptr, c_ptr] + [c_int] * 7 + [c_ptr],
     "e4s_modconv_prep_weights_mx": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_region_modconv3x3_mx": [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr, c_int] + [c_int] * 7 + [c_ptr, c_i64] + [c_ptr] * 10,
+    "e4s_upblock_mx_weight_bytes": [c_int, c_int, c_ptr],
+    "e4s_modconv_prep_weights_upblock_mx": [c_ptr, c_ptr, c_int, c_int, c_ptr],
+    "e4s_masked_upconv_blocks_mx": [c_ptr] * 9 + [c_ptr, c_int, c_ptr, c_ptr] + [c_int] * 7 + [c_ptr],
     "e4s_modconv_mxe_weight_bytes": [c_int, c_int, c_int, c_ptr],
     "e4s_modconv_prep_weights_mxe": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
     "e4s_region_modconv3x3_mxe": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr, c_int] + [c_int] * 7 + [c_ptr, c_i64] + [c_ptr] * 8,
@@ -45,7 +48,6 @@ _PROTOS = {
     "e4s_conv3x3_s2_mx3": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_conv3x3_mx3_phased": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_uniform_blocks": [c_ptr, c_ptr, c_ptr, c_ptr] + [c_int] * 8 + [c_ptr],
-    "e4s_masked_upconv_blocks": [c_ptr] * 11 + [c_int, c_ptr, c_ptr] + [c_int] * 8 + [c_ptr],
     "e4s_modconv_tconv_sb": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_modconv_up_fused_sb": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr],
     "e4s_swap_head_mask": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],

@@ -49,7 +49,7 @@ __device__ __forceinline__ void dma16_asm(const void* gbase, unsigned voff, unsi
 }
 __device__ __forceinline__ void dma4_asm(const void* gbase, unsigned voff, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(gbase), "s"(lds_dst)
                  : "memory");

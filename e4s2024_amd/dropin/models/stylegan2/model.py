@@ -137,6 +137,7 @@ class ModulatedConv2d(nn.Module):
         self._prepared_mx = ops.PreparedMx()
         self._prepared_mx4 = ops.PreparedMx()      # the same weight as the four-parity up kernel reads it (arith 4)
         self._prepared_mxe = ops.PreparedMx()      # ... as the entry kernel reads it (arith 6: csrc/modconv_mxe.hip)
+        self._prepared_ubmx = ops.PreparedMx()     # ... as the region-uniform block kernel reads it (arith 7: csrc/modconv_upblock_mx.hip)
         self._prepared_hc = ops.PreparedHc()
 
     def __repr__(self):
@@ -201,11 +202,11 @@ class ModulatedConv2d(nn.Module):
         wt, s, d = self.tables(styles, masked=labels is not None)
         saved = (s, d, self._weights(labels is not None)[1]) if labels is not None else None
         up_blocks = None
-        if (self.upsample and labels is not None and ops.UP_BLOCKS and ops.MODCONV_MODE == "sb" and self.kernel_size == 3
-                and input.shape[-1] >= max(32, ops.UP_BLOCKS_MIN_WIDTH)
-                and self.out_channel >= 128 and not torch.is_grad_enabled()):
-            # region-uniform 16 x 16 output blocks run in the transposed-conv form (a second preparation of the same weight)
-            up_blocks = (self._prepared_tconv.get(self.weight, None, False, self.demodulate, tconv=True)[0], self.blur.kernel)
+        if (self.upsample and labels is not None and ops.UP_BLOCKS and ops.MODCONV_MODE == "sb" and self.kernel_size == 3 and ops.mx_arith() == 1
+                and input.shape[-1] >= max(32, ops.UP_BLOCKS_MIN_WIDTH) and self.out_channel >= 128 and self.in_channel % 32 == 0 and self.in_channel <= 512
+                and not torch.is_grad_enabled()):
+            # region-uniform 16 x 16 output blocks run in the transposed-conv form on f16 + fp6 (csrc/modconv_upblock_mx.hip: a third preparation of the same weight)
+            up_blocks = (self._prepared_ubmx.get(self.weight, None, False, 7), self.blur.kernel)
         mx = mx4 = mxe = None
         if (self.kernel_size == 3 and not (x_nhwc or out_nhwc) and isinstance(wt, tuple)
                 and ops.mx_eligible(self.in_channel, self.out_channel, input.shape[-1], labels is not None)):

@@ -544,6 +544,14 @@ class PreparedMx(_Prepared):
             lib().call("e4s_conv_prep_weights_mx3" if arith == 3 else "e4s_conv_prep_weights_mx3_s2", _p(wmx), _p(w), cout, cin, _stream())
             self._publish(key, (wmx,))
             return wmx
+        if arith == 7:            # the region-uniform block kernel's tap-pair units (csrc/modconv_upblock_mx.hip): the transposed-conv taps, not blur-composed
+            if plain:
+                raise ValueError("arith 7 (modconv_upblock_mx) is a ModulatedConv2d layout")
+            lib().call("e4s_upblock_mx_weight_bytes", cout, cin, ctypes.byref(nbytes))
+            wmx = torch.empty((nbytes.value,), dtype=torch.uint8, device=w.device)
+            lib().call("e4s_modconv_prep_weights_upblock_mx", _p(wmx), _p(w), cout, cin, _stream())
+            self._publish(key, (wmx,))
+            return wmx
         if arith == 6:            # the entry kernel's unit slots (csrc/modconv_mxe.hip)
             if plain:
                 raise ValueError("arith 6 (modconv_mxe) is a ModulatedConv2d layout")
@@ -973,7 +981,8 @@ def can_fuse_rgb(cout: int, w: int, up: bool, masked: bool) -> bool:
     return FUSE_RGB and MODCONV_MODE == "sb" and not up and w >= 32 and (cout <= 64 or (masked and cout == 128))
 
 
-UP_BLOCKS = os.environ.get("E4S_UP_BLOCKS", "1") != "0"    # masked up layers: region-uniform 16 x 16 output blocks in the transposed-conv form
+UP_BLOCKS = os.environ.get("E4S_UP_BLOCKS", "1") != "0"    # masked up layers: region-uniform 16 x 16 output blocks in the transposed-conv form (csrc/modconv_upblock_mx.hip: f16 + fp6 only —
+                                                           # under the split-bf16 arithmetic, incl. the exact re-runs of ops.mx_exact, the whole layer runs in the composed form)
 UP_BLOCK = 16
 # smallest input width of a masked up layer that tries the block path (128: the 128 -> 256 layer only).  A layer that tries costs two small
 # launches and gives up its K split, and below 128 a tile of the composed kernel is half or all of the map's width: on portrait-shaped and
@@ -981,10 +990,7 @@ UP_BLOCK = 16
 # portrait-shaped maps 1086 / 1080 / 1082 / 1084 (a second box: 1044 / - / 1031 / -), 4 x 4-cell maps 1092 / 1229 / 1203 / 1139, the bench's
 # blocky maps 1084 / 1113 / 1126 / 1127 (tools/sweep_blocks_minw.sh).  E4S_UP_BLOCKS_MINW=64 / 32 for maps made of large cells.
 UP_BLOCKS_MIN_WIDTH = int(os.environ.get("E4S_UP_BLOCKS_MINW", "128"))
-UP_SUBBLOCKS = False   # (no environment switch: measured slower for two rounds; the GPU tests that pin the variant set this attribute)   also blocks made of four uniform 8 x 8 sub-blocks (slower than the composed form on the benchmark maps)
 
-
-UP_BLOCK_QUAD = 254      # block map value: four region-uniform 8 x 8 sub-blocks with different regions
 
 
 UP_BLOCKS_MIN_PERCENT_SMALL = 90   # the same for a layer whose composed launch fits the chip at once
@@ -994,7 +1000,7 @@ UP_BLOCKS_MIN_PERCENT = 40   # below this share of qualifying tiles a layer stay
 def uniform_blocks(labels: torch.Tensor, ho: int, wo: int, nreg: int, with_ctrl: bool = False, min_percent: int = None):
     """``(blocks [bs, ho/16, wo/16], sub [bs, ho/8, wo/8])`` uint8 (``e4s_uniform_blocks``): ``sub`` = the region shared by all pixels of an
     8 x 8 output sub-block (labels sampled 'nearest' at ``ho`` x ``wo``), 255 if they differ; ``blocks`` = the region of a 16 x 16 block whose
-    four sub-blocks share one, 254 if each sub-block is uniform but they differ, 255 otherwise — and 255 for a whole row of four blocks (a tile
+    four sub-blocks share one, 255 otherwise — and 255 for a whole row of four blocks (a tile
     of the composed kernel) unless all four qualify.  ``with_ctrl``: also the control words (``ctrl[2]`` = 1 if at least
     ``UP_BLOCKS_MIN_PERCENT`` of those rows qualify: the consumers leave the layer in the composed form otherwise)."""
     lab = _labels_u8(labels, "labels")
@@ -1007,7 +1013,7 @@ def uniform_blocks(labels: torch.Tensor, ho: int, wo: int, nreg: int, with_ctrl:
     ctrl = getattr(ctx, "up_ctrl", None)
     if ctrl is None or ctrl.device != lab.device:
         ctrl = ctx.up_ctrl = torch.zeros((4,), dtype=torch.int32, device=lab.device)      # per stream; every launch leaves its counters zeroed
-    lib().call("e4s_uniform_blocks", _p(blocks), _p(sub), _p(ctrl), _p(lab), bs, lh, lw, ho, wo, nreg, int(UP_SUBBLOCKS),
+    lib().call("e4s_uniform_blocks", _p(blocks), _p(sub), _p(ctrl), _p(lab), bs, lh, lw, ho, wo, nreg, 0,
                UP_BLOCKS_MIN_PERCENT if min_percent is None else int(min_percent), _stream())
     return (blocks, sub, ctrl) if with_ctrl else (blocks, sub)
 
@@ -1024,8 +1030,8 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
     and returns ``(None, rgb_image)``.  ``x_nhwc`` / ``out_nhwc``: the activation is channel-blocked, ``[bs, c/8, h, w, 8]`` (split-bf16
     kernel, width >= 32; the 256x256-and-up layers can chain in this layout inside ``Generator.forward``).  ``s_next [bs, 1, cout]`` (masked
     layer with a fused ToRGB): the activation is written as split planes ``[2, bs, cout/8, h, w, 8]`` modulated for a single-region consumer.
-    ``up_blocks = (wt_tconv, blur_kernel)`` (masked up layer, inference): the 16 x 16 output blocks under ONE region are computed in the
-    transposed-conv form (``e4s_masked_upconv_blocks``, a quarter of the composed form's MACs per block), the composed kernel keeps the rest."""
+    ``up_blocks = (wmx_blocks, blur_kernel)`` (masked up layer, inference, f16 + fp6 arithmetic; ``PreparedMx.get(..., arith=7)``): the 16 x 16 output blocks under ONE
+    region are computed in the transposed-conv form (``e4s_masked_upconv_blocks_mx``: a quarter of the composed form's MACs per block), the composed kernel keeps the rest."""
     x = _c(x, "input")
     if x_nhwc:
         bs, cb, h, w, _ = x.shape          # channel-blocked [bs, cin/8, h, w, 8]
@@ -1063,20 +1069,19 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
         ws = _workspace(x.device, wsn)
     sb = isinstance(wt, tuple)
     blocks = bctrl = None
-    if (up_blocks is not None and UP_BLOCKS and sb and up and labels is not None and w >= max(32, UP_BLOCKS_MIN_WIDTH) and cout >= 128 and h % 8 == 0 and w % 8 == 0
-            and cin % 16 == 0 and rgb is None and not (x_nhwc or out_nhwc) and sn is None):
-        wt_t, blur_k = up_blocks
+    if (up_blocks is not None and UP_BLOCKS and sb and up and labels is not None and mx is not None and mx[1] == 1 and w >= max(32, UP_BLOCKS_MIN_WIDTH) and cout >= 128
+            and h % 8 == 0 and w % 16 == 0 and cin % 32 == 0 and cin <= 512 and rgb is None and not (x_nhwc or out_nhwc) and sn is None):
+        wmx_blocks, blur_k = up_blocks
         # A layer whose composed launch is one round of workgroups (two per CU) gains nothing from losing some of them — `tools/time_blocks.py 4 tophalf`:
         # 64 -> 128 at batch 4 with half its tiles moved to the block kernel costs 0.42 + 0.21 ms against 0.47 — so it needs (nearly) all tiles to qualify
         composed_wgs = (wo // 64) * (ho // 16) * 4 * -(-cout // 128) * bs
         blocks, sub, bctrl = uniform_blocks(labels, ho, wo, nreg, with_ctrl=True,
                                             min_percent=max(UP_BLOCKS_MIN_PERCENT, UP_BLOCKS_MIN_PERCENT_SMALL) if composed_wgs <= 512 else UP_BLOCKS_MIN_PERCENT)
         evb = _timed("masked_upconv_blocks", f"{cin}->{cout} @{h} up")
-        lib().call("e4s_masked_upconv_blocks", _p(out), _p(x), _p(wt_t[0]), _p(wt_t[1]), _p(s), _p(d), _p(blocks), _p(sub), _p(bctrl), _p(_c(blur_k, "blur kernel")), _p(nz),
-                   nbs or 0, _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, int(UP_SUBBLOCKS), _stream())
+        lib().call("e4s_masked_upconv_blocks_mx", _p(out), _p(x), _p(wmx_blocks), _p(mx_flags(x.device)), _p(s), _p(d), _p(blocks), _p(bctrl), _p(_c(blur_k, "blur kernel")),
+                   _p(nz), nbs or 0, _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, _stream())
         if evb is not None:
             evb.record()
-    use_mxe = sb and mx is not None and mxe is not None and mx[1] == 1 and blocks is None and cin % 32 == 0
     # (timing key: the entry kernel's launches count with the masked kernel they replace — bench.py prices the group as one kernel and says so)
     ev = _timed(modconv_kernel_name(cout, w, sb, labels is not None, cin, mx[1] if (sb and mx is not None) else None), f"{cin}->{cout} @{h}{' up' if up else ''}")
     rgb_out = None

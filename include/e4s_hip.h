@@ -167,6 +167,16 @@ E4S_API int e4s_modconv_prep_weights_mx4(void* dst, const float* weight, const f
 E4S_API int e4s_region_upconv_mx4(float* out, const float* x, const void* wmx4, const void* wmx, int* flags, const float* s, const float* d, const uint8_t* labels,
                                   int lh, int lw, const float* noise, int noise_bs, const float* noise_weight, const float* act_bias, int act, int bs, int cin,
                                   int cout, int h, int w, int nreg, void* stream);
+/* Round 5: the region-uniform 16 x 16 output blocks of a masked up layer (models/stylegan2/model.py:287-300, 385-400; the map: e4s_uniform_blocks) on the f16 + 2 x MX-fp6
+ * arithmetic with operands prepared once at staging (csrc/modconv_upblock_mx.hip): x * s[region] -> f16 + two fp6 terms per patch pixel and 32-channel chunk, weights as
+ * tap-pair units by LDS-DMA, the same 1x transposed-conv form and blur epilogue.  wmx from e4s_modconv_prep_weights_upblock_mx (weight [cout,cin,3,3] or [1,cout,cin,3,3],
+ * NOT blur-composed; size e4s_upblock_mx_weight_bytes); cin % 32 == 0, cin <= 512; blocks / ctrl from e4s_uniform_blocks (want_quad = 0); flags as for
+ * e4s_region_modconv3x3_mx; s [bs][nreg][cin], d [bs][nreg][cout], blur [4][4], out fp32 [bs][cout][2h][2w] (only the blocks < nreg are written); w % 16 == 0. */
+E4S_API int e4s_upblock_mx_weight_bytes(int cout, int cin, int64_t* bytes);
+E4S_API int e4s_modconv_prep_weights_upblock_mx(void* dst, const float* weight, int cout, int cin, void* stream);
+E4S_API int e4s_masked_upconv_blocks_mx(float* out, const float* x, const void* wmx, int* flags, const float* s, const float* d, const uint8_t* blocks, const int* ctrl,
+                                        const float* blur, const float* noise, int noise_bs, const float* noise_weight, const float* act_bias, int act, int bs, int cin,
+                                        int cout, int h, int w, int nreg, void* stream);
 /* Round 5: the same masked layer (models/stylegan2/model.py:276-320, 385-400) with CLASS-PREPARED operands (csrc/modconv_mxe.hip): the unit of staging is an entry =
  * (patch pixel, region) for every region that occurs among the output pixels reading that patch pixel; x * s[region] is split into f16 + two MX-fp6 terms ONCE per entry
  * and 32-channel chunk, and the K loop (conv_mx3's two-phase loop) only reads LDS and issues MFMAs.  A 32 x 8-pixel tile with more than 512 entries runs the tile of
@@ -213,18 +223,14 @@ E4S_API int e4s_conv3x3_mx3_phased(float* out, const float* x, const void* wmx3,
  * pixels has ONE region):
  *   e4s_uniform_blocks: sub[b][2by+sy][2bx+sx] = the region of an 8 x 8 output sub-block (labels uint8 [bs][lh][lw] sampled 'nearest' at
  *   ho x wo), 255 = mixed / no region; blocks[b][by][bx] = the region of a 16 x 16 block if its four sub-blocks share one, 254 if each of
- *   them is uniform but they differ (only with want_quad; e4s_masked_upconv_blocks then needs sub_blocks = 1), 255 otherwise — and 255 for a
+ *   them is uniform but they differ (only with want_quad), 255 otherwise — and 255 for a
  *   whole row of four blocks (one tile of the composed kernel) unless all four qualify; ctrl: four ints, [0] and [1] zero on entry (every launch leaves them zero again: one buffer per stream serves all layers), ctrl[2] becomes 1
  *   if at least min_percent of those rows qualify, else 0 (both consumers then leave the layer in the composed form);
- *   e4s_masked_upconv_blocks: computes exactly the blocks != 255 in the transposed-conv form (weights: e4s_modconv_prep_weights_sb of the
- *   bare 3x3 weight), s [bs][nreg][cin], d [bs][nreg][cout], blur [4][4], out fp32 [bs][cout][2h][2w];
- *   e4s_region_modconv3x3_sb(..., uniform_blocks = the same block map) then computes the remaining blocks in the composed form. */
+ *   e4s_masked_upconv_blocks_mx (above) computes exactly the blocks < nreg in the transposed-conv form; e4s_region_modconv3x3_mx / _upconv_mx4(..., uniform_blocks = the
+ *   same block map) compute the remaining blocks in the composed form.  (want_quad = 1 additionally marks blocks of four uniform 8 x 8 sub-blocks with 254: the round-2
+ *   sub-block kernel that consumed them was measured slower than the composed form and deleted in round 5 — pass 0.) */
 E4S_API int e4s_uniform_blocks(uint8_t* blocks, uint8_t* sub, int* ctrl, const uint8_t* labels, int bs, int lh, int lw, int ho, int wo, int nreg,
                                int want_quad, int min_percent, void* stream);
-E4S_API int e4s_masked_upconv_blocks(float* out, const float* x, const uint16_t* whi, const uint16_t* wlo, const float* s, const float* d,
-                                     const uint8_t* blocks, const uint8_t* sub, const int* ctrl, const float* blur, const float* noise, int noise_bs,
-                                     const float* noise_weight, const float* act_bias, int act, int bs, int cin, int cout, int h, int w, int nreg,
-                                     int sub_blocks, void* stream);
 /* rgb_* (all NULL = off): fuse the single-region ToRGB that follows this layer (model.py:439-479) into the epilogue — allowed for
  * same-resolution layers of width >= 32 whose Cout fits one workgroup tile (<= 64, or <= 128 on masked layers): rgb_out [bs,3,h,w] =
  * sum_co out[co] * rgb_wt[co][o] * rgb_s[b][co] + rgb_bias[o] + upfirdn2d(rgb_skip, rgb_up_kernel, up=2, pad=(2,1)), so the layer's

@@ -177,3 +177,61 @@ def test_generator256_with_the_fused_torgb_layer_on_the_entry_kernel(sg2, mxe_sw
     record_parity(f"mxe_generator256_{labels}_vs_oracle", d_new, 1e-3, note=f"pixels; the round-3 kernel on the same inputs: {d_old:.2e}")
     assert d_new <= 1e-3
     assert float((imgs[True] - imgs[False]).abs().max()) <= 5e-4
+
+
+# ---------------------------------------------------------------------------------------------- region-uniform blocks of the masked up layers on f16 + fp6
+#             bs cin cout  h   w  nreg lh  lw
+UB_SHAPES = [(2, 32, 128, 32, 32, 5, 64, 64),          # one chunk
+             (1, 64, 128, 32, 32, 5, 64, 64),          # two chunks
+             (2, 128, 136, 32, 48, 12, 64, 96),        # an output-channel tail (three 64-channel tiles), several block columns
+             (1, 256, 128, 64, 64, 12, 512, 512)]      # the 128 -> 256 layer's channel plan at half its size, labels at the mask resolution
+
+
+@pytest.mark.parametrize("shape", UB_SHAPES)
+def test_uniform_block_kernel_on_f16_fp6_against_the_oracle_and_the_composed_form(sg2, shape):
+    """csrc/modconv_upblock_mx.hip: maps made of 16 x 16 output blocks of one region each, one row of blocks with per-pixel noise (mixed: composed form) and a corner
+    without a region — every block written by exactly one kernel, the block kernel's f16 + fp6 output against the oracle and against the all-composed route."""
+    bs, cin, cout, h, w, nreg, lh, lw = shape
+    rs = np.random.RandomState(13 * cin + h)
+    ho, wo = 2 * h, 2 * w
+    cy, cx = 16 * lh // ho, 16 * lw // wo
+    cells = rs.randint(0, nreg, (bs, ho // 16, wo // 16)).astype(np.uint8)
+    lab = np.repeat(np.repeat(cells, cy, axis=1), cx, axis=2)
+    lab[:, cy:2 * cy, : lw // 2] = rs.randint(0, nreg, (bs, cy, lw // 2))       # second row of blocks: noise in its left half
+    lab[:, lh - cy // 2:, lw - cx // 2:] = 255                                  # no region
+    onehot = torch.zeros(bs, nreg, lh, lw)
+    for c in range(nreg):
+        onehot[:, c] = T((lab == c).astype(np.float32))
+    m = sg2.StyledConv(cin, cout, 3, 512, upsample=True, mask_op=True)
+    with torch.no_grad():
+        m.conv.weight.copy_(T(rs.standard_normal(m.conv.weight.shape).astype(np.float32)))
+        m.conv.modulation.weight.copy_(T(rs.standard_normal(m.conv.modulation.weight.shape).astype(np.float32)))
+        m.noise.weight.fill_(0.21)
+        m.activate.bias.copy_(T(0.1 * rs.standard_normal(cout).astype(np.float32)))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = T(rs.standard_normal((bs, cin, h, w)).astype(np.float32))
+    st = T(rs.standard_normal((bs, nreg, 512)).astype(np.float32))
+    nz = T(rs.standard_normal((bs, 1, ho, wo)).astype(np.float32))
+    m = m.to(DEV)
+    labd = T(lab).to(DEV)
+    keep = (ops.UP_BLOCKS, ops.UP_BLOCKS_MIN_WIDTH, ops.UP_BLOCKS_MIN_PERCENT, ops.UP_BLOCKS_MIN_PERCENT_SMALL)
+    ops.UP_BLOCKS_MIN_WIDTH, ops.UP_BLOCKS_MIN_PERCENT, ops.UP_BLOCKS_MIN_PERCENT_SMALL = 32, 1, 1
+    ys = {}
+    try:
+        with torch.no_grad():
+            for on in (False, True):
+                ops.UP_BLOCKS = on
+                with _Calls() as calls:
+                    ys[on] = m(x.to(DEV), st.to(DEV), labd, noise=nz.to(DEV)).cpu()
+                assert ("e4s_masked_upconv_blocks_mx" in calls.names) == on, calls.names
+            again = m(x.to(DEV), st.to(DEV), labd, noise=nz.to(DEV)).cpu()
+    finally:
+        ops.UP_BLOCKS, ops.UP_BLOCKS_MIN_WIDTH, ops.UP_BLOCKS_MIN_PERCENT, ops.UP_BLOCKS_MIN_PERCENT_SMALL = keep
+    assert torch.equal(again, ys[True])
+    ref = O.styled_conv(sd, "", x, st, onehot, nz, masked=True, upsample=True)
+    scale = max(1.0, float(ref.abs().max()))
+    e_new = float((ys[True] - ref).abs().max()) / scale
+    e_old = float((ys[False] - ref).abs().max()) / scale
+    record_parity(f"upblock_mx_{cin}to{cout}_{h}x{w}", e_new, MXE_LAYER_TOL, note=f"f16 + fp6 block kernel against the oracle, relative to the output scale {scale:.1f}; the all-composed route: {e_old:.2e}")
+    assert e_new <= MXE_LAYER_TOL and torch.isfinite(ys[True]).all(), (shape, e_new, e_old)
+    assert not ops.mx_overflowed()

@@ -39,7 +39,7 @@ KEYS = {
                                     "128->256 up layer's launch leaves at once); dword activation loads, 16-byte weight DMA: FETCH_SIZE x2 (calibrated; an upper bound by the halo columns' half-line requests)",
                                     (823900000 - 4 * (256 * 128 * 128 * 4 + 128 * 256 * 256 * 4)) // 7),
     "region_modconv_mx_kernel<0>": (["region_modconv_mx_kernel<0"], 2.0, "as <1> with the split-bf16 arithmetic", (823900000 - 4 * (256 * 128 * 128 * 4 + 128 * 256 * 256 * 4)) // 7),
-    "masked_upconv_blocks": (["masked_up_block_kernel"], 2.0, "1 launch per step (the 256 -> 128 @128 masked up layer: every 16 x 16 output block of the benchmark maps lies under one "
+    "masked_upconv_blocks": (["masked_up_block_mx_kernel"], 2.0, "1 launch per step (the 256 -> 128 @128 masked up layer: every 16 x 16 output block of the benchmark maps lies under one "
                              "region); algorithmic bytes = its input [4,256,128,128] + its output [4,128,256,256], fp32; dword loads, FETCH_SIZE x2 (calibrated)",
                              4 * (256 * 128 * 128 * 4 + 128 * 256 * 256 * 4)),
     "chain_conv3x3<32>": (["chain_conv_kernel<1, 2"], 2.0, "LDS-DMA dwordx4 only: FETCH_SIZE x2 (guide)", 4 * (32 * 1024 * 1024 * 4 + 3 * 1024 * 1024 * 4 + 3 * 512 * 512 * 4)),
