@@ -1082,6 +1082,7 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
                    _p(nz), nbs or 0, _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, _stream())
         if evb is not None:
             evb.record()
+    use_mxe = sb and mx is not None and mxe is not None and mx[1] == 1 and blocks is None and cin % 32 == 0
     # (timing key: the entry kernel's launches count with the masked kernel they replace — bench.py prices the group as one kernel and says so)
     ev = _timed(modconv_kernel_name(cout, w, sb, labels is not None, cin, mx[1] if (sb and mx is not None) else None), f"{cin}->{cout} @{h}{' up' if up else ''}")
     rgb_out = None
