@@ -107,6 +107,8 @@ def test_encoder_unit_heals_an_f16_overflow():
     that is 512, so the unit is fed a pre-normalised tensor scaled instead (the convolution kernel takes its statistics as an argument)."""
     if ops.mx_arith() != 1:
         pytest.skip("the f16 + fp6 arithmetic is off (E4S_MX)")
+    if ops.ENC_ROUTE_BY_IMAGE:
+        pytest.skip("E4S_ENC_ROUTE_BY_IMAGE=1 keeps this shape off the f16 + fp6 convolution kernel")
     g = torch.Generator(device=DEV).manual_seed(5)
     bs, cin, cout, h = 16, 256, 256, 64
     x = torch.randn(bs, cin, h, h, device=DEV, generator=g)
@@ -129,6 +131,8 @@ def test_encoder_unit_heals_an_f16_overflow():
 def test_swap_batch_defers_and_heals(gpu_net3, bisenet_sd):
     """pipeline.swap_batch brackets parser + encoder + synthesis with ONE guard: by default it waits for it and re-runs; with guard=[] the caller does."""
     from e4s2024_amd import pipeline
+    if ops.mx_arith() != 1:
+        pytest.skip("the f16 + fp6 arithmetic is off (E4S_MX / E4S_MODCONV): nothing on the path can leave the f16 range")
     install_dropin()
     from swap_face_fine.face_parsing.face_parsing_demo import FaceParser
     parser = FaceParser(seg_ckpt=None, device=DEV)
