@@ -22,6 +22,7 @@ Rank 0 prints ONE JSON line with the contract fields plus
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -184,6 +185,10 @@ def main():
     ap.add_argument("--labels", choices=["blocky", "coarse", "portrait", "iid"], default="blocky",
                     help="region maps: 16 x 16 constant cells on the 512 x 512 map (default, BASELINE configs[1]), 4 x 4 cells (face-sized regions), or i.i.d. per pixel")
     ap.add_argument("--soak-seconds", type=float, default=2.0, help="after the timed K steps: the same steps for at least this long (sustained rate, a side field); 0 skips it")
+    ap.add_argument("--timed-events", choices=["dominant", "none"], default="none",
+                    help="HIP events inside the timed region: on the dominant kernel's launches (roofline.in_overlapped_region comes from the timed steps themselves) or none "
+                         "(that view then comes from an instrumented repeat of the same K steps right behind the timed region)")
+    ap.add_argument("--settle-seconds", type=float, default=0.0, help="experiment: untimed steps for this long in front of the warm-up (clock / power settling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-in-run-ab", action="store_true", help="skip the extra one-stream pass on the previous rounds' kernels (roofline.in_run_ab); the profiling scripts use it "
                                                                    "so that their kernel tables list the default routes only")
@@ -255,6 +260,13 @@ def main():
         img = step()
     s0 = k0.summary()
     dom0 = max(s0, key=lambda k: s0[k][1]) if s0 else None
+    if args.settle_seconds > 0:
+        t_set = time.perf_counter()
+        with pipe:
+            while time.perf_counter() - t_set < args.settle_seconds:
+                for _ in range(args.steps):
+                    img = pipe.submit(step)
+                torch.cuda.synchronize()
     with pipe:
         for _ in range(max(args.warmup, 2 * args.streams if args.warmup else 0)):      # (every stream's workspace / control words exist)
             img = pipe.submit(step)
@@ -263,7 +275,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    with ops.KernelTimer(only={dom0} if (args.streams > 1 and dom0) else None) as kt:
+    bare = args.timed_events == "none" and args.streams > 1
+    with (ops.KernelTimer(only={dom0} if (args.streams > 1 and dom0) else None) if not bare else contextlib.nullcontext()) as kt:
         with pipe:
             for _ in range(args.steps):
                 img = pipe.submit(step)
@@ -272,6 +285,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+    if bare:                                   # the overlapped view of the dominant kernel: the same K steps once more, instrumented
+        with ops.KernelTimer(only={dom0} if dom0 else None) as kt:
+            with pipe:
+                for _ in range(args.steps):
+                    img = pipe.submit(step)
+            torch.cuda.synchronize()
     kt_overlap = kt if args.streams > 1 else None
     # sustained rate: the same step on the same streams for >= --soak-seconds (the K = 20 steps of the contract last ~60 ms, shorter than the board's
     # power / clock settling); reported beside `value`, never instead of it
@@ -315,7 +334,7 @@ def main():
         one_stream = {"faces_per_s": round(args.steps * bs / e1a, 1), "ms_per_step": round(e1a / args.steps * 1e3, 3),
                       "faces_per_s_every_launch_timed": round(args.steps * bs / e1, 1),
                       "images_equal_overlapped": bool(torch.equal(img1, img)),
-                      "what": "the same K steps on one stream: `faces_per_s` with the timed region's instrumentation (events on the dominant kernel only), "
+                      "what": "the same K steps on one stream: `faces_per_s` with events on the dominant kernel's launches only (comparable with earlier rounds' one-stream figures), "
                               "`faces_per_s_every_launch_timed` with every instrumented launch bracketed by HIP events (the pass `roofline` is computed from)"}
         del img1
     ksum = kt.summary()
@@ -753,7 +772,10 @@ def main():
                     "whole_job_frac_on_split_bf16_basis": round(job_ach / (BF16_MATRIX_PEAK_TFLOPS / 3.0), 4) if sb else None,
                     "vs_fp32_mfma_peak": round(ach / FP32_MATRIX_PEAK_TFLOPS, 3),
                     "measured_over": ("the one-stream pass of the same K steps inside this run (`one_stream`): between its own HIP events a kernel shows its rate only "
-                                      "while it has the chip to itself; `in_overlapped_region` = the same launches inside the timed region, where two batches share the chip")
+                                      "while it has the chip to itself; `in_overlapped_region` = the same launches where two batches share the chip: "
+                                      + ("an instrumented repeat of the K overlapped steps right behind the timed region (the timed steps carry no events: "
+                                         "14 events per step cost `value` 1.0 % and its run-to-run spread, profiles/r05_ab_timed_events.txt)" if bare
+                                         else "the timed region itself (--timed-events dominant)"))
                     if kt_overlap is not None else "the timed region (one stream)",
                     "in_overlapped_region": _overlap_view(kt_overlap, dom, per_launch_flops, peak),
                     "launches_per_step": calls // args.steps, "avg_launch_ms": round(avg_ms, 4),

@@ -29,6 +29,7 @@ SWAP_CHAINS = 2     # 2 = driven | target; 4 = each additionally split into half
 # parse + encode 4.3 + 13.7 ms for 16 images against 2 x (2.5 + 8.1) ms on one stream and 21.0 ms on two streams).
 SWAP_BATCHED = True
 PARSE_BESIDE_ENCODE = True    # (batched route) the face parser on a side stream next to the encoder body
+ENCODE_ISSUED_FIRST = os.environ.get("E4S_SWAP_ENC_FIRST", "1") != "0"     # (with PARSE_BESIDE_ENCODE) host issue order: encoder body, then the parser
 
 
 def _side_stream(device, idx=0):
@@ -114,15 +115,28 @@ def _swap_batch_once(net, parser, driven, target, comp_indices, randomize_noise,
             # the encoder's body.  Driven and target faces go through both as ONE batch, but the 2 x bs full-size images are never concatenated,
             # shifted to [0, 1] or copied: the two down-sampling kernels in front of parser and encoder read them where they are.
             main, side = torch.cuda.current_stream(), _side_stream(driven.device, 0)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                lab = parser.parse_batch((driven, target), seg12=True, pm1=True)      # uint8 [2 bs, 512, 512]
-            driven.record_stream(side)
-            target.record_stream(side)
+
+            def parse_on_side():
+                with torch.cuda.stream(side):
+                    out = parser.parse_batch((driven, target), seg12=True, pm1=True)   # uint8 [2 bs, 512, 512]
+                driven.record_stream(side)
+                target.record_stream(side)
+                return out
+            if ENCODE_ISSUED_FIRST:
+                # the encoder body is the critical path of a batch (9 ms against the parser's 3): its launches are issued first, the parser's ~40 behind them —
+                # the other way round the encoder's first kernel waits for the HOST to have issued the whole parser
+                inputs_ready = torch.cuda.Event()
+                inputs_ready.record(main)
+            else:
+                side.wait_stream(main)
+                lab = parse_on_side()
             small = torch.empty((2 * bs, driven.shape[1], 256, 256), dtype=torch.float32, device=driven.device)
             ops.bilinear_resize(driven, (256, 256), align_corners=False, out=small[:bs])             # Net3._encode (networks.py:217)
             ops.bilinear_resize(target, (256, 256), align_corners=False, out=small[bs:])
             taps = enc.features(small)
+            if ENCODE_ISSUED_FIRST:
+                side.wait_event(inputs_ready)
+                lab = parse_on_side()
             main.wait_stream(side)
             lab.record_stream(main)
             vec, _ = enc.codes(taps, lab)
