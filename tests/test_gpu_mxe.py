@@ -235,3 +235,47 @@ def test_uniform_block_kernel_on_f16_fp6_against_the_oracle_and_the_composed_for
     record_parity(f"upblock_mx_{cin}to{cout}_{h}x{w}", e_new, MXE_LAYER_TOL, note=f"f16 + fp6 block kernel against the oracle, relative to the output scale {scale:.1f}; the all-composed route: {e_old:.2e}")
     assert e_new <= MXE_LAYER_TOL and torch.isfinite(ys[True]).all(), (shape, e_new, e_old)
     assert not ops.mx_overflowed()
+
+
+def test_new_kernels_back_to_back_on_two_streams_keep_their_bits(sg2, mxe_switch):
+    """The hazard of round 5 (a VALU-written SGPR read by an asm-issued vector-memory request five wait states too early, csrc/sb_common.h) showed only under
+    back-to-back launches: the entry kernel and the region-uniform block kernel, 60 launches each, alternating over two HIP streams with nothing between them —
+    every output equals the first one's bits, nothing faults, the f16 flag stays down."""
+    shape = (2, 128, 128, 64, 64, 12, 64, 64)
+    m1, _, x1, st1, lab1, _, nz1 = _layer(sg2, shape, "cells8", 21)
+    bs, cin, cout, h, w, nreg = 2, 128, 128, 32, 32, 12
+    rs = np.random.RandomState(22)
+    lab2 = np.repeat(np.repeat(rs.randint(0, nreg, (bs, 4, 4)).astype(np.uint8), 16, axis=1), 16, axis=2)      # 64 x 64: every 16 x 16 output block under one region
+    m2 = sg2.StyledConv(cin, cout, 3, 512, upsample=True, mask_op=True)
+    with torch.no_grad():
+        m2.conv.weight.copy_(T(rs.standard_normal(m2.conv.weight.shape).astype(np.float32)))
+        m2.conv.modulation.weight.copy_(T(rs.standard_normal(m2.conv.modulation.weight.shape).astype(np.float32)))
+    m2 = m2.to(DEV)
+    x2 = T(rs.standard_normal((bs, cin, h, w)).astype(np.float32)).to(DEV)
+    st2 = T(rs.standard_normal((bs, nreg, 512)).astype(np.float32)).to(DEV)
+    nz2 = T(rs.standard_normal((bs, 1, 2 * h, 2 * w)).astype(np.float32)).to(DEV)
+    a1 = (x1.to(DEV), st1.to(DEV), T(lab1).to(DEV), nz1.to(DEV))
+    a2 = (x2, st2, T(lab2).to(DEV), nz2)
+    keep = (ops.UP_BLOCKS, ops.UP_BLOCKS_MIN_WIDTH, ops.UP_BLOCKS_MIN_PERCENT, ops.UP_BLOCKS_MIN_PERCENT_SMALL)
+    ops.UP_BLOCKS, ops.UP_BLOCKS_MIN_WIDTH, ops.UP_BLOCKS_MIN_PERCENT, ops.UP_BLOCKS_MIN_PERCENT_SMALL = True, 32, 1, 1
+    mxe_switch(True)
+    ops.mx_overflowed()
+    streams = [torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)]
+    try:
+        with torch.no_grad():
+            with _Calls() as calls:
+                r1 = m1(a1[0], a1[1], a1[2], noise=a1[3])
+                r2 = m2(a2[0], a2[1], a2[2], noise=a2[3])
+            assert "e4s_region_modconv3x3_mxe" in calls.names and "e4s_masked_upconv_blocks_mx" in calls.names, calls.names
+            torch.cuda.synchronize()
+            outs = []
+            for i in range(60):
+                for j, (m, a) in enumerate(((m1, a1), (m2, a2))):
+                    with torch.cuda.stream(streams[(i + j) & 1]):
+                        outs.append((j, m(a[0], a[1], a[2], noise=a[3])))
+            torch.cuda.synchronize()
+    finally:
+        ops.UP_BLOCKS, ops.UP_BLOCKS_MIN_WIDTH, ops.UP_BLOCKS_MIN_PERCENT, ops.UP_BLOCKS_MIN_PERCENT_SMALL = keep
+    for j, y in outs:
+        assert torch.equal(y, r1 if j == 0 else r2)
+    assert not ops.mx_overflowed()
