@@ -47,6 +47,7 @@ _PROTOS = {
     "e4s_conv_prep_weights_mx3_s2": [c_ptr, c_ptr, c_int, c_int, c_ptr],
     "e4s_conv3x3_s2_mx3": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_conv3x3_mx3_phased": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr],
+    "e4s_conv3x3_mx3_ex": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_uniform_blocks": [c_ptr, c_ptr, c_ptr, c_ptr] + [c_int] * 8 + [c_ptr],
     "e4s_modconv_tconv_sb": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_modconv_up_fused_sb": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr],

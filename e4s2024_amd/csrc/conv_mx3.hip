@@ -42,6 +42,7 @@ typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4v __attribute__((ext_vector_type(4)));
 typedef int i32x2v __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TN = 128;                      // output channels per workgroup
 constexpr int CK = 32;                       // input channels per chunk
@@ -76,6 +77,8 @@ struct Mx3Params {
     int bs, cin, cout, h, w_, tiles_x, tiles_y;
     int ho, wo;                  // output size (= h, w_ at stride 1; h / 2, w_ / 2 at stride 2)
     int phased;                  // stride 1: the OUTPUT is written as phase planes; stride 2: the INPUT is read as phase planes  ([b][c][2 py + px][h / 2][w / 2], h and w even)
+    int out_c4;                  // the OUTPUT is channel-blocked: [b][c / 4][plane layout as above][4 floats] — a pixel's four channels are one 16-byte element (the C4 template
+                                 // flag says the same of the INPUT): the hand-over between the two convolutions of an IR-SE unit, which nothing else reads (round 5)
 };
 
 __device__ __forceinline__ unsigned pack_f16_rne(float a, float b) {
@@ -90,7 +93,7 @@ __device__ __forceinline__ i32x8 op6(uint4 lo, uint2 hi) {      // six registers
 // LDS-DMA, 16 bytes per lane from (scalar base + 32-bit lane offset) to LDS address `lds_dst` + 16 * lane (see modconv_mx.hip for why it is asm)
 __device__ __forceinline__ void dma16(const void* gbase, unsigned voff, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(gbase), "s"(lds_dst)
                  : "memory");
@@ -98,7 +101,15 @@ __device__ __forceinline__ void dma16(const void* gbase, unsigned voff, unsigned
 // a global load hipcc does not count: the destination is valid only behind one of the kernel's own vmcnt waits
 __device__ __forceinline__ float load_uncounted(const float* gbase, unsigned voff) {
     float v;
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(gbase) : "memory");
+    // (s_nop 4: five wait states between a VALU write of the base SGPRs — a spilled scalar restored by v_readlane — and this read of them; hipcc's hazard pass does not
+    //  look into asm statements.  Round 5: csrc/sb_common.h)
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(gbase) : "memory");
+    return v;
+}
+// the same for a 16-byte element (four channels of one pixel of a channel-blocked map)
+__device__ __forceinline__ f32x4 load4_uncounted(const float* gbase, unsigned voff) {
+    f32x4 v;
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(gbase) : "memory");
     return v;
 }
 template <typename T>
@@ -174,8 +185,11 @@ __global__ __launch_bounds__(256) void prep_weights_mx3_kernel(unsigned char* __
 // u4 = (1,1) + nothing on phase (0,0) — each of the nine taps once.  (Phase order 3, 1, 2, 0: phases (py, 1) and (py, 0) share their cache lines, so the stagings
 // behind a one-unit sub-chunk — (1,0) after (0,1), (0,0) after (1,0) — find theirs in L2, and the cold lines of (0,1) are requested with two units of cover.)  Weight ring, refills, waits and the two-phase schedule are the stride-1 kernel's; a sub-chunk's
 // prefetch is requested at the top of its predecessor's first unit, so the one-unit sub-chunks have ONE unit of cover for it (the stride-1 kernel has five).
-template <bool S2>
+// C4 (round 5): the input is channel-blocked ([b][c / 4][...][4]): a patch thread requests its pixel's 32 channels of a chunk as EIGHT 16-byte loads instead of 32
+// dword loads — a quarter of the wave requests through the CU's address unit (~18 - 30 cycles each, the issuing wave stalled meanwhile: 2 300 - 2 600 cycles per chunk).
+template <bool S2, bool C4>
 __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) {
+    constexpr int NLD = C4 ? CK / 4 : CK;            // load requests of a prefetch, per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -229,14 +243,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
             in = t < PATCH && ppy <= TH && ppx <= TW && qy >= 0 && qy < p.ho && qx >= 0 && qx < p.wo;      // (taps reach rows 0 .. TH and columns 0 .. TW of the patch only)
             // phase planes (the producer wrote them: consecutive lanes read consecutive floats) or the plain map (every other float of a row: twice the lines per request)
             const unsigned off = p.phased ? (unsigned)(ph * (p.ho * p.wo) + qy * p.wo + qx) : (unsigned)((2 * qy + (ph >> 1)) * p.w_ + 2 * qx + (ph & 1));
-            return in ? off * 4u : 0u;
+            return in ? off * (C4 ? 16u : 4u) : 0u;
         } else {
             const int pgy = y0 - 1 + ppy, pgx = x0 - 1 + ppx;
             in = t < PATCH && pgy >= 0 && pgy < p.h && pgx >= 0 && pgx < p.w_;
-            return in ? (unsigned)(pgy * p.w_ + pgx) * 4u : 0u;
+            return in ? (unsigned)(pgy * p.w_ + pgx) * (C4 ? 16u : 4u) : 0u;
         }
     };
-    float xr[CK];
+    float xr[C4 ? 1 : CK];
+    f32x4 xr4[C4 ? CK / 4 : 1];
     // the next chunk's 32 channels of this thread's pixel: requested between the store phase's barriers, where the wave would otherwise idle (spread over the
     // read phases the requests' issue — the address unit takes a wave request per ~18 cycles and stalls the issuing wave — made every read phase longer than
     // the MFMA phase beside it); waves 6 and 7 own no patch pixel and request nothing
@@ -244,8 +259,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
         if (wave < 6) {
             bool p_in;
             const unsigned goff = patch_pixel(p_in, ph);
+            if constexpr (C4) {
 #pragma unroll
-            for (int c = 0; c < CK; ++c) xr[c] = load_uncounted(xb + (size_t)(chunk * CK + c) * hw, goff);
+                for (int c4 = 0; c4 < CK / 4; ++c4) xr4[c4] = load4_uncounted(xb + (size_t)(chunk * CK + 4 * c4) * hw, goff);      // (plane c / 4 starts at c hw floats)
+            } else {
+#pragma unroll
+                for (int c = 0; c < CK; ++c) xr[c] = load_uncounted(xb + (size_t)(chunk * CK + c) * hw, goff);
+            }
         }
     };
     unsigned ovf = 0u;
@@ -266,8 +286,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int c4 = half * 4 + k;
-                const float a0 = __builtin_fmaf(xr[4 * c4], r4[k].x, b4[k].x), a1v = __builtin_fmaf(xr[4 * c4 + 1], r4[k].y, b4[k].y);
-                const float a2v = __builtin_fmaf(xr[4 * c4 + 2], r4[k].z, b4[k].z), a3 = __builtin_fmaf(xr[4 * c4 + 3], r4[k].w, b4[k].w);
+                float v0, v1, v2, v3;
+                if constexpr (C4) { v0 = xr4[c4][0]; v1 = xr4[c4][1]; v2 = xr4[c4][2]; v3 = xr4[c4][3]; }
+                else { v0 = xr[4 * c4]; v1 = xr[4 * c4 + 1]; v2 = xr[4 * c4 + 2]; v3 = xr[4 * c4 + 3]; }
+                const float a0 = __builtin_fmaf(v0, r4[k].x, b4[k].x), a1v = __builtin_fmaf(v1, r4[k].y, b4[k].y);
+                const float a2v = __builtin_fmaf(v2, r4[k].z, b4[k].z), a3 = __builtin_fmaf(v3, r4[k].w, b4[k].w);
                 q1[2 * c4] = pack_f16_rne(a0, a1v);
                 q1[2 * c4 + 1] = pack_f16_rne(a2v, a3);
                 q2[2 * c4] = resid_pair_f16(a0, a1v, q1[2 * c4]);
@@ -322,9 +345,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
     // pieces, waves 5-7: three) and (lx) the activation prefetch (32 loads, waves 0-5)
     auto wait_units = [&](bool d, bool lx) __attribute__((always_inline)) {
         if (wave < 5) {
-            if (d && lx) E4S_WAIT_VM(4 + CK); else if (d) E4S_WAIT_VM(4); else if (lx) E4S_WAIT_VM(CK); else E4S_WAIT_VM(0);
+            if (d && lx) E4S_WAIT_VM(4 + NLD); else if (d) E4S_WAIT_VM(4); else if (lx) E4S_WAIT_VM(NLD); else E4S_WAIT_VM(0);
         } else if (wave == 5) {
-            if (d && lx) E4S_WAIT_VM(3 + CK); else if (d) E4S_WAIT_VM(3); else if (lx) E4S_WAIT_VM(CK); else E4S_WAIT_VM(0);
+            if (d && lx) E4S_WAIT_VM(3 + NLD); else if (d) E4S_WAIT_VM(3); else if (lx) E4S_WAIT_VM(NLD); else E4S_WAIT_VM(0);
         } else {
             if (d) E4S_WAIT_VM(3); else E4S_WAIT_VM(0);
         }
@@ -522,7 +545,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
         if (y < oh && x < ow) {
             // (stride 1, phased: pixel (y, x) of a channel plane goes to plane 2 (y & 1) + (x & 1), position (y / 2, x / 2) — the layout the stride-2 form reads coalesced)
             const size_t pix = (!S2 && p.phased) ? (size_t)(2 * (y & 1) + (x & 1)) * (ohw >> 2) + (size_t)(y >> 1) * (ow >> 1) + (x >> 1) : (size_t)y * ow + x;
-            float* op = p.out + (size_t)b * p.cout * ohw + pix;
+            float* op = p.out + (size_t)b * p.cout * ohw + (p.out_c4 ? pix * 4 : pix);
+            if (p.out_c4) {
+                // channel-blocked: registers 4 q .. 4 q + 3 of a block are channels 8 q + 4 khalf .. + 3 — one 16-byte element of the pixel (cout % 4 == 0: the launcher)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = chh * 64 + cb * 32 + 8 * q + 4 * khalf;
+                        f32x4 v4;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { const float v = acc[cb][pb][4 * q + i]; v4[i] = v > 0.f ? v : v * sl[n + i]; }
+                        if (co0 + n < p.cout) *reinterpret_cast<f32x4*>(op + (size_t)(co0 + n) * ohw) = v4;      // (plane (co0 + n) / 4 starts at (co0 + n) ohw floats)
+                    }
+            } else {
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -532,6 +568,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
                     v = v > 0.f ? v : v * sl[n];
                     if (co0 + n < p.cout) op[(size_t)(co0 + n) * ohw] = v;
                 }
+            }
         }
     }
 }
@@ -565,15 +602,18 @@ extern "C" int e4s_conv_prep_weights_mx3_s2(void* dst, const float* weight, int 
 
 // out = PReLU(conv3x3(norm(x), W)), stride 1, pad 1.  in_mean / in_rstd [bs][cin] (optional, together), prelu_slope [cout] optional; flags[0] bit 0 is raised
 // when a normalised activation leaves the f16 range (the result is then invalid; the kernel does not fall back by itself — ops.MxGuard notices the counter flags[1] moving and the entry points re-run the pass on the split-bf16 kernels).
-template <bool S2>
+// layouts: bit 0 = phase planes (stride 1: of the output; stride 2: of the input), bit 1 = channel-blocked [c / 4][...][4]
+template <bool S2, bool C4>
 static int conv3x3_mx3(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
-                       int bs, int cin, int cout, int h, int w, int phased, void* stream) {
+                       int bs, int cin, int cout, int h, int w, int phased, int out_c4, void* stream) {
     E4S_REQUIRE(out && x && wmx3, "conv3x3_mx3: null tensor");
     E4S_REQUIRE((in_mean == nullptr) == (in_rstd == nullptr), "conv3x3_mx3: in_mean and in_rstd go together");
     E4S_REQUIRE(bs >= 0 && bs <= 65535 && cin >= CK && cin % CK == 0 && cin <= MAX_CIN && cout >= 1 && h >= 1 && w >= 1, "conv3x3_mx3: bad size (cin %% 32 == 0, cin <= 512)");
     E4S_REQUIRE(!(S2 || phased) || (h % 2 == 0 && w % 2 == 0), "conv3x3_mx3: stride 2 / phase planes need an even height and width");
     E4S_REQUIRE(((uintptr_t)wmx3 & 15) == 0, "conv3x3_mx3: the weights must be 16-byte aligned");
     E4S_REQUIRE((int64_t)cin * h * w * 4 < (int64_t)1 << 32, "conv3x3_mx3: a sample's input must stay below 4 GB (32-bit lane offsets)");
+    E4S_REQUIRE(!out_c4 || cout % 4 == 0, "conv3x3_mx3: a channel-blocked output needs cout %% 4 == 0");
+    E4S_REQUIRE(!(C4 || out_c4) || ((((uintptr_t)x | (uintptr_t)out) & 15) == 0), "conv3x3_mx3: channel-blocked maps must be 16-byte aligned");
     if (bs == 0) return 0;
     Mx3Params p;
     memset(&p, 0, sizeof(p));
@@ -582,29 +622,43 @@ static int conv3x3_mx3(float* out, const float* x, const void* wmx3, int* flags,
     p.bs = bs; p.cin = cin; p.cout = cout; p.h = h; p.w_ = w;
     p.ho = S2 ? h / 2 : h; p.wo = S2 ? w / 2 : w;
     p.phased = phased ? 1 : 0;
+    p.out_c4 = out_c4 ? 1 : 0;
     p.tiles_x = cdiv(p.wo, TW); p.tiles_y = cdiv(p.ho, TH);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mx3_kernel<S2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mx3_kernel<S2, C4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return fail((int)attr, "conv3x3_mx3: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
     dim3 grid(p.tiles_x * p.tiles_y, cdiv(cout, TN), bs);
-    hipLaunchKernelGGL(conv3x3_mx3_kernel<S2>, grid, dim3(512), LDS_BYTES, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((conv3x3_mx3_kernel<S2, C4>), grid, dim3(512), LDS_BYTES, (hipStream_t)stream, p);
     return check_launch(S2 ? "conv3x3_s2_mx3" : "conv3x3_mx3");
 }
 
 extern "C" int e4s_conv3x3_mx3(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
                                int bs, int cin, int cout, int h, int w, void* stream) {
-    return conv3x3_mx3<false>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, 0, stream);
+    return conv3x3_mx3<false, false>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, 0, 0, stream);
 }
 
 // e4s_conv3x3_mx3 whose result is written as PHASE PLANES, out[b][c][2 py + px][h / 2][w / 2] = result[b][c][2 y + py][2 x + px] (h, w even): the layout
 // e4s_conv3x3_s2_mx3(in_phased = 1) reads with consecutive lanes on consecutive floats
 extern "C" int e4s_conv3x3_mx3_phased(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
                                       int bs, int cin, int cout, int h, int w, void* stream) {
-    return conv3x3_mx3<false>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, 1, stream);
+    return conv3x3_mx3<false, false>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, 1, 0, stream);
+}
+
+// e4s_conv3x3_mx3 with explicit memory layouts (round 5).  Bit 1 (value 2) of either = CHANNEL-BLOCKED: the map is [bs][c / 4][h][w][4 floats] (c % 4 == 0, 16-byte
+// aligned) — a pixel's four channels are one 16-byte element, so the consumer's patch threads request 8 elements per 32-channel chunk instead of 32 floats and the
+// producer stores 16 bytes per request.  Bit 0 (value 1) of out_layout = phase planes as e4s_conv3x3_mx3_phased ([bs][c (/ 4)][2 py + px][h / 2][w / 2]([4])).
+// in_layout: 0 or 2.  The arithmetic does not depend on the layouts: the same values as e4s_conv3x3_mx3, bit for bit.
+extern "C" int e4s_conv3x3_mx3_ex(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
+                                  int bs, int cin, int cout, int h, int w, int in_layout, int out_layout, void* stream) {
+    E4S_REQUIRE((in_layout == 0 || in_layout == 2) && out_layout >= 0 && out_layout <= 3, "conv3x3_mx3_ex: in_layout is 0 or 2, out_layout 0 .. 3");
+    if (in_layout & 2) return conv3x3_mx3<false, true>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, out_layout & 1, out_layout & 2, stream);
+    return conv3x3_mx3<false, false>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, out_layout & 1, out_layout & 2, stream);
 }
 
 // out [bs, cout, h / 2, w / 2] = PReLU(conv3x3(norm(x), W, stride 2, pad 1)); h, w even; weights from e4s_conv_prep_weights_mx3_s2; in_phased: x is in the phase-plane
-// layout of e4s_conv3x3_mx3_phased.  Everything else as e4s_conv3x3_mx3.
+// layout of e4s_conv3x3_mx3_phased; in_phased is a layout word like e4s_conv3x3_mx3_ex's (bit 0: phase planes, bit 1: channel-blocked).  Everything else as e4s_conv3x3_mx3.
 extern "C" int e4s_conv3x3_s2_mx3(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
                                   int bs, int cin, int cout, int h, int w, int in_phased, void* stream) {
-    return conv3x3_mx3<true>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, in_phased, stream);
+    E4S_REQUIRE(in_phased >= 0 && in_phased <= 3, "conv3x3_s2_mx3: in_phased is a layout, 0 .. 3");
+    if (in_phased & 2) return conv3x3_mx3<true, true>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, in_phased & 1, 0, stream);
+    return conv3x3_mx3<true, false>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, in_phased & 1, 0, stream);
 }

@@ -1403,6 +1403,9 @@ MX3 = os.environ.get("E4S_MX3", "1") != "0"     # plain f16 + fp6 convolutions o
 MX_CONV_MIN_WORKGROUPS = 128       # (layers that can also take the Winograd route) below half a round of the chip Winograd / the direct kernel serve a launch better
 MX_CONV_MIN_WORKGROUPS_PER_IMAGE = 64
 UP_MX4 = True      # masked up layers: tiles whose positions' 2 x 2 outputs share a region on the four-parity kernel (csrc/modconv_mx4.hip); no environment switch — bench.py's in-run A/B flips it
+# the map between the two 3x3 convolutions of an IR-SE unit is handed over channel-blocked ([bs, c / 4, h, w, 4]) when both run on the two-phase kernel
+# (ops_encode.conv3x3_s1_c4_pair; csrc/conv_mx3.hip, round 5).  0: plain NCHW planes as before — the values are the same, bit for bit
+ENC_C4_LINK = os.environ.get("E4S_ENC_C4", "1") != "0"
 S2_MX3 = True           # the encoder's stride-2 3x3 convolutions on the stride-2 form of csrc/conv_mx3.hip (attribute; off: the direct split-bf16 kernel)
 # The squeeze-excite gate of an IR-SE unit is sigmoid(fc2 . relu(fc1 . mean(IN(r)))) with bias-free 1x1 convolutions (helpers.py:56-72) behind an affine-free
 # InstanceNorm2d (helpers.py:128-139): the pooled vector is the mean of an instance-normalised plane — exactly 0 — so the gate is sigmoid(0) = 1/2 for every channel of

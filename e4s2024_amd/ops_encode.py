@@ -256,29 +256,37 @@ def mx_conv_eligible(x: torch.Tensor, cout: int) -> bool:
 
 
 def conv3x3_mx(x: torch.Tensor, wmx: torch.Tensor, arith: int, cout: int, *, in_norm=None, prelu: Optional[torch.Tensor] = None,
-               out_phased: bool = False) -> torch.Tensor:
+               out_phased: bool = False, out_c4: bool = False) -> torch.Tensor:
     """``PReLU(conv3x3(norm(x), W))``, stride 1, pad 1, on ``e4s_conv3x3_mx`` / ``e4s_conv3x3_mx3`` (``arith`` 3) (``wmx`` from ``PreparedMx.get`` of the
-    plain weight with the same ``arith``).  ``out_phased`` (``arith`` 3, even maps): the result's MEMORY is phase planes — ``[bs, cout, 2, 2, h / 2, w / 2]``,
-    plane ``(py, px)`` = ``result[..., py::2, px::2]`` — which only ``conv3x3_s2_mx(in_phased=True)`` reads; the returned tensor has that shape."""
+    plain weight with the same ``arith``).  Hand-over layouts of the two-phase kernel (``arith`` 3), which only another ``conv3x3_mx`` / ``conv3x3_s2_mx`` reads:
+    ``out_phased`` (even maps): the result's MEMORY is phase planes — ``[bs, cout, 2, 2, h / 2, w / 2]``, plane ``(py, px)`` = ``result[..., py::2, px::2]``;
+    ``out_c4``: channel-blocked — ``[bs, cout / 4, h, w, 4]`` (with ``out_phased``: ``[bs, cout / 4, 2, 2, h / 2, w / 2, 4]``), a pixel's four channels one
+    16-byte element.  The returned tensor has that shape; a 5-D INPUT is such a channel-blocked map.  Same values in every layout."""
     x = _c(x, "input")
-    bs, cin, h, w = x.shape
-    if out_phased:
-        if arith != 3 or h % 2 or w % 2:
-            raise ValueError("conv3x3_mx: out_phased needs the two-phase kernel (arith 3) and an even map")
-        out = torch.empty((bs, cout, 2, 2, h // 2, w // 2), dtype=torch.float32, device=x.device)
-        mean, rstd = (_c(in_norm[0], "in_mean"), _c(in_norm[1], "in_rstd")) if in_norm is not None else (None, None)
+    in_c4 = x.dim() == 5
+    if in_c4:
+        if x.shape[4] != 4:
+            raise ValueError("conv3x3_mx: a channel-blocked input is [bs, cin / 4, h, w, 4]")
+        bs, cin, h, w = x.shape[0], 4 * x.shape[1], x.shape[2], x.shape[3]
+    else:
+        bs, cin, h, w = x.shape
+    mean = rstd = None
+    if in_norm is not None:
+        mean, rstd = _c(in_norm[0], "in_mean"), _c(in_norm[1], "in_rstd")
+    pr = _p(_c(prelu.detach(), "prelu")) if prelu is not None else None
+    if out_phased or out_c4 or in_c4:
+        if arith != 3 or (out_phased and (h % 2 or w % 2)) or (out_c4 and cout % 4):
+            raise ValueError("conv3x3_mx: hand-over layouts need the two-phase kernel (arith 3); phase planes an even map, channel blocks cout % 4 == 0")
+        shape = (bs, cout // 4 if out_c4 else cout) + ((2, 2, h // 2, w // 2) if out_phased else (h, w)) + ((4,) if out_c4 else ())
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
         ev = _timed("conv3x3_mx<3>", f"{cin}->{cout} @{h}")
-        lib().call("e4s_conv3x3_mx3_phased", _p(out), _p(x), _p(wmx), _p(mx_flags(x.device)), _p(mean), _p(rstd),
-                   _p(_c(prelu.detach(), "prelu")) if prelu is not None else None, bs, cin, cout, h, w, _stream())
+        lib().call("e4s_conv3x3_mx3_ex", _p(out), _p(x), _p(wmx), _p(mx_flags(x.device)), _p(mean), _p(rstd), pr, bs, cin, cout, h, w,
+                   2 if in_c4 else 0, (1 if out_phased else 0) | (2 if out_c4 else 0), _stream())
         if ev is not None:
             ev.record()
         return out
     out = torch.empty((bs, cout, h, w), dtype=torch.float32, device=x.device)
-    mean = rstd = None
-    if in_norm is not None:
-        mean, rstd = _c(in_norm[0], "in_mean"), _c(in_norm[1], "in_rstd")
     ev = _timed(f"conv3x3_mx<{arith}>", f"{cin}->{cout} @{h}")
-    pr = _p(_c(prelu.detach(), "prelu")) if prelu is not None else None
     if arith == 3:
         lib().call("e4s_conv3x3_mx3", _p(out), _p(x), _p(wmx), _p(mx_flags(x.device)), _p(mean), _p(rstd), pr, bs, cin, cout, h, w, _stream())
     else:
@@ -291,13 +299,13 @@ def conv3x3_mx(x: torch.Tensor, wmx: torch.Tensor, arith: int, cout: int, *, in_
 def conv3x3_s2_mx(x: torch.Tensor, wmx: torch.Tensor, cout: int, *, in_norm=None, prelu: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``PReLU(conv3x3(norm(x), W, stride 2, pad 1))`` on ``e4s_conv3x3_s2_mx3`` (f16 + 2 x MX fp6; ``wmx`` from ``PreparedMx.get(weight, None, False, 5)``);
     the input's height and width must be even, ``cin % 32 == 0``, ``cin <= 512``.  A 6-D input ``[bs, cin, 2, 2, h / 2, w / 2]`` is the phase-plane
-    hand-over of ``conv3x3_mx(out_phased=True)``."""
+    hand-over of ``conv3x3_mx(out_phased=True)``, a 7-D one ``[bs, cin / 4, 2, 2, h / 2, w / 2, 4]`` that of ``conv3x3_mx(out_phased=True, out_c4=True)``."""
     x = _c(x, "input")
-    in_phased = x.dim() == 6
+    in_phased, in_c4 = x.dim() in (6, 7), x.dim() == 7
     if in_phased:
-        if x.shape[2] != 2 or x.shape[3] != 2:
-            raise ValueError("conv3x3_s2_mx: a phase-plane input is [bs, cin, 2, 2, h / 2, w / 2]")
-        bs, cin, h, w = x.shape[0], x.shape[1], 2 * x.shape[4], 2 * x.shape[5]
+        if x.shape[2] != 2 or x.shape[3] != 2 or (in_c4 and x.shape[6] != 4):
+            raise ValueError("conv3x3_s2_mx: a phase-plane input is [bs, cin, 2, 2, h / 2, w / 2] or [bs, cin / 4, 2, 2, h / 2, w / 2, 4]")
+        bs, cin, h, w = x.shape[0], x.shape[1] * (4 if in_c4 else 1), 2 * x.shape[4], 2 * x.shape[5]
     else:
         bs, cin, h, w = x.shape
     if h % 2 or w % 2:
@@ -308,12 +316,11 @@ def conv3x3_s2_mx(x: torch.Tensor, wmx: torch.Tensor, cout: int, *, in_norm=None
         mean, rstd = _c(in_norm[0], "in_mean"), _c(in_norm[1], "in_rstd")
     ev = _timed("conv3x3_s2_mx<3>", f"{cin}->{cout} @{h}")
     pr = _p(_c(prelu.detach(), "prelu")) if prelu is not None else None
-    lib().call("e4s_conv3x3_s2_mx3", _p(out), _p(x), _p(wmx), _p(mx_flags(x.device)), _p(mean), _p(rstd), pr, bs, cin, cout, h, w, 1 if in_phased else 0, _stream())
+    lib().call("e4s_conv3x3_s2_mx3", _p(out), _p(x), _p(wmx), _p(mx_flags(x.device)), _p(mean), _p(rstd), pr, bs, cin, cout, h, w,
+               (1 if in_phased else 0) | (2 if in_c4 else 0), _stream())
     if ev is not None:
         ev.record()
     return out
-
-
 
 
 def conv3x3_s2_takes_mx(bs: int, cin: int, cout: int, h: int, w: int, device) -> bool:
@@ -335,7 +342,7 @@ class _ShapeOnly:
 def conv3x3_s2(x: torch.Tensor, weight: torch.Tensor, caches) -> torch.Tensor:
     """A stride-2, pad-1 3x3 convolution: the DMA-fed f16 + fp6 kernel where it fits and fills the chip (``conv3x3_s2_takes_mx``), else the direct kernel.
     ``caches = (PreparedConv, PreparedWinograd, PreparedMx)`` of the layer.  ``x`` may be the phase-plane hand-over of ``conv3x3_s1(out_phased=True)``."""
-    if x.dim() == 6:
+    if x.dim() in (6, 7):
         return conv3x3_s2_mx(x, caches[2].get(weight, None, False, 5), weight.shape[0])
     bs, cin, h, w = x.shape
     if len(caches) > 2 and conv3x3_s2_takes_mx(bs, cin, weight.shape[0], h, w, x.device):
@@ -349,14 +356,28 @@ def conv3x3_s1_takes_mx3(x: torch.Tensor, cout: int) -> bool:
             and x.shape[1] % 32 == 0 and x.shape[1] <= 512)
 
 
-def conv3x3_s1(x: torch.Tensor, weight: torch.Tensor, caches, *, in_norm=None, prelu: Optional[torch.Tensor] = None, out_phased: bool = False) -> torch.Tensor:
+def conv3x3_s1_c4_pair(x: torch.Tensor, depth: int, cout2: int, stride2: int) -> bool:
+    """Do BOTH 3x3 convolutions of an IR-SE unit — ``x -> depth`` at stride 1, ``depth -> cout2`` at ``stride2`` — run on the two-phase kernel, so that the map between
+    them can be handed over channel-blocked (``ops.ENC_C4_LINK``)?"""
+    if not (ops.ENC_C4_LINK and x.dim() == 4 and depth % 4 == 0 and conv3x3_s1_takes_mx3(x, depth)):
+        return False
+    bs, _, h, w = x.shape
+    if stride2 == 2:
+        return h % 2 == 0 and w % 2 == 0 and conv3x3_s2_takes_mx(bs, depth, cout2, h, w, x.device)
+    return stride2 == 1 and conv3x3_s1_takes_mx3(_ShapeOnly(bs, depth, h, w, x.device), cout2)
+
+
+def conv3x3_s1(x: torch.Tensor, weight: torch.Tensor, caches, *, in_norm=None, prelu: Optional[torch.Tensor] = None, out_phased: bool = False,
+               out_c4: bool = False) -> torch.Tensor:
     """A stride-1, pad-1 3x3 convolution by whichever route fits the launch: Winograd (``winograd_route``: small batches), the DMA-fed kernel
     (``mx_conv_eligible``: launches that fill the chip) or the direct kernel; ``caches = (PreparedConv, PreparedWinograd, PreparedMx)`` of the layer.
     ``out_phased``: see ``conv3x3_mx`` — the caller has checked ``conv3x3_s1_takes_mx3``."""
-    if out_phased:
+    if x.dim() == 5:          # the channel-blocked hand-over of a conv3x3_s1(out_c4=True): the producer checked conv3x3_s1_c4_pair
+        return conv3x3_mx(x, caches[2].get(weight, None, False, 3), 3, weight.shape[0], in_norm=in_norm, prelu=prelu, out_phased=out_phased, out_c4=out_c4)
+    if out_phased or out_c4:
         if not (len(caches) > 2 and conv3x3_s1_takes_mx3(x, weight.shape[0])):
-            raise RuntimeError("conv3x3_s1: out_phased on a layer that does not run on the two-phase kernel")
-        return conv3x3_mx(x, caches[2].get(weight, None, False, 3), 3, weight.shape[0], in_norm=in_norm, prelu=prelu, out_phased=True)
+            raise RuntimeError("conv3x3_s1: a hand-over layout on a layer that does not run on the two-phase kernel")
+        return conv3x3_mx(x, caches[2].get(weight, None, False, 3), 3, weight.shape[0], in_norm=in_norm, prelu=prelu, out_phased=out_phased, out_c4=out_c4)
     route = winograd_route(x, x.shape[1], 1)
     if route == "f32":
         return conv2d_winograd(x, caches[1].get(weight), in_norm=in_norm, prelu=prelu)
@@ -589,4 +610,4 @@ def tensor2im_u8(img: torch.Tensor) -> torch.Tensor:
     return out
 
 
-__all__ = ['ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'PreparedConv', '_is_f16x3', 'conv2d', 'PreparedWinograd', 'winograd_route', 'mx4_eligible', 'mx_conv_eligible', 'conv3x3_mx', 'conv3x3_s2_mx', 'conv3x3_s2_takes_mx', '_ShapeOnly', 'conv3x3_s2', 'conv3x3_s1_takes_mx3', 'conv3x3_s1', 'conv2d_winograd', 'plane_stats', 'vec_fc', 'se_gate', '_half_gates', 'half_gate', 'norm_gate_add', 'masked_avg_pool', '_out_like', 'bilinear_resize', 'maxpool3x3s2', 'gate_add_upsample', 'bilinear_argmax', 'bicubic_down_normalize', 'tensor2im_u8']
+__all__ = ['conv3x3_s1_c4_pair', 'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'PreparedConv', '_is_f16x3', 'conv2d', 'PreparedWinograd', 'winograd_route', 'mx4_eligible', 'mx_conv_eligible', 'conv3x3_mx', 'conv3x3_s2_mx', 'conv3x3_s2_takes_mx', '_ShapeOnly', 'conv3x3_s2', 'conv3x3_s1_takes_mx3', 'conv3x3_s1', 'conv2d_winograd', 'plane_stats', 'vec_fc', 'se_gate', '_half_gates', 'half_gate', 'norm_gate_add', 'masked_avg_pool', '_out_like', 'bilinear_resize', 'maxpool3x3s2', 'gate_add_upsample', 'bilinear_argmax', 'bicubic_down_normalize', 'tensor2im_u8']

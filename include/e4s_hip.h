@@ -219,6 +219,13 @@ E4S_API int e4s_conv3x3_s2_mx3(float* out, const float* x, const void* wmx3, int
  * map costs it two cache lines per useful one. */
 E4S_API int e4s_conv3x3_mx3_phased(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
                                    int bs, int cin, int cout, int h, int w, void* stream);
+/* e4s_conv3x3_mx3 with explicit memory layouts (round 5): a layout word's bit 0 (1) = phase planes as above, bit 1 (2) = CHANNEL-BLOCKED — the map is
+ * [bs][c/4][plane layout][4 floats], a pixel's four channels one 16-byte element (c % 4 == 0, 16-byte aligned).  It is the hand-over between the two convolutions
+ * of a bottleneck_IR_SE_Ours unit (models/encoders/helpers.py:128-139: Conv2d -> PReLU -> Conv2d with nothing between them and no other reader): the producer
+ * stores 16 bytes per request, the consumer's patch threads request 8 elements per 32-channel chunk instead of 32 floats.  in_layout: 0 or 2; out_layout: 0..3;
+ * e4s_conv3x3_s2_mx3's in_phased argument is such a word too (0..3).  Values do not depend on the layouts (bit for bit those of e4s_conv3x3_mx3). */
+E4S_API int e4s_conv3x3_mx3_ex(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
+                               int bs, int cin, int cout, int h, int w, int in_layout, int out_layout, void* stream);
 /* Masked up-sampling layers, region-uniform output blocks (model.py:287-300 per region == one transposed conv + blur where a block of output
  * pixels has ONE region):
  *   e4s_uniform_blocks: sub[b][2by+sy][2bx+sx] = the region of an 8 x 8 output sub-block (labels uint8 [bs][lh][lw] sampled 'nearest' at

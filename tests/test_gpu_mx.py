@@ -377,3 +377,84 @@ def test_encoder_at_batch_16_takes_the_mx_route_and_matches_the_direct_route(mx_
     record_parity("encoder_bs16_mx_vs_direct_route.style_vectors", d, 1e-3, note=f"relative to the largest style vector entry {scale:.2f}")
     assert d <= 1e-3
     assert not ops.mx_overflowed()
+
+
+def _to_c4(t):
+    """[bs, c, ...] -> [bs, c / 4, ..., 4]: the channel-blocked hand-over layout."""
+    bs, c = t.shape[:2]
+    return t.reshape(bs, c // 4, 4, *t.shape[2:]).movedim(2, -1).contiguous()
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 160, 40, 36), (1, 128, 128, 64, 64), (3, 32, 256, 24, 70)])
+def test_channel_blocked_hand_over_between_two_convolutions_keeps_every_bit(shape):
+    """Round 5 (csrc/conv_mx3.hip, ``e4s_conv3x3_mx3_ex``): the map between the two 3x3 convolutions of an IR-SE unit (helpers.py:128-139) handed over as
+    ``[bs, c / 4, h, w, 4]`` — the producer's blocked output IS the plain output permuted, the consumer's result from it IS its result from the plain map; the same
+    for the stride-2 pair (phase planes + channel blocks); ragged maps, an output-channel tail."""
+    if ops.mx_arith() != 1 or not ops.MX3:
+        pytest.skip("the two-phase f16 + fp6 kernel is off")
+    bs, cin, depth, h, w = shape
+    g = torch.Generator(device=DEV).manual_seed(7 * cin + w)
+    x = torch.randn(bs, cin, h, w, device=DEV, generator=g) * 1.5 + 0.3
+    w1 = torch.randn(depth, cin, 3, 3, device=DEV, generator=g) / (cin * 9) ** 0.5
+    w2 = torch.randn(depth, depth, 3, 3, device=DEV, generator=g) / (depth * 9) ** 0.5
+    slope = torch.rand(depth, device=DEV, generator=g) * 0.5
+    mean = x.mean((2, 3))
+    rstd = 1.0 / torch.sqrt(x.var((2, 3), unbiased=False) + 1e-5)
+    with torch.no_grad():
+        w13, w23, w25 = (ops.PreparedMx().get(w1, None, False, 3), ops.PreparedMx().get(w2, None, False, 3), ops.PreparedMx().get(w2, None, False, 5))
+        r = ops.conv3x3_mx(x, w13, 3, depth, in_norm=(mean, rstd), prelu=slope)
+        r4 = ops.conv3x3_mx(x, w13, 3, depth, in_norm=(mean, rstd), prelu=slope, out_c4=True)
+        assert tuple(r4.shape) == (bs, depth // 4, h, w, 4) and torch.equal(r4, _to_c4(r))
+        y = ops.conv3x3_mx(r, w23, 3, depth)
+        assert torch.equal(ops.conv3x3_mx(r4, w23, 3, depth), y)
+        # blocked in, blocked out (a chain of such links), with the consumer's own normalisation and PReLU
+        m2, s2 = r.mean((2, 3)), 1.0 / torch.sqrt(r.var((2, 3), unbiased=False) + 1e-5)
+        y2 = ops.conv3x3_mx(r, w23, 3, depth, in_norm=(m2, s2), prelu=slope)
+        assert torch.equal(ops.conv3x3_mx(r4, w23, 3, depth, in_norm=(m2, s2), prelu=slope, out_c4=True), _to_c4(y2))
+        if h % 2 == 0 and w % 2 == 0:
+            rp = ops.conv3x3_mx(x, w13, 3, depth, in_norm=(mean, rstd), prelu=slope, out_phased=True, out_c4=True)
+            r6 = torch.stack([torch.stack([r[:, :, py::2, px::2] for px in (0, 1)], 2) for py in (0, 1)], 2).contiguous()
+            assert tuple(rp.shape) == (bs, depth // 4, 2, 2, h // 2, w // 2, 4) and torch.equal(rp, _to_c4(r6))
+            ys = ops.conv3x3_s2_mx(r, w25, depth)
+            assert torch.equal(ops.conv3x3_s2_mx(rp, w25, depth), ys)
+    assert not ops.mx_overflowed()
+
+
+def test_encoder_units_take_the_channel_blocked_link_and_keep_their_values():
+    """An IR-SE unit at the full swap's launch size (16 faces) with the link on and off: the same output bits, and the link IS taken (stride 1 and stride 2)."""
+    if ops.mx_arith() != 1 or not ops.MX3:
+        pytest.skip("the two-phase f16 + fp6 kernel is off")
+    from conftest import install_dropin
+    install_dropin()
+    from models.encoders.psp_encoders import bottleneck_IR_SE_Ours
+    g = torch.Generator(device=DEV).manual_seed(31)
+    for cin, depth, stride, h in ((256, 256, 1, 64), (128, 256, 2, 128)):
+        unit = bottleneck_IR_SE_Ours(cin, depth, stride).to(DEV).eval()
+        with torch.no_grad():
+            for p_ in unit.parameters():
+                p_.copy_(torch.randn(p_.shape, device=DEV, generator=g) * (0.05 if p_.dim() == 4 else 0.25))
+        x = torch.randn(16, cin, h, h, device=DEV, generator=g)
+        keep = ops.ENC_C4_LINK
+        outs = {}
+        try:
+            for on in (False, True):
+                ops.ENC_C4_LINK = on
+                names = []
+                orig = ops.lib().call
+
+                def call(name, *a, _names=names, _orig=orig):
+                    _names.append((name, a[-3], a[-2]) if name == "e4s_conv3x3_mx3_ex" else (name, a[-2]) if name == "e4s_conv3x3_s2_mx3" else (name,))
+                    return _orig(name, *a)
+                ops.lib().call = call
+                try:
+                    with torch.no_grad():
+                        outs[on] = unit(x).clone()
+                finally:
+                    ops.lib().call = orig
+                blocked_out = [n for n in names if n[0] == "e4s_conv3x3_mx3_ex" and n[2] & 2]
+                blocked_in = [n for n in names if (n[0] == "e4s_conv3x3_mx3_ex" and n[1] & 2) or (n[0] == "e4s_conv3x3_s2_mx3" and n[1] & 2)]
+                assert (len(blocked_out), len(blocked_in)) == ((1, 1) if on else (0, 0)), (cin, stride, on, names)
+        finally:
+            ops.ENC_C4_LINK = keep
+        assert torch.equal(outs[False], outs[True])
+    assert not ops.mx_overflowed()
