@@ -18,7 +18,7 @@ def timeit(f, n=20):
     for _ in range(n):
         t0 = time.perf_counter(); f(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
     ts.sort(); return ts[len(ts) // 2]
-for bs in (1, 2):
+for bs in ([int(a) for a in sys.argv[1:]] or [1, 2]):
     d = seeded.seeded_image(5, bs, 1024).to(dev); t = seeded.seeded_image(6, bs, 1024).to(dev)
     eager = timeit(lambda: pipeline.swap_batch(net, parser, d, t))
     g = graphs.graphed_swap(net, parser, d, t)
