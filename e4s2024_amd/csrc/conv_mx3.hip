@@ -77,6 +77,7 @@ struct Mx3Params {
     int bs, cin, cout, h, w_, tiles_x, tiles_y;
     int ho, wo;                  // output size (= h, w_ at stride 1; h / 2, w_ / 2 at stride 2)
     int phased;                  // stride 1: the OUTPUT is written as phase planes; stride 2: the INPUT is read as phase planes  ([b][c][2 py + px][h / 2][w / 2], h and w even)
+    int out_prep;                // the OUTPUT is written as PREPARED OPERANDS (see the IN == 2 template flag): what the consumer's staging would compute, computed here once per pixel
     int out_c4;                  // the OUTPUT is channel-blocked: [b][c / 4][plane layout as above][4 floats] — a pixel's four channels are one 16-byte element (the C4 template
                                  // flag says the same of the INPUT): the hand-over between the two convolutions of an IR-SE unit, which nothing else reads (round 5)
 };
@@ -121,6 +122,45 @@ __device__ __forceinline__ unsigned resid_pair_f16(float a, float b, unsigned a1
     asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(r) : "v"(b), "v"(a1));
     return r;
 }
+
+// 16 raw bytes / 4 raw bytes of a prepared-operand map (same caveats as load_uncounted)
+// (the asm's output registers are returned AS THEY ARE: any conversion here would be a register copy in front of the kernel's wait — stale data)
+__device__ __forceinline__ i32x4v load16_uncounted(const unsigned char* gbase, unsigned voff) {
+    i32x4v v;
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(gbase) : "memory");
+    return v;
+}
+__device__ __forceinline__ uint4 as_uint4(i32x4v v) { return make_uint4((unsigned)v[0], (unsigned)v[1], (unsigned)v[2], (unsigned)v[3]); }
+__device__ __forceinline__ unsigned load4u_uncounted(const unsigned char* gbase, unsigned voff) {
+    unsigned v;
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(gbase) : "memory");
+    return v;
+}
+// One pixel's 32 channels -> the operands the K loop reads: a1 = f16(a) (q1: pairs), fp6(a1) and fp6(a - a1) under the block scales 2^(E - 2) / 2^(E - 13) (c1, c2),
+// the scale bytes, and whether a value left the f16 range.  The staging's arithmetic (store_x below), instruction for instruction: a map prepared with this by its
+// PRODUCER gives the consumer the bits its own staging would have made.
+__device__ __forceinline__ void encode32(const float (&a)[32], u32x16& q1, u32x6& c1, u32x6& c2, unsigned& scales, unsigned& ovf) {
+    u32x16 q2;
+    unsigned m = 0u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        q1[j] = pack_f16_rne(a[2 * j], a[2 * j + 1]);
+        q2[j] = resid_pair_f16(a[2 * j], a[2 * j + 1], q1[j]);
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        const u16x2 mm = __builtin_elementwise_max(__builtin_bit_cast(u16x2, m), __builtin_bit_cast(u16x2, q1[j] & 0x7fff7fffu));
+        m = __builtin_bit_cast(unsigned, mm);
+    }
+    const unsigned mh = (m & 0xffffu) > (m >> 16) ? (m & 0xffffu) : (m >> 16);
+    const unsigned e16 = mh >> 10;
+    ovf |= e16 >= 31u ? 1u : 0u;
+    const unsigned ex = (e16 ? e16 : 1u) + 112u;
+    const unsigned e1 = ex > 3u ? ex - 2u : 1u, e2 = ex > 14u ? ex - 13u : 1u;
+    c1 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, q1), __builtin_bit_cast(float, e1 << 23));
+    c2 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, q2), __builtin_bit_cast(float, e2 << 23));
+    scales = e1 | (e2 << 8);
+}
+// bytes of a prepared-operand map per pixel and 32-channel block: a1 4 x 16 | codes 2 x 16 | code tails 16 (term 0: 8, term 1: 8) | scales 4
+constexpr int PREPB = 116;
 
 // ============================================================================ weight preparation
 // One thread per (chunk, co tile, unit, k half, co): tap 2 unit + half, its 32 channels.
@@ -187,9 +227,14 @@ __global__ __launch_bounds__(256) void prep_weights_mx3_kernel(unsigned char* __
 // prefetch is requested at the top of its predecessor's first unit, so the one-unit sub-chunks have ONE unit of cover for it (the stride-1 kernel has five).
 // C4 (round 5): the input is channel-blocked ([b][c / 4][...][4]): a patch thread requests its pixel's 32 channels of a chunk as EIGHT 16-byte loads instead of 32
 // dword loads — a quarter of the wave requests through the CU's address unit (~18 - 30 cycles each, the issuing wave stalled meanwhile: 2 300 - 2 600 cycles per chunk).
-template <bool S2, bool C4>
+// IN == 2 (round 5): the input is a PREPARED-OPERAND map, written by the producing convolution's epilogue (out_prep) — per image, 32-channel block kb and pixel pi of
+// the hw pixels (phase-plane order for the stride-2 consumer):  a1 [slot 4][pi] x 16 B | codes [term 2][pi] x 16 B | code tails [pi] x 16 B | scales [pi] x 4 B  = 116 hw
+// bytes per block, exactly the patch's entries.  Staging is then eight loads and seven LDS writes per thread: no normalisation, no conversion (the store phase between two
+// chunks was 2 600 cycles of a chunk's 16 000 - 19 000; the stride-2 form has four of them per chunk).
+template <bool S2, int IN>
 __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) {
-    constexpr int NLD = C4 ? CK / 4 : CK;            // load requests of a prefetch, per thread
+    constexpr bool C4 = IN == 1, PREP = IN == 2;
+    constexpr int NLD = IN ? CK / 4 : CK;            // load requests of a prefetch, per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -243,15 +288,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
             in = t < PATCH && ppy <= TH && ppx <= TW && qy >= 0 && qy < p.ho && qx >= 0 && qx < p.wo;      // (taps reach rows 0 .. TH and columns 0 .. TW of the patch only)
             // phase planes (the producer wrote them: consecutive lanes read consecutive floats) or the plain map (every other float of a row: twice the lines per request)
             const unsigned off = p.phased ? (unsigned)(ph * (p.ho * p.wo) + qy * p.wo + qx) : (unsigned)((2 * qy + (ph >> 1)) * p.w_ + 2 * qx + (ph & 1));
-            return in ? off * (C4 ? 16u : 4u) : 0u;
+            return in ? off * (IN ? 16u : 4u) : 0u;
         } else {
             const int pgy = y0 - 1 + ppy, pgx = x0 - 1 + ppx;
             in = t < PATCH && pgy >= 0 && pgy < p.h && pgx >= 0 && pgx < p.w_;
-            return in ? (unsigned)(pgy * p.w_ + pgx) * (C4 ? 16u : 4u) : 0u;
+            return in ? (unsigned)(pgy * p.w_ + pgx) * (IN ? 16u : 4u) : 0u;
         }
     };
-    float xr[C4 ? 1 : CK];
+    float xr[IN ? 1 : CK];
     f32x4 xr4[C4 ? CK / 4 : 1];
+    i32x4v xq[PREP ? 7 : 1];
+    unsigned xs = 0u;
     // the next chunk's 32 channels of this thread's pixel: requested between the store phase's barriers, where the wave would otherwise idle (spread over the
     // read phases the requests' issue — the address unit takes a wave request per ~18 cycles and stalls the issuing wave — made every read phase longer than
     // the MFMA phase beside it); waves 6 and 7 own no patch pixel and request nothing
@@ -259,7 +306,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
         if (wave < 6) {
             bool p_in;
             const unsigned goff = patch_pixel(p_in, ph);
-            if constexpr (C4) {
+            if constexpr (PREP) {
+                const unsigned char* blk = reinterpret_cast<const unsigned char*>(p.x) + ((size_t)b * nchunk + chunk) * ((size_t)PREPB * hw);
+                const unsigned plane = 16u * (unsigned)hw;          // (one scalar base, the element's plane in the lane offset: eight 64-bit bases spill scalars; 116 hw < 2^32: the launcher)
+#pragma unroll
+                for (int e = 0; e < 7; ++e) xq[e] = load16_uncounted(blk, goff + (unsigned)e * plane);
+                xs = load4u_uncounted(blk, 7u * plane + (goff >> 2));
+            } else if constexpr (C4) {
 #pragma unroll
                 for (int c4 = 0; c4 < CK / 4; ++c4) xr4[c4] = load4_uncounted(xb + (size_t)(chunk * CK + 4 * c4) * hw, goff);      // (plane c / 4 starts at c hw floats)
             } else {
@@ -274,6 +327,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
         // outside the map and the threads beyond the patch compute on a clamped pixel's data and are zeroed afterwards; only the final writes are predicated.
         bool p_in;
         (void)patch_pixel(p_in, ph);
+        if constexpr (PREP) {          // the producer's entries as they are (zeros for the padding)
+            if (tid < PATCH) {
+                const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+                uint4* a1p = reinterpret_cast<uint4*>(lds + PATCH0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) a1p[s * PST + tid] = p_in ? as_uint4(xq[s]) : z;
+                uint4* clo = reinterpret_cast<uint4*>(lds + PATCH0 + P_A1);
+                uint2* chi = reinterpret_cast<uint2*>(lds + PATCH0 + P_A1 + P_CLO);
+                clo[tid] = p_in ? as_uint4(xq[4]) : z;
+                clo[PST + tid] = p_in ? as_uint4(xq[5]) : z;
+                chi[tid] = p_in ? make_uint2((unsigned)xq[6][0], (unsigned)xq[6][1]) : make_uint2(0u, 0u);
+                chi[PST + tid] = p_in ? make_uint2((unsigned)xq[6][2], (unsigned)xq[6][3]) : make_uint2(0u, 0u);
+                reinterpret_cast<unsigned*>(lds + PATCH0 + P_A1 + P_CLO + P_CHI)[tid] = p_in ? xs : (111u | (100u << 8));      // (what the staging makes of a zero pixel)
+            }
+            return;
+        }
         const float4* nr = reinterpret_cast<const float4*>(lds + NORM0) + chunk * (CK / 4);
         const float4* nb = reinterpret_cast<const float4*>(lds + NORM0 + MAX_CIN * 4) + chunk * (CK / 4);
         u32x16 q1, q2;
@@ -530,7 +599,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0)
         printf("wave %d: loop %llu cyc | R %llu  wait after R %llu  M %llu  wait after M %llu | store: vm wait %llu  store_x %llu  barrier 1 %llu  barrier 2 %llu  (units %d)\n", wave, __builtin_readcyclecounter() - tLoop, tR, tWR, tM, tWM, tS1, tS2, tS3, tST, nunits);
 #endif
-    if (p.flags && __builtin_amdgcn_ballot_w64(ovf != 0u) != 0 && (threadIdx.x & 63) == 0) { atomicOr(p.flags, 1); atomicAdd(p.flags + 1, 1); }   // one report per wave: sticky bit + moving counter (ops.MxGuard)
+    auto report_ovf = [&]() __attribute__((always_inline)) {
+        if (p.flags && __builtin_amdgcn_ballot_w64(ovf != 0u) != 0 && (threadIdx.x & 63) == 0) { atomicOr(p.flags, 1); atomicAdd(p.flags + 1, 1); }   // one report per wave: sticky bit + moving counter (ops.MxGuard)
+    };
+    report_ovf();
+    ovf = 0u;
 
     // ---- epilogue: PReLU, stores (lane = pixel column: consecutive lanes write consecutive floats of one channel plane)
     __syncthreads();
@@ -538,6 +611,49 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
     if (tid < TN) sl[tid] = (p.slope && co0 + tid < p.cout) ? p.slope[co0 + tid] : 1.f;
     __syncthreads();
     const int x = x0 + l5;
+    if constexpr (!S2) {
+        if (p.out_prep) {
+            // PREPARED OPERANDS for the consuming convolution (see IN == 2): a lane holds 16 of a pixel's 32 channels of a block (those of its k half) for each of
+            // its two pixel rows; one v_permlane32_swap per register pair gives lanes 0-31 all 32 channels of row 0 and lanes 32-63 those of row 1
+            const int y = y0 + 2 * pr + khalf;
+            const size_t ohw = (size_t)hw;
+            const bool ok = y < p.h && x < p.w_;
+            const size_t pi = p.phased ? (size_t)(2 * (y & 1) + (x & 1)) * (ohw >> 2) + (size_t)(y >> 1) * (p.w_ >> 1) + (x >> 1) : (size_t)y * p.w_ + x;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                float a[32];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = chh * 64 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    float v0 = acc[cb][0][r], v1 = acc[cb][1][r];
+                    v0 = v0 > 0.f ? v0 : v0 * sl[n];
+                    v1 = v1 > 0.f ? v1 : v1 * sl[n];
+                    // lanes 32-63 of the first <-> lanes 0-31 of the second: [0] = (own row 0 | lower lanes' row 1), [1] = (upper lanes' row 0 | own row 1)
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1), false, false);
+                    a[8 * (r >> 2) + (r & 3)] = __builtin_bit_cast(float, (unsigned)sw[0]);           // channels 8 q + i      (the k half 0 lanes' registers)
+                    a[8 * (r >> 2) + 4 + (r & 3)] = __builtin_bit_cast(float, (unsigned)sw[1]);       // channels 8 q + 4 + i  (the k half 1 lanes')
+                }
+                u32x16 q1;
+                u32x6 c1, c2;
+                unsigned sc;
+                encode32(a, q1, c1, c2, sc, ovf);
+                const int kb = (co0 + chh * 64 + cb * 32) >> 5;
+                if (ok && kb * 32 < p.cout) {
+                    unsigned char* blk = reinterpret_cast<unsigned char*>(p.out) + ((size_t)b * (p.cout >> 5) + kb) * ((size_t)PREPB * ohw);
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+                        *reinterpret_cast<uint4*>(blk + ((size_t)s4 * ohw + pi) * 16) = make_uint4(q1[4 * s4], q1[4 * s4 + 1], q1[4 * s4 + 2], q1[4 * s4 + 3]);
+                    *reinterpret_cast<uint4*>(blk + ((size_t)4 * ohw + pi) * 16) = make_uint4(c1[0], c1[1], c1[2], c1[3]);
+                    *reinterpret_cast<uint4*>(blk + ((size_t)5 * ohw + pi) * 16) = make_uint4(c2[0], c2[1], c2[2], c2[3]);
+                    *reinterpret_cast<uint4*>(blk + ((size_t)6 * ohw + pi) * 16) = make_uint4(c1[4], c1[5], c2[4], c2[5]);
+                    *reinterpret_cast<unsigned*>(blk + (size_t)112 * ohw + pi * 4) = sc;
+                }
+            }
+            if (!ok) ovf = 0u;          // (a pixel outside the map: whatever the tile computed there is not part of the result)
+            report_ovf();
+            return;
+        }
+    }
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
         const int y = y0 + 2 * pr + pb;
@@ -603,9 +719,9 @@ extern "C" int e4s_conv_prep_weights_mx3_s2(void* dst, const float* weight, int 
 // out = PReLU(conv3x3(norm(x), W)), stride 1, pad 1.  in_mean / in_rstd [bs][cin] (optional, together), prelu_slope [cout] optional; flags[0] bit 0 is raised
 // when a normalised activation leaves the f16 range (the result is then invalid; the kernel does not fall back by itself — ops.MxGuard notices the counter flags[1] moving and the entry points re-run the pass on the split-bf16 kernels).
 // layouts: bit 0 = phase planes (stride 1: of the output; stride 2: of the input), bit 1 = channel-blocked [c / 4][...][4]
-template <bool S2, bool C4>
+template <bool S2, int IN>
 static int conv3x3_mx3(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
-                       int bs, int cin, int cout, int h, int w, int phased, int out_c4, void* stream) {
+                       int bs, int cin, int cout, int h, int w, int phased, int out_c4, int out_prep, void* stream) {
     E4S_REQUIRE(out && x && wmx3, "conv3x3_mx3: null tensor");
     E4S_REQUIRE((in_mean == nullptr) == (in_rstd == nullptr), "conv3x3_mx3: in_mean and in_rstd go together");
     E4S_REQUIRE(bs >= 0 && bs <= 65535 && cin >= CK && cin % CK == 0 && cin <= MAX_CIN && cout >= 1 && h >= 1 && w >= 1, "conv3x3_mx3: bad size (cin %% 32 == 0, cin <= 512)");
@@ -613,7 +729,10 @@ static int conv3x3_mx3(float* out, const float* x, const void* wmx3, int* flags,
     E4S_REQUIRE(((uintptr_t)wmx3 & 15) == 0, "conv3x3_mx3: the weights must be 16-byte aligned");
     E4S_REQUIRE((int64_t)cin * h * w * 4 < (int64_t)1 << 32, "conv3x3_mx3: a sample's input must stay below 4 GB (32-bit lane offsets)");
     E4S_REQUIRE(!out_c4 || cout % 4 == 0, "conv3x3_mx3: a channel-blocked output needs cout %% 4 == 0");
-    E4S_REQUIRE(!(C4 || out_c4) || ((((uintptr_t)x | (uintptr_t)out) & 15) == 0), "conv3x3_mx3: channel-blocked maps must be 16-byte aligned");
+    E4S_REQUIRE(!(IN || out_c4 || out_prep) || ((((uintptr_t)x | (uintptr_t)out) & 15) == 0), "conv3x3_mx3: channel-blocked / prepared maps must be 16-byte aligned");
+    E4S_REQUIRE(!(IN == 2) || (in_mean == nullptr && (h * w) % 4 == 0), "conv3x3_mx3: a prepared-operand input takes no normalisation and needs h * w %% 4 == 0");
+    E4S_REQUIRE(!out_prep || (!S2 && !out_c4 && cout % 32 == 0 && (h * w) % 4 == 0), "conv3x3_mx3: prepared-operand output: stride 1, cout %% 32 == 0, h * w %% 4 == 0");
+    E4S_REQUIRE((int64_t)PREPB * h * w < (int64_t)1 << 32, "conv3x3_mx3: map too large for 32-bit lane offsets");
     if (bs == 0) return 0;
     Mx3Params p;
     memset(&p, 0, sizeof(p));
@@ -623,42 +742,49 @@ static int conv3x3_mx3(float* out, const float* x, const void* wmx3, int* flags,
     p.ho = S2 ? h / 2 : h; p.wo = S2 ? w / 2 : w;
     p.phased = phased ? 1 : 0;
     p.out_c4 = out_c4 ? 1 : 0;
+    p.out_prep = out_prep ? 1 : 0;
     p.tiles_x = cdiv(p.wo, TW); p.tiles_y = cdiv(p.ho, TH);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mx3_kernel<S2, C4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mx3_kernel<S2, IN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return fail((int)attr, "conv3x3_mx3: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
     dim3 grid(p.tiles_x * p.tiles_y, cdiv(cout, TN), bs);
-    hipLaunchKernelGGL((conv3x3_mx3_kernel<S2, C4>), grid, dim3(512), LDS_BYTES, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((conv3x3_mx3_kernel<S2, IN>), grid, dim3(512), LDS_BYTES, (hipStream_t)stream, p);
     return check_launch(S2 ? "conv3x3_s2_mx3" : "conv3x3_mx3");
 }
 
 extern "C" int e4s_conv3x3_mx3(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
                                int bs, int cin, int cout, int h, int w, void* stream) {
-    return conv3x3_mx3<false, false>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, 0, 0, stream);
+    return conv3x3_mx3<false, 0>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, 0, 0, 0, stream);
 }
 
 // e4s_conv3x3_mx3 whose result is written as PHASE PLANES, out[b][c][2 py + px][h / 2][w / 2] = result[b][c][2 y + py][2 x + px] (h, w even): the layout
 // e4s_conv3x3_s2_mx3(in_phased = 1) reads with consecutive lanes on consecutive floats
 extern "C" int e4s_conv3x3_mx3_phased(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
                                       int bs, int cin, int cout, int h, int w, void* stream) {
-    return conv3x3_mx3<false, false>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, 1, 0, stream);
+    return conv3x3_mx3<false, 0>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, 1, 0, 0, stream);
 }
 
 // e4s_conv3x3_mx3 with explicit memory layouts (round 5).  Bit 1 (value 2) of either = CHANNEL-BLOCKED: the map is [bs][c / 4][h][w][4 floats] (c % 4 == 0, 16-byte
 // aligned) — a pixel's four channels are one 16-byte element, so the consumer's patch threads request 8 elements per 32-channel chunk instead of 32 floats and the
 // producer stores 16 bytes per request.  Bit 0 (value 1) of out_layout = phase planes as e4s_conv3x3_mx3_phased ([bs][c (/ 4)][2 py + px][h / 2][w / 2]([4])).
-// in_layout: 0 or 2.  The arithmetic does not depend on the layouts: the same values as e4s_conv3x3_mx3, bit for bit.
+// Bit 2 (value 4) = PREPARED OPERANDS (alone, or 5 = in phase-plane pixel order): per image and 32-channel block 116 h w bytes — a1 [slot 4][pixel] x 16 | codes [term 2]
+// [pixel] x 16 | code tails [pixel] x 16 | scales [pixel] x 4 — the entries the consumer's staging would compute from the fp32 map (f16 part, two fp6 code sets, their
+// block scales), computed once per pixel in the producer's epilogue instead (cout % 32 == 0; as an input: no in_mean / in_rstd).
+// in_layout: 0, 2 or 4.  The arithmetic does not depend on the layouts: the same values as e4s_conv3x3_mx3, bit for bit.
 extern "C" int e4s_conv3x3_mx3_ex(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
                                   int bs, int cin, int cout, int h, int w, int in_layout, int out_layout, void* stream) {
-    E4S_REQUIRE((in_layout == 0 || in_layout == 2) && out_layout >= 0 && out_layout <= 3, "conv3x3_mx3_ex: in_layout is 0 or 2, out_layout 0 .. 3");
-    if (in_layout & 2) return conv3x3_mx3<false, true>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, out_layout & 1, out_layout & 2, stream);
-    return conv3x3_mx3<false, false>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, out_layout & 1, out_layout & 2, stream);
+    E4S_REQUIRE((in_layout == 0 || in_layout == 2 || in_layout == 4) && out_layout >= 0 && out_layout <= 5, "conv3x3_mx3_ex: in_layout is 0, 2 or 4, out_layout 0 .. 5");
+    const int ph = out_layout & 1, c4 = out_layout & 2, prep = out_layout & 4;
+    if (in_layout == 4) return conv3x3_mx3<false, 2>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, ph, c4, prep, stream);
+    if (in_layout == 2) return conv3x3_mx3<false, 1>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, ph, c4, prep, stream);
+    return conv3x3_mx3<false, 0>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, ph, c4, prep, stream);
 }
 
 // out [bs, cout, h / 2, w / 2] = PReLU(conv3x3(norm(x), W, stride 2, pad 1)); h, w even; weights from e4s_conv_prep_weights_mx3_s2; in_phased: x is in the phase-plane
 // layout of e4s_conv3x3_mx3_phased; in_phased is a layout word like e4s_conv3x3_mx3_ex's (bit 0: phase planes, bit 1: channel-blocked).  Everything else as e4s_conv3x3_mx3.
 extern "C" int e4s_conv3x3_s2_mx3(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
                                   int bs, int cin, int cout, int h, int w, int in_phased, void* stream) {
-    E4S_REQUIRE(in_phased >= 0 && in_phased <= 3, "conv3x3_s2_mx3: in_phased is a layout, 0 .. 3");
-    if (in_phased & 2) return conv3x3_mx3<true, true>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, in_phased & 1, 0, stream);
-    return conv3x3_mx3<true, false>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, in_phased & 1, 0, stream);
+    E4S_REQUIRE(in_phased >= 0 && in_phased <= 5, "conv3x3_s2_mx3: in_phased is a layout, 0 .. 5");
+    if (in_phased & 4) return conv3x3_mx3<true, 2>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, in_phased & 1, 0, 0, stream);
+    if (in_phased & 2) return conv3x3_mx3<true, 1>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, in_phased & 1, 0, 0, stream);
+    return conv3x3_mx3<true, 0>(out, x, wmx3, flags, in_mean, in_rstd, prelu_slope, bs, cin, cout, h, w, in_phased & 1, 0, 0, stream);
 }

@@ -90,8 +90,11 @@ class bottleneck_IR_SE_Ours(Module):
         phased = (self.stride == 2 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and ops.conv3x3_s1_takes_mx3(x, depth)
                   and ops.conv3x3_s2_takes_mx(x.shape[0], depth, rl[3].weight.shape[0], x.shape[2], x.shape[3], x.device))
         # (and channel-blocked whenever both run there — ops.conv3x3_s1_c4_pair: the map between the two convolutions has no other reader, helpers.py:128-139)
-        c4 = (self.stride == 1 or phased) and ops.conv3x3_s1_c4_pair(x, depth, rl[3].weight.shape[0], self.stride)
-        r = ops.conv3x3_s1(x, rl[1].weight, self._wino[0], in_norm=(mean, rstd), prelu=rl[2].weight, out_phased=phased, out_c4=c4)      # direct kernel or Winograd (ops.winograd_route)
+        #  or, better, as the consumer's prepared operands — ops.ENC_PREP_LINK)
+        link = (self.stride == 1 or phased) and ops.conv3x3_s1_c4_pair(x, depth, rl[3].weight.shape[0], self.stride)
+        prep = link and ops.ENC_PREP_LINK and depth % 32 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0
+        r = ops.conv3x3_s1(x, rl[1].weight, self._wino[0], in_norm=(mean, rstd), prelu=rl[2].weight, out_phased=phased,      # direct kernel or Winograd (ops.winograd_route)
+                           out_c4=link and not prep and ops.ENC_C4_LINK, out_prep=prep)
         if self.stride == 1:
             r = ops.conv3x3_s1(r, rl[3].weight, self._wino[1])
         else:

@@ -1406,6 +1406,9 @@ UP_MX4 = True      # masked up layers: tiles whose positions' 2 x 2 outputs shar
 # the map between the two 3x3 convolutions of an IR-SE unit is handed over channel-blocked ([bs, c / 4, h, w, 4]) when both run on the two-phase kernel
 # (ops_encode.conv3x3_s1_c4_pair; csrc/conv_mx3.hip, round 5).  0: plain NCHW planes as before — the values are the same, bit for bit
 ENC_C4_LINK = os.environ.get("E4S_ENC_C4", "1") != "0"
+# ... and, where the unit's width allows (depth % 32 == 0), as the consumer's OPERANDS (ops_encode.MxOperandMap: f16 part, fp6 codes, block scales — the producer's epilogue
+# computes once per pixel what the consumer's staging computed per patch pixel and chunk; the same bits again).  0: the channel-blocked / plain hand-over
+ENC_PREP_LINK = os.environ.get("E4S_ENC_PREP", "1") != "0"
 S2_MX3 = True           # the encoder's stride-2 3x3 convolutions on the stride-2 form of csrc/conv_mx3.hip (attribute; off: the direct split-bf16 kernel)
 # The squeeze-excite gate of an IR-SE unit is sigmoid(fc2 . relu(fc1 . mean(IN(r)))) with bias-free 1x1 convolutions (helpers.py:56-72) behind an affine-free
 # InstanceNorm2d (helpers.py:128-139): the pooled vector is the mean of an instance-normalised plane — exactly 0 — so the gate is sigmoid(0) = 1/2 for every channel of

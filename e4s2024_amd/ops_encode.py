@@ -255,16 +255,43 @@ def mx_conv_eligible(x: torch.Tensor, cout: int) -> bool:
     return bs * per_image >= ops.MX_CONV_MIN_WORKGROUPS
 
 
-def conv3x3_mx(x: torch.Tensor, wmx: torch.Tensor, arith: int, cout: int, *, in_norm=None, prelu: Optional[torch.Tensor] = None,
-               out_phased: bool = False, out_c4: bool = False) -> torch.Tensor:
+class MxOperandMap:
+    """The hand-over of ``conv3x3_mx(out_prep=True)``: an activation map ``[bs, c, h, w]`` stored as the f16 + fp6 OPERANDS of the consuming two-phase convolution
+    (per image and 32-channel block ``116 h w`` bytes: f16 part, two fp6 code sets, block scales — ``e4s_conv3x3_mx3_ex``, layout bit 4), in plain or phase-plane pixel
+    order.  Only ``conv3x3_mx`` / ``conv3x3_s2_mx`` (through ``conv3x3_s1`` / ``conv3x3_s2``) read it; ``data`` is ``float32 [bs, c / 32, 29 h w]`` raw storage."""
+    __slots__ = ("data", "bs", "c", "h", "w", "phased")
+
+    def __init__(self, data, bs, c, h, w, phased):
+        self.data, self.bs, self.c, self.h, self.w, self.phased = data, bs, c, h, w, bool(phased)
+
+    shape = property(lambda self: (self.bs, self.c, self.h, self.w))
+    device = property(lambda self: self.data.device)
+    is_cuda = property(lambda self: self.data.is_cuda)
+
+    def dim(self):
+        return 4
+
+
+def conv3x3_mx(x, wmx: torch.Tensor, arith: int, cout: int, *, in_norm=None, prelu: Optional[torch.Tensor] = None,
+               out_phased: bool = False, out_c4: bool = False, out_prep: bool = False):
     """``PReLU(conv3x3(norm(x), W))``, stride 1, pad 1, on ``e4s_conv3x3_mx`` / ``e4s_conv3x3_mx3`` (``arith`` 3) (``wmx`` from ``PreparedMx.get`` of the
     plain weight with the same ``arith``).  Hand-over layouts of the two-phase kernel (``arith`` 3), which only another ``conv3x3_mx`` / ``conv3x3_s2_mx`` reads:
     ``out_phased`` (even maps): the result's MEMORY is phase planes — ``[bs, cout, 2, 2, h / 2, w / 2]``, plane ``(py, px)`` = ``result[..., py::2, px::2]``;
     ``out_c4``: channel-blocked — ``[bs, cout / 4, h, w, 4]`` (with ``out_phased``: ``[bs, cout / 4, 2, 2, h / 2, w / 2, 4]``), a pixel's four channels one
-    16-byte element.  The returned tensor has that shape; a 5-D INPUT is such a channel-blocked map.  Same values in every layout."""
-    x = _c(x, "input")
-    in_c4 = x.dim() == 5
-    if in_c4:
+    16-byte element.  The returned tensor has that shape; a 5-D INPUT is such a channel-blocked map.  ``out_prep``: the result as the consumer's OPERANDS
+    (``MxOperandMap``; with ``out_phased`` in phase-plane pixel order), ``cout % 32 == 0``; an ``MxOperandMap`` INPUT takes no ``in_norm``.  Same values in every layout."""
+    in_prep = isinstance(x, MxOperandMap)
+    if in_prep:
+        if arith != 3 or in_norm is not None or x.phased:
+            raise ValueError("conv3x3_mx: a prepared-operand input goes to the two-phase kernel, un-normalised, in plain pixel order")
+        bs, cin, h, w = x.shape
+        x, in_c4 = _c(x.data, "input"), False
+    else:
+        x = _c(x, "input")
+        in_c4 = x.dim() == 5
+    if in_prep:
+        pass
+    elif in_c4:
         if x.shape[4] != 4:
             raise ValueError("conv3x3_mx: a channel-blocked input is [bs, cin / 4, h, w, 4]")
         bs, cin, h, w = x.shape[0], 4 * x.shape[1], x.shape[2], x.shape[3]
@@ -274,17 +301,21 @@ def conv3x3_mx(x: torch.Tensor, wmx: torch.Tensor, arith: int, cout: int, *, in_
     if in_norm is not None:
         mean, rstd = _c(in_norm[0], "in_mean"), _c(in_norm[1], "in_rstd")
     pr = _p(_c(prelu.detach(), "prelu")) if prelu is not None else None
-    if out_phased or out_c4 or in_c4:
-        if arith != 3 or (out_phased and (h % 2 or w % 2)) or (out_c4 and cout % 4):
-            raise ValueError("conv3x3_mx: hand-over layouts need the two-phase kernel (arith 3); phase planes an even map, channel blocks cout % 4 == 0")
-        shape = (bs, cout // 4 if out_c4 else cout) + ((2, 2, h // 2, w // 2) if out_phased else (h, w)) + ((4,) if out_c4 else ())
-        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    if out_phased or out_c4 or in_c4 or in_prep or out_prep:
+        if arith != 3 or (out_phased and (h % 2 or w % 2)) or (out_c4 and cout % 4) or (out_prep and (cout % 32 or (h * w) % 4 or out_c4)):
+            raise ValueError("conv3x3_mx: hand-over layouts need the two-phase kernel (arith 3); phase planes an even map, channel blocks cout % 4 == 0, "
+                             "prepared operands cout % 32 == 0 and h w % 4 == 0")
+        if out_prep:
+            out = torch.empty((bs, cout // 32, 29 * h * w), dtype=torch.float32, device=x.device)
+        else:
+            shape = (bs, cout // 4 if out_c4 else cout) + ((2, 2, h // 2, w // 2) if out_phased else (h, w)) + ((4,) if out_c4 else ())
+            out = torch.empty(shape, dtype=torch.float32, device=x.device)
         ev = _timed("conv3x3_mx<3>", f"{cin}->{cout} @{h}")
         lib().call("e4s_conv3x3_mx3_ex", _p(out), _p(x), _p(wmx), _p(mx_flags(x.device)), _p(mean), _p(rstd), pr, bs, cin, cout, h, w,
-                   2 if in_c4 else 0, (1 if out_phased else 0) | (2 if out_c4 else 0), _stream())
+                   4 if in_prep else 2 if in_c4 else 0, (1 if out_phased else 0) | (2 if out_c4 else 0) | (4 if out_prep else 0), _stream())
         if ev is not None:
             ev.record()
-        return out
+        return MxOperandMap(out, bs, cout, h, w, out_phased) if out_prep else out
     out = torch.empty((bs, cout, h, w), dtype=torch.float32, device=x.device)
     ev = _timed(f"conv3x3_mx<{arith}>", f"{cin}->{cout} @{h}")
     if arith == 3:
@@ -299,10 +330,20 @@ def conv3x3_mx(x: torch.Tensor, wmx: torch.Tensor, arith: int, cout: int, *, in_
 def conv3x3_s2_mx(x: torch.Tensor, wmx: torch.Tensor, cout: int, *, in_norm=None, prelu: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``PReLU(conv3x3(norm(x), W, stride 2, pad 1))`` on ``e4s_conv3x3_s2_mx3`` (f16 + 2 x MX fp6; ``wmx`` from ``PreparedMx.get(weight, None, False, 5)``);
     the input's height and width must be even, ``cin % 32 == 0``, ``cin <= 512``.  A 6-D input ``[bs, cin, 2, 2, h / 2, w / 2]`` is the phase-plane
-    hand-over of ``conv3x3_mx(out_phased=True)``, a 7-D one ``[bs, cin / 4, 2, 2, h / 2, w / 2, 4]`` that of ``conv3x3_mx(out_phased=True, out_c4=True)``."""
-    x = _c(x, "input")
-    in_phased, in_c4 = x.dim() in (6, 7), x.dim() == 7
-    if in_phased:
+    hand-over of ``conv3x3_mx(out_phased=True)``, a 7-D one ``[bs, cin / 4, 2, 2, h / 2, w / 2, 4]`` that of ``conv3x3_mx(out_phased=True, out_c4=True)``, an
+    ``MxOperandMap`` that of ``conv3x3_mx(out_prep=True)`` (no ``in_norm`` then)."""
+    in_prep = isinstance(x, MxOperandMap)
+    if in_prep:
+        if in_norm is not None:
+            raise ValueError("conv3x3_s2_mx: a prepared-operand input is not normalised")
+        bs, cin, h, w = x.shape
+        in_phased, in_c4, x = x.phased, False, _c(x.data, "input")
+    else:
+        x = _c(x, "input")
+        in_phased, in_c4 = x.dim() in (6, 7), x.dim() == 7
+    if in_prep:
+        pass
+    elif in_phased:
         if x.shape[2] != 2 or x.shape[3] != 2 or (in_c4 and x.shape[6] != 4):
             raise ValueError("conv3x3_s2_mx: a phase-plane input is [bs, cin, 2, 2, h / 2, w / 2] or [bs, cin / 4, 2, 2, h / 2, w / 2, 4]")
         bs, cin, h, w = x.shape[0], x.shape[1] * (4 if in_c4 else 1), 2 * x.shape[4], 2 * x.shape[5]
@@ -317,7 +358,7 @@ def conv3x3_s2_mx(x: torch.Tensor, wmx: torch.Tensor, cout: int, *, in_norm=None
     ev = _timed("conv3x3_s2_mx<3>", f"{cin}->{cout} @{h}")
     pr = _p(_c(prelu.detach(), "prelu")) if prelu is not None else None
     lib().call("e4s_conv3x3_s2_mx3", _p(out), _p(x), _p(wmx), _p(mx_flags(x.device)), _p(mean), _p(rstd), pr, bs, cin, cout, h, w,
-               (1 if in_phased else 0) | (2 if in_c4 else 0), _stream())
+               (1 if in_phased else 0) | (2 if in_c4 else 0) | (4 if in_prep else 0), _stream())
     if ev is not None:
         ev.record()
     return out
@@ -342,7 +383,7 @@ class _ShapeOnly:
 def conv3x3_s2(x: torch.Tensor, weight: torch.Tensor, caches) -> torch.Tensor:
     """A stride-2, pad-1 3x3 convolution: the DMA-fed f16 + fp6 kernel where it fits and fills the chip (``conv3x3_s2_takes_mx``), else the direct kernel.
     ``caches = (PreparedConv, PreparedWinograd, PreparedMx)`` of the layer.  ``x`` may be the phase-plane hand-over of ``conv3x3_s1(out_phased=True)``."""
-    if x.dim() in (6, 7):
+    if isinstance(x, MxOperandMap) or x.dim() in (6, 7):
         return conv3x3_s2_mx(x, caches[2].get(weight, None, False, 5), weight.shape[0])
     bs, cin, h, w = x.shape
     if len(caches) > 2 and conv3x3_s2_takes_mx(bs, cin, weight.shape[0], h, w, x.device):
@@ -358,8 +399,8 @@ def conv3x3_s1_takes_mx3(x: torch.Tensor, cout: int) -> bool:
 
 def conv3x3_s1_c4_pair(x: torch.Tensor, depth: int, cout2: int, stride2: int) -> bool:
     """Do BOTH 3x3 convolutions of an IR-SE unit — ``x -> depth`` at stride 1, ``depth -> cout2`` at ``stride2`` — run on the two-phase kernel, so that the map between
-    them can be handed over channel-blocked (``ops.ENC_C4_LINK``)?"""
-    if not (ops.ENC_C4_LINK and x.dim() == 4 and depth % 4 == 0 and conv3x3_s1_takes_mx3(x, depth)):
+    them can be handed over channel-blocked (``ops.ENC_C4_LINK``) or as prepared operands (``ops.ENC_PREP_LINK``: ``depth % 32 == 0``, ``h w % 4 == 0`` on top)?"""
+    if not ((ops.ENC_C4_LINK or ops.ENC_PREP_LINK) and x.dim() == 4 and depth % 4 == 0 and conv3x3_s1_takes_mx3(x, depth)):
         return False
     bs, _, h, w = x.shape
     if stride2 == 2:
@@ -367,17 +408,17 @@ def conv3x3_s1_c4_pair(x: torch.Tensor, depth: int, cout2: int, stride2: int) ->
     return stride2 == 1 and conv3x3_s1_takes_mx3(_ShapeOnly(bs, depth, h, w, x.device), cout2)
 
 
-def conv3x3_s1(x: torch.Tensor, weight: torch.Tensor, caches, *, in_norm=None, prelu: Optional[torch.Tensor] = None, out_phased: bool = False,
-               out_c4: bool = False) -> torch.Tensor:
+def conv3x3_s1(x, weight: torch.Tensor, caches, *, in_norm=None, prelu: Optional[torch.Tensor] = None, out_phased: bool = False,
+               out_c4: bool = False, out_prep: bool = False):
     """A stride-1, pad-1 3x3 convolution by whichever route fits the launch: Winograd (``winograd_route``: small batches), the DMA-fed kernel
     (``mx_conv_eligible``: launches that fill the chip) or the direct kernel; ``caches = (PreparedConv, PreparedWinograd, PreparedMx)`` of the layer.
     ``out_phased``: see ``conv3x3_mx`` — the caller has checked ``conv3x3_s1_takes_mx3``."""
-    if x.dim() == 5:          # the channel-blocked hand-over of a conv3x3_s1(out_c4=True): the producer checked conv3x3_s1_c4_pair
-        return conv3x3_mx(x, caches[2].get(weight, None, False, 3), 3, weight.shape[0], in_norm=in_norm, prelu=prelu, out_phased=out_phased, out_c4=out_c4)
-    if out_phased or out_c4:
+    if isinstance(x, MxOperandMap) or x.dim() == 5:          # the hand-over of a conv3x3_s1(out_prep / out_c4 = True): the producer checked conv3x3_s1_c4_pair
+        return conv3x3_mx(x, caches[2].get(weight, None, False, 3), 3, weight.shape[0], in_norm=in_norm, prelu=prelu, out_phased=out_phased, out_c4=out_c4, out_prep=out_prep)
+    if out_phased or out_c4 or out_prep:
         if not (len(caches) > 2 and conv3x3_s1_takes_mx3(x, weight.shape[0])):
             raise RuntimeError("conv3x3_s1: a hand-over layout on a layer that does not run on the two-phase kernel")
-        return conv3x3_mx(x, caches[2].get(weight, None, False, 3), 3, weight.shape[0], in_norm=in_norm, prelu=prelu, out_phased=out_phased, out_c4=out_c4)
+        return conv3x3_mx(x, caches[2].get(weight, None, False, 3), 3, weight.shape[0], in_norm=in_norm, prelu=prelu, out_phased=out_phased, out_c4=out_c4, out_prep=out_prep)
     route = winograd_route(x, x.shape[1], 1)
     if route == "f32":
         return conv2d_winograd(x, caches[1].get(weight), in_norm=in_norm, prelu=prelu)
@@ -610,4 +651,4 @@ def tensor2im_u8(img: torch.Tensor) -> torch.Tensor:
     return out
 
 
-__all__ = ['conv3x3_s1_c4_pair', 'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'PreparedConv', '_is_f16x3', 'conv2d', 'PreparedWinograd', 'winograd_route', 'mx4_eligible', 'mx_conv_eligible', 'conv3x3_mx', 'conv3x3_s2_mx', 'conv3x3_s2_takes_mx', '_ShapeOnly', 'conv3x3_s2', 'conv3x3_s1_takes_mx3', 'conv3x3_s1', 'conv2d_winograd', 'plane_stats', 'vec_fc', 'se_gate', '_half_gates', 'half_gate', 'norm_gate_add', 'masked_avg_pool', '_out_like', 'bilinear_resize', 'maxpool3x3s2', 'gate_add_upsample', 'bilinear_argmax', 'bicubic_down_normalize', 'tensor2im_u8']
+__all__ = ['MxOperandMap', 'conv3x3_s1_c4_pair', 'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'PreparedConv', '_is_f16x3', 'conv2d', 'PreparedWinograd', 'winograd_route', 'mx4_eligible', 'mx_conv_eligible', 'conv3x3_mx', 'conv3x3_s2_mx', 'conv3x3_s2_takes_mx', '_ShapeOnly', 'conv3x3_s2', 'conv3x3_s1_takes_mx3', 'conv3x3_s1', 'conv2d_winograd', 'plane_stats', 'vec_fc', 'se_gate', '_half_gates', 'half_gate', 'norm_gate_add', 'masked_avg_pool', '_out_like', 'bilinear_resize', 'maxpool3x3s2', 'gate_add_upsample', 'bilinear_argmax', 'bicubic_down_normalize', 'tensor2im_u8']

@@ -222,8 +222,13 @@ E4S_API int e4s_conv3x3_mx3_phased(float* out, const float* x, const void* wmx3,
 /* e4s_conv3x3_mx3 with explicit memory layouts (round 5): a layout word's bit 0 (1) = phase planes as above, bit 1 (2) = CHANNEL-BLOCKED — the map is
  * [bs][c/4][plane layout][4 floats], a pixel's four channels one 16-byte element (c % 4 == 0, 16-byte aligned).  It is the hand-over between the two convolutions
  * of a bottleneck_IR_SE_Ours unit (models/encoders/helpers.py:128-139: Conv2d -> PReLU -> Conv2d with nothing between them and no other reader): the producer
- * stores 16 bytes per request, the consumer's patch threads request 8 elements per 32-channel chunk instead of 32 floats.  in_layout: 0 or 2; out_layout: 0..3;
- * e4s_conv3x3_s2_mx3's in_phased argument is such a word too (0..3).  Values do not depend on the layouts (bit for bit those of e4s_conv3x3_mx3). */
+ * stores 16 bytes per request, the consumer's patch threads request 8 elements per 32-channel chunk instead of 32 floats.
+ * Bit 2 (4) = PREPARED OPERANDS (4, or 5 = in phase-plane pixel order; not combined with bit 1): the map is stored as what the consuming convolution's staging would
+ * compute from it — per image and 32-channel block 116 h w bytes: f16 part [slot 4][pixel] x 16 B (slot s = channels 8s..8s+7) | MX-fp6 codes of the f16 part and of the
+ * residual, first 16 B [term 2][pixel] | their last 8 B each [pixel] x 16 B | the two E8M0 block scales [pixel] x 4 B (bytes 0, 1) — made once per pixel in the
+ * producer's epilogue (cout % 32 == 0, h w % 4 == 0; the producer raises the f16 flag for an output beyond the f16 range); as an input it takes no in_mean / in_rstd.
+ * in_layout: 0, 2 or 4; out_layout: 0..5; e4s_conv3x3_s2_mx3's in_phased argument is such a word too (0..5).  Values do not depend on the layouts (bit for bit those
+ * of e4s_conv3x3_mx3). */
 E4S_API int e4s_conv3x3_mx3_ex(float* out, const float* x, const void* wmx3, int* flags, const float* in_mean, const float* in_rstd, const float* prelu_slope,
                                int bs, int cin, int cout, int h, int w, int in_layout, int out_layout, void* stream);
 /* Masked up-sampling layers, region-uniform output blocks (model.py:287-300 per region == one transposed conv + blur where a block of output

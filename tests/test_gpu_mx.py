@@ -417,11 +417,40 @@ def test_channel_blocked_hand_over_between_two_convolutions_keeps_every_bit(shap
             assert tuple(rp.shape) == (bs, depth // 4, 2, 2, h // 2, w // 2, 4) and torch.equal(rp, _to_c4(r6))
             ys = ops.conv3x3_s2_mx(r, w25, depth)
             assert torch.equal(ops.conv3x3_s2_mx(rp, w25, depth), ys)
+        # the map as the consumer's prepared operands (ops.MxOperandMap): conversion once per pixel in the producer's epilogue, the consumer's staging a copy
+        if depth % 32 == 0 and (h * w) % 4 == 0:
+            ro = ops.conv3x3_mx(x, w13, 3, depth, in_norm=(mean, rstd), prelu=slope, out_prep=True)
+            assert isinstance(ro, ops.MxOperandMap) and ro.shape == (bs, depth, h, w) and tuple(ro.data.shape) == (bs, depth // 32, 29 * h * w)
+            assert torch.equal(ops.conv3x3_mx(ro, w23, 3, depth), y)
+            assert torch.equal(ops.conv3x3_mx(ro, w23, 3, depth, prelu=slope, out_c4=True), _to_c4(ops.conv3x3_mx(r, w23, 3, depth, prelu=slope)))
+            if h % 2 == 0 and w % 2 == 0:
+                rop = ops.conv3x3_mx(x, w13, 3, depth, in_norm=(mean, rstd), prelu=slope, out_phased=True, out_prep=True)
+                assert rop.phased and torch.equal(ops.conv3x3_s2_mx(rop, w25, depth), ys)
     assert not ops.mx_overflowed()
 
 
+def test_prepared_operand_producer_reports_the_f16_range():
+    """The consumer of a prepared-operand map does not see fp32 values any more: the PRODUCER's epilogue raises the f16 flag for an output beyond the range."""
+    if ops.mx_arith() != 1 or not ops.MX3:
+        pytest.skip("the two-phase f16 + fp6 kernel is off")
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(1, 32, 32, 32, device=DEV, generator=g)
+    w1 = torch.randn(64, 32, 3, 3, device=DEV, generator=g) / (32 * 9) ** 0.5
+    with torch.no_grad():
+        w13 = ops.PreparedMx().get(w1, None, False, 3)
+        ops.mx_overflowed()
+        ops.conv3x3_mx(x, w13, 3, 64, out_prep=True)
+        assert not ops.mx_overflowed()
+        big = ops.PreparedMx().get(w1 * 1e5, None, False, 3)
+        ops.conv3x3_mx(x, big, 3, 64)                       # plain fp32 output: values of 1e5 are fine there
+        assert not ops.mx_overflowed()
+        ops.conv3x3_mx(x, big, 3, 64, out_prep=True)        # ... but not as f16 operands
+        assert ops.mx_overflowed()
+
+
 def test_encoder_units_take_the_channel_blocked_link_and_keep_their_values():
-    """An IR-SE unit at the full swap's launch size (16 faces) with the link on and off: the same output bits, and the link IS taken (stride 1 and stride 2)."""
+    """An IR-SE unit at the full swap's launch size (16 faces) with the hand-over between its two convolutions plain, channel-blocked and as prepared operands:
+    the same output bits, and each link IS taken (stride 1 and stride 2)."""
     if ops.mx_arith() != 1 or not ops.MX3:
         pytest.skip("the two-phase f16 + fp6 kernel is off")
     from conftest import install_dropin
@@ -434,11 +463,11 @@ def test_encoder_units_take_the_channel_blocked_link_and_keep_their_values():
             for p_ in unit.parameters():
                 p_.copy_(torch.randn(p_.shape, device=DEV, generator=g) * (0.05 if p_.dim() == 4 else 0.25))
         x = torch.randn(16, cin, h, h, device=DEV, generator=g)
-        keep = ops.ENC_C4_LINK
+        keep = (ops.ENC_C4_LINK, ops.ENC_PREP_LINK)
         outs = {}
         try:
-            for on in (False, True):
-                ops.ENC_C4_LINK = on
+            for on in (False, "c4", "prep"):
+                ops.ENC_C4_LINK, ops.ENC_PREP_LINK = on == "c4", on == "prep"
                 names = []
                 orig = ops.lib().call
 
@@ -451,10 +480,11 @@ def test_encoder_units_take_the_channel_blocked_link_and_keep_their_values():
                         outs[on] = unit(x).clone()
                 finally:
                     ops.lib().call = orig
-                blocked_out = [n for n in names if n[0] == "e4s_conv3x3_mx3_ex" and n[2] & 2]
-                blocked_in = [n for n in names if (n[0] == "e4s_conv3x3_mx3_ex" and n[1] & 2) or (n[0] == "e4s_conv3x3_s2_mx3" and n[1] & 2)]
-                assert (len(blocked_out), len(blocked_in)) == ((1, 1) if on else (0, 0)), (cin, stride, on, names)
+                bit = {"c4": 2, "prep": 4}.get(on, 6)
+                linked_out = [n for n in names if n[0] == "e4s_conv3x3_mx3_ex" and n[2] & bit]
+                linked_in = [n for n in names if (n[0] == "e4s_conv3x3_mx3_ex" and n[1] & bit) or (n[0] == "e4s_conv3x3_s2_mx3" and n[1] & bit)]
+                assert (len(linked_out), len(linked_in)) == ((1, 1) if on else (0, 0)), (cin, stride, on, names)
         finally:
-            ops.ENC_C4_LINK = keep
-        assert torch.equal(outs[False], outs[True])
+            ops.ENC_C4_LINK, ops.ENC_PREP_LINK = keep
+        assert torch.equal(outs[False], outs["c4"]) and torch.equal(outs[False], outs["prep"])
     assert not ops.mx_overflowed()
