@@ -402,6 +402,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
         const int chunk = g / NUNIT, u = g - chunk * NUNIT;
         return p.w + (((size_t)chunk * ncot + cotile) * NUNIT + u) * UNITB;
     };
+    // (Measured and dropped in round 5: a wave's last piece requested behind its MFMA phase instead of in its read phase — the read phase is the longer one with prepared
+    //  operands, 1 190 against 880 cycles — made the 512 -> 512 @32 launch 3 % SLOWER (144.6 -> 149.3 us): the request costs the MFMA phase what it saves the read phase.
+    //  A ninth loader wave does not fit the register file: two waves per SIMD hold 2 x 256 registers.)
     auto dma_unit = [&](int g, int slot) __attribute__((always_inline)) {
         const unsigned char* src = unit_src(g);
 #pragma unroll

@@ -20,9 +20,14 @@ with torch.no_grad():
     r6 = ops.conv3x3_mx(x, w3, 3, cout, out_phased=True)
     r7 = ops.conv3x3_mx(x, w3, 3, cout, out_phased=True, out_c4=True)
     r5 = ops.conv3x3_mx(x, w3, 3, cout, out_c4=True)
+    ro = ops.conv3x3_mx(x, w3, 3, cout, out_prep=True)
+    rop = ops.conv3x3_mx(x, w3, 3, cout, out_phased=True, out_prep=True)
     torch.cuda.synchronize()
-    for name, fn in (("stride 1, blocked in", lambda: ops.conv3x3_mx(r5, w3, 3, cout)),
+    which = sys.argv[3] if len(sys.argv) > 3 else "all"
+    for name, fn in [t for t in (("stride 1, blocked in", lambda: ops.conv3x3_mx(r5, w3, 3, cout)),
+                     ("stride 1, prepared in", lambda: ops.conv3x3_mx(ro, w3, 3, cout)),
                      ("stride 2, phase planes in", lambda: ops.conv3x3_s2_mx(r6, w5, cout)),
-                     ("stride 2, phased + blocked in", lambda: ops.conv3x3_s2_mx(r7, w5, cout))):
+                     ("stride 2, phased + blocked in", lambda: ops.conv3x3_s2_mx(r7, w5, cout)),
+                     ("stride 2, prepared in", lambda: ops.conv3x3_s2_mx(rop, w5, cout))) if which == "all" or which in t[0]]:
         print("==", name, flush=True)
         fn(); torch.cuda.synchronize()
