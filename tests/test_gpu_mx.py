@@ -314,18 +314,32 @@ def test_conv3x3_s2_mx3_is_bit_stable_beside_another_stream():
         x6 = torch.stack([torch.stack([x[:, :, py::2, px::2] for px in (0, 1)], 2) for py in (0, 1)], 2).contiguous()
         assert torch.equal(ops.conv3x3_s2_mx(x6, w5, 256), ref)
         ref2 = ops.conv3x3_mx(x2, w3, 3, 256).clone()
+        # (round 5) the same inputs as channel-blocked maps and as prepared operands: eight / eight requests per patch thread instead of 32, their own wait counts
+        x7 = x6.reshape(8, 64, 4, 2, 2, 64, 64).movedim(2, -1).contiguous()
+        ident = torch.zeros(256, 256, 3, 3, device=DEV)
+        ident[torch.arange(256), torch.arange(256), 1, 1] = 1.0          # the identity convolution writes x itself as prepared operands (f16-exact inputs below)
+        xh = x.half().float()
+        ref_h = ops.conv3x3_s2_mx(xh, w5, 256).clone()
+        xo = ops.conv3x3_mx(xh, ops.PreparedMx().get(ident, None, False, 3), 3, 256, out_phased=True, out_prep=True)
+        assert torch.equal(ops.conv3x3_s2_mx(x7, w5, 256), ref) and torch.equal(ops.conv3x3_s2_mx(xo, w5, 256), ref_h)
+        x2o = ops.conv3x3_mx(x2.half().float(), ops.PreparedMx().get(ident, None, False, 3), 3, 256, out_prep=True)
+        ref2_h = ops.conv3x3_mx(x2.half().float(), w3, 3, 256).clone()
+        assert torch.equal(ops.conv3x3_mx(x2o, w3, 3, 256), ref2_h)
         torch.cuda.synchronize()
         s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
         t0, rounds, bad = time.time(), 0, 0
         while time.time() - t0 < 3.0 and rounds < 300:
             with torch.cuda.stream(s1):
-                outs = [ops.conv3x3_s2_mx(x if i % 2 else x6, w5, 256) for i in range(6)]
+                outs = [ops.conv3x3_s2_mx((x, x6, x7)[i % 3], w5, 256) for i in range(6)]
+                outs_h = [ops.conv3x3_s2_mx(xo, w5, 256) for _ in range(3)]
             with torch.cuda.stream(s2):
-                outs2 = [ops.conv3x3_mx(x2, w3, 3, 256) for _ in range(6)]
+                outs2 = [ops.conv3x3_mx(x2, w3, 3, 256) for _ in range(4)]
+                outs2_h = [ops.conv3x3_mx(x2o, w3, 3, 256) for _ in range(4)]
             torch.cuda.synchronize()
             bad += sum(not torch.equal(o, ref) for o in outs) + sum(not torch.equal(o, ref2) for o in outs2)
+            bad += sum(not torch.equal(o, ref_h) for o in outs_h) + sum(not torch.equal(o, ref2_h) for o in outs2_h)
             rounds += 1
-    record_parity("conv3x3_s2_mx3.two_stream_mismatches", bad, 0, note=f"{rounds} rounds of 6 + 6 launches")
+    record_parity("conv3x3_s2_mx3.two_stream_mismatches", bad, 0, note=f"{rounds} rounds of 9 + 8 launches (plain, phase-plane, channel-blocked, prepared-operand inputs)")
     assert rounds >= 5 and bad == 0
     assert not ops.mx_overflowed()
 
