@@ -20,6 +20,11 @@
 // outputs, so a register copy between the request and that wait would copy stale data: the prefetch is requested at the TOP of the iteration that consumes it (not in the
 // previous iteration's store phase, where it was one barrier earlier: measured <= 0.4 % of the encoder) — the registers are defined and used inside one iteration, there
 // is no loop-carried value for the compiler to merge, and the loop has ONE call site (the prologue's request is waited for and consumed before the loop).
+// Memory formats (round 5; e4s_conv3x3_mx3_ex): the INPUT is fp32 planes [b][c][h][w] (IN = 0: normalised and converted while staging), channel-blocked fp32
+// [b][c / 4][h][w][4] (IN = 1: the same staging from 8 x 16-byte requests per thread instead of 32 dwords) or a PREPARED-OPERAND map (IN = 2: the producing convolution's
+// epilogue already wrote the patch's entries, 116 bytes per pixel and 32-channel block; staging copies them); the OUTPUT is any of the three (out_c4 / out_prep; fp32 and
+// channel-blocked also as the stride-2 consumer's phase planes).  The formats other than fp32 planes exist for ONE edge of the graph: between the two convolutions of a
+// bottleneck_IR_SE_Ours unit (helpers.py:128-139), where nothing else reads the map.  Every format gives the same bits.
 // Measured (16 images, in-run against e4s_conv3x3_mx): 512 -> 512 @32^2 0.1776 -> 0.1498 ms (516 algorithmic TFLOP/s), 256 -> 256 @64^2 0.184 -> 0.163;
 // cycle stamps (-DMX3_PROF): read phase 1 000 - 1 150 cycles (550 of LDS reads + the wave's share of the refill requests: the CU's address unit takes ~30
 // cycles per 1 KB request and stalls the issuing wave), MFMA phase 870; without the in-loop refills (-DMX3_NODMA) the kernel takes 0.134 ms.
