@@ -166,7 +166,7 @@ def conv2d(x: torch.Tensor, prepared: PreparedConv, stride: int = 1, pad: int = 
             ev.record()
         return out
     sb = isinstance(prepared.wt, tuple)
-    ev = _timed(f"conv2d_{'sb_' if sb else ''}kernel<{kh},{stride}>")
+    ev = _timed(f"conv2d_{'sb_' if sb else ''}kernel<{kh},{stride}>", f"{cin}->{cout} @{h}")
     pr = _p(_c(prelu.detach(), "prelu")) if prelu is not None else None
     if sb and _is_f16x3(prepared):
         lib().call("e4s_conv2d_f16x3", _p(out), _p(x), _p(x1), c0, _p(prepared.wt[0]), _p(prepared.wt[1]), _p(prepared.bias), _p(mean), _p(rstd),
