@@ -239,6 +239,9 @@ __global__ __launch_bounds__(256) void prep_weights_mx3_kernel(unsigned char* __
 template <bool S2, int IN>
 __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) {
     constexpr bool C4 = IN == 1, PREP = IN == 2;
+#ifdef MX3_PROF
+    const unsigned long long tKernel = __builtin_readcyclecounter();
+#endif
     constexpr int NLD = IN ? CK / 4 : CK;            // load requests of a prefetch, per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
     E4S_WAIT_VM(0);
 #ifdef MX3_PROF
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0)
-        printf("wave %d: loop %llu cyc | R %llu  wait after R %llu  M %llu  wait after M %llu | store: vm wait %llu  store_x %llu  barrier 1 %llu  barrier 2 %llu  (units %d)\n", wave, __builtin_readcyclecounter() - tLoop, tR, tWR, tM, tWM, tS1, tS2, tS3, tST, nunits);
+        printf("wave %d: prologue %llu  loop %llu cyc | R %llu  wait after R %llu  M %llu  wait after M %llu | store: vm wait %llu  store_x %llu  barrier 1 %llu  barrier 2 %llu  (units %d)\n", wave, tLoop - tKernel, __builtin_readcyclecounter() - tLoop, tR, tWR, tM, tWM, tS1, tS2, tS3, tST, nunits);
 #endif
     auto report_ovf = [&]() __attribute__((always_inline)) {
         if (p.flags && __builtin_amdgcn_ballot_w64(ovf != 0u) != 0 && (threadIdx.x & 63) == 0) { atomicOr(p.flags, 1); atomicAdd(p.flags + 1, 1); }   // one report per wave: sticky bit + moving counter (ops.MxGuard)
@@ -695,6 +698,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mx3_kernel(const Mx3Params p) 
             }
         }
     }
+#ifdef MX3_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) printf("wave %d: whole kernel %llu cyc\n", wave, __builtin_readcyclecounter() - tKernel);
+#endif
 }
 
 }  // namespace
