@@ -57,7 +57,7 @@ class GraphedCall:
                 dst.copy_(src, non_blocking=True)
         # f16 range guard around the replay (the two snapshots are ordinary stream-ordered copies, outside the graph): ``self.guard.tripped()`` tells
         # the caller — where it synchronises anyway — whether this replay's frames can be trusted; ``checked()`` does that and heals by itself
-        self.guard = ops.MxGuard() if guard else None
+        self.guard = ops.MxGuard() if guard else _Unguarded()
         self.graph.replay()
         if guard:
             self.guard.arm()
@@ -74,12 +74,25 @@ class GraphedCall:
         return out
 
 
+class _Unguarded:
+    """``GraphedCall.guard`` after a bare replay: there is nothing to ask — say so instead of an ``AttributeError`` on ``None`` (or a wrong ``False``)."""
+
+    def arm(self):
+        return self
+
+    def tripped(self):
+        raise RuntimeError("this replay ran without an f16 range guard: replay with g(..., guard=True) and then ask g.guard.tripped(), or use g.checked(...)")
+
+
 def graphed_gen_img(net, codes: torch.Tensor, labels: torch.Tensor, randomize_noise: bool = False) -> GraphedCall:
-    """``g(codes, labels) -> image`` for a fixed batch size; ``labels`` = uint8 region maps ``[bs, 512, 512]`` or one-hot masks."""
+    """``g(codes, labels) -> image`` for a fixed batch size; ``labels`` = uint8 region maps ``[bs, 512, 512]`` or one-hot masks.
+    A plain ``g(...)`` replays WITHOUT the f16 range guard (``ops.guarded`` is bypassed inside a capture): with trained weights call ``g.checked(...)``
+    or ``g(..., guard=True)`` + ``g.guard.tripped()``."""
     return GraphedCall(lambda c, m: net.gen_img(None, c, m, randomize_noise=randomize_noise)[0], [codes, labels])
 
 
 def graphed_swap(net, parser, driven: torch.Tensor, target: torch.Tensor, randomize_noise: bool = False) -> GraphedCall:
-    """``g(driven, target) -> (uint8 frames [bs,1024,1024,3], target region maps)`` — the whole full-swap unit as one graph."""
+    """``g(driven, target) -> (uint8 frames [bs,1024,1024,3], target region maps)`` — the whole full-swap unit as one graph.
+    A plain ``g(...)`` replays WITHOUT the f16 range guard: with trained weights call ``g.checked(...)`` or ``g(..., guard=True)`` + ``g.guard.tripped()``."""
     from . import pipeline
     return GraphedCall(lambda d, t: pipeline.swap_batch(net, parser, d, t, randomize_noise=randomize_noise), [driven, target])

@@ -1002,6 +1002,7 @@ UP_BLOCKS_MIN_WIDTH = int(os.environ.get("E4S_UP_BLOCKS_MINW", "128"))
 
 
 
+UP_BLOCKS_ONLY_ONE_KERNEL = None   # tests: "blocks" / "composed" = NaN-prefill the output and launch only that kernel of the pair (who writes which block)
 UP_BLOCKS_MIN_PERCENT_SMALL = 90   # the same for a layer whose composed launch fits the chip at once
 UP_BLOCKS_MIN_PERCENT = 40   # below this share of qualifying tiles a layer stays entirely in the composed form
 
@@ -1086,12 +1087,17 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
         composed_wgs = (wo // 64) * (ho // 16) * 4 * -(-cout // 128) * bs
         blocks, sub, bctrl = uniform_blocks(labels, ho, wo, nreg, with_ctrl=True,
                                             min_percent=max(UP_BLOCKS_MIN_PERCENT, UP_BLOCKS_MIN_PERCENT_SMALL) if composed_wgs <= 512 else UP_BLOCKS_MIN_PERCENT)
+        if UP_BLOCKS_ONLY_ONE_KERNEL is not None:          # tests: which kernel writes which output block (every block by exactly one of the two)
+            out.fill_(float("nan"))
         evb = _timed("masked_upconv_blocks", f"{cin}->{cout} @{h} up")
-        lib().call("e4s_masked_upconv_blocks_mx", _p(out), _p(x), _p(wmx_blocks), _p(mx_flags(x.device)), _p(s), _p(d), _p(blocks), _p(bctrl), _p(_c(blur_k, "blur kernel")),
-                   _p(nz), nbs or 0, _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, _stream())
+        if UP_BLOCKS_ONLY_ONE_KERNEL != "composed":
+            lib().call("e4s_masked_upconv_blocks_mx", _p(out), _p(x), _p(wmx_blocks), _p(mx_flags(x.device)), _p(s), _p(d), _p(blocks), _p(bctrl), _p(_c(blur_k, "blur kernel")),
+                       _p(nz), nbs or 0, _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, _stream())
         if evb is not None:
             evb.record()
-    use_mxe = sb and mx is not None and mxe is not None and mx[1] == 1 and blocks is None and cin % 32 == 0
+        if UP_BLOCKS_ONLY_ONE_KERNEL == "blocks":
+            return out
+    use_mxe = sb and mx is not None and mxe is not None and mx[1] == 1 and blocks is None and cin % 32 == 0 and not up
     # (timing key: the entry kernel's launches count with the masked kernel they replace — bench.py prices the group as one kernel and says so)
     ev = _timed(modconv_kernel_name(cout, w, sb, labels is not None, cin, mx[1] if (sb and mx is not None) else None), f"{cin}->{cout} @{h}{' up' if up else ''}")
     rgb_out = None
@@ -1440,3 +1446,17 @@ from .ops_encode import *     # noqa: E402,F401,F403   a8 - a10: encoder and par
 from .ops_post import *       # noqa: E402,F401,F403   f2 / f3: mask surgery, paste-back masks, Pillow resize, multi-band blend
 from .ops_post import _labels_u8, _pil_bicubic_tables, _pil_tables      # noqa: E402,F401
 from .ops_grad import *       # noqa: E402,F401,F403   f1: native gradients
+
+
+def __getattr__(name):        # PEP 562
+    """The star imports above only see what a stage module has defined when THIS module finishes importing — if ``e4s2024_amd.ops_grad`` (or ``ops_encode`` /
+    ``ops_post``) is imported first, it is still empty at that point.  Names they define later resolve here, on first use."""
+    import importlib
+    import sys
+    if not name.startswith("__"):
+        for mod in ("ops_encode", "ops_post", "ops_grad"):
+            m = sys.modules.get(f"{__package__}.{mod}") or importlib.import_module(f".{mod}", __package__)
+            if name in m.__dict__:
+                globals()[name] = m.__dict__[name]
+                return m.__dict__[name]
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

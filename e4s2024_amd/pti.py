@@ -197,7 +197,7 @@ def prepare_clip(labels: torch.Tensor, erode_radius: Optional[int] = None, size=
 
 def tune_clip(net, optimizer, images: torch.Tensor, labels: torch.Tensor, style_vectors: torch.Tensor, steps: int,
               erode_radius: Optional[int] = None, l2_lambda: float = 1.0, extra_loss=None, group=None, graphed: Optional[bool] = None,
-              randomize_noise: bool = True, step_fn=None, on_epoch=None):
+              randomize_noise: bool = True, step_fn=None, on_epoch=None, local_only: bool = False):
     """The fine-tuning loop of ``VideoSwapPTICoach.train_e4s`` (training/video_swap_ft_coach.py:242-317) for the part on the hot path:
     ``steps`` passes over the clip's frames, one optimiser step per frame — ``cal_style_codes`` -> ``gen_img`` on the (eroded) region map ->
     L2 against the frame under the foreground weight (+ ``extra_loss`` for the perceptual / identity / parsing nets of ``calc_loss``) ->
@@ -209,9 +209,11 @@ def tune_clip(net, optimizer, images: torch.Tensor, labels: torch.Tensor, style_
     sequential steps: no parity claim for this mode).  A rank whose block is shorter takes part in the remaining rounds with no gradient.
 
     Single GPU: the step runs as one replayed hipGraph (``GraphedPTIStep``) unless ``graphed=False``.
+    ``local_only``: ignore an initialised process group (this rank tunes on the frames it is given, no collective) — the pre-flight step of
+    ``bench.py``'s multi-GPU section.
     ``step_fn(net, optimizer, vec, map, image, fg, group, active) -> loss`` replaces the step (tests).  Returns the mean loss of each pass."""
     from .runner import shard_range
-    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    distributed = (not local_only) and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0
     n = images.shape[0]

@@ -272,6 +272,20 @@ class _null_context:
         return False
 
 
+class _Verdict:
+    """What is left of a checked ``ops.MxGuard`` in ``StreamPipeline.guards``: the answer, without the guard's pinned words and event."""
+    __slots__ = ("moved",)
+
+    def __init__(self, moved: bool):
+        self.moved = bool(moved)
+
+    def tripped(self) -> bool:
+        return self.moved
+
+    def arm(self):
+        return self
+
+
 class StreamPipeline:
     """Independent batches on alternating HIP streams of one GPU.
 
@@ -292,12 +306,16 @@ class StreamPipeline:
         self.streams = [torch.cuda.Stream(device=device) for _ in range(self.n)] if self.n > 1 else []
         self._i = 0
         self._main = None
-        self.guards = []          # one ops.MxGuard (or None) per submitted call since the last __enter__
+        self.guards = []          # one ops.MxGuard / verdict (or None) per submitted call since the last __enter__
+        self.healed = []          # indices of the calls this pipeline re-ran in the exact arithmetic (results copied into the returned tensors)
+        self._pending = []        # (index, guard, stream, fn, args, kwargs, out) of the calls whose guard nobody has looked at yet
         self.own_guards = True    # False: the submitted functions bracket their own work (run_clip_streamed's rounds do)
 
     def __enter__(self):
         self._main = None
         self.guards = []
+        self.healed = []
+        self._pending = []
         if self.streams:
             self._main = main = torch.cuda.current_stream()
             for st in self.streams:
@@ -314,16 +332,23 @@ class StreamPipeline:
             for o in out:
                 self._hand_over(o, depth + 1)
 
+    MAX_PENDING = 32          # unchecked guards kept alive at most (each holds two pinned words, an event and the call's arguments)
+
     def submit(self, fn, *args, **kwargs):
         """f16 range (``ops.MxGuard``): a drop-in module called without a guard scope checks its own pass — one host synchronisation per call, which would
-        serialise the batches this pipeline is there to overlap.  ``submit`` therefore owns the scope of every call that is not inside one already: the call's
-        armed guard is appended to ``self.guards`` (one per submitted call, ``None`` where the caller's own scope was in force) and the CALLER checks
-        ``sp.guards[i].tripped()`` where it synchronises anyway, recomputing that call under ``with ops.mx_exact():`` (``tripped_calls()`` lists them)."""
+        serialise the batches this pipeline is there to overlap.  ``submit`` therefore owns the scope of every call that is not inside one already, and the
+        pipeline stays SELF-HEALING by default: a call whose f16 arithmetic left its range is re-run under ``ops.mx_exact()`` on its own stream and the exact
+        results are copied INTO the tensors ``submit`` returned (same shapes: the caller's references stay valid) — lazily, for calls whose guard has already
+        landed when a later ``submit`` looks (no host wait), at the latest in ``__exit__``.  ``self.guards`` holds one entry per submitted call (``None`` where
+        the caller's own scope was in force); a caller that prefers to do the re-run itself checks ``sp.guards[i].tripped()`` / ``tripped_calls()`` before the
+        block ends — a guard the caller has looked at is the caller's, the pipeline leaves that call alone."""
         if not self.streams:
             return fn(*args, **kwargs)
         from . import ops
+        self._reap(block=len(self._pending) >= self.MAX_PENDING)
         st = self.streams[self._i % self.n]
         self._i += 1
+        g = None
         with torch.cuda.stream(st):
             if not self.own_guards or ops.mx_guard_owned():
                 out = fn(*args, **kwargs)
@@ -333,16 +358,51 @@ class StreamPipeline:
                     out = fn(*args, **kwargs)
                     g.arm()
                 self.guards.append(g)
+        if g is not None and g._live:
+            self._pending.append((len(self.guards) - 1, g, st, fn, args, kwargs, out))
         self._hand_over(out)
         return out
 
+    @staticmethod
+    def _copy_into(dst, src, depth=0):
+        if isinstance(dst, torch.Tensor):
+            dst.copy_(src)
+        elif isinstance(dst, (tuple, list)) and depth < 2:
+            for d, s_ in zip(dst, src):
+                StreamPipeline._copy_into(d, s_, depth + 1)
+
+    def _reap(self, block: bool = False, everything: bool = False):
+        """Check the pending guards in submission order: those whose "after" snapshot has landed (all of them when ``everything``; the oldest one in any case
+        when ``block``), heal the calls that tripped, and replace each checked guard by its verdict so that its pinned words and event go away."""
+        from . import ops
+        while self._pending:
+            idx, g, st, fn, args, kwargs, out = self._pending[0]
+            if g._done:                                    # the caller looked at it: the caller's call
+                self._pending.pop(0)
+                continue
+            if not (everything or block or g._ev.query()):
+                break
+            block = False
+            self._pending.pop(0)
+            moved = g.tripped()
+            if moved:
+                ops.mx_fallbacks += 1
+                with torch.cuda.stream(st), torch.no_grad(), ops.mx_exact(), ops.mx_guard_scope():
+                    self._copy_into(out, fn(*args, **kwargs))
+                self.healed.append(idx)
+            self.guards[idx] = _Verdict(moved)
+
     def tripped_calls(self):
-        """Indices (in submission order since the pipeline was entered) of the calls whose f16 arithmetic left its range: their results must be recomputed under
-        ``ops.mx_exact()``.  Waits for each call's guard (a host synchronisation with that call's stream)."""
-        return [i for i, g in enumerate(self.guards) if g is not None and g.tripped()]
+        """Indices (in submission order since the pipeline was entered) of the calls whose f16 arithmetic left its range and which the pipeline has NOT healed
+        (``self.healed`` lists the ones it has): their results must be recomputed under ``ops.mx_exact()`` by the caller.  Waits for each call's guard (a host
+        synchronisation with that call's stream)."""
+        return [i for i, g in enumerate(self.guards) if g is not None and i not in self.healed and g.tripped()]
 
     def __exit__(self, *exc):
         if self.streams:
+            if exc[0] is None:
+                self._reap(everything=True)                # (waits for each unchecked guard's snapshot: the block's calls are complete behind it)
+            self._pending.clear()
             main = torch.cuda.current_stream()
             for st in self.streams:
                 main.wait_stream(st)

@@ -388,18 +388,33 @@ def test_masked_up_layer_uniform_blocks_against_oracle_and_composed_form(sg2, sh
             _ops.UP_BLOCKS = True
             y = m(x.to(DEV), st.to(DEV), labd, noise=nz.to(DEV))
             y2 = m(x.to(DEV), st.to(DEV), labd, noise=nz.to(DEV))
+            # single writer: the output NaN-prefilled, each kernel of the pair alone — every element is written by exactly one of them
+            _ops.UP_BLOCKS_ONLY_ONE_KERNEL = "blocks"
+            yb = m(x.to(DEV), st.to(DEV), labd, noise=nz.to(DEV))
+            _ops.UP_BLOCKS_ONLY_ONE_KERNEL = "composed"
+            ym = m(x.to(DEV), st.to(DEV), labd, noise=nz.to(DEV))
+            _ops.UP_BLOCKS_ONLY_ONE_KERNEL = None
             _ops.UP_BLOCKS = False
             yc = m(x.to(DEV), st.to(DEV), labd, noise=nz.to(DEV))
     finally:
-        _ops.UP_BLOCKS, _ops.UP_BLOCKS_MIN_WIDTH = old, old_w
+        _ops.UP_BLOCKS, _ops.UP_BLOCKS_MIN_WIDTH, _ops.UP_BLOCKS_ONLY_ONE_KERNEL = old, old_w, None
         _ops.UP_BLOCKS_MIN_PERCENT, _ops.UP_BLOCKS_MIN_PERCENT_SMALL = old_pc
+    wb, wm = torch.isfinite(yb), torch.isfinite(ym)
+    assert wb.any() and wm.any(), "both kernels of the pair must have work here"
+    assert not (wb & wm).any(), "an output element written by both kernels"
+    assert (wb | wm).all(), "an output element written by neither kernel"
+    # ... in whole 16 x 16 blocks of all channels, and what each wrote is what the pair writes together
+    wb16 = wb.reshape(bs, cout, ho // 16, 16, wo // 16, 16)
+    assert (wb16.all(dim=(1, 3, 5)) | (~wb16).all(dim=(1, 3, 5))).all()
+    assert torch.equal(torch.where(wb, yb, ym), y)
     ref = O.styled_conv(sd, "", x, st, onehot, nz, masked=True, upsample=True)
     scale = max(1.0, float(ref.abs().max()))
     assert torch.equal(y, y2)
     d_or, d_co = maxdiff(y, ref), (y - yc).abs().max().item()
     record_parity(f"masked_up_blocks.{cin}to{cout}_{h}x{w}.vs_oracle", d_or / scale, LAYER_TOL)
     # block route against composed route: two kernels on the same f16 + fp6 arithmetic with different block-scale groupings and summation orders
-    assert d_or <= LAYER_TOL * scale and d_co <= LAYER_TOL * scale, (shape, d_or, d_co, scale)
+    # (measured 2e-5 .. 5e-5 of the output scale: a bound tighter than the bar against the oracle)
+    assert d_or <= LAYER_TOL * scale and d_co <= 1e-4 * scale, (shape, d_or, d_co, scale)
 
 
 def test_batched_style_tables_match_the_one_layer_launches():
