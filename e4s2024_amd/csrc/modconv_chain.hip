@@ -75,6 +75,7 @@ struct ChainParams {
     int tiles_x, tiles_y, ntile;
     const float* zeros;      // >= 64 zero bytes (source of absent noise / skip / bias elements)
     int exp;                 // tuning experiments (E4S_CHAIN_EXP): 1 = no epilogue, 2 = no MFMAs, 4 = no activation DMA
+    int walk;                // (conv kernel) bit 0: XCD-aware start offsets, bits 8..: band height of the tile enumeration (sb_common.h)
 };
 
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(CT_NT) void chain_conv_kernel(const ChainParams p) 
         if (tid < 16) epw[C::EP_KF + tid] = p.rgb_upk ? p.rgb_upk[15 - tid] : 0.f;
         if (tid < 3) epw[C::EP_KF + 16 + tid] = p.rgb_bias[tid];
     }
-    const int first = blockIdx.x, stride = gridDim.x;
+    const int stride = gridDim.x, first = walk_offset(blockIdx.x, stride, p.walk & 1);
     const int my_tiles = (p.ntile - first + stride - 1) / stride;
     const int per_img = p.tiles_x * p.tiles_y;
 
@@ -137,10 +138,10 @@ __global__ __launch_bounds__(CT_NT) void chain_conv_kernel(const ChainParams p) 
         const int cb8 = p.cin >> 3;
         auto tile_coords = [&](int t, int& b, int& y0, int& x0) {
             b = t / per_img;
-            const int r = t - b * per_img;
-            const int ty = r / p.tiles_x;
+            int ty, tx;
+            walk_tile_xy(t - b * per_img, p.tiles_x, p.tiles_y, p.walk >> 8, ty, tx);
             y0 = ty * CT_TH;
-            x0 = (r - ty * p.tiles_x) * CT_TW;
+            x0 = tx * CT_TW;
         };
         auto tile_of = [&](int k) {
             int i = k / NCH;
@@ -795,6 +796,8 @@ extern "C" int e4s_chain_conv3x3(const E4sChainLayer* L, void* stream) {
     if (int rc = fill_chain_params(p, L, L->h, L->w, "chain_conv3x3")) return rc;
     p.tiles_x = L->w / CT_TW; p.tiles_y = L->h / CT_TH;
     p.ntile = p.tiles_x * p.tiles_y * L->bs;
+    static const int walk = [] { const char* e = getenv("E4S_WALK"); return e ? atoi(e) : (1 | (8 << 8)); }();     // (E4S_WALK=0: every eighth tile, row-major)
+    p.walk = walk;
     hipStream_t st = (hipStream_t)stream;
     const bool rgb = L->rgb_out != nullptr, osp = L->out_sp != nullptr;
     // the shapes of the chain (Generator(1024): 64 -> 64 at 512 x 512, 32 -> 32 at 1024 x 1024); anything else stays on e4s_region_modconv3x3_sb

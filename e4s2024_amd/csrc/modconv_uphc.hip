@@ -47,6 +47,8 @@ struct UpHcParams {
     int tiles_x, tiles_y;
     int ntile, ncot;                 // (persistent form) tiles_x * tiles_y * bs, cout / 32
     int exp;                         // tuning experiments of the -DE4S_PHASE_PROF build (E4S_HC_EXP): 1 = no epilogue, 2 = no MFMAs, 4 = no output stores
+    int rev;                         // (persistent form) walk the tiles last to first: see e4s_modconv_up_hc
+    int walk;                        // (persistent form) bit 0: XCD-aware start offsets, bits 8..: band height of the tile enumeration (sb_common.h)
     int64_t plane_in, plane_out;     // uint4 per plane
 };
 
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(HP_NT) void up_hcp_kernel(const UpHcParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hw = p.h * p.w, wo = 2 * p.w;
     const int nchunk = p.cin >> 4, NU = 2 * nchunk;
-    const int first = blockIdx.x, stride = gridDim.x;
+    const int stride = gridDim.x, first = walk_offset(blockIdx.x, stride, p.walk & 1);
     const int my_tiles = (p.ntile - first + stride - 1) / stride;
     const int my_items = my_tiles * p.ncot;
     const int per_img = p.tiles_x * p.tiles_y;
@@ -357,12 +359,11 @@ __global__ __launch_bounds__(HP_NT) void up_hcp_kernel(const UpHcParams p) {
     // item i of this workgroup: tile first + (i / ncot) * stride, co tile i % ncot
     auto item_coords = [&](int i, int& b, int& cot, int& tyt, int& txt) __attribute__((always_inline)) {
         i = i < my_items ? i : my_items - 1;                               // (ghost items past the end repeat the last one)
-        const int t = first + (i / p.ncot) * stride;
+        int t = first + (i / p.ncot) * stride;
+        t = p.rev ? p.ntile - 1 - t : t;
         cot = i % p.ncot;
         b = t / per_img;
-        const int r = t - b * per_img;
-        tyt = r / p.tiles_x;
-        txt = r - tyt * p.tiles_x;
+        walk_tile_xy(t - b * per_img, p.tiles_x, p.tiles_y, p.walk >> 8, tyt, txt);
     };
 
     if (wave == HP_NCW) {
@@ -588,6 +589,12 @@ extern "C" int e4s_modconv_up_hc(uint16_t* out_sp, const uint16_t* x_sp, const u
     p.ntile = p.tiles_x * p.tiles_y * bs; p.ncot = cout / 32;
     p.plane_in = (int64_t)bs * (cin / 8) * h * w;
     p.plane_out = (int64_t)bs * (cout / 8) * 4 * h * w;
+    // Tile order.  The chain's hand-overs at 512^2 / 1024^2 (268 / 537 MB per batch of 4) are larger than the 256 MB Infinity Cache: a consumer that walks the tensor in its
+    // producer's order reads what was written longest ago.  The up layers walk their tiles LAST TO FIRST, the same-resolution layers first to last: every layer of the
+    // chain starts with the bytes its producer wrote last (E4S_HC_REV=0: the old order; tools/time_chain.py).
+    static const int rev = [] { const char* e = getenv("E4S_HC_REV"); return e ? atoi(e) : 1; }();
+    static const int walk = [] { const char* e = getenv("E4S_WALK"); return e ? atoi(e) : (1 | (8 << 8)); }();     // (E4S_WALK=0: every eighth tile, row-major)
+    p.rev = rev; p.walk = walk;
 #ifdef E4S_PHASE_PROF
     { const char* e = getenv("E4S_HC_EXP"); p.exp = e ? atoi(e) : 0; }      // (tuning build only)
 #else

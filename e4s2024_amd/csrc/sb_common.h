@@ -56,6 +56,24 @@ __device__ __forceinline__ void dma4_asm(const void* gbase, unsigned voff, unsig
 }
 // s_waitcnt vmcnt(n) with a literal n, and a workgroup barrier that leaves LDS-DMA in flight (a __syncthreads() would drain it: its fence waits
 // vmcnt(0) while a DMA is pending)
+// Tile walk of the persistent kernels (one workgroup per CU, workgroup b of G takes tiles off(b), off(b) + G, ...).
+// XCD-aware start offset: block b runs on XCD b % 8 (observed, speed only) and each XCD has its own L2, so the G / 8 workgroups of one XCD take G / 8 CONSECUTIVE
+// tiles of the enumeration per step (off = (b % 8) * G / 8 + b / 8) instead of every eighth one: with the band-blocked enumeration below, what neighbouring tiles share
+// (a patch's halo rows / columns) is then fetched into that L2 once.  A pure permutation of the start offsets: every count of the walk stays as it was.
+__device__ __forceinline__ int walk_offset(int b, int G, int xcd_aware) {
+    return (xcd_aware && (G & 7) == 0) ? (b & 7) * (G >> 3) + (b >> 3) : b;
+}
+// Band-blocked enumeration of an image's tiles_x x tiles_y tiles: bands of `bh` tile rows, column-major inside a band — 32 consecutive indices are a 4 x 8 block of
+// tiles (bh = 8) instead of a row segment.  r = index inside the image; bh <= 1: row-major.
+__device__ __forceinline__ void walk_tile_xy(int r, int tiles_x, int tiles_y, int bh, int& ty, int& tx) {
+    if (bh <= 1) { ty = r / tiles_x; tx = r - ty * tiles_x; return; }
+    const int band = r / (bh * tiles_x);
+    const int rr = r - band * bh * tiles_x;
+    const int rows = tiles_y - band * bh < bh ? tiles_y - band * bh : bh;      // (a ragged last band)
+    tx = rr / rows;
+    ty = band * bh + (rr - tx * rows);
+}
+
 #define E4S_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define E4S_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
