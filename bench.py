@@ -174,6 +174,50 @@ def _overlap_view(kt, dom, per_launch_flops, peak):
     return {"avg_launch_ms": round(avg_ms, 4), "achieved": round(ach, 2), "frac": round(ach / peak, 4), "launches": s[0]}
 
 
+class _BoardSampler:
+    """Package power and shader clock while a block runs, read from `rocm-smi --showpower --showclocks` four times a second on a host thread (no GPU work, no
+    root).  Round 6 finding (tools/power_probe.sh, tools/power_by_kernel.py): every kernel of the step runs at the board's power limit and the shader clock
+    settles near 2.0 GHz instead of 2.4 — the ceiling the roofline fractions are quoted against (2 500 TFLOP/s at 2.4 GHz) is not reachable on this workload."""
+
+    def __init__(self):
+        self.samples = []
+        self._stop = None
+        self._th = None
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self._stop.is_set():
+            try:
+                txt = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+                pw = re.search(r"Power \(W\): ([0-9.]+)", txt)
+                ck = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", txt)
+                if pw and ck:
+                    self.samples.append((time.perf_counter(), float(pw.group(1)), int(ck.group(1))))
+            except Exception:      # noqa: BLE001 - a side measurement
+                return
+            self._stop.wait(0.25)
+
+    def __enter__(self):
+        import threading
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+        self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._th.join(timeout=10)
+
+    def summary(self, t0):
+        """Mean over the samples taken later than 0.5 s after ``t0`` (the settled part)."""
+        s = [x for x in self.samples if x[0] >= t0 + 0.5] or self.samples
+        if not s:
+            return None
+        return {"power_w": round(sum(x[1] for x in s) / len(s), 0), "sclk_mhz": round(sum(x[2] for x in s) / len(s), 0), "samples": len(s),
+                "what": "rocm-smi package power / shader clock during the soak (the timed step repeated): the board's power limit, not issue slots, sets the clock"}
+
+
 def _compact_line(line, one_stream, ksum, steps, detail_path):
     """The ONE stdout line: the contract fields, `roofline` / `cpu_baseline` with scalars only, and the secondary metrics as flat scalars (< 2 000 characters)."""
     def short(v, n=120):
@@ -210,6 +254,8 @@ def _compact_line(line, one_stream, ksum, steps, detail_path):
     out["stage_ms"] = stage
     out["one_stream_faces_per_s"] = get(line, "one_stream", "faces_per_s")
     out["soak_faces_per_s"] = get(line, "soak", "faces_per_s")
+    out["soak_power_w"] = get(line, "soak", "board", "power_w")
+    out["soak_sclk_mhz"] = get(line, "soak", "board", "sclk_mhz")
     fs = line.get("full_swap") or {}
     out["full_swap_p50_ms_per_frame"] = fs.get("p50_ms_per_frame")
     out["full_swap_swaps_per_s"] = fs.get("swaps_per_s")
@@ -353,7 +399,7 @@ def main():
     if args.soak_seconds > 0 and world == 1:
         n_soak = 0
         t_s0 = time.perf_counter()
-        with pipe:
+        with _BoardSampler() as board, pipe:
             while True:
                 for _ in range(2 * args.steps):
                     img_s = pipe.submit(step)
@@ -363,7 +409,8 @@ def main():
                     break
         t_soak = time.perf_counter() - t_s0
         soak = {"seconds": round(t_soak, 3), "steps": n_soak, "faces_per_s": round(n_soak * bs / t_soak, 1), "ms_per_step": round(t_soak / n_soak * 1e3, 3),
-                "streams": args.streams, "what": "the timed region's step repeated for at least --soak-seconds (synchronised every 2K steps)"}
+                "streams": args.streams, "what": "the timed region's step repeated for at least --soak-seconds (synchronised every 2K steps)",
+                "board": board.summary(t_s0)}
         del img_s
     one_stream = None
     if args.streams > 1:
