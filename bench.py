@@ -248,7 +248,7 @@ def _compact_line(line, one_stream, ksum, steps, detail_path):
     stage = None
     if ksum and one_stream:
         ms = lambda pred: sum(v[1] for k, v in ksum.items() if pred(k)) / steps    # noqa: E731
-        masked = ms(lambda k: k.startswith(("region_modconv_mx_kernel", "region_modconv_sb_kernel<4,", "masked_upconv_blocks", "region_conv_mxe")))
+        masked = ms(lambda k: k.startswith(("region_modconv_mx_kernel", "region_modconv_sb_kernel<4,", "masked_upconv_blocks")))
         ge512 = ms(lambda k: k.startswith(("modconv_up_hc", "modconv_up_fused_sb", "chain_conv3x3", "chain_fused1024", "modconv_tconv_sb")))
         stage = {"masked": round(masked, 3), "ge512": round(ge512, 3), "rest": round(max(0.0, one_stream["ms_per_step"] - masked - ge512), 3)}
     out["stage_ms"] = stage
@@ -874,9 +874,7 @@ def main():
             job_peak = BF16_MATRIX_PEAK_TFLOPS / job_cost
             job_ach = value * 148.52e9 / 1e12 / world
             roof = {"bound": "mfma", "kernel": dom,
-                    **({"kernel_launches": ("region_conv_mxe_kernel (csrc/modconv_mxe.hip: the masked same-resolution layers with class-prepared operands; its tiles with more than 512 "
-                                            "(pixel, region) pairs run the tile of region_modconv_mx_kernel<1> inside the same launch), " if ops.MXE else "") +
-                                           "region_modconv_mx_kernel<1, ...> (csrc/modconv_mx.hip) and, for masked up layers whose launch fills the chip with 64-channel tiles "
+                    **({"kernel_launches": "region_modconv_mx_kernel<1, ...> (csrc/modconv_mx.hip) and, for masked up layers whose launch fills the chip with 64-channel tiles "
                                            "(512->256 @64 at this batch), region_upconv_mx4_kernel (csrc/modconv_mx4.hip): the same tile code or its four-parity form, "
                                            "chosen per workgroup — profiler tables list the two names, this object counts them as one kernel"}
                        if (ops.UP_MX4 and dom and dom.startswith("region_modconv_mx_kernel<1")) else {}),

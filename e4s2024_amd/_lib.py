@@ -36,9 +36,6 @@ _PROTOS = {
     "e4s_upblock_mx_weight_bytes": [c_int, c_int, c_ptr],
     "e4s_modconv_prep_weights_upblock_mx": [c_ptr, c_ptr, c_int, c_int, c_ptr],
     "e4s_masked_upconv_blocks_mx": [c_ptr] * 9 + [c_ptr, c_int, c_ptr, c_ptr] + [c_int] * 7 + [c_ptr],
-    "e4s_modconv_mxe_weight_bytes": [c_int, c_int, c_int, c_ptr],
-    "e4s_modconv_prep_weights_mxe": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
-    "e4s_region_modconv3x3_mxe": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_int, c_ptr, c_ptr, c_int] + [c_int] * 7 + [c_ptr, c_i64] + [c_ptr] * 8,
     "e4s_conv_prep_weights_mx": [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
     "e4s_conv3x3_mx": [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_conv3x3_mx3_weight_bytes": [c_int, c_int, c_ptr],
@@ -98,7 +95,6 @@ _PROTOS = {
     "e4s_tensor2im_u8": [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr],
     "e4s_to_split_planes": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr],
     "e4s_chain_conv3x3": [c_ptr, c_ptr],
-    "e4s_chain_upconv": [c_ptr, c_ptr, c_ptr],
     "e4s_modconv_prep_weights_hc": [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr],
     "e4s_modconv_up_hc": [c_ptr] * 7 + [c_int, c_ptr, c_ptr, c_int] + [c_int] * 5 + [c_ptr, c_ptr],
     "e4s_small_map": [c_ptr, c_ptr, c_ptr, c_int, c_int, c_i64, c_int, c_int, c_ptr],

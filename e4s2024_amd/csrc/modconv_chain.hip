@@ -1,4 +1,4 @@
-// a3/a4, the single-region chain (layers past remaining_layer_idx: 256->512 up, 512 conv, 512->1024 up, 1024 conv): persistent
+// a3/a4, the single-region chain's same-resolution layers (past remaining_layer_idx: 512 conv, 1024 conv; the up layers: modconv_uphc.hip): persistent
 // workgroups fed by LDS-DMA from PRE-MODULATED, PRE-SPLIT activation planes.
 //
 // Why.  The single-region layers are short-K (32-128 input channels) and their old kernels (modconv_sb.hip UNI path, modconv_upfused.hip)
@@ -432,288 +432,6 @@ int launch_chain_conv(ChainParams& p, hipStream_t st) {
     return check_launch("chain_conv3x3");
 }
 
-// ====================================================================================================================================
-// Up-sampling single-region StyledConv on split planes: stride-2 transposed 3x3 conv at 1x its MACs -> pre-blur tile in LDS -> 4x4 blur
-// + demodulation + noise + bias + leaky-relu -> split planes for the next layer.  Geometry of modconv_upfused.hip (16 x 16 positions per
-// tile, 28 x 28 outputs, 1.31x MACs for the 2-position overlap), staging / roles of the conv kernel above.  One work item = (tile, 32
-// output channels): cout / 32 items per tile, neighbours in the walk order.
-// ====================================================================================================================================
-constexpr int CU_T = 16, CU_STEP = CU_T - 2, CU_OUT = 2 * CU_STEP;          // positions per side, new positions, outputs per side (28)
-constexpr int CU_PW = CU_T + 1, CU_PATCH = CU_PW * CU_PW;                     // 289 patch pixels
-constexpr int CU_NPIECE = (CU_PATCH + 63) / 64;                               // 5
-constexpr int CU_ZS = 34, CU_ZCS = 32 * CU_ZS + 8;                            // pre-blur tile: row stride, channel stride (floats)
-constexpr int CU_TN = 32;
-constexpr int CU_NOISE = CU_OUT * CU_OUT;                                     // 784
-
-template <int NCH, int NSTAGE>
-struct UpCfg {
-    static constexpr int W4 = 36 * CU_TN, XS4 = 4 * CU_PATCH, STAGE4 = XS4 + W4;
-    static constexpr int ZT_OFF = NSTAGE * STAGE4 * 16;                        // bytes
-    static constexpr int EP_OFF = ZT_OFF + 8 * CU_ZCS * 4;
-    static constexpr int EP_NOISE = 0, EP_D = EP_NOISE + 13 * 64, EP_SN = EP_D + 64, EP_BIAS = EP_SN + 64, EP_DESC = EP_BIAS + 64, EP_FLOATS = EP_DESC + 4;
-    static constexpr int LDS_BYTES = EP_OFF + EP_FLOATS * 4;
-    static constexpr int NWPIECE = W4 / 64;
-    static constexpr int GL = 4 * CU_NPIECE + NWPIECE;                        // 38
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS per CU");
-    static_assert(NSTAGE >= 2 && NSTAGE - 1 <= NCH && (NSTAGE - 2) * GL <= 63, "prefetch distance / vmcnt field");
-};
-
-template <int NCH, int NSTAGE>
-__global__ __launch_bounds__(CT_NT) void chain_up_kernel(const ChainParams p) {
-    using C = UpCfg<NCH, NSTAGE>;
-    constexpr int D = NSTAGE - 1;
-    constexpr int NPASS = 4;                                                   // 8 output channels per blur pass
-    // (plain local constants for the lambdas below: hipcc 7.2's HOST pass silently drops the kernel's stub — undefined symbol at load time —
-    //  when a dependent static member like C::XS4 appears in an argument of the LDS-DMA builtin inside a lambda)
-    constexpr int K_XS4 = C::XS4, K_STAGE4 = C::STAGE4, K_NWPIECE = C::NWPIECE, K_GL = C::GL;
-    constexpr int K_EP_NOISE = C::EP_NOISE, K_EP_D = C::EP_D, K_EP_SN = C::EP_SN, K_EP_BIAS = C::EP_BIAS, K_EP_DESC = C::EP_DESC;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    uint4* lds4 = reinterpret_cast<uint4*>(lds_raw);
-    float* zt = reinterpret_cast<float*>(lds_raw + C::ZT_OFF);
-    float* epw = reinterpret_cast<float*>(lds_raw + C::EP_OFF);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hw = p.h * p.w;
-    const int ho = 2 * p.h, wo = 2 * p.w;
-    const int ncot = p.cout / CU_TN;
-    const int first = blockIdx.x, stride = gridDim.x;
-    const int my_items = (p.ntile - first + stride - 1) / stride;
-    const int per_img = p.tiles_x * p.tiles_y * ncot;
-
-    if (wave == CT_NCW) {
-        // =================================================================================== loader
-        const int cb8 = p.cin >> 3;
-        auto item_coords = [&](int t, int& b, int& cot, int& tyt, int& txt) {
-            b = t / per_img;
-            int r = t - b * per_img;
-            cot = r % ncot;
-            r /= ncot;
-            tyt = r / p.tiles_x;
-            txt = r - tyt * p.tiles_x;
-        };
-        auto item_of = [&](int k) {
-            int i = k / NCH;
-            i = i < my_items ? i : my_items - 1;
-            return first + i * stride;
-        };
-        lds_byte* const lds_b = (lds_byte*)lds_raw;
-        constexpr unsigned K_EPB = C::EP_OFF;
-        const unsigned zero_off = (unsigned)(2 * p.plane_in * 16);             // the 16 zero bytes behind the two input planes
-        auto issue_group = [&](int k) __attribute__((always_inline)) {
-            const unsigned st_off = (unsigned)(k % NSTAGE) * (unsigned)(K_STAGE4 * 16);
-            const int c = k % NCH;
-            int b, cot, tyt, txt;
-            item_coords(item_of(k), b, cot, tyt, txt);
-            const int p0y = tyt * CU_STEP - 1, p0x = txt * CU_STEP - 1;
-            if (!(p.exp & 4)) {
-                const unsigned cb0 = (unsigned)((b * cb8 + 2 * c) * hw);
-#pragma unroll
-                for (int j = 0; j < CU_NPIECE; ++j) {
-                    const int e = j * 64 + lane;
-                    const int py = e / CU_PW, px = e - py * CU_PW;
-                    const int gy = p0y - 1 + py, gx = p0x - 1 + px;
-                    const bool inb = gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
-                    const unsigned pix = (unsigned)(gy * p.w + gx);
-                    if (e < CU_PATCH) {
-#pragma unroll
-                        for (int combo = 0; combo < 4; ++combo) {
-                            const unsigned cbase = (unsigned)((combo >> 1) * p.plane_in) + cb0 + (unsigned)((combo & 1) * hw);
-                            dma16(p.xsp, inb ? (cbase + pix) * 16u : zero_off, lds_b + st_off + (combo * CU_PATCH + j * 64) * 16);
-                        }
-                    }
-                }
-            }
-            // weight chunk c of this item's 32 output channels: global rows [tap][half][cout] -> LDS [hl][tap][half][32]
-#pragma unroll
-            for (int piece = 0; piece < K_NWPIECE; ++piece) {
-                const int hl = piece * 64 / (18 * CU_TN);                        // 18 x 32 = 9 pieces per slab
-                const int rem = piece * 64 - hl * 18 * CU_TN + lane;             // [tap][half][32] index
-                const int th = rem >> 5, n = rem & 31;
-                dma16(hl ? p.wlo : p.whi, (unsigned)((((c * 18 + th) * p.cout) + cot * CU_TN + n) * 16), lds_b + st_off + (K_XS4 + piece * 64) * 16);
-            }
-        };
-        auto item_setup = [&](int t) __attribute__((always_inline)) {            // epilogue operands of item t, all by DMA: 13 (x2) + 3 pieces
-            int b, cot, tyt, txt;
-            item_coords(t, b, cot, tyt, txt);
-#pragma unroll
-            for (int piece = 0; piece < 13; ++piece) {
-                const int e = piece * 64 + lane;
-                const int ry = e / CU_OUT, rx = e - ry * CU_OUT;
-                const int ny = tyt * CU_OUT + ry, nx = txt * CU_OUT + rx;
-                const bool ok = p.noise && e < CU_NOISE && ny < ho && nx < wo;
-                if (ok) dma4(p.noise, (unsigned)((b * p.noise_bstride + ny * wo + nx) * 4), lds_b + K_EPB + (K_EP_NOISE + piece * 64) * 4);
-                else dma4(p.zeros, 0u, lds_b + K_EPB + (K_EP_NOISE + piece * 64) * 4);
-            }
-            {
-                const unsigned co4 = (unsigned)((cot * CU_TN + (lane & 31)) * 4);
-                dma4(p.d, (unsigned)(b * p.cout * 4) + co4, lds_b + K_EPB + K_EP_D * 4);
-                dma4(p.s_next, (unsigned)(b * p.cout * 4) + co4, lds_b + K_EPB + K_EP_SN * 4);
-                dma4(p.act_bias ? p.act_bias : p.zeros, p.act_bias ? co4 : 0u, lds_b + K_EPB + K_EP_BIAS * 4);
-            }
-            if (lane == 0) {
-                int* desc = reinterpret_cast<int*>(epw + K_EP_DESC);
-                desc[0] = b; desc[1] = cot; desc[2] = tyt; desc[3] = txt;
-            }
-        };
-        item_setup(first);
-#pragma unroll
-        for (int k = 0; k < D; ++k) issue_group(k);
-        const int total = my_items * NCH;
-#pragma unroll 1
-        for (int k = 0; k < total; ++k) {
-            wait_vm((D - 1) * K_GL);
-            CH_BARRIER();
-            if (k > 0 && k % NCH == 0) item_setup(item_of(k));
-            issue_group(k + D);
-            if (k % NCH == NCH - 1) {                                            // the compute waves' blur passes: 2 barriers each
-#pragma unroll 1
-                for (int i = 0; i < 2 * NPASS; ++i) CH_BARRIER();
-            }
-        }
-        CH_WAIT_VM(0);
-        return;
-    }
-
-    // ======================================================================================= compute waves
-    const int l5 = lane & 31, khalf = lane >> 5;
-    const float nw = p.noise ? p.noise_weight[0] : 0.f;
-    const int pty = 2 * wave + (l5 >> 4), ptx = l5 & 15;                       // this lane's position inside the tile
-    const int xoff = pty * CU_PW + ptx;
-    float kf[16];                                                              // kf[ty*4+tx] = blur[3-ty][3-tx]  (uniform loads -> scalar registers)
-#pragma unroll
-    for (int t = 0; t < 16; ++t) kf[t] = p.blur[15 - t];
-    // blur item of this thread: channel pair cp, 7 output rows [7 rg, 7 rg + 7), output column x  (448 of the 512 compute threads)
-    const int it_cp = tid & 3, it_rem = tid >> 2;
-    const int it_rg = it_rem / CU_OUT, it_x = it_rem - it_rg * CU_OUT;
-    const bool it_on = tid < 4 * 4 * CU_OUT;
-    if (blockIdx.x == 0 && tid < 4) p.out_sp[(size_t)p.plane_out * 8 + tid] = 0u;     // the zero element behind the output planes
-
-#pragma unroll 1
-    for (int ti = 0; ti < my_items; ++ti) {
-        f32x16 accs[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accs[a][r] = 0.f;
-#pragma unroll 1
-        for (int c = 0; c < NCH; ++c) {
-            const int k = ti * NCH + c;
-            CH_BARRIER();
-            unsigned xb_i = (unsigned)((k % NSTAGE) * C::STAGE4 + khalf * CU_PATCH + xoff);
-            unsigned wb_i = (unsigned)((k % NSTAGE) * C::STAGE4 + C::XS4 + khalf * CU_TN + l5);
-            asm volatile("" : "+v"(xb_i), "+v"(wb_i));
-            const uint4* xs = lds4 + xb_i;
-            const uint4* whalf = lds4 + wb_i;
-            if (p.exp & 2) continue;
-            uint4 bh[2], bl[2], ah[2], al[2];
-            auto fetch = [&](int tap, int slot) __attribute__((always_inline)) {
-                const int ky = tap / 3, kx = tap % 3;
-                const int eo = (1 - (ky >> 1)) * CU_PW + (1 - (kx >> 1));
-                bh[slot] = xs[eo];
-                bl[slot] = xs[2 * CU_PATCH + eo];
-                ah[slot] = whalf[tap * 2 * CU_TN];
-                al[slot] = whalf[18 * CU_TN + tap * 2 * CU_TN];
-            };
-            fetch(0, 0);
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int cs = tap & 1;
-                if (tap + 1 < 9) fetch(tap + 1, cs ^ 1);
-                const int ai = 2 * ((tap / 3) & 1) + ((tap % 3) & 1);
-                accs[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[cs]), __builtin_bit_cast(bf16x8, bh[cs]), accs[ai], 0, 0, 0);
-                accs[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[cs]), __builtin_bit_cast(bf16x8, bl[cs]), accs[ai], 0, 0, 0);
-                accs[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[cs]), __builtin_bit_cast(bf16x8, bh[cs]), accs[ai], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-
-        // ---- epilogue: 8 output channels per pass through the pre-blur tile in LDS
-        int b, cot, tyt, txt;
-        {
-            const int* desc = reinterpret_cast<const int*>(epw + C::EP_DESC);
-            b = __builtin_amdgcn_readfirstlane(desc[0]); cot = __builtin_amdgcn_readfirstlane(desc[1]);
-            tyt = __builtin_amdgcn_readfirstlane(desc[2]); txt = __builtin_amdgcn_readfirstlane(desc[3]);
-        }
-        const int oy0 = tyt * CU_OUT + it_rg * 7, ox = txt * CU_OUT + it_x;
-        const bool it_ok = it_on && ox < wo && oy0 < ho && !(p.exp & 1);
-        const int nrow = it_ok ? (ho - oy0 < 7 ? ho - oy0 : 7) : 0;
-        const float neg = p.act ? 0.2f : 1.f, gain = p.act ? 1.41421356237309515f : 1.f;
-#pragma unroll 1
-        for (int g = 0; g < NPASS; ++g) {
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int col = 4 * khalf + rr;   // channel (within the group of 8) held by register 4g+rr of this half-wave
-                float v[4];
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {     // (g is a run-time index: select the register quartet without dynamic register indexing)
-                    const f32x16& A = accs[a];
-                    v[a] = g == 0 ? A[rr] : (g == 1 ? A[4 + rr] : (g == 2 ? A[8 + rr] : A[12 + rr]));
-                }
-#pragma unroll
-                for (int ci = 0; ci < 2; ++ci)
-                    *reinterpret_cast<float2*>(&zt[col * CU_ZCS + (2 * pty + ci) * CU_ZS + 2 * ptx]) = make_float2(v[2 * ci], v[2 * ci + 1]);
-            }
-            CH_BARRIER();
-            if (nrow > 0) {
-                const int cl = 8 * g + 2 * it_cp;                                    // first channel of the pair, inside the item's 32
-                const float* tab = epw + C::EP_D;
-                unsigned hi[7], lo[7];
-                float out2[2][7];
-#pragma unroll
-                for (int ch = 0; ch < 2; ++ch) {
-                    const float dd = tab[cl + ch], bi = tab[(C::EP_BIAS - C::EP_D) + cl + ch], sn = tab[(C::EP_SN - C::EP_D) + cl + ch];
-                    const float* zc = zt + (2 * it_cp + ch) * CU_ZCS + (it_rg * 7 + 1) * CU_ZS + it_x + 1;   // z row (local) of output row r, tap t: r + 1 + t
-                    float a[7];
-#pragma unroll
-                    for (int r = 0; r < 7; ++r) a[r] = 0.f;
-#pragma unroll
-                    for (int zr = 0; zr < 10; ++zr) {
-                        const float* zp = zc + zr * CU_ZS;
-                        const float z0 = zp[0], z1 = zp[1], z2 = zp[2], z3 = zp[3];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const int r = zr - t;
-                            if (r >= 0 && r < 7) {
-                                a[r] = __builtin_fmaf(z0, kf[t * 4], a[r]);
-                                a[r] = __builtin_fmaf(z1, kf[t * 4 + 1], a[r]);
-                                a[r] = __builtin_fmaf(z2, kf[t * 4 + 2], a[r]);
-                                a[r] = __builtin_fmaf(z3, kf[t * 4 + 3], a[r]);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 7; ++r) {
-                        float v = __builtin_fmaf(a[r], dd, bi) + __fmul_rn(nw, epw[C::EP_NOISE + (it_rg * 7 + r) * CU_OUT + it_x]);
-                        v = fmaxf(v, v * neg) * gain;
-                        out2[ch][r] = __fmul_rn(v, sn);
-                    }
-                }
-                const size_t o4 = (((size_t)b * (p.cout >> 3) + (size_t)(cot * 4 + g)) * ho * wo + (size_t)oy0 * wo + ox) * 4 + it_cp;   // dword index
-#pragma unroll
-                for (int r = 0; r < 7; ++r) split2(out2[0][r], out2[1][r], hi[r], lo[r]);
-#pragma unroll
-                for (int r = 0; r < 7; ++r)
-                    if (r < nrow) {
-                        p.out_sp[o4 + (size_t)r * wo * 4] = hi[r];
-                        p.out_sp[(size_t)p.plane_out * 4 + o4 + (size_t)r * wo * 4] = lo[r];
-                    }
-            }
-            CH_BARRIER();
-        }
-    }
-}
-
-template <int NCH, int NSTAGE>
-int launch_chain_up(ChainParams& p, hipStream_t st) {
-    using C = UpCfg<NCH, NSTAGE>;
-    auto kern = &chain_up_kernel<NCH, NSTAGE>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    if (attr != hipSuccess) return fail((int)attr, "chain_upconv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
-    hipLaunchKernelGGL(kern, dim3(chain_grid(p.ntile)), dim3(CT_NT), C::LDS_BYTES, st, p);
-    return check_launch("chain_upconv");
-}
 
 // fp32 activation -> split planes, modulated by s[b][c]: out[hl][b][c/8][p][c%8] = split(x[b][c][p] * s[b][c])
 __global__ __launch_bounds__(256) void to_split_planes_kernel(uint4* __restrict__ out, int64_t plane, const float* __restrict__ x, const float* __restrict__ s, int bs,
@@ -805,23 +523,4 @@ extern "C" int e4s_chain_conv3x3(const E4sChainLayer* L, void* stream) {
     if (L->cin == 64 && L->cout == 64 && rgb && osp) return launch_chain_conv<2, 4, false, 2, true, true>(p, st);
     return fail(E4S_ERR_ARG, "chain_conv3x3: no kernel for %d -> %d channels, rgb %d, out %d (built: 32 -> 32 + ToRGB, 64 -> 64 + ToRGB + split-plane output)",
                 L->cin, L->cout, (int)rgb, (int)osp);
-}
-
-extern "C" int e4s_chain_upconv(const E4sChainLayer* L, const float* blur, void* stream) {
-    E4S_REQUIRE(L && blur, "chain_upconv: null layer / blur kernel");
-    E4S_REQUIRE(L->x_sp && L->whi && L->wlo && L->d && L->out_sp && L->s_next, "chain_upconv: null tensor (d, out_sp and s_next are required)");
-    E4S_REQUIRE(!L->rgb_out, "chain_upconv: no fused ToRGB on up layers");
-    E4S_REQUIRE(L->bs >= 0 && L->bs <= 32768 && L->h >= 1 && L->w >= 1 && L->cout % CU_TN == 0 && L->cin % 16 == 0, "chain_upconv: bad size");
-    E4S_REQUIRE(!L->noise || (L->noise_weight && (L->noise_bs == 1 || L->noise_bs == L->bs)), "chain_upconv: noise needs its weight and batch 1 or bs");
-    E4S_REQUIRE((((uintptr_t)L->x_sp | (uintptr_t)L->whi | (uintptr_t)L->wlo | (uintptr_t)L->out_sp) & 15) == 0, "chain_upconv: tensors must be 16-byte aligned");
-    if (L->bs == 0) return 0;
-    ChainParams p;
-    if (int rc = fill_chain_params(p, L, 2 * L->h, 2 * L->w, "chain_upconv")) return rc;
-    p.blur = blur;
-    p.tiles_x = cdiv(2 * L->w, CU_OUT); p.tiles_y = cdiv(2 * L->h, CU_OUT);
-    p.ntile = p.tiles_x * p.tiles_y * (L->cout / CU_TN) * L->bs;
-    hipStream_t st = (hipStream_t)stream;
-    if (L->cin == 64) return launch_chain_up<4, 3>(p, st);
-    if (L->cin == 128) return launch_chain_up<8, 3>(p, st);
-    return fail(E4S_ERR_ARG, "chain_upconv: no kernel for %d input channels (built: 64, 128)", L->cin);
 }

@@ -271,7 +271,7 @@ __device__ __forceinline__ void sb_epilogue(const SbParams& p, unsigned char* ld
         }
     }
     if constexpr (RGB && WC_ == 2) {
-        // WC == 2 (modconv_mxe.hip: 2 x 64 channels per pixel in waves wc = 0 / 1): the upper channel half's partial sums cross through LDS behind the tables
+        // WC == 2 (2 x 64 channels per pixel in waves wc = 0 / 1): the upper channel half's partial sums cross through LDS behind the tables
         float* xch = snt + C::TN;                    // [3][NPB * 32]
         if (wc == 1 && khalf == 0) {
 #pragma unroll
@@ -298,7 +298,5 @@ __device__ __forceinline__ void sb_epilogue(const SbParams& p, unsigned char* ld
 
 // modconv_mx.hip: the DMA-fed 128 co x 256 px masked kernel (p.wmx set).  Returns E4S_OK or an error code.
 int launch_modconv_mx(SbParams& p, int arith, hipStream_t st, float* workspace, int64_t workspace_floats, bool plain_conv = false);
-// modconv_mxe.hip: the same tile on class-prepared operands (p.wmx = unit slots of e4s_modconv_prep_weights_mxe, p.whi = the row slots above for the tiles that fall back).
-int launch_modconv_mxe(SbParams& p, hipStream_t st, float* workspace, int64_t workspace_floats);
 
 }  // namespace e4s

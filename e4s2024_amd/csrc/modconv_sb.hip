@@ -547,8 +547,7 @@ static int region_modconv3x3_sb_impl(float* out, const float* x, const uint16_t*
                                      const float* act_bias, int act, int bs, int cin, int cout, int h, int w, int nreg, int up,
                                      float* workspace, int64_t workspace_floats, float* rgb_out, const float* rgb_wt, const float* rgb_s,
                                      const float* rgb_bias, const float* rgb_skip, const float* rgb_up_kernel, const float* s_next,
-                                     const uint8_t* uniform_blocks, const int* uniform_ctrl, const void* wmx, int arith, int* flags, void* stream,
-                                     const void* wmxe = nullptr) {
+                                     const uint8_t* uniform_blocks, const int* uniform_ctrl, const void* wmx, int arith, int* flags, void* stream) {
     const int layout = up & (E4S_X_NHWC | E4S_OUT_NHWC | E4S_OUT_SP);
     up &= 1;
     E4S_REQUIRE(!(layout & E4S_OUT_SP) || (s_next && rgb_out && out && cout % 8 == 0 && !(layout & E4S_OUT_NHWC) && ((uintptr_t)out & 15) == 0),
@@ -594,12 +593,7 @@ static int region_modconv3x3_sb_impl(float* out, const float* x, const uint16_t*
     if (wmx) {      // the DMA-fed masked kernel (modconv_mx.hip)
         E4S_REQUIRE(labels && w >= 32 && cout >= 128 && cin % CKS == 0 && !layout_in_out_nhwc(layout) && ((uintptr_t)wmx & 15) == 0 && (arith == 0 || arith == 1),
                     "region_modconv3x3_mx: built for masked layers of width >= 32, cout >= 128, cin %% 16 == 0, channels-first activations");
-        if (wmxe) {     // class-prepared operands (modconv_mxe.hip); wmx serves the tiles that fall back
-            E4S_REQUIRE(arith == 1 && cin % 32 == 0 && !uniform_blocks && ((uintptr_t)wmxe & 15) == 0, "region_modconv3x3_mxe: f16 + fp6 arithmetic, cin %% 32 == 0, no block map");
-            p.whi = reinterpret_cast<const uint4*>(wmx);
-            p.wmx = reinterpret_cast<const unsigned char*>(wmxe);
-            if (int rc = launch_modconv_mxe(p, st, ws, wf)) return rc;
-        } else if (int rc = launch_modconv_mx(p, arith, st, ws, wf)) return rc;
+        if (int rc = launch_modconv_mx(p, arith, st, ws, wf)) return rc;
         if (p.ksplit > 1) {
             const int64_t out_floats = (int64_t)bs * cout * ho * wo;
             const int g = (int)(cdiv64(out_floats, 256) < 2048 ? cdiv64(out_floats, 256) : 2048);
@@ -652,18 +646,6 @@ extern "C" int e4s_region_modconv3x3_mx(float* out, const float* x, const void* 
     E4S_REQUIRE(wmx, "region_modconv3x3_mx: null weights");
     return region_modconv3x3_sb_impl(out, x, nullptr, nullptr, s, d, labels, lh, lw, noise, noise_bs, noise_weight, act_bias, act, bs, cin, cout, h, w, nreg, up, workspace,
                                      workspace_floats, rgb_out, rgb_wt, rgb_s, rgb_bias, rgb_skip, rgb_up_kernel, s_next, uniform_blocks, uniform_ctrl, wmx, arith, flags, stream);
-}
-
-// The same layer with class-prepared operands (csrc/modconv_mxe.hip): `wmxe` from e4s_modconv_prep_weights_mxe; `wmx` (e4s_modconv_prep_weights_mx, arith 1) serves the
-// tiles with more than 512 (patch pixel, region) pairs, which run the kernel above's tile inside the same launch.  f16 + 2 x MX fp6 arithmetic; cin % 32 == 0.
-extern "C" int e4s_region_modconv3x3_mxe(float* out, const float* x, const void* wmxe, const void* wmx, int* flags, const float* s, const float* d,
-                                         const uint8_t* labels, int lh, int lw, const float* noise, int noise_bs, const float* noise_weight,
-                                         const float* act_bias, int act, int bs, int cin, int cout, int h, int w, int nreg, int up,
-                                         float* workspace, int64_t workspace_floats, float* rgb_out, const float* rgb_wt, const float* rgb_s,
-                                         const float* rgb_bias, const float* rgb_skip, const float* rgb_up_kernel, const float* s_next, void* stream) {
-    E4S_REQUIRE(wmxe && wmx, "region_modconv3x3_mxe: null weights");
-    return region_modconv3x3_sb_impl(out, x, nullptr, nullptr, s, d, labels, lh, lw, noise, noise_bs, noise_weight, act_bias, act, bs, cin, cout, h, w, nreg, up, workspace,
-                                     workspace_floats, rgb_out, rgb_wt, rgb_s, rgb_bias, rgb_skip, rgb_up_kernel, s_next, nullptr, nullptr, wmx, 1, flags, stream, wmxe);
 }
 
 // ============================================================================ single-region up layer in two launches

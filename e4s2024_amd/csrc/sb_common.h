@@ -41,7 +41,7 @@ __device__ __forceinline__ void dma4(const void* gbase, unsigned voff, lds_byte*
 __device__ __forceinline__ void dma16_asm(const void* gbase, unsigned voff, unsigned lds_dst) {
     unsigned keep;
     // (s_nop 2: with the two s_mov in front of it, five wait states between a VALU write of the base SGPRs — v_readlane of a spilled SGPR right in front of the block, which
-    //  hipcc's hazard pass cannot pair with an instruction inside it — and the vector-memory read of them; round 5, see modconv_mxe.hip)
+    //  hipcc's hazard pass cannot pair with an instruction inside it — and the vector-memory read of them; round 5)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(gbase), "s"(lds_dst)

@@ -136,7 +136,6 @@ class ModulatedConv2d(nn.Module):
         self._prepared_tconv = ops.PreparedWeights()
         self._prepared_mx = ops.PreparedMx()
         self._prepared_mx4 = ops.PreparedMx()      # the same weight as the four-parity up kernel reads it (arith 4)
-        self._prepared_mxe = ops.PreparedMx()      # ... as the entry kernel reads it (arith 6: csrc/modconv_mxe.hip)
         self._prepared_ubmx = ops.PreparedMx()     # ... as the region-uniform block kernel reads it (arith 7: csrc/modconv_upblock_mx.hip)
         self._prepared_hc = ops.PreparedHc()
 
@@ -207,7 +206,7 @@ class ModulatedConv2d(nn.Module):
                 and not torch.is_grad_enabled()):
             # region-uniform 16 x 16 output blocks run in the transposed-conv form on f16 + fp6 (csrc/modconv_upblock_mx.hip: a third preparation of the same weight)
             up_blocks = (self._prepared_ubmx.get(self.weight, None, False, 7), self.blur.kernel)
-        mx = mx4 = mxe = None
+        mx = mx4 = None
         if (self.kernel_size == 3 and not (x_nhwc or out_nhwc) and isinstance(wt, tuple)
                 and ops.mx_eligible(self.in_channel, self.out_channel, input.shape[-1], labels is not None)):
             arith = ops.mx_arith()         # the DMA-fed masked kernel (csrc/modconv_mx.hip), inference only
@@ -215,10 +214,8 @@ class ModulatedConv2d(nn.Module):
             if (self.upsample and arith == 1 and up_blocks is None and rgb is None
                     and ops.mx4_eligible(self.in_channel, self.out_channel, input.shape[-2], input.shape[-1], input.shape[0])):
                 mx4 = self._prepared_mx4.get(self.weight, self.blur.kernel, True, 4)      # the four-parity kernel's copy (csrc/modconv_mx4.hip)
-            if ops.mxe_eligible(self.in_channel, self.out_channel, input.shape[-1], labels is not None, self.upsample):
-                mxe = self._prepared_mxe.get(self.weight, None, False, 6)                  # class-prepared operands (csrc/modconv_mxe.hip)
         out = ops.region_modconv3x3(input, wt, s, d, labels, noise, noise_weight, act_bias, act, self.out_channel, self.upsample, rgb=rgb,
-                                    want_out=want_out, x_nhwc=x_nhwc, out_nhwc=out_nhwc, s_next=s_next, up_blocks=up_blocks, mx=mx, mx4=mx4, mxe=mxe)
+                                    want_out=want_out, x_nhwc=x_nhwc, out_nhwc=out_nhwc, s_next=s_next, up_blocks=up_blocks, mx=mx, mx4=mx4)
         if x_nhwc or out_nhwc or s_next is not None:
             return out              # inference only (Generator.forward takes this route under no_grad)
         if rgb is not None:

@@ -514,17 +514,6 @@ def mx_eligible(cin: int, cout: int, w: int, masked: bool) -> bool:
     return mx_arith() is not None and masked and w >= 32 and cout >= 128 and cin % 16 == 0 and not torch.is_grad_enabled()
 
 
-# Round 5: the masked same-resolution layers with class-prepared operands (csrc/modconv_mxe.hip): entries = (patch pixel, region) pairs prepared once per 32-channel chunk,
-# conversion-free two-phase K loop; tiles with more than 512 entries run the kernel above's tile inside the same launch.  OPT-IN (E4S_MXE=1): measured in round 5 it ties
-# with the round-3 kernel inside the pipeline (1 359-1 365 against 1 354-1 374 faces/s on the benchmark's maps, 0.90-0.97 of its time on portrait-shaped maps layer by
-# layer: DESIGN.md section 4) — the loop's VALU work is gone but its read phase (38 LDS reads + 4 DMA requests per unit) is longer than the MFMA phase beside it.
-MXE = os.environ.get("E4S_MXE", "0") != "0"
-
-
-def mxe_eligible(cin: int, cout: int, w: int, masked: bool, up: bool) -> bool:
-    return MXE and mx_arith() == 1 and mx_eligible(cin, cout, w, masked) and not up and cin % 32 == 0
-
-
 class PreparedMx(_Prepared):
     """A ModulatedConv2d weight as the row slots ``e4s_region_modconv3x3_mx`` DMAs (``e4s_modconv_prep_weights_mx``); rebuilt when the parameter,
     the blur buffer or the arithmetic changes.  Inference only (``mx_eligible``), so the copy is always cacheable."""
@@ -559,14 +548,6 @@ class PreparedMx(_Prepared):
             lib().call("e4s_upblock_mx_weight_bytes", cout, cin, ctypes.byref(nbytes))
             wmx = torch.empty((nbytes.value,), dtype=torch.uint8, device=w.device)
             lib().call("e4s_modconv_prep_weights_upblock_mx", _p(wmx), _p(w), cout, cin, _stream())
-            self._publish(key, (wmx,))
-            return wmx
-        if arith == 6:            # the entry kernel's unit slots (csrc/modconv_mxe.hip)
-            if plain:
-                raise ValueError("arith 6 (modconv_mxe) is a ModulatedConv2d layout")
-            lib().call("e4s_modconv_mxe_weight_bytes", cout, cin, 1 if up else 0, ctypes.byref(nbytes))
-            wmx = torch.empty((nbytes.value,), dtype=torch.uint8, device=w.device)
-            lib().call("e4s_modconv_prep_weights_mxe", _p(wmx), _p(w), _p(bk), cout, cin, 1 if up else 0, _stream())
             self._publish(key, (wmx,))
             return wmx
         if arith == 4:            # the four-parity up kernel's row slots (csrc/modconv_mx4.hip)
@@ -1029,12 +1010,10 @@ def uniform_blocks(labels: torch.Tensor, ho: int, wo: int, nreg: int, with_ctrl:
 
 
 def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: bool, cout: int, up: bool, rgb=None, want_out: bool = True,
-                      x_nhwc: bool = False, out_nhwc: bool = False, s_next=None, up_blocks=None, mx=None, mx4=None, mxe=None):
+                      x_nhwc: bool = False, out_nhwc: bool = False, s_next=None, up_blocks=None, mx=None, mx4=None):
     """``mx = (wmx, arith)`` (``PreparedMx``, a layer ``mx_eligible`` accepts): run on the DMA-fed kernel of csrc/modconv_mx.hip.
     ``mx4`` (with ``mx``, arith 1, an up layer ``mx4_eligible`` accepts; ``PreparedMx.get(..., arith=4)``): one launch of csrc/modconv_mx4.hip — the tiles whose
     positions' 2 x 2 outputs share a region as four-parity tiles, the others as the composed kernel's tiles (bit-identical results either way).
-    ``mxe`` (with ``mx``, arith 1; ``PreparedMx.get(..., arith=6)``, a layer ``mxe_eligible`` accepts): the launch of csrc/modconv_mxe.hip — class-prepared operands,
-    the tiles with too many (pixel, region) pairs as the round-3 kernel's tiles.
     ``rgb = (wt_rgb [cout,3], s_rgb [bs,1,cout], bias [1,3,1,1], skip or None, up_kernel)`` fuses the following single-region
     ToRGB; the call then returns ``(out, rgb_image)``.  ``want_out=False`` (with ``rgb``) skips writing the layer's own activation
     and returns ``(None, rgb_image)``.  ``x_nhwc`` / ``out_nhwc``: the activation is channel-blocked, ``[bs, c/8, h, w, 8]`` (split-bf16
@@ -1097,8 +1076,6 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
             evb.record()
         if UP_BLOCKS_ONLY_ONE_KERNEL == "blocks":
             return out
-    use_mxe = sb and mx is not None and mxe is not None and mx[1] == 1 and blocks is None and cin % 32 == 0 and not up
-    # (timing key: the entry kernel's launches count with the masked kernel they replace — bench.py prices the group as one kernel and says so)
     ev = _timed(modconv_kernel_name(cout, w, sb, labels is not None, cin, mx[1] if (sb and mx is not None) else None), f"{cin}->{cout} @{h}{' up' if up else ''}")
     rgb_out = None
     if rgb is not None:
@@ -1116,11 +1093,7 @@ def region_modconv3x3(x, wt, s, d, labels, noise, noise_weight, act_bias, act: b
         if labels is None or w < 32 or cout < 128 or cin % 16 or x_nhwc or out_nhwc:
             raise ValueError("region_modconv3x3: the mx kernel is built for masked layers of width >= 32, cout >= 128, cin % 16 == 0, channels-first")
         wmx, arith = mx
-        if use_mxe:
-            lib().call("e4s_region_modconv3x3_mxe", _p(out), _p(x), _p(mxe), _p(wmx), _p(mx_flags(x.device)), _p(s), _p(d), _p(labels), lh, lw,
-                       _p(nz), nbs or 0, _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg,
-                       (1 if up else 0) | (16 if sn is not None else 0), _p(ws), wsn, *rgb_args, _p(sn), _stream())
-        elif mx4 is not None and up and arith == 1 and blocks is None and rgb is None and sn is None and cout % 128 == 0:
+        if mx4 is not None and up and arith == 1 and blocks is None and rgb is None and sn is None and cout % 128 == 0:
             lib().call("e4s_region_upconv_mx4", _p(out), _p(x), _p(mx4), _p(wmx), _p(mx_flags(x.device)), _p(s), _p(d), _p(labels), lh, lw, _p(nz), nbs or 0,
                        _p(noise_weight) if nz is not None else None, _p(act_bias), 1 if act else 0, bs, cin, cout, h, w, nreg, _stream())
         else:
@@ -1184,38 +1157,6 @@ def chain_supported(cin: int, cout: int, h: int, w: int, up: bool, last: bool = 
     if up:
         return UP_FUSED and UP_TWO_STAGE and cin % 16 == 0 and cout % 32 == 0
     return (cin, cout) == ((32, 32) if last else (64, 64)) and h % 16 == 0 and w % 32 == 0
-
-
-def chain_upconv(x_sp: torch.Tensor, wt, d, blur, noise, noise_weight, act_bias, act: bool, cout: int, s_next) -> torch.Tensor:
-    """Single-region up-sampling ``StyledConv`` (transposed conv + blur) on split planes ``[2, bs, cin/8, h, w, 8]`` -> split planes of its
-    ``[bs, cout, 2h, 2w]`` activation, modulated by ``s_next [bs, 1, cout]`` for the next layer.  ``wt`` = bare 3x3 slabs
-    (``PreparedWeights.get(..., tconv=True)``)."""
-    from ._lib import ChainLayer
-    _req(x_sp, "x_sp", torch.int16)
-    if x_sp.dim() != 6 or x_sp.shape[0] != 2 or x_sp.shape[-1] != 8 or not x_sp.is_contiguous():
-        raise ValueError("chain_upconv: x_sp must be contiguous split planes [2, bs, C/8, H, W, 8]")
-    _, bs, cb, h, w, _ = x_sp.shape
-    L = ChainLayer()
-    dd, sn, bk = _c(d, "d").reshape(bs, cout), _c(s_next, "s_next").reshape(bs, cout), _c(blur, "blur kernel")
-    out_sp = _alloc_split_planes(bs, cout, 2 * h, 2 * w, x_sp.device)
-    keep = [x_sp, dd, sn, bk, out_sp]
-    L.x_sp, L.whi, L.wlo, L.d, L.out_sp, L.s_next = x_sp.data_ptr(), wt[0].data_ptr(), wt[1].data_ptr(), dd.data_ptr(), out_sp.data_ptr(), sn.data_ptr()
-    if noise is not None:
-        nz = _c(noise, "noise")
-        if nz.numel() != nz.shape[0] * 4 * h * w or nz.shape[0] not in (1, bs):
-            raise ValueError(f"noise shape {tuple(nz.shape)} does not match output {2 * h}x{2 * w}")
-        keep += [nz, noise_weight]
-        L.noise, L.noise_bs, L.noise_weight = nz.data_ptr(), nz.shape[0], noise_weight.data_ptr()
-    if act_bias is not None:
-        L.act_bias = act_bias.data_ptr()
-    L.act = 1 if act else 0
-    L.bs, L.cin, L.cout, L.h, L.w = bs, cb * 8, cout, h, w
-    ev = _timed(f"chain_upconv<{cb * 8}>")
-    lib().call("e4s_chain_upconv", ctypes.byref(L), _p(bk), _stream())
-    if ev is not None:
-        ev.record()
-    del keep
-    return out_sp
 
 
 def chain_conv3x3(x_sp: torch.Tensor, wt, d, noise, noise_weight, act_bias, act: bool, cout: int, s_next=None, rgb=None):

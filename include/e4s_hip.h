@@ -177,21 +177,6 @@ E4S_API int e4s_modconv_prep_weights_upblock_mx(void* dst, const float* weight, 
 E4S_API int e4s_masked_upconv_blocks_mx(float* out, const float* x, const void* wmx, int* flags, const float* s, const float* d, const uint8_t* blocks, const int* ctrl,
                                         const float* blur, const float* noise, int noise_bs, const float* noise_weight, const float* act_bias, int act, int bs, int cin,
                                         int cout, int h, int w, int nreg, void* stream);
-/* Round 5: the same masked layer (models/stylegan2/model.py:276-320, 385-400) with CLASS-PREPARED operands (csrc/modconv_mxe.hip): the unit of staging is an entry =
- * (patch pixel, region) for every region that occurs among the output pixels reading that patch pixel; x * s[region] is split into f16 + two MX-fp6 terms ONCE per entry
- * and 32-channel chunk, and the K loop (conv_mx3's two-phase loop) only reads LDS and issues MFMAs.  A 32 x 8-pixel tile with more than 512 entries runs the tile of
- * e4s_region_modconv3x3_mx inside the same launch (wmx: e4s_modconv_prep_weights_mx(up, arith 1)).  wmxe from e4s_modconv_prep_weights_mxe (size
- * e4s_modconv_mxe_weight_bytes); cin % 32 == 0, cout >= 128, w >= 32; every other argument as for e4s_region_modconv3x3_mx (up: bit 0 = up layer in the composed
- * four-parity form, bit 4 = split-plane output with the fused ToRGB). */
-E4S_API int e4s_modconv_mxe_weight_bytes(int cout, int cin, int up, int64_t* bytes);
-E4S_API int e4s_modconv_prep_weights_mxe(void* dst, const float* weight, const float* blur, int cout, int cin, int up, void* stream);
-E4S_API int e4s_region_modconv3x3_mxe(float* out, const float* x, const void* wmxe, const void* wmx, int* flags, const float* s, const float* d,
-                                      const uint8_t* labels, int lh, int lw,
-                                      const float* noise, int noise_bs, const float* noise_weight, const float* act_bias, int act,
-                                      int bs, int cin, int cout, int h, int w, int nreg, int up,
-                                      float* workspace, int64_t workspace_floats,
-                                      float* rgb_out, const float* rgb_wt, const float* rgb_s, const float* rgb_bias, const float* rgb_skip,
-                                      const float* rgb_up_kernel, const float* s_next, void* stream);
 /* The regional-style encoder's stride-1, pad-1 3x3 convolutions (models/encoders/helpers.py:128-139) on the same kernel in its plain-convolution mode:
  *   out[bs,cout,h,w] = PReLU( conv3x3( (x - in_mean[b,ci]) * in_rstd[b,ci], W ) )          in_mean / in_rstd (together) and prelu_slope optional
  * cin % 16 == 0; padding is exactly 0 (the normalisation applies to in-image pixels only).  wmx from e4s_conv_prep_weights_mx (weight [cout,cin,3,3],
@@ -278,8 +263,7 @@ E4S_API int e4s_modconv_up_fused_sb(float* out, const float* x, const uint16_t* 
  *   e4s_chain_conv3x3   : StyledConv (same resolution) reading split planes; out_sp (optional) = its activation as split planes modulated
  *                         by s_next[bs][cout]; rgb_* (optional) = the following single-region ToRGB fused as in e4s_region_modconv3x3_sb.
  *                         h % 16 == 0, w % 32 == 0; built for 32 -> 32 and 64 -> 64 channels (the 1024 / 512 stages of Generator(1024)).
- *   e4s_chain_upconv    : the up-sampling StyledConv (transposed conv + 4x4 blur, model.py:287-300) reading split planes [bs,cin,h,w],
- *                         writing its [bs,cout,2h,2w] activation as split planes; built for 128 -> 64 and 64 -> 32 channels.
+ *   (the chain's up-sampling layers: e4s_modconv_up_hc below; a rank-1 blur kernel is required there, anything else takes e4s_modconv_up_fused_sb)
  * L is a HOST struct; every pointer inside is a device pointer.  whi / wlo from e4s_modconv_prep_weights_sb(up = 0). */
 typedef struct E4sChainLayer {
     const uint16_t* x_sp;
@@ -301,7 +285,6 @@ typedef struct E4sChainLayer {
 } E4sChainLayer;
 E4S_API int e4s_to_split_planes(uint16_t* out_sp, const float* x, const float* s, int bs, int c, int h, int w, int x_nhwc, void* stream);
 E4S_API int e4s_chain_conv3x3(const E4sChainLayer* L, void* stream);
-E4S_API int e4s_chain_upconv(const E4sChainLayer* L, const float* blur, void* stream);
 
 /* The chain's up layer in the HALF-COMPOSED form (csrc/modconv_uphc.hip; model.py:287-301 + 417-421, single-region case).  The 4 x 4 blur of the
  * reference is an outer product kv x kh (model.py:23-31 make_kernel of a 1-D list): its VERTICAL factor is composed into the weights — two output-row

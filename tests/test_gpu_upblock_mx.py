@@ -1,7 +1,7 @@
-"""GPU parity of the entry kernel (csrc/modconv_mxe.hip, round 5): the masked 3x3 layer with class-prepared operands against the faithful CPU oracle
-(models/stylegan2/model.py:385-400 restated in oracle/e4s_oracle.py) and against the round-3 kernel it replaces, on every kind of region map: cells of 16 / 8 /
-4 pixels (4 and finer: the workgroup falls back to the round-3 tile inside the launch), one region, portrait-shaped maps, i.i.d. labels (all tiles fall back),
-region-less pixels, ragged sizes, an output-channel tail, the split-K route, the fused ToRGB + split-plane hand-over of the 256 x 256 layer."""
+"""GPU parity of the region-uniform block kernel of the masked up layers (csrc/modconv_upblock_mx.hip, round 5: f16 + 2 x MX-fp6) against the faithful CPU oracle
+(models/stylegan2/model.py:385-400 restated in oracle/e4s_oracle.py) and against the all-composed route, and a two-stream back-to-back stress of the DMA-fed
+kernels (the asm-issued request hazard of round 5, csrc/sb_common.h).  (The entry kernel csrc/modconv_mxe.hip these tests also covered in round 5 tied with
+the kernel it was to replace; round 6's loop probe — profiles/r06_tile_probe.txt — says why, and it was deleted.)"""
 import numpy as np
 import pytest
 import torch
@@ -10,10 +10,10 @@ from conftest import install_dropin, record_parity
 from e4s2024_amd import ops, seeded
 from oracle import e4s_oracle as O
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(ops.MODCONV_MODE != "sb" or ops.MX_MODE < 2, reason="the entry kernel is the f16 + fp6 route of the split-arithmetic kernels")]
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(ops.MODCONV_MODE != "sb" or ops.MX_MODE < 2, reason="the block kernel is the f16 + fp6 route of the split-arithmetic kernels")]
 DEV = "cuda:0"
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
-MXE_LAYER_TOL = 2e-4      # of the layer's output scale: the single-layer bar of tests/test_gpu_mx.py
+UB_LAYER_TOL = 2e-4      # of the layer's output scale: the single-layer bar of tests/test_gpu_mx.py
 
 
 @pytest.fixture(scope="module")
@@ -21,16 +21,6 @@ def sg2():
     install_dropin()
     from models.stylegan2 import model
     return model
-
-
-@pytest.fixture
-def mxe_switch():
-    keep = ops.MXE
-
-    def set_(v):
-        ops.MXE = v
-    yield set_
-    ops.MXE = keep
 
 
 class _Calls:
@@ -90,95 +80,6 @@ def _layer(sg2, shape, kind, seed, hole=True):
     return m.to(DEV), sd, x, st, lab, onehot, nz
 
 
-#        bs cin cout  h   w  nreg lh  lw
-SHAPES = [(2, 64, 128, 32, 32, 5, 32, 32),         # one tile row of workgroups per image, one output-channel tile
-          (1, 96, 136, 40, 36, 12, 80, 72),        # ragged: partial tiles, an output-channel tail (two co tiles), labels at twice the resolution
-          (1, 512, 512, 32, 32, 12, 512, 512),     # the 32 x 32 layer of the generator: long K, split over workgroups
-          (3, 32, 256, 64, 64, 7, 64, 64),         # one chunk
-          (2, 128, 128, 128, 64, 12, 128, 64)]     # several tile rows and columns
-KINDS = ["cells16", "cells8", "cells4", "one", "portrait", "iid"]
-
-
-@pytest.mark.parametrize("shape", SHAPES)
-@pytest.mark.parametrize("kind", KINDS)
-def test_entry_kernel_against_the_oracle_and_the_round3_kernel(sg2, mxe_switch, shape, kind):
-    m, sd, x, st, lab, onehot, nz = _layer(sg2, shape, kind, 17 * shape[1] + shape[3] + len(kind))
-    ys = {}
-    with torch.no_grad():
-        for on in (False, True):
-            mxe_switch(on)
-            with _Calls() as calls:
-                ys[on] = m(x.to(DEV), st.to(DEV), T(lab).to(DEV), noise=nz.to(DEV)).cpu()
-            assert ("e4s_region_modconv3x3_mxe" in calls.names) == on, calls.names
-    ref = O.styled_conv(sd, "", x, st, onehot, nz, masked=True, upsample=False)
-    scale = max(1.0, float(ref.abs().max()))
-    e_new = float((ys[True] - ref).abs().max()) / scale
-    e_old = float((ys[False] - ref).abs().max()) / scale
-    record_parity(f"mxe_layer_{kind}_{shape[1]}to{shape[2]}_{shape[3]}x{shape[4]}", e_new, MXE_LAYER_TOL,
-                  note=f"class-prepared operands against the oracle, relative to the output scale {scale:.1f}; the round-3 kernel on the same layer: {e_old:.2e}")
-    assert e_new <= MXE_LAYER_TOL, (shape, kind, e_new, e_old)
-    assert torch.isfinite(ys[True]).all()
-    assert not ops.mx_overflowed()
-
-
-def test_entry_kernel_is_bit_stable_and_all_fallback_maps_equal_the_round3_kernel(sg2, mxe_switch):
-    """Repeated launches give the same bits; with i.i.d. labels every 32 x 8 tile has more than 512 (pixel, region) pairs, so every workgroup runs the round-3
-    tile: the layer's output must then EQUAL that kernel's."""
-    shape = (2, 128, 128, 64, 64, 12, 64, 64)
-    m, sd, x, st, lab, onehot, nz = _layer(sg2, shape, "cells8", 3)
-    mxe_switch(True)
-    with torch.no_grad():
-        a = m(x.to(DEV), st.to(DEV), T(lab).to(DEV), noise=nz.to(DEV))
-        for _ in range(5):
-            assert torch.equal(a, m(x.to(DEV), st.to(DEV), T(lab).to(DEV), noise=nz.to(DEV)))
-    shape = (3, 128, 128, 128, 128, 12, 128, 128)          # (enough workgroups that neither launcher splits K: the same sums in the same order)
-    m, sd, x, st, lab, onehot, nz = _layer(sg2, shape, "iid", 4, hole=False)
-    with torch.no_grad():
-        mxe_switch(True)
-        y1 = m(x.to(DEV), st.to(DEV), T(lab).to(DEV), noise=nz.to(DEV))
-        mxe_switch(False)
-        y0 = m(x.to(DEV), st.to(DEV), T(lab).to(DEV), noise=nz.to(DEV))
-    assert torch.equal(y0, y1)
-
-
-def test_entry_kernel_raises_the_f16_flag(sg2, mxe_switch):
-    m, sd, x, st, lab, onehot, nz = _layer(sg2, SHAPES[0], "cells8", 9)
-    mxe_switch(True)
-    with torch.no_grad():
-        m(x.to(DEV), st.to(DEV), T(lab).to(DEV), noise=nz.to(DEV))
-        assert not ops.mx_overflowed()
-        m((x * 3.0e4).to(DEV), st.to(DEV), T(lab).to(DEV), noise=nz.to(DEV))       # |x * s| well past 65504
-        assert ops.mx_overflowed()
-        assert not ops.mx_overflowed()
-
-
-@pytest.mark.parametrize("labels", ["blocky", "portrait"])
-def test_generator256_with_the_fused_torgb_layer_on_the_entry_kernel(sg2, mxe_switch, labels):
-    """Generator(256): its 32 ... 256 masked same-resolution layers, the last of them with the fused single-region ToRGB and the split-plane hand-over to the
-    chain (csrc/modconv_sb.h's epilogue with two wave groups per pixel) — pixels against the round-3 kernel's and against the oracle."""
-    torch.manual_seed(3)
-    g = sg2.Generator(256, 512, 8, remaining_layer_idx=9).eval()
-    seeded.apply_seeded(g, 21, "net3", prefix="G.")
-    sd = {"G." + k: v.clone() for k, v in g.state_dict().items()}
-    g = g.to(DEV)
-    codes = seeded.seeded_codes(1, 2, 12, g.n_latent, seeded.seeded_latent_avg(2, g.n_latent))
-    lab = seeded.blocky_labels(3, 2, 12, 512, 16) if labels == "blocky" else seeded.facelike_labels(3, 2, 512)
-    mask = seeded.labels_to_onehot(lab, 12)
-    imgs = {}
-    with torch.no_grad():
-        for on in (False, True):
-            mxe_switch(on)
-            with _Calls() as calls:
-                imgs[on] = g([codes.to(DEV)], None, mask.to(DEV), input_is_latent=True, randomize_noise=False)[0].cpu()
-            assert ("e4s_region_modconv3x3_mxe" in calls.names) == on
-        ref, _ = O.generator_forward(sd, codes, mask, None, size=256, remaining_layer_idx=9)
-    d_old = float((imgs[False] - ref).abs().max())
-    d_new = float((imgs[True] - ref).abs().max())
-    record_parity(f"mxe_generator256_{labels}_vs_oracle", d_new, 1e-3, note=f"pixels; the round-3 kernel on the same inputs: {d_old:.2e}")
-    assert d_new <= 1e-3
-    assert float((imgs[True] - imgs[False]).abs().max()) <= 5e-4
-
-
 # ---------------------------------------------------------------------------------------------- region-uniform blocks of the masked up layers on f16 + fp6
 #             bs cin cout  h   w  nreg lh  lw
 UB_SHAPES = [(2, 32, 128, 32, 32, 5, 64, 64),          # one chunk
@@ -232,14 +133,14 @@ def test_uniform_block_kernel_on_f16_fp6_against_the_oracle_and_the_composed_for
     scale = max(1.0, float(ref.abs().max()))
     e_new = float((ys[True] - ref).abs().max()) / scale
     e_old = float((ys[False] - ref).abs().max()) / scale
-    record_parity(f"upblock_mx_{cin}to{cout}_{h}x{w}", e_new, MXE_LAYER_TOL, note=f"f16 + fp6 block kernel against the oracle, relative to the output scale {scale:.1f}; the all-composed route: {e_old:.2e}")
-    assert e_new <= MXE_LAYER_TOL and torch.isfinite(ys[True]).all(), (shape, e_new, e_old)
+    record_parity(f"upblock_mx_{cin}to{cout}_{h}x{w}", e_new, UB_LAYER_TOL, note=f"f16 + fp6 block kernel against the oracle, relative to the output scale {scale:.1f}; the all-composed route: {e_old:.2e}")
+    assert e_new <= UB_LAYER_TOL and torch.isfinite(ys[True]).all(), (shape, e_new, e_old)
     assert not ops.mx_overflowed()
 
 
-def test_new_kernels_back_to_back_on_two_streams_keep_their_bits(sg2, mxe_switch):
+def test_dma_fed_kernels_back_to_back_on_two_streams_keep_their_bits(sg2):
     """The hazard of round 5 (a VALU-written SGPR read by an asm-issued vector-memory request five wait states too early, csrc/sb_common.h) showed only under
-    back-to-back launches: the entry kernel and the region-uniform block kernel, 60 launches each, alternating over two HIP streams with nothing between them —
+    back-to-back launches: the masked same-resolution kernel and the region-uniform block kernel, 60 launches each, alternating over two HIP streams with nothing between them —
     every output equals the first one's bits, nothing faults, the f16 flag stays down."""
     shape = (2, 128, 128, 64, 64, 12, 64, 64)
     m1, _, x1, st1, lab1, _, nz1 = _layer(sg2, shape, "cells8", 21)
@@ -258,7 +159,6 @@ def test_new_kernels_back_to_back_on_two_streams_keep_their_bits(sg2, mxe_switch
     a2 = (x2, st2, T(lab2).to(DEV), nz2)
     keep = (ops.UP_BLOCKS, ops.UP_BLOCKS_MIN_WIDTH, ops.UP_BLOCKS_MIN_PERCENT, ops.UP_BLOCKS_MIN_PERCENT_SMALL)
     ops.UP_BLOCKS, ops.UP_BLOCKS_MIN_WIDTH, ops.UP_BLOCKS_MIN_PERCENT, ops.UP_BLOCKS_MIN_PERCENT_SMALL = True, 32, 1, 1
-    mxe_switch(True)
     ops.mx_overflowed()
     streams = [torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)]
     try:
@@ -266,7 +166,7 @@ def test_new_kernels_back_to_back_on_two_streams_keep_their_bits(sg2, mxe_switch
             with _Calls() as calls:
                 r1 = m1(a1[0], a1[1], a1[2], noise=a1[3])
                 r2 = m2(a2[0], a2[1], a2[2], noise=a2[3])
-            assert "e4s_region_modconv3x3_mxe" in calls.names and "e4s_masked_upconv_blocks_mx" in calls.names, calls.names
+            assert "e4s_region_modconv3x3_mx" in calls.names and "e4s_masked_upconv_blocks_mx" in calls.names, calls.names
             torch.cuda.synchronize()
             outs = []
             for i in range(60):

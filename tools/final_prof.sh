@@ -1,10 +1,11 @@
 # Round evidence: GPU test suite, default bench line, kernel-trace stats of the bench / full swap / PTI, three PMC passes of the bench.
 # Everything lands as small text / JSON under gpurun_out/ (copy what is to be judged into profiles/); the result databases are deleted on the box.
-# usage: bash tools/final_prof.sh <tag>      (e.g. r05_final)
-export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; T=${1:-r05_final}; mkdir -p $R/gpurun_out; cd $R
+# usage: bash tools/final_prof.sh <tag>      (e.g. r06_final)
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; T=${1:-r06_final}; mkdir -p $R/gpurun_out; cd $R
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/${T}_gpu_tests.txt; cat gpurun_out/${T}_gpu_tests.txt
 cp gpurun_out/parity.json gpurun_out/${T}_parity.json 2>/dev/null
 timeout 900 python bench.py 2> gpurun_out/${T}_bench.err | grep '^{' > gpurun_out/${T}_bench.json; cut -c1-300 gpurun_out/${T}_bench.json
+cp gpurun_out/bench_detail.json gpurun_out/${T}_bench_detail.json 2>/dev/null      # (the compact line is what the driver sees; the detail object carries by_layer, in_run_ab ...)
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench -o bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-in-run-ab --no-full-swap --no-pti --clip 0 --soak-seconds 0 > $R/gpurun_out/prof_bench.log 2>&1
 grep '^{' $R/gpurun_out/prof_bench.log > $R/gpurun_out/${T}_bench_under_rocprof.json
@@ -29,9 +30,6 @@ rm -rf gpurun_out/prof_pti
 bash tools/pmc_pass.sh "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" pmc_sq
 cd $R; python tools/rocpd_pmc.py gpurun_out/pmc_sq/pmc_results.db region_modconv > gpurun_out/${T}_pmc_sq.txt; python tools/rocpd_pmc.py gpurun_out/pmc_sq/pmc_results.db region_upconv >> gpurun_out/${T}_pmc_sq.txt; python tools/rocpd_pmc.py gpurun_out/pmc_sq/pmc_results.db up_hc >> gpurun_out/${T}_pmc_sq.txt; python tools/rocpd_pmc.py gpurun_out/pmc_sq/pmc_results.db masked_up_block >> gpurun_out/${T}_pmc_sq.txt
 python tools/rocpd_pmc.py gpurun_out/pmc_sq/pmc_results.db chain_conv >> gpurun_out/${T}_pmc_sq.txt; rm -rf gpurun_out/pmc_sq
-# the same counters with the opt-in entry kernel on the masked same-resolution layers (E4S_MXE=1: csrc/modconv_mxe.hip)
-E4S_MXE=1 bash tools/pmc_pass.sh "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" pmc_sq_mxe
-cd $R; python tools/rocpd_pmc.py gpurun_out/pmc_sq_mxe/pmc_results.db region_conv_mxe > gpurun_out/${T}_pmc_sq_mxe.txt; rm -rf gpurun_out/pmc_sq_mxe
 bash tools/pmc_pass.sh "FETCH_SIZE" pmc_fetch
 cd $R; python tools/rocpd_pmc.py gpurun_out/pmc_fetch/pmc_results.db > gpurun_out/${T}_pmc_fetch.txt; rm -rf gpurun_out/pmc_fetch
 bash tools/pmc_pass.sh "WRITE_SIZE" pmc_write

@@ -95,8 +95,9 @@ def chain_up(cin, cout, res):
     nw, ab = torch.tensor([0.1], device=dev), torch.randn(cout, device=dev)
     s_next = torch.randn(bs, 1, cout, device=dev)
     xsp = ops.to_split_planes(x, s)
+    hc = ops.PreparedHc().get(w, blur)
     del x
-    run(f"chain up {cin}->{cout} @{res}->{2 * res}", lambda: ops.chain_upconv(xsp, wt, d, blur, noise, nw, ab, True, cout, s_next), 2.0 * cin * cout * 9 * res * res * bs)
+    run(f"chain up {cin}->{cout} @{res}->{2 * res}", lambda: ops.modconv_up_single(xsp, wt, s, d, blur, noise, nw, ab, True, cout, s_next=s_next, hc=hc), 2.0 * cin * cout * 9 * res * res * bs)
 
 
 chain_conv(32, 1024, False)

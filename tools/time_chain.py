@@ -78,7 +78,8 @@ def up_case(cin, cout, res, bs=4):
     xn = to_blocked(x)
     old = lambda: ops.modconv_up_single(xn, wt, s, d, blur, noise, nw, ab, True, cout, x_nhwc=True, out_nhwc=True)
     xsp = ops.to_split_planes(x, s)
-    new = lambda: ops.chain_upconv(xsp, wt, d, blur, noise, nw, ab, True, cout, s_next)
+    hc = ops.PreparedHc().get(w, blur)
+    new = lambda: ops.modconv_up_single(xsp, wt, s, d, blur, noise, nw, ab, True, cout, s_next=s_next, hc=hc)
     o_old, o_new = old(), new()
     ref_sp = ops.to_split_planes(o_old, s_next, x_nhwc=True)
     a_, b_ = ops.from_split_planes(ref_sp), ops.from_split_planes(o_new)
