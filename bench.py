@@ -124,7 +124,7 @@ def _by_layer(kt, kernel, bs, peak, uniform_frac):
     return rows
 
 
-TRAFFIC_FILE = "profiles/r05_traffic.json"
+TRAFFIC_FILE = "profiles/r06_traffic.json"
 
 
 def _pmc_traffic(kernel_key):
