@@ -367,9 +367,12 @@ class StreamPipeline:
     def _copy_into(dst, src, depth=0):
         if isinstance(dst, torch.Tensor):
             dst.copy_(src)
-        elif isinstance(dst, (tuple, list)) and depth < 2:
+        elif isinstance(dst, (tuple, list)) and depth < 3:
             for d, s_ in zip(dst, src):
                 StreamPipeline._copy_into(d, s_, depth + 1)
+        elif isinstance(dst, dict) and depth < 3:
+            for k in dst:
+                StreamPipeline._copy_into(dst[k], src[k], depth + 1)
 
     def _reap(self, block: bool = False, everything: bool = False):
         """Check the pending guards in submission order: those whose "after" snapshot has landed (all of them when ``everything``; the oldest one in any case

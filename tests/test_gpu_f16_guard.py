@@ -71,6 +71,43 @@ def test_generator_heals_an_f16_overflow(hostile_layer):
     assert (img2.cpu() - ref2).abs().max().item() <= 1e-3
 
 
+def test_stream_pipeline_heals_the_calls_nobody_checked():
+    """``runner.StreamPipeline.submit`` owns each call's guard; a caller that never looks at ``sp.guards`` must still get right frames: the pipeline re-runs a
+    tripped call under ``ops.mx_exact()`` and copies the exact results INTO the tensors it returned (round-5 advisor finding).  Four calls on two streams, calls
+    1 and 3 through a hostile generator: healed in place, listed in ``sp.healed``, counted; the healthy calls untouched; a guard the caller checked is left alone."""
+    if ops.mx_arith() != 1:
+        pytest.skip("the f16 + fp6 arithmetic is off (E4S_MX)")
+    from e4s2024_amd.runner import StreamPipeline
+    size, rli, bs = 256, 13, 1
+    good, sd_good = _generator(size, rli)
+    bad, sd_bad = _generator(size, rli, 5)
+    codes, mask = _inputs(size, bs)
+    refs = [O.generator_forward(sd, codes, mask, None, size=size, remaining_layer_idx=rli, split_layer_idx=5)[0] for sd in (sd_good, sd_bad)]
+    good, bad = good.to(DEV).eval(), bad.to(DEV).eval()
+    c, m = codes.to(DEV), mask.to(DEV)
+
+    def run(gen):
+        with torch.no_grad():
+            return gen([c], None, m, input_is_latent=True, randomize_noise=False)[0]
+    before = ops.mx_fallbacks
+    with StreamPipeline(2, device=DEV) as sp:
+        outs = [sp.submit(run, g) for g in (good, bad, good, bad)]
+    torch.cuda.synchronize()
+    # (the counter the guards watch is device-wide: a healthy call whose window overlapped a hostile call's on the other stream trips too and is healed as well —
+    #  conservative, never a missed overflow; ops.mx_false_trips counts those)
+    assert {1, 3} <= set(sp.healed) and ops.mx_fallbacks == before + len(sp.healed)
+    assert sp.guards[1].tripped() and sp.guards[3].tripped() and not sp.guards[0].tripped()      # (verdicts: the guards' pinned words are gone)
+    for i, o in enumerate(outs):
+        assert torch.isfinite(o).all()
+        assert (o.cpu() - refs[i & 1]).abs().max().item() <= 1e-3, i
+    # a caller that checks a guard itself keeps the call: the pipeline does not heal it a second time
+    with StreamPipeline(2, device=DEV) as sp:
+        o = sp.submit(run, bad)
+        assert sp.guards[0].tripped()
+    assert sp.healed == [] and sp.tripped_calls() == [0]
+    assert not (torch.isfinite(o).all() and (o.cpu() - refs[1]).abs().max().item() <= 1e-3), "the unhealed call really is broken"
+
+
 def test_trained_like_gains_show_where_the_default_path_trips():
     """Per-layer activation magnitudes 10^2 .. 10^5 (seeded weights x a growing modulation gain): below the f16 range the default path holds the bar
     without a re-run, above it the guard takes over; either way the pixels stay within 1e-3 of the fp32 oracle."""
