@@ -243,7 +243,7 @@ def _compact_line(line, one_stream, ksum, steps, detail_path):
     out["roofline"] = r
     out["cpu_baseline"] = scalars(line.get("cpu_baseline"), {"value", "unit", "cores", "kind", "sample", "max_abs_pixel_diff_vs_gpu"})
     if out["cpu_baseline"] and "sample" in out["cpu_baseline"]:
-        out["cpu_baseline"]["sample"] = short(out["cpu_baseline"]["sample"], 90)
+        out["cpu_baseline"]["sample"] = short(out["cpu_baseline"]["sample"], 56)
     # stage split of a one-stream step (ms): masked 3x3 layers 32^2..256^2, the single-region >= 512^2 stage, everything else (4^2-16^2 head, ToRGBs, tables)
     stage = None
     if ksum and one_stream:
@@ -256,6 +256,11 @@ def _compact_line(line, one_stream, ksum, steps, detail_path):
     out["soak_faces_per_s"] = get(line, "soak", "faces_per_s")
     out["soak_power_w"] = get(line, "soak", "board", "power_w")
     out["soak_sclk_mhz"] = get(line, "soak", "board", "sclk_mhz")
+    # at the board's power limit the honest ceiling is the nominal one scaled by the clock the board grants (2 400 MHz nominal), and the figure of merit is energy per face
+    pw, ck, fps = out["soak_power_w"], out["soak_sclk_mhz"], out["soak_faces_per_s"]
+    if r is not None and ck:
+        r["frac_at_soak_sclk"] = round(r["frac"] * 2400.0 / ck, 4)
+    out["soak_joules_per_face"] = round(pw / fps, 3) if (pw and fps) else None
     fs = line.get("full_swap") or {}
     out["full_swap_p50_ms_per_frame"] = fs.get("p50_ms_per_frame")
     out["full_swap_swaps_per_s"] = fs.get("swaps_per_s")
@@ -271,7 +276,7 @@ def _compact_line(line, one_stream, ksum, steps, detail_path):
     msn = line.get("mask_sensitivity") or {}
     out["mask_faces_per_s"] = {k.split("_")[0]: v.get("faces_per_s") for k, v in msn.items()} or None
     out["f16_overflowed"] = get(line, "f16_range", "overflowed_in_the_measured_passes")
-    out["detail"] = "stderr" + (" + gpurun_out/bench_detail.json" if detail_path else "")
+    out["detail"] = "stderr" + (", gpurun_out/bench_detail.json" if detail_path else "")
     return out
 
 
