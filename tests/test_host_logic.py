@@ -189,6 +189,44 @@ def test_bench_flop_accounting():
     assert abs((sum(fl.values()) + rgb) / 1e9 - 148.52) < 0.05
 
 
+def test_bench_compact_line_fits_the_drivers_window_whatever_the_detail_holds():
+    """bench.py prints ONE line on stdout and the driver keeps its last 2 000 characters: the compact line must stay below that with every secondary leg present,
+    with legs that failed (error strings), and with none; it carries the contract fields and both headline metrics of BASELINE.json as flat scalars."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    long = "x" * 900
+    base = {"metric": "1024x1024 faces/sec (StyleGAN2 regional synthesis, gen_img)", "value": 12345.678, "unit": "faces/s", "n_gpus": 8, "steps": 20, "warmup": 5,
+            "ms_per_step": 12.345, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16+mxfp6x2 (masked 3x3 layers >= 32^2) / bf16x3 (all other layers)",
+            "data": "synthetic", "config": {"workload": long, "batch_per_gpu": 4, "global_batch": 32, "parallelism": "frames x8", "streams_per_gpu": 2, "step_overlap": long}}
+    roof = {"bound": "mfma", "kernel": "region_modconv_mx_kernel<1>", "kernel_launches": long, "achieved": 1234.56, "peak": 1500.0, "unit": "TFLOP/s", "frac": 0.1234,
+            "traffic": 273230028, "traffic_source": long, "peak_basis": long, "whole_job_frac": 0.1909, "launches_per_step": 7, "avg_launch_ms": 0.1834,
+            "algorithmic_gflop_per_launch": 44.177, "in_overlapped_region": {"avg_launch_ms": 0.3032}, "by_layer": [{"layer": long}] * 7, "in_run_ab": {"what": long},
+            "all_modconv3x3": {"by_kernel_ms_per_step": {"region_modconv_mx_kernel<1>": 1.3, "modconv_up_hc": 0.55, "chain_conv3x3<32>": 0.29}}}
+    full = dict(base, roofline=roof, one_stream={"faces_per_s": 1294.9, "ms_per_step": 3.089, "what": long}, soak={"faces_per_s": 1407.4, "board": {"power_w": 1223.0, "sclk_mhz": 2046.0}},
+                cpu_baseline={"value": 0.3661, "unit": "faces/s", "cores": 16, "host_hardware_threads": 256, "kind": "port", "sample": long, "max_abs_pixel_diff_vs_gpu": 1.997e-4},
+                full_swap={"p50_ms_per_frame": 2.115, "swaps_per_s": 472.8, "overlapped_batches": {"ms_per_frame": 2.008}, "roofline": {"frac": 0.2402, "peak_basis": long},
+                           "parity": {"max_abs_pixel_diff_vs_oracle": 2.066e-4, "parser_label_flips_vs_oracle": 0, "how": long}, "unit_of_work": long},
+                pti={"s_per_iter": 0.01213, "roofline": {"frac": 0.0441, "what": long}, "how": long, "clip_loop": {"what": long}},
+                clip={"frames_per_s": 469.9, "ms_per_frame": 2.128, "unit_of_work": long, "collectives_in_timed_region": long},
+                mask_sensitivity={"portrait_like_ellipses": {"faces_per_s": 1278.9}, "coarse_4x4_cells": {"faces_per_s": 1367.7}, "iid_per_pixel": {"faces_per_s": 1276.9}},
+                f16_range={"overflowed_in_the_measured_passes": False, "what": long})
+    ksum = {k: (20, v * 20) for k, v in roof["all_modconv3x3"]["by_kernel_ms_per_step"].items()}
+    failed = dict(full, full_swap=None, pti={"error": long}, clip={"error": long}, mask_sensitivity=None, cpu_baseline=None, soak=None)
+    bare = dict(base, roofline=None, one_stream=None, soak=None, cpu_baseline=None, full_swap=None, pti=None, clip=None, mask_sensitivity=None, f16_range={})
+    for line, one, ks in ((full, full["one_stream"], ksum), (failed, full["one_stream"], ksum), (bare, None, None)):
+        out = bench._compact_line(line, one, ks, 20, "gpurun_out/bench_detail.json")
+        text = json.dumps(out)
+        assert len(text) < 2000, len(text)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                  "roofline", "cpu_baseline", "full_swap_p50_ms_per_frame", "pti_s_per_iter", "clip_frames_per_s"):
+            assert k in out, k
+        assert "workload" in out["config"] and "model" not in out["config"]
+    out = bench._compact_line(full, full["one_stream"], ksum, 20, None)
+    assert out["full_swap_p50_ms_per_frame"] == 2.115 and out["pti_s_per_iter"] == 0.01213 and out["stage_ms"]["ge512"] == round(0.55 + 0.29, 3)
+    assert out["roofline"]["frac_at_soak_sclk"] == round(0.1234 * 2400.0 / 2046.0, 4) and out["soak_joules_per_face"] == round(1223.0 / 1407.4, 3)
+
+
 # ------------------------------------------------------------------------------------------------ frame sharding (gloo, world 2)
 def test_shard_range_partitions_every_frame_once():
     from e4s2024_amd.runner import shard_range
