@@ -287,6 +287,27 @@ def style_tables_saved(styles, weight, mod_w, mod_b, s, d, wsq, mod_scale, mod_l
     return s_out, ws, (d_out if d is not None else None)
 
 
+_flip_cache = {}
+
+
+def _flipped(k: torch.Tensor) -> torch.Tensor:
+    """``torch.flip(k, (0, 1))`` of a constant FIR kernel (a registered buffer: ``blur.kernel`` / ``upsample.kernel``), made once per tensor version instead of once
+    per layer and step (12 launches of a PTI step).  An entry lives as long as its source tensor (a captured hipGraph may hold the flipped copy's address) and is
+    valid for that very tensor object at that version only."""
+    import weakref
+    key = id(k)
+    ent = _flip_cache.get(key)
+    if ent is not None and ent[0]() is k and ent[1] == k._version:
+        return ent[2]
+    flipped = torch.flip(k.detach(), (0, 1))
+    if torch.cuda.is_current_stream_capturing():
+        return flipped                       # (made inside the capture: it belongs to the graph's pool, not to this cache)
+    for dead in [i for i, e in _flip_cache.items() if e[0]() is None]:
+        del _flip_cache[dead]
+    _flip_cache[key] = (weakref.ref(k), k._version, flipped)
+    return flipped
+
+
 class _ToRGBGrad(torch.autograd.Function):
     """``ToRGB.forward`` (model.py:439-479) with a known forward value: ``out = Σ_c [c(p)=c] · W · (s_c ⊙ x) + bias + upsample(skip)``
     (1x1, no demodulation; ``lab`` None = one region).  Gradients of x, the scaled weight ``w [3,cin,1,1]``, ``s [bs,nreg,cin]``, the
@@ -315,7 +336,7 @@ class _ToRGBGrad(torch.autograd.Function):
         g_b = _sum_dim(dbias, 0).view(ctx.bias_shape) if (need_b and ctx.bias_shape is not None) else None
         g_skip = None
         if need_skip and ctx.skip_shape is not None:      # transpose of upfirdn2d(skip, k, up=2, pad=(2,1)) (op/upfirdn2d.py:100-105)
-            g_skip = upfirdn2d_raw(g, torch.flip(up_kernel, (0, 1)), (1, 1), (2, 2), (1, 1, 1, 1)).view(ctx.skip_shape)
+            g_skip = upfirdn2d_raw(g, _flipped(up_kernel), (1, 1), (2, 2), (1, 1, 1, 1)).view(ctx.skip_shape)
         return dx, None if dw is None else dw[0], ds, g_b, g_skip, None, None, None
 
 
@@ -360,7 +381,7 @@ class _SingleStyledConvGrad(torch.autograd.Function):
         dx = dw = None
         if blur is not None:
             # out = fir(conv_transpose(x), pad (1,1)): the FIR's transpose is the FIR with the flipped kernel and pad (2,2)
-            g = upfirdn2d_raw(g.view(bs * cout, 1, out.shape[2], out.shape[3]), torch.flip(blur, (0, 1)), (1, 1), (1, 1), (2, 2, 2, 2))
+            g = upfirdn2d_raw(g.view(bs * cout, 1, out.shape[2], out.shape[3]), _flipped(blur), (1, 1), (1, 1), (2, 2, 2, 2))
             g = g.view(bs, cout, 2 * h + 1, 2 * w + 1)
         if need_x:
             # data gradient on the MFMA conv kernel (three-way bf16 split: fp32-class), one sample at a time (its weights are per sample):
@@ -369,8 +390,9 @@ class _SingleStyledConvGrad(torch.autograd.Function):
             if blur is None:
                 wd = wd.flip(3, 4)
             if cout >= 16 and k in (1, 3):
-                dx = torch.cat([conv2d(g[b:b + 1], PreparedConv(exact="sb3").get(wd[b].contiguous()), 1 if blur is None else 2,
-                                       k // 2 if blur is None else 0) for b in range(bs)])
+                parts = [conv2d(g[b:b + 1], PreparedConv(exact="sb3").get(wd[b].contiguous()), 1 if blur is None else 2,
+                                k // 2 if blur is None else 0) for b in range(bs)]
+                dx = parts[0] if bs == 1 else torch.cat(parts)      # (batch 1 is the PTI case: no 134 MB copy of the 1024^2 gradient)
         if need_w and k in (1, 3):
             # weight gradient as an implicit GEMM (e4s_mconv_wgrad; odd widths: one unfold + e4s_gemm_sb per sample group): dW[o,(i,k)] = Σ_p g'[o,p] · x[i,p+k-pad], or for the
             # transposed conv dWt[i,(o,k)] = Σ_q x[i,q] · gT[o,2q+k]
