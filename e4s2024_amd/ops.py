@@ -1377,6 +1377,10 @@ _SCALE_CHUNK_PX = 8192
 GEMM_SPLITK_CAP_FLOATS = 64 << 20     # at most 256 MB of split-K partial products per call
 # the data / style gradient of a masked 3x3 layer as one kernel instead of the GEMM that writes U + the fold that reads it twice.  Off by default:
 # measured slower on all but the two largest masked layers (csrc/mconv_dgrad.hip, STATUS)
+# arithmetic of the single-region layers' data gradient (a 3x3 correlation on csrc/conv.hip): False = the two-way bf16 split the forward itself uses (3 MFMAs per
+# product; default since round 6: every gradient bar keeps its margin — worst parameter at 0.48 of its bar either way — and the PTI step loses 0.23 ms), "sb3" = the
+# three-way split (6 MFMAs, fp32-class; E4S_DGRAD_SPLIT=sb3)
+DGRAD_SINGLE_SPLIT = "sb3" if os.environ.get("E4S_DGRAD_SPLIT", "sb") == "sb3" else False
 DGRAD_FUSED = False           # e4s_mconv_dgrad (csrc/mconv_dgrad.hip): measured slower than GEMM + fold on all but the two largest masked layers; no environment
 DGRAD_FUSED_MIN_WIDTH = 32    # switch any more — the parity tests and tools/time_dgrad.py set the attribute
 

@@ -390,7 +390,7 @@ class _SingleStyledConvGrad(torch.autograd.Function):
             if blur is None:
                 wd = wd.flip(3, 4)
             if cout >= 16 and k in (1, 3):
-                parts = [conv2d(g[b:b + 1], PreparedConv(exact="sb3").get(wd[b].contiguous()), 1 if blur is None else 2,
+                parts = [conv2d(g[b:b + 1], PreparedConv(exact=ops.DGRAD_SINGLE_SPLIT).get(wd[b].contiguous()), 1 if blur is None else 2,
                                 k // 2 if blur is None else 0) for b in range(bs)]
                 dx = parts[0] if bs == 1 else torch.cat(parts)      # (batch 1 is the PTI case: no 134 MB copy of the 1024^2 gradient)
         if need_w and k in (1, 3):
