@@ -404,12 +404,17 @@ class Generator(nn.Module):
 
         self.n_latent = self.log_size * 2 - 2
 
-    def _table_jobs(self, latent):
-        """(layer, W+ slice) pairs in the order ``forward`` visits them — reference :661-690."""
+    def _table_jobs(self, latent, lat=None):
+        """(layer, W+ slice) pairs in the order ``forward`` visits them — reference :661-690.  ``lat``: the per-index code tensors ``forward`` hands to the layers (under
+        autograd they are slices of a transposed COPY of ``latent``): the plan is keyed on the very tensor a layer will ask with, so the jobs must be built from those —
+        built from ``latent`` itself the plan missed under autograd and every layer launched its own two table kernels (43 launches of a PTI step, round 6)."""
         rli = self.remaining_layer_idx
 
         def job(layer, masked, idx):
-            st = latent[:, :, idx] if masked else latent[:, 0, idx][:, None, :]
+            if lat is not None:
+                st = lat[idx] if masked else lat[idx][:, 0][:, None, :]
+            else:
+                st = latent[:, :, idx] if masked else latent[:, 0, idx][:, None, :]
             return layer.conv.table_job(st, masked)
         jobs = [job(self.conv1, True, 0), job(self.to_rgb1, True, 1)]
         for j, to_rgb in enumerate(self.to_rgbs):
@@ -487,15 +492,15 @@ class Generator(nn.Module):
             latent = torch.cat([latent, latent2], 1)
 
         rli = self.remaining_layer_idx
-        if latent.ndim == 4 and latent.is_cuda:
-            ops.style_demod_plan(self._table_jobs(latent))     # every layer's modulation / demodulation table in two launches
-        out = self.input(latent)
         # one view per W+ index: under autograd the 18 views are one unbind (its backward one stack), not 26 zero-filled slice gradients
         if latent.ndim == 4 and latent.is_cuda and torch.is_grad_enabled():
             # (the layers' gradient kernels want dense [bs, regions, 512] codes: one transposed copy here instead of one per layer)
             lat = latent.permute(2, 0, 1, 3).contiguous().unbind(0)
         else:
             lat = latent.unbind(2) if latent.ndim == 4 else None
+        if latent.ndim == 4 and latent.is_cuda:
+            ops.style_demod_plan(self._table_jobs(latent, lat))     # every layer's modulation / demodulation table in two launches
+        out = self.input(latent)
         out = self.conv1(out, lat[0] if lat is not None else latent[:, :, 0], mask, noise=noise[0])
         skip = self.to_rgb1(out, lat[1] if lat is not None else latent[:, :, 1], mask)
 
